@@ -1,0 +1,169 @@
+/*
+ * gscan_hip.h — C ABI of libgscan_hip.so, the MI355X (gfx950) implementation of the
+ * training hot path of LauraRuis/multimodal_seq2seq_gSCAN.
+ *
+ * The reference has no native boundary: its hot path is the Python class surface
+ * seq2seq/model.py:206-219 (Model.forward), :147-160 (get_loss), :162-170 (auxiliary head)
+ * and the optimiser lines of seq2seq/train.py:110-113.  Each entry point below replaces the
+ * arithmetic behind one of those call sites; INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.  Plain pointers and sizes only: every pointer is a
+ * DEVICE pointer unless the parameter name ends in _host; `stream` is a hipStream_t passed
+ * as void*.  Every function returns 0 on success, non-zero on failure
+ * (gscan_last_error() gives the text).  Nothing here allocates device memory or
+ * synchronises the stream, so a caller may capture any sequence of calls in a hipGraph.
+ *
+ * Layouts are the reference's own: parameters are the tensors of Model.state_dict()
+ * (row-major [out, in], LSTM gate order i,f,g,o); commands [B,L] and targets [B,T] are
+ * int64 token ids; world is float32 [B,G,G,C] indexed [row][col][channel];
+ * log-probabilities are float32 [B,T,V].
+ */
+#ifndef GSCAN_HIP_H
+#define GSCAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSCAN_ABI_VERSION 1
+
+/* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
+typedef struct gscan_dims {
+    int32_t B;             /* rows in this batch                                   */
+    int32_t L;             /* padded command length                                */
+    int32_t T;             /* padded target length                                 */
+    int32_t G;             /* grid side                                            */
+    int32_t C;             /* num_cnn_channels                                     */
+    int32_t Co;            /* cnn_hidden_num_channels                              */
+    int32_t K3;            /* cnn_kernel_size (conv_3); conv_1 is 1, conv_2 is 5   */
+    int32_t E;             /* embedding_dimension                                  */
+    int32_t He;            /* encoder_hidden_size                                  */
+    int32_t H;             /* decoder_hidden_size                                  */
+    int32_t Vi;            /* input_vocabulary_size                                */
+    int32_t V;             /* target_vocabulary_size                               */
+    int32_t conditional;   /* conditional_attention                                */
+    int32_t auxiliary;     /* auxiliary_task                                       */
+    int32_t bidirectional; /* encoder_bidirectional                                */
+    int32_t pad_in;        /* input_padding_idx                                    */
+    int32_t pad_tgt;       /* target_pad_idx                                       */
+} gscan_dims;
+
+/* One pointer per reference parameter (named_parameters() order, seq2seq/model.py:47-87).
+ * The same struct addresses the gradients.  Entries that do not exist for a configuration
+ * (w_q2k/b_q2k without conditional attention, *_rev when unidirectional) are NULL. */
+typedef struct gscan_params {
+    float *conv1_w, *conv1_b, *conv2_w, *conv2_b, *conv3_w, *conv3_b;
+    float *vis_key_w, *vis_query_w, *vis_energy_w;
+    float *enc_emb;
+    float *enc_w_ih, *enc_w_hh, *enc_b_ih, *enc_b_hh;
+    float *enc_w_ih_rev, *enc_w_hh_rev, *enc_b_ih_rev, *enc_b_hh_rev;
+    float *bridge_w, *bridge_b;
+    float *txt_key_w, *txt_query_w, *txt_energy_w;
+    float *q2k_w, *q2k_b;
+    float *dec_emb;
+    float *dec_w_ih, *dec_w_hh, *dec_b_ih, *dec_b_hh;
+    float *out2hid_w, *hid2out_w;
+} gscan_params;
+
+/* The reference's batch tuple (seq2seq/gSCAN_dataset.py:229-231) as device arrays. */
+typedef struct gscan_batch {
+    const int64_t *commands;     /* [B,L]                                           */
+    const int32_t *cmd_lengths;  /* [B]  number of real tokens per command          */
+    const float   *world;        /* [B,G,G,C]                                       */
+    const int64_t *targets;      /* [B,T]                                           */
+} gscan_batch;
+
+/* Scaled dropout masks (0 or 1/(1-p)), or NULL for "no dropout" (eval mode / p = 0).
+ * cnn [B,G*G,3*Co], enc [B,L,E], dec [B,T,H] in batch-row order.  The caller either draws
+ * them with gscan_dropout_mask() or supplies masks of its own (host-mask parity mode). */
+typedef struct gscan_masks {
+    const float *cnn, *enc, *dec;
+} gscan_masks;
+
+int         gscan_abi_version(void);
+const char *gscan_last_error(void);
+
+/* Bytes of device scratch gscan_forward/gscan_backward need for `dims`.  The same buffer
+ * must be passed to the backward call that follows a forward call (it holds the saved
+ * activations).  Returns 0 if the dimensions are unsupported (see gscan_last_error). */
+size_t gscan_workspace_bytes(const gscan_dims *dims);
+
+/* Byte offset and float count of one named activation inside the workspace (for tests and
+ * debugging: "feat", "enc_out", "pkt", "S", "gates", "delta", ...; see csrc/step.hip). */
+int gscan_workspace_find(const gscan_dims *dims, const char *name, size_t *offset_bytes, size_t *count);
+
+/* Model.forward (seq2seq/model.py:206-219): CNN + BiLSTM encoders, joint-attention LSTM
+ * decoder over all T steps, output head, log_softmax.  Writes logp [B,T,V] and, when
+ * dims->auxiliary, aux_logp [B,G*G] (= log_softmax of the summed visual attention,
+ * model.py:166-170).  aux_logp may be NULL otherwise. */
+int gscan_forward(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                  const gscan_masks *masks, void *workspace, float *logp, float *aux_logp, void *stream);
+
+/* Reverse of gscan_forward: given d(loss)/d(logp) [B,T,V] and (optionally, may be NULL)
+ * d(loss)/d(aux_logp) [B,G*G], ADDS d(loss)/d(parameter) into `grads` (the caller zeroes
+ * them, as optimizer.zero_grad() does in seq2seq/train.py:113).  Replaces the autograd
+ * replay behind loss.backward() (train.py:110). */
+int gscan_backward(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                   const gscan_masks *masks, void *workspace, const float *dlogp, const float *daux_logp,
+                   const gscan_params *grads, void *stream);
+
+/* Model.get_loss (seq2seq/model.py:147-160): NLL of targets shifted left by one with a PAD
+ * appended, over positions whose shifted target != pad.  Writes loss_sum[0] = sum of -logp
+ * and count[0] = number of such positions (as float); the reference's loss is
+ * loss_sum/count.  dlogp (may be NULL) receives -1 at the picked entries and 0 elsewhere,
+ * i.e. d(loss_sum)/d(logp). */
+int gscan_sequence_nll(const float *logp, const int64_t *targets, int B, int T, int V, int pad,
+                       float *loss_sum, float *count, float *dlogp, void *stream);
+
+/* Model.get_auxiliary_loss (seq2seq/model.py:162-164): loss_sum[0] = sum_b -aux_logp[b,pos[b]];
+ * daux (may be NULL) = d(loss_sum)/d(aux_logp). */
+int gscan_position_nll(const float *aux_logp, const int64_t *positions, int B, int M,
+                       float *loss_sum, float *daux, void *stream);
+
+/* Model.get_metrics (seq2seq/model.py:117-137): out[0] = correct tokens, out[1] = non-pad
+ * tokens, out[2] = rows with every non-pad token correct. */
+int gscan_sequence_metrics(const float *logp, const int64_t *targets, int B, int T, int V, int pad,
+                           float *out3, void *stream);
+
+/* torch.optim.Adam step + LambdaLR factor of seq2seq/train.py:67-70,111-112 over one flat
+ * buffer of n floats: lr_t = lr * lr_decay^((step-1)/lr_decay_steps), step is 1-based.
+ * The gradient is multiplied by grad_scale[0] (device pointer, may be NULL = 1) before
+ * use — the data-parallel step passes 1/global_token_count there without a host sync. */
+int gscan_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                    float lr, float beta1, float beta2, float eps, float lr_decay, float lr_decay_steps,
+                    int64_t step, const float *grad_scale, void *stream);
+
+/* Counter-based (Philox-4x32-10) scaled dropout mask: out[i] = keep ? 1/(1-p) : 0. */
+int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, void *stream);
+
+/* ---- building blocks, exported so that each kernel can be parity-tested on its own ---- */
+
+/* C[M,N] = act(alpha * A.B + beta * C + bias[n]) * mask[m,n]
+ * A(m,k) at a[m*sam + k*sak], B(k,n) at b[k*sbk + n*sbn], C and mask row-major with ldc.
+ * act: 0 none, 1 relu, 2 tanh.  bias/mask may be NULL.  split_k > 1 accumulates partial
+ * products with float atomics and requires beta == 1, act == 0, bias == mask == NULL. */
+int gscan_gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak,
+                   const float *b, int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc,
+                   const float *bias, int act, const float *mask, int split_k, void *stream);
+
+/* im2col of the world tensor for the three convolutions (seq2seq/cnn_model.py:28-31):
+ * xcol [B*G*G, C*(1+25+K3*K3)], column (conv, ch, kh, kw) holds world[b, r+kw-p, c+kh-p, ch]. */
+int gscan_world_im2col(const float *world, int B, int G, int C, int K3, float *xcol, void *stream);
+
+/* Masked per-row LSTM over the command (seq2seq/seq2seq_model.py:62-88).
+ * gx [B,L,D,4He] = W_ih x + b_ih (D directions); out [B,L,He] = sum of directions,
+ * zero at t >= len; h_final [B,He].  gates/cells/hprev [B,L,D,*] are saved for backward. */
+int gscan_encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths,
+                               const float *w_hh_fwd, const float *b_hh_fwd, const float *w_hh_rev,
+                               const float *b_hh_rev, float *out, float *h_final, float *gates,
+                               float *cells, float *hprev, void *stream);
+int gscan_encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_fwd,
+                                const float *w_hh_rev, const float *gates, const float *cells,
+                                const float *d_out, const float *d_h_final, float *delta, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSCAN_HIP_H */

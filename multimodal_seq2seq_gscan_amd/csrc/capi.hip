@@ -1,0 +1,127 @@
+// extern "C" surface of libgscan_hip.so (declared in include/gscan_hip.h).
+#include <string.h>
+
+#include "step.h"
+
+namespace gscan {
+static thread_local char g_error[1024] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+}  // namespace gscan
+
+using namespace gscan;
+
+#define ARG(cond, ...) do { if (!(cond)) { set_error(__VA_ARGS__); return 1; } } while (0)
+
+extern "C" {
+
+int gscan_abi_version(void) { return GSCAN_ABI_VERSION; }
+const char *gscan_last_error(void) { return g_error; }
+
+size_t gscan_workspace_bytes(const gscan_dims *dims) {
+    if (!dims) { set_error("workspace_bytes: dims is NULL"); return 0; }
+    if (check_dims(*dims)) return 0;
+    Workspace ws;
+    workspace_layout(*dims, &ws);
+    return (size_t)ws.total_floats * sizeof(float);
+}
+
+int gscan_workspace_find(const gscan_dims *dims, const char *name, size_t *offset_bytes, size_t *count) {
+    ARG(dims && name && offset_bytes && count, "workspace_find: NULL argument");
+    if (int rc = check_dims(*dims)) return rc;
+    Workspace ws;
+    workspace_layout(*dims, &ws);
+    for (int i = 0; i < ws.nslots; ++i)
+        if (strcmp(ws.slot[i].name, name) == 0) {
+            *offset_bytes = (size_t)ws.slot[i].offset * sizeof(float);
+            *count = (size_t)ws.slot[i].count;
+            return 0;
+        }
+    set_error("workspace_find: no slot named '%s'", name);
+    return 1;
+}
+
+int gscan_forward(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                  const gscan_masks *masks, void *workspace, float *logp, float *aux_logp, void *stream) {
+    ARG(dims && params && batch && workspace, "forward: NULL argument");
+    ARG(batch->commands && batch->cmd_lengths && batch->world && batch->targets, "forward: NULL batch array");
+    gscan_masks none{nullptr, nullptr, nullptr};
+    return step_forward(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, logp, aux_logp,
+                        (hipStream_t)stream);
+}
+
+int gscan_backward(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                   const gscan_masks *masks, void *workspace, const float *dlogp, const float *daux_logp,
+                   const gscan_params *grads, void *stream) {
+    ARG(dims && params && batch && workspace && grads, "backward: NULL argument");
+    gscan_masks none{nullptr, nullptr, nullptr};
+    return step_backward(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, dlogp, daux_logp, *grads,
+                         (hipStream_t)stream);
+}
+
+int gscan_sequence_nll(const float *logp, const int64_t *targets, int B, int T, int V, int pad, float *loss_sum,
+                       float *count, float *dlogp, void *stream) {
+    ARG(logp && targets && loss_sum && count && B > 0 && T > 0 && V > 0, "sequence_nll: bad argument");
+    return sequence_nll(logp, targets, B, T, V, pad, loss_sum, count, dlogp, (hipStream_t)stream);
+}
+
+int gscan_position_nll(const float *aux_logp, const int64_t *positions, int B, int M, float *loss_sum, float *daux,
+                       void *stream) {
+    ARG(aux_logp && positions && loss_sum && B > 0 && M > 0, "position_nll: bad argument");
+    return position_nll(aux_logp, positions, B, M, loss_sum, daux, (hipStream_t)stream);
+}
+
+int gscan_sequence_metrics(const float *logp, const int64_t *targets, int B, int T, int V, int pad, float *out3,
+                           void *stream) {
+    ARG(logp && targets && out3 && B > 0 && T > 0 && V > 0, "sequence_metrics: bad argument");
+    return sequence_metrics(logp, targets, B, T, V, pad, out3, (hipStream_t)stream);
+}
+
+int gscan_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr,
+                    float beta1, float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step,
+                    const float *grad_scale, void *stream) {
+    ARG(param && grad && exp_avg && exp_avg_sq && n > 0, "adam_step: bad argument");
+    return adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, lr_decay, lr_decay_steps, step,
+                     grad_scale, (hipStream_t)stream);
+}
+
+int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, void *stream) {
+    ARG(out || n == 0, "dropout_mask: NULL output");
+    return dropout_mask(out, n, p, seed, stream_id, (hipStream_t)stream);
+}
+
+int gscan_gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
+                   int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
+                   const float *mask, int split_k, void *stream) {
+    return gemm_f32(M, N, K, alpha, a, sam, sak, b, sbk, sbn, beta, c, ldc, bias, act, mask, split_k,
+                    (hipStream_t)stream);
+}
+
+int gscan_world_im2col(const float *world, int B, int G, int C, int K3, float *xcol, void *stream) {
+    ARG(world && xcol, "im2col: NULL argument");
+    return world_im2col(world, B, G, C, K3, xcol, (hipStream_t)stream);
+}
+
+int gscan_encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths,
+                               const float *w_hh_fwd, const float *b_hh_fwd, const float *w_hh_rev,
+                               const float *b_hh_rev, float *out, float *h_final, float *gates, float *cells,
+                               float *hprev, void *stream) {
+    ARG(gx && lengths && w_hh_fwd && b_hh_fwd && out && h_final && gates && cells && hprev,
+        "encoder_lstm_forward: NULL argument");
+    return encoder_lstm_forward(B, L, He, D, gx, lengths, w_hh_fwd, b_hh_fwd, w_hh_rev, b_hh_rev, out, h_final, gates,
+                                cells, hprev, (hipStream_t)stream);
+}
+
+int gscan_encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_fwd,
+                                const float *w_hh_rev, const float *gates, const float *cells, const float *d_out,
+                                const float *d_h_final, float *delta, void *stream) {
+    ARG(lengths && w_hh_fwd && gates && cells && d_out && d_h_final && delta, "encoder_lstm_backward: NULL argument");
+    return encoder_lstm_backward(B, L, He, D, lengths, w_hh_fwd, w_hh_rev, gates, cells, d_out, d_h_final, delta,
+                                 (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,270 @@
+// Small memory-bound kernels of the training step: im2col of the world tensor, embedding
+// gather / gradient scatter, ReLU+dropout backward, column sums (bias gradients), the
+// attention value-path gradient, fused Adam and the Philox dropout-mask generator.
+// All are one-pass, coalesced along the innermost (feature) dimension.
+#include "step.h"
+
+namespace gscan {
+
+// ------------------------------------------------------------------------------------------
+// im2col for conv_1 (k=1), conv_2 (k=5), conv_3 (k=K3) — seq2seq/cnn_model.py:28-31.
+// Column (conv, ch, kh, kw) of row (b, r, c) = world[b, r + kw - p, c + kh - p, ch]: the
+// reference convolves the transposed image, so kh walks grid columns and kw grid rows.
+// ------------------------------------------------------------------------------------------
+__global__ void im2col_kernel(const float *__restrict__ world, int B, int G, int C, int K3, int Ktot,
+                              float *__restrict__ xcol) {
+    const int64_t total = (int64_t)B * G * G * Ktot;
+    const int k2 = 25 * C, k1 = C;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(idx % Ktot);
+        const int64_t row = idx / Ktot;
+        const int c = (int)(row % G), r = (int)((row / G) % G);
+        const int64_t b = row / ((int64_t)G * G);
+        int kk, local;
+        if (col < k1) { kk = 1; local = col; }
+        else if (col < k1 + k2) { kk = 5; local = col - k1; }
+        else { kk = K3; local = col - k1 - k2; }
+        const int p = kk / 2;
+        const int kw = local % kk, kh = (local / kk) % kk, ch = local / (kk * kk);
+        const int rr = r + kw - p, cc = c + kh - p;
+        float v = 0.f;
+        if (rr >= 0 && rr < G && cc >= 0 && cc < G) v = world[((b * G + rr) * G + cc) * C + ch];
+        xcol[idx] = v;
+    }
+}
+
+int world_im2col(const float *world, int B, int G, int C, int K3, float *xcol, hipStream_t stream) {
+    GSCAN_CHECK(B > 0 && G > 0 && C > 0 && K3 > 0 && (K3 & 1), "im2col: bad dims B=%d G=%d C=%d K3=%d", B, G, C, K3);
+    const int Ktot = C * (1 + 25 + K3 * K3);
+    const int64_t total = (int64_t)B * G * G * Ktot;
+    const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 256 * 16);
+    hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, stream, world, B, G, C, K3, Ktot, xcol);
+    GSCAN_LAUNCHED("im2col_kernel");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// out[row, 0:D] (row stride ldo) = table[tok[row], :] * mask[row, :]
+// nn.Embedding + nn.Dropout of seq2seq_model.py:58-59 and :383-384.
+// ------------------------------------------------------------------------------------------
+__global__ void embed_kernel(const int64_t *__restrict__ tok, const float *__restrict__ table, int vocab,
+                             const float *__restrict__ mask, int rows, int D, float *__restrict__ out, int64_t ldo) {
+    const int64_t total = (int64_t)rows * D;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % D);
+        const int64_t row = idx / D;
+        int64_t t = tok[row];
+        float v = (t >= 0 && t < vocab) ? table[t * D + d] : 0.f;
+        if (mask) v *= mask[idx];
+        out[row * ldo + d] = v;
+    }
+}
+
+int embed_rows(const int64_t *tok, const float *table, int vocab, const float *mask, int rows, int D, float *out,
+               int64_t ldo, hipStream_t stream) {
+    const int64_t total = (int64_t)rows * D;
+    hipLaunchKernelGGL(embed_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, stream, tok,
+                       table, vocab, mask, rows, D, out, ldo);
+    GSCAN_LAUNCHED("embed_kernel");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// dtable[v, :] += sum over rows with tok[row] == v, v != pad of g[row, :] * mask[row, :]
+// (the padding row of nn.Embedding(padding_idx=...) never receives gradient).
+// One workgroup per (vocab entry, row chunk); in-register sum, one atomic per column.
+// ------------------------------------------------------------------------------------------
+__global__ void embed_grad_kernel(const int64_t *__restrict__ tok, const float *__restrict__ g, int64_t ldg,
+                                  const float *__restrict__ mask, int rows, int D, int pad,
+                                  float *__restrict__ dtable, int rows_per_block) {
+    const int v = blockIdx.x;
+    if (v == pad) return;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            if (tok[r] == v) {
+                float x = g[(int64_t)r * ldg + d];
+                if (mask) x *= mask[(int64_t)r * D + d];
+                acc += x;
+            }
+        }
+        if (acc != 0.f) atomicAdd(&dtable[(int64_t)v * D + d], acc);
+    }
+}
+
+int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mask, int rows, int D, int vocab,
+               int pad, float *dtable, hipStream_t stream) {
+    const int rpb = 256;
+    hipLaunchKernelGGL(embed_grad_kernel, dim3(vocab, cdiv(rows, rpb)), dim3(128), 0, stream, tok, g, ldg, mask,
+                       rows, D, pad, dtable, rpb);
+    GSCAN_LAUNCHED("embed_grad_kernel");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// ReLU + dropout backward for the conv features (cnn_model.py:32-35):
+// feat = relu(x) * mask  =>  dx = (feat != 0) ? dfeat * mask : 0.   In place on dfeat.
+// ------------------------------------------------------------------------------------------
+__global__ void relu_mask_bwd_kernel(float *__restrict__ dfeat, const float *__restrict__ feat,
+                                     const float *__restrict__ mask, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float d = dfeat[i];
+        d = (feat[i] != 0.f) ? (mask ? d * mask[i] : d) : 0.f;
+        dfeat[i] = d;
+    }
+}
+
+int relu_mask_backward(float *dfeat, const float *feat, const float *mask, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3((int)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0, stream,
+                       dfeat, feat, mask, n);
+    GSCAN_LAUNCHED("relu_mask_bwd_kernel");
+    return 0;
+}
+
+// out[i] = a[i] + b[i]  (sum of the two LSTM bias vectors)
+__global__ void vec_add_kernel(const float *a, const float *b, float *out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+int vec_add(const float *a, const float *b, float *out, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, a, b, out, n);
+    GSCAN_LAUNCHED("vec_add_kernel");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Column sums: out1[n] += sum_r x[r*ld + n]  (and out2[n] += the same, for the twin LSTM
+// biases b_ih / b_hh which always receive identical gradients).  Rows are split over
+// blockIdx.y, columns over lanes; one atomic per (block, column).
+// ------------------------------------------------------------------------------------------
+__global__ void colsum_kernel(const float *__restrict__ x, int64_t ld, int rows, int N, float *out1, float *out2,
+                              int rows_per_block) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += x[(int64_t)r * ld + n];
+    atomicAdd(&out1[n], acc);
+    if (out2) atomicAdd(&out2[n], acc);
+}
+
+int colsum_add(const float *x, int64_t ld, int rows, int N, float *out1, float *out2, hipStream_t stream) {
+    const int rpb = 128;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), cdiv(rows, rpb)), dim3(64), 0, stream, x, ld, rows, N, out1,
+                       out2, rpb);
+    GSCAN_LAUNCHED("colsum_kernel");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Value-path gradient of additive attention (seq2seq_model.py:138, values = projected keys):
+//   dkeys[b, m, :] (+)= sum_t alpha[b, t, m] * dctx[b, t, :]
+// alpha [B,T,Mld] (first M used), dctx rows at dctx[(b*T+t)*ldd + 0:H], dkeys [B,M,H].
+// One workgroup per batch row; thread owns (m, k) pairs and walks t.
+// ------------------------------------------------------------------------------------------
+__global__ void attn_value_grad_kernel(const float *__restrict__ alpha, int Mld, const float *__restrict__ dctx,
+                                       int64_t ldd, int T, int M, int H, float *__restrict__ dkeys, int accumulate) {
+    const int b = blockIdx.x;
+    for (int idx = threadIdx.x; idx < M * H; idx += blockDim.x) {
+        const int m = idx / H, k = idx % H;
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t)
+            acc += alpha[((int64_t)b * T + t) * Mld + m] * dctx[((int64_t)b * T + t) * ldd + k];
+        float *p = dkeys + ((int64_t)b * M + m) * H + k;
+        *p = accumulate ? (*p + acc) : acc;
+    }
+}
+
+int attn_value_grad(const float *alpha, int Mld, const float *dctx, int64_t ldd, int B, int T, int M, int H,
+                    float *dkeys, int accumulate, hipStream_t stream) {
+    hipLaunchKernelGGL(attn_value_grad_kernel, dim3(B), dim3(256), 0, stream, alpha, Mld, dctx, ldd, T, M, H, dkeys,
+                       accumulate);
+    GSCAN_LAUNCHED("attn_value_grad_kernel");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused Adam over the flat parameter buffer (torch.optim.Adam semantics, train.py:68,111).
+// ------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                            float *__restrict__ v, size_t n, float step_size, float beta1, float beta2, float eps,
+                            float inv_sqrt_bc2, const float *__restrict__ grad_scale) {
+    const float gs = grad_scale ? grad_scale[0] : 1.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gs;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+int adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+              float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
+              hipStream_t stream) {
+    GSCAN_CHECK(step >= 1, "adam: step is 1-based (got %lld)", (long long)step);
+    const double lr_t = (double)lr * pow((double)lr_decay, (double)(step - 1) / (double)lr_decay_steps);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((int)std::min<size_t>(cdiv(n, 256), 2048)), dim3(256), 0, stream, param, grad,
+                       exp_avg, exp_avg_sq, n, (float)(lr_t / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)),
+                       grad_scale);
+    GSCAN_LAUNCHED("adam_kernel");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox-4x32-10 counter RNG -> scaled Bernoulli keep mask.  Counter = element index / 4,
+// key = seed, stream id in the high counter words; four outputs per counter.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0,
+                                             uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__global__ void dropout_mask_kernel(float *__restrict__ out, size_t n, float p, float scale, uint64_t seed,
+                                    uint64_t stream_id) {
+    const size_t nquad = (n + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (size_t)gridDim.x * blockDim.x) {
+        uint32_t c0 = (uint32_t)q, c1 = (uint32_t)(q >> 32), c2 = (uint32_t)stream_id, c3 = (uint32_t)(stream_id >> 32);
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c0, c1, c2, c3, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const uint32_t rnd[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = q * 4 + j;
+            if (i < n) {
+                const float u = (float)(rnd[j] >> 8) * (1.0f / 16777216.0f);   // [0,1)
+                out[i] = (u >= p) ? scale : 0.f;
+            }
+        }
+    }
+}
+
+int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream) {
+    GSCAN_CHECK(p >= 0.f && p < 1.f, "dropout: p=%g out of [0,1)", p);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)std::min<size_t>(cdiv((n + 3) / 4, 256), 2048)), dim3(256), 0,
+                       stream, out, n, p, 1.0f / (1.0f - p), seed, stream_id);
+    GSCAN_LAUNCHED("dropout_mask_kernel");
+    return 0;
+}
+
+}  // namespace gscan

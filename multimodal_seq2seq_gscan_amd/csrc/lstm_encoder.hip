@@ -1,0 +1,215 @@
+// Command encoder recurrence (seq2seq/seq2seq_model.py:62-88), forward and backward.
+//
+// The reference sorts rows by length, packs them and calls nn.LSTM.  Rows are independent,
+// so here one workgroup owns one command for its whole length: the recurrent matrix W_hh
+// (4He x He floats) lives in the VGPRs of the workgroup for all time steps (thread j holds
+// row j), h is broadcast from LDS, and there is no global traffic inside the loop except the
+// precomputed input projection gx[t] coming in and the saved activations going out.  Length
+// masking replaces packing: a row simply stops after its own length (the reverse direction
+// starts at its last real token), outputs at padded positions are written as zeros.
+//
+// Backward keeps the transposed ownership: thread (s, k) holds W_hh[s*He .. s*He+He-1][k], so
+// dh_{t-1}[k] = sum_j W_hh[j][k] * delta[j] is four in-register partial dots plus one LDS sum.
+// The kernel emits only the gate pre-activation gradients delta[b,t,dir,4He]; all weight
+// gradients are dense GEMMs over those afterwards.
+#include "step.h"
+
+namespace gscan {
+
+template <int HE>
+__device__ __forceinline__ float dot_lds(const float (&w)[HE], const float *v) {
+    static_assert(HE % 4 == 0, "hidden size must be a multiple of 4");
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float4 *v4 = reinterpret_cast<const float4 *>(v);
+#pragma unroll
+    for (int i = 0; i < HE / 4; ++i) {
+        const float4 x = v4[i];          // same address in every lane: LDS broadcast
+        a0 = fmaf(w[4 * i + 0], x.x, a0);
+        a1 = fmaf(w[4 * i + 1], x.y, a1);
+        a2 = fmaf(w[4 * i + 2], x.z, a2);
+        a3 = fmaf(w[4 * i + 3], x.w, a3);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+template <int HE>
+__global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_fwd_kernel(int L, int D, const float *__restrict__ gx,
+                                        const int32_t *__restrict__ lengths, const float *__restrict__ w_hh_f,
+                                        const float *__restrict__ b_hh_f, const float *__restrict__ w_hh_r,
+                                        const float *__restrict__ b_hh_r, float *__restrict__ out,
+                                        float *__restrict__ h_final, float *__restrict__ gates,
+                                        float *__restrict__ cells, float *__restrict__ hprev) {
+    __shared__ __attribute__((aligned(16))) float h_s[HE];
+    __shared__ float gate_s[4 * HE];
+    const int b = blockIdx.x, j = threadIdx.x;
+    int len = lengths[b];
+    len = max(0, min(len, L));
+    const bool is_gate = j < 4 * HE, is_unit = j < HE;
+    float w[HE];
+
+    // padded positions: zero output, zero saved h_prev (it multiplies delta = 0 in a GEMM later)
+    for (int idx = j; idx < (L - len) * HE; idx += blockDim.x) {
+        const int t = len + idx / HE, k = idx % HE;
+        out[((int64_t)b * L + t) * HE + k] = 0.f;
+        for (int d = 0; d < D; ++d) hprev[(((int64_t)b * L + t) * D + d) * HE + k] = 0.f;
+    }
+
+    for (int dir = 0; dir < D; ++dir) {
+        const float *w_hh = dir ? w_hh_r : w_hh_f;
+        const float *b_hh = dir ? b_hh_r : b_hh_f;
+        float bias = 0.f;
+        if (is_gate) {
+#pragma unroll
+            for (int k = 0; k < HE; ++k) w[k] = w_hh[(int64_t)j * HE + k];
+            bias = b_hh[j];
+        }
+        float c = 0.f;
+        if (is_unit) h_s[j] = 0.f;
+        __syncthreads();
+        for (int s = 0; s < len; ++s) {
+            const int t = dir ? (len - 1 - s) : s;
+            const int64_t row = ((int64_t)b * L + t) * D + dir;
+            if (is_gate) {
+                float pre = gx[row * 4 * HE + j] + bias + dot_lds<HE>(w, h_s);
+                const float a = (j >= 2 * HE && j < 3 * HE) ? tanhf_(pre) : sigmoidf_(pre);
+                gate_s[j] = a;
+                gates[row * 4 * HE + j] = a;
+            }
+            if (is_unit) hprev[row * HE + j] = h_s[j];
+            __syncthreads();
+            if (is_unit) {
+                const float ig = gate_s[j], fg = gate_s[HE + j], gg = gate_s[2 * HE + j], og = gate_s[3 * HE + j];
+                c = fg * c + ig * gg;
+                const float h = og * tanhf_(c);
+                cells[row * HE + j] = c;
+                h_s[j] = h;
+                float *o = out + ((int64_t)b * L + t) * HE + j;
+                *o = dir ? (*o + h) : h;          // directions are summed (seq2seq_model.py:77-79)
+            }
+            __syncthreads();
+        }
+        if (is_unit) {
+            float *hf = h_final + (int64_t)b * HE + j;
+            *hf = dir ? (*hf + h_s[j]) : h_s[j];  // final states are summed too (:80-81)
+        }
+        __syncthreads();
+    }
+}
+
+template <int HE>
+__global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_bwd_kernel(int L, int D, const int32_t *__restrict__ lengths,
+                                        const float *__restrict__ w_hh_f, const float *__restrict__ w_hh_r,
+                                        const float *__restrict__ gates, const float *__restrict__ cells,
+                                        const float *__restrict__ d_out, const float *__restrict__ d_h_final,
+                                        float *__restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) float delta_s[4 * HE];
+    __shared__ float part_s[4 * HE];
+    __shared__ float dh_s[HE];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    int len = lengths[b];
+    len = max(0, min(len, L));
+    const bool active = tid < 4 * HE, is_unit = tid < HE;
+    const int seg = tid / HE, k = tid % HE;
+    const float *w_hh = dir ? w_hh_r : w_hh_f;
+    float wt[HE];
+    if (active) {
+#pragma unroll
+        for (int jj = 0; jj < HE; ++jj) wt[jj] = w_hh[(int64_t)(seg * HE + jj) * HE + k];
+    }
+    for (int idx = tid; idx < (L - len) * 4 * HE; idx += blockDim.x) {
+        const int t = len + idx / (4 * HE), jj = idx % (4 * HE);
+        delta[(((int64_t)b * L + t) * D + dir) * 4 * HE + jj] = 0.f;
+    }
+    float dc = 0.f;
+    if (is_unit) dh_s[tid] = d_h_final[(int64_t)b * HE + tid];
+    __syncthreads();
+    for (int s = len - 1; s >= 0; --s) {
+        const int t = dir ? (len - 1 - s) : s;
+        const int64_t row = ((int64_t)b * L + t) * D + dir;
+        if (is_unit) {
+            const float dh = dh_s[tid] + d_out[((int64_t)b * L + t) * HE + tid];
+            const float *g = gates + row * 4 * HE;
+            const float ig = g[tid], fg = g[HE + tid], gg = g[2 * HE + tid], og = g[3 * HE + tid];
+            const float c = cells[row * HE + tid];
+            float c_prev = 0.f;
+            if (s > 0) {
+                const int tp = dir ? (t + 1) : (t - 1);
+                c_prev = cells[(((int64_t)b * L + tp) * D + dir) * HE + tid];
+            }
+            const float tc = tanhf_(c);
+            const float dct = dc + dh * og * (1.f - tc * tc);
+            const float di = dct * gg * ig * (1.f - ig);
+            const float df = dct * c_prev * fg * (1.f - fg);
+            const float dg = dct * ig * (1.f - gg * gg);
+            const float d_o = dh * tc * og * (1.f - og);
+            dc = dct * fg;
+            delta_s[tid] = di; delta_s[HE + tid] = df; delta_s[2 * HE + tid] = dg; delta_s[3 * HE + tid] = d_o;
+            float *dg_out = delta + row * 4 * HE;
+            dg_out[tid] = di; dg_out[HE + tid] = df; dg_out[2 * HE + tid] = dg; dg_out[3 * HE + tid] = d_o;
+        }
+        __syncthreads();
+        if (active) part_s[tid] = dot_lds<HE>(wt, delta_s + seg * HE);
+        __syncthreads();
+        if (is_unit) dh_s[tid] = (part_s[tid] + part_s[HE + tid]) + (part_s[2 * HE + tid] + part_s[3 * HE + tid]);
+        __syncthreads();
+    }
+}
+
+template <int HE>
+static int launch_fwd(int B, int L, int D, const float *gx, const int32_t *lengths, const float *wf, const float *bf,
+                      const float *wr, const float *br, float *out, float *hfin, float *gates, float *cells,
+                      float *hprev, hipStream_t stream) {
+    const int nt = cdiv(4 * HE, 64) * 64;
+    hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B), dim3(nt), 0, stream, L, D, gx, lengths, wf, bf, wr, br,
+                       out, hfin, gates, cells, hprev);
+    GSCAN_LAUNCHED("encoder_lstm_fwd_kernel");
+    return 0;
+}
+template <int HE>
+static int launch_bwd(int B, int L, int D, const int32_t *lengths, const float *wf, const float *wr,
+                      const float *gates, const float *cells, const float *d_out, const float *d_hfin, float *delta,
+                      hipStream_t stream) {
+    const int nt = cdiv(4 * HE, 64) * 64;
+    hipLaunchKernelGGL(encoder_lstm_bwd_kernel<HE>, dim3(B, D), dim3(nt), 0, stream, L, D, lengths, wf, wr, gates,
+                       cells, d_out, d_hfin, delta);
+    GSCAN_LAUNCHED("encoder_lstm_bwd_kernel");
+    return 0;
+}
+
+#define GSCAN_HIDDEN_SIZES(X) X(20) X(32) X(64) X(100) X(128)
+
+bool hidden_size_supported(int h) {
+#define X(n) if (h == n) return true;
+    GSCAN_HIDDEN_SIZES(X)
+#undef X
+    return false;
+}
+
+int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths, const float *w_hh_f,
+                         const float *b_hh_f, const float *w_hh_r, const float *b_hh_r, float *out, float *h_final,
+                         float *gates, float *cells, float *hprev, hipStream_t stream) {
+    GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm: bad dims B=%d L=%d D=%d", B, L, D);
+    GSCAN_CHECK(D == 1 || (w_hh_r && b_hh_r), "encoder lstm: reverse weights missing");
+    switch (He) {
+#define X(n) case n: return launch_fwd<n>(B, L, D, gx, lengths, w_hh_f, b_hh_f, w_hh_r, b_hh_r, out, h_final, gates, cells, hprev, stream);
+        GSCAN_HIDDEN_SIZES(X)
+#undef X
+        default: break;
+    }
+    GSCAN_CHECK(false, "encoder_hidden_size %d has no compiled kernel (supported: 20 32 64 100 128)", He);
+}
+
+int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_f,
+                          const float *w_hh_r, const float *gates, const float *cells, const float *d_out,
+                          const float *d_h_final, float *delta, hipStream_t stream) {
+    GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm bwd: bad dims B=%d L=%d D=%d", B, L, D);
+    switch (He) {
+#define X(n) case n: return launch_bwd<n>(B, L, D, lengths, w_hh_f, w_hh_r, gates, cells, d_out, d_h_final, delta, stream);
+        GSCAN_HIDDEN_SIZES(X)
+#undef X
+        default: break;
+    }
+    GSCAN_CHECK(false, "encoder_hidden_size %d has no compiled kernel (supported: 20 32 64 100 128)", He);
+}
+
+}  // namespace gscan

@@ -1,0 +1,91 @@
+// Internal C++ interface between the kernels (one .hip per family) and the step sequencer.
+#pragma once
+#include "common.h"
+#include "gscan_hip.h"
+
+namespace gscan {
+
+// gemm.hip
+int gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
+             int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
+             const float *mask, int split_k, hipStream_t stream);
+
+// elementwise.hip
+int world_im2col(const float *world, int B, int G, int C, int K3, float *xcol, hipStream_t stream);
+int embed_rows(const int64_t *tok, const float *table, int vocab, const float *mask, int rows, int D, float *out,
+               int64_t ldo, hipStream_t stream);
+int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mask, int rows, int D, int vocab,
+               int pad, float *dtable, hipStream_t stream);
+int relu_mask_backward(float *dfeat, const float *feat, const float *mask, int64_t n, hipStream_t stream);
+int vec_add(const float *a, const float *b, float *out, int n, hipStream_t stream);
+int colsum_add(const float *x, int64_t ld, int rows, int N, float *out1, float *out2, hipStream_t stream);
+int attn_value_grad(const float *alpha, int Mld, const float *dctx, int64_t ldd, int B, int T, int M, int H,
+                    float *dkeys, int accumulate, hipStream_t stream);
+int adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+              float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
+              hipStream_t stream);
+int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream);
+
+// loss.hip
+int log_softmax_rows(const float *x, float *y, int rows, int n, hipStream_t stream);
+int log_softmax_rows_backward(const float *y, const float *dy, float *dx, int rows, int n, hipStream_t stream);
+int sequence_nll(const float *logp, const int64_t *targets, int B, int T, int V, int pad, float *loss_sum,
+                 float *count, float *dlogp, hipStream_t stream);
+int position_nll(const float *aux, const int64_t *pos, int B, int M, float *loss_sum, float *daux,
+                 hipStream_t stream);
+int sequence_metrics(const float *logp, const int64_t *targets, int B, int T, int V, int pad, float *out3,
+                     hipStream_t stream);
+
+// lstm_encoder.hip
+bool hidden_size_supported(int h);
+int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths, const float *w_hh_f,
+                         const float *b_hh_f, const float *w_hh_r, const float *b_hh_r, float *out, float *h_final,
+                         float *gates, float *cells, float *hprev, hipStream_t stream);
+int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_f,
+                          const float *w_hh_r, const float *gates, const float *cells, const float *d_out,
+                          const float *d_h_final, float *delta, hipStream_t stream);
+
+// decoder.hip
+struct DecoderArgs {
+    int T, L, M;                       // target steps, command memories, grid memories (G*G)
+    const int32_t *cmd_lengths;        // [B]
+    const float *pk_t, *u_t, *u2_t;    // [B,L,H] [B,L,4H] [B,L,H]
+    const float *pk_v, *u_v;           // [B,M,H] [B,M,4H]
+    const float *ge;                   // [B,T,4H] embedding part of the gates + both biases
+    const float *w_hh, *w_qt, *w_qv, *w_q2k, *b_q2k, *v_t, *v_v;
+    float *hprev;                      // [B,T,H]  hprev[b,0] = h0 = c0 on entry; kernel fills t+1
+    float *s;                          // [B,T,4H] = [e | ctx_text | ctx_vis | h_t]; kernel fills 3 parts
+    float *cells, *gates;              // [B,T,H] [B,T,4H]
+    float *alpha_c, *alpha_s;          // [B,T,L] [B,T,M]
+    float *q2, *qt, *qv;               // [B,T,H] conditional query, projected text / visual query
+    float *att_sum;                    // [B,M] sum_t alpha_s (auxiliary head input)
+    // backward only
+    const float *ds;                   // [B,T,4H] external grads wrt [e | ctx_text | ctx_vis | h_t] (head)
+    const float *datt;                 // [B,M] grad wrt att_sum or NULL
+    float *delta, *dzq, *dqt, *dqv;    // [B,T,4H] [B,T,H] [B,T,H] [B,T,H]
+    float *dpk_t, *dpk_v;              // [B,L,H] [B,M,H]  score-path key gradients
+    float *dv_t, *dv_v;                // [B,H] per-row energy-vector gradients
+    float *dh0;                        // [B,H] gradient wrt the bridge pre-activation
+};
+bool decoder_hidden_supported(int h);
+size_t decoder_lds_bytes(int H, int L, int M, bool cond, bool backward);
+int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
+
+// step.hip
+struct WorkspaceSlot { const char *name; int64_t offset, count; };
+struct Workspace {
+    int64_t xcol, feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
+        ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, dlogits, dpreo,
+        dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat;
+    WorkspaceSlot slot[64];
+    int nslots;
+    int64_t total_floats;
+};
+int check_dims(const gscan_dims &d);
+int workspace_layout(const gscan_dims &d, Workspace *ws);
+int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
+                 float *logp, float *aux_logp, hipStream_t st);
+int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
+                  const float *dlogp, const float *daux, const gscan_params &g, hipStream_t st);
+
+}  // namespace gscan

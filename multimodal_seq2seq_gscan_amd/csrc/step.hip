@@ -1,0 +1,325 @@
+// Host-side sequencing of one training step: Model.forward (seq2seq/model.py:206-219) and
+// its reverse.  Pure launch code — no allocation, no synchronisation, one stream — so the
+// whole step can be captured in a hipGraph by the caller.
+//
+// Data layout in HBM.  Parameters and gradients keep the reference's state_dict layout and
+// are consumed in place through strided GEMM operands.  Activations live in one caller-owned
+// workspace, carved by workspace_layout() below; rows are always (batch, time|cell)-major with
+// the feature dimension innermost, so every dense product is a plain [rows, K] x [K, N] GEMM:
+//   S[b,t,:] = [ e_t | ctx_text_t | ctx_vis_t | h_t ]  (4H)  feeds the LSTM weight-gradient GEMM,
+//   the output head and the context gradients without any copy or concat.
+#include "step.h"
+
+namespace gscan {
+
+// --------------------------------------------------------------------------------------
+// workspace
+// --------------------------------------------------------------------------------------
+int workspace_layout(const gscan_dims &d, Workspace *ws) {
+    const int64_t B = d.B, L = d.L, T = d.T, M = (int64_t)d.G * d.G, Co = d.Co, F = 3 * Co, E = d.E, He = d.He,
+                  H = d.H, V = d.V, D = d.bidirectional ? 2 : 1;
+    const int64_t Ktot = (int64_t)d.C * (1 + 25 + (int64_t)d.K3 * d.K3);
+    int64_t p = 0;
+    int n = 0;
+    auto take = [&](const char *name, int64_t count) {
+        ws->slot[n].name = name;
+        ws->slot[n].offset = p;
+        ws->slot[n].count = count;
+        ++n;
+        p += (count + 63) / 64 * 64;          // 256-byte aligned slots
+        return ws->slot[n - 1].offset;
+    };
+#define SLOT(field, count) ws->field = take(#field, (count))
+    SLOT(xcol, B * M * Ktot);
+    SLOT(feat, B * M * F);
+    SLOT(pkv, B * M * H);
+    SLOT(uv, B * M * 4 * H);
+    SLOT(xe, B * L * E);
+    SLOT(gx, B * L * D * 4 * He);
+    SLOT(enc_out, B * L * He);
+    SLOT(hN, B * He);
+    SLOT(enc_gates, B * L * D * 4 * He);
+    SLOT(enc_cells, B * L * D * He);
+    SLOT(enc_hprev, B * L * D * He);
+    SLOT(pkt, B * L * H);
+    SLOT(ut, B * L * 4 * H);
+    SLOT(u2t, B * L * H);
+    SLOT(bsum, 4 * H);
+    SLOT(hprev, B * T * H);
+    SLOT(S, B * T * 4 * H);
+    SLOT(ge, B * T * 4 * H);
+    SLOT(cells, B * T * H);
+    SLOT(gates, B * T * 4 * H);
+    SLOT(alpha_c, B * T * L);
+    SLOT(alpha_s, B * T * M);
+    SLOT(q2, B * T * H);
+    SLOT(qt, B * T * H);
+    SLOT(qv, B * T * H);
+    SLOT(att_sum, B * M);
+    SLOT(preo, B * T * H);
+    SLOT(logits, B * T * V);
+    SLOT(logp_saved, B * T * V);
+    SLOT(aux_saved, B * M);
+    // backward scratch
+    SLOT(dlogits, B * T * V);
+    SLOT(dpreo, B * T * H);
+    SLOT(dS, B * T * 4 * H);
+    SLOT(datt, B * M);
+    SLOT(delta, B * T * 4 * H);
+    SLOT(dzq, B * T * H);
+    SLOT(dqt, B * T * H);
+    SLOT(dqv, B * T * H);
+    SLOT(dpk_t, B * L * H);
+    SLOT(dpk_v, B * M * H);
+    SLOT(dv_t, B * H);
+    SLOT(dv_v, B * H);
+    SLOT(dh0, B * H);
+    SLOT(denc, B * L * He);
+    SLOT(dhN, B * He);
+    SLOT(enc_delta, B * L * D * 4 * He);
+    SLOT(dxe, B * L * E);
+    SLOT(dfeat, B * M * F);
+#undef SLOT
+    ws->nslots = n;
+    ws->total_floats = p;
+    return 0;
+}
+
+int check_dims(const gscan_dims &d) {
+    GSCAN_CHECK(d.B > 0 && d.L > 0 && d.T > 0 && d.G > 0 && d.C > 0 && d.Co > 0 && d.E > 0 && d.V > 1 && d.Vi > 1,
+                "dims: non-positive dimension (B=%d L=%d T=%d G=%d C=%d Co=%d E=%d V=%d Vi=%d)", d.B, d.L, d.T, d.G,
+                d.C, d.Co, d.E, d.V, d.Vi);
+    GSCAN_CHECK(d.K3 > 0 && (d.K3 & 1), "dims: cnn_kernel_size must be odd (got %d)", d.K3);
+    GSCAN_CHECK(hidden_size_supported(d.He), "dims: encoder_hidden_size %d has no compiled kernel (20 32 64 100 128)",
+                d.He);
+    GSCAN_CHECK(decoder_hidden_supported(d.H), "dims: decoder_hidden_size %d has no compiled kernel (20 32 64 100)",
+                d.H);
+    GSCAN_CHECK(d.L <= 64, "dims: commands longer than 64 tokens are not supported (L=%d)", d.L);
+    GSCAN_CHECK(d.G * d.G <= 64, "dims: grids larger than 8x8 are not supported (G=%d)", d.G);
+    const size_t lds = decoder_lds_bytes(d.H, d.L, d.G * d.G, d.conditional != 0, true);
+    GSCAN_CHECK(lds <= 160 * 1024, "dims: the decoder needs %zu bytes of LDS per row (limit 163840): L=%d G=%d H=%d", lds,
+                d.L, d.G, d.H);
+    return 0;
+}
+
+static int pick_split(int M, int N, int K) {
+    const int tiles = cdiv(M, 64) * cdiv(N, 64);
+    int s = cdiv(1024, tiles);
+    s = std::min(s, std::max(1, K / 128));
+    return std::max(1, s);
+}
+
+// C[M,N] (+)= A[M,K] . B[K,N], every operand described by (pointer, row stride, col stride)
+static inline int mm(hipStream_t st, int M, int N, int K, const float *a, int64_t sam, int64_t sak, const float *b,
+                     int64_t sbk, int64_t sbn, float *c, int64_t ldc, float beta = 0.f, const float *bias = nullptr,
+                     int act = 0, const float *mask = nullptr) {
+    return gemm_f32(M, N, K, 1.f, a, sam, sak, b, sbk, sbn, beta, c, ldc, bias, act, mask, 1, st);
+}
+// weight gradient: C[M,N] += A^T . B with the long dimension (rows of the activations) as K
+static inline int mm_grad(hipStream_t st, int M, int N, int K, const float *a, int64_t sam, int64_t sak,
+                          const float *b, int64_t sbk, int64_t sbn, float *c, int64_t ldc) {
+    return gemm_f32(M, N, K, 1.f, a, sam, sak, b, sbk, sbn, 1.f, c, ldc, nullptr, 0, nullptr, pick_split(M, N, K), st);
+}
+
+#define TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
+
+// --------------------------------------------------------------------------------------
+// forward
+// --------------------------------------------------------------------------------------
+int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk,
+                 float *w, float *logp, float *aux_logp, hipStream_t st) {
+    TRY(check_dims(d));
+    Workspace ws;
+    TRY(workspace_layout(d, &ws));
+    const int B = d.B, L = d.L, T = d.T, M = d.G * d.G, C = d.C, Co = d.Co, F = 3 * Co, E = d.E, He = d.He, H = d.H,
+              V = d.V, D = d.bidirectional ? 2 : 1;
+    const int Ktot = C * (1 + 25 + d.K3 * d.K3);
+    const bool cond = d.conditional != 0;
+    GSCAN_CHECK(!cond || (p.q2k_w && p.q2k_b), "forward: conditional attention needs queries_to_keys parameters");
+    GSCAN_CHECK(D == 1 || (p.enc_w_ih_rev && p.enc_w_hh_rev && p.enc_b_ih_rev && p.enc_b_hh_rev),
+                "forward: bidirectional encoder needs the *_reverse parameters");
+    GSCAN_CHECK(logp != nullptr, "forward: logp is NULL");
+    GSCAN_CHECK(!d.auxiliary || aux_logp, "forward: auxiliary task set but aux_logp is NULL");
+
+    // ---- world encoder (cnn_model.py:22-36): im2col + 3 GEMMs with bias/ReLU/dropout epilogue
+    TRY(world_im2col(bt.world, B, d.G, C, d.K3, w + ws.xcol, st));
+    {
+        const float *cw[3] = {p.conv1_w, p.conv2_w, p.conv3_w};
+        const float *cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
+        const int kk[3] = {C, 25 * C, d.K3 * d.K3 * C};
+        int off = 0;
+        for (int i = 0; i < 3; ++i) {
+            TRY(mm(st, B * M, Co, kk[i], w + ws.xcol + off, Ktot, 1, cw[i], 1, kk[i], w + ws.feat + i * Co, F, 0.f,
+                   cb[i], 1, mk.cnn ? mk.cnn + i * Co : nullptr));
+            off += kk[i];
+        }
+    }
+    // projected visual keys (seq2seq_model.py:466-467) and their image under W_ih[:, ctx_vis]
+    TRY(mm(st, B * M, H, F, w + ws.feat, F, 1, p.vis_key_w, 1, F, w + ws.pkv, H));
+    TRY(mm(st, B * M, 4 * H, H, w + ws.pkv, H, 1, p.dec_w_ih + 2 * H, 1, 3 * H, w + ws.uv, 4 * H));
+
+    // ---- command encoder (seq2seq_model.py:47-89)
+    TRY(embed_rows(bt.commands, p.enc_emb, d.Vi, mk.enc, B * L, E, w + ws.xe, E, st));
+    TRY(mm(st, B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih, 1, E, w + ws.gx, (int64_t)D * 4 * He, 0.f, p.enc_b_ih));
+    if (D == 2)
+        TRY(mm(st, B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih_rev, 1, E, w + ws.gx + 4 * He, (int64_t)D * 4 * He,
+               0.f, p.enc_b_ih_rev));
+    TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, p.enc_w_hh, p.enc_b_hh, p.enc_w_hh_rev,
+                             p.enc_b_hh_rev, w + ws.enc_out, w + ws.hN, w + ws.enc_gates, w + ws.enc_cells,
+                             w + ws.enc_hprev, st));
+    // projected textual keys (:468-469) and their images under W_ih[:, ctx_text] and W_q2k[:, ctx_text]
+    TRY(mm(st, B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H));
+    TRY(mm(st, B * L, 4 * H, H, w + ws.pkt, H, 1, p.dec_w_ih + H, 1, 3 * H, w + ws.ut, 4 * H));
+    if (cond) TRY(mm(st, B * L, H, H, w + ws.pkt, H, 1, p.q2k_w + H, 1, 2 * H, w + ws.u2t, H));
+
+    // ---- bridge (model.py:195): h0 = c0 = tanh(W hN + b), written as row t=0 of hprev
+    TRY(mm(st, B, H, He, w + ws.hN, He, 1, p.bridge_w, 1, He, w + ws.hprev, (int64_t)T * H, 0.f, p.bridge_b, 2));
+
+    // ---- decoder inputs known for all t (teacher forcing): embeddings and their gate image
+    TRY(embed_rows(bt.targets, p.dec_emb, V, mk.dec, B * T, H, w + ws.S, 4 * H, st));
+    TRY(vec_add(p.dec_b_ih, p.dec_b_hh, w + ws.bsum, 4 * H, st));
+    TRY(mm(st, B * T, 4 * H, H, w + ws.S, 4 * H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge, 4 * H, 0.f, w + ws.bsum));
+
+    // ---- the T-step recurrence
+    DecoderArgs a{};
+    a.T = T; a.L = L; a.M = M;
+    a.cmd_lengths = bt.cmd_lengths;
+    a.pk_t = w + ws.pkt; a.u_t = w + ws.ut; a.u2_t = w + ws.u2t;
+    a.pk_v = w + ws.pkv; a.u_v = w + ws.uv;
+    a.ge = w + ws.ge;
+    a.w_hh = p.dec_w_hh; a.w_qt = p.txt_query_w; a.w_qv = p.vis_query_w; a.w_q2k = p.q2k_w; a.b_q2k = p.q2k_b;
+    a.v_t = p.txt_energy_w; a.v_v = p.vis_energy_w;
+    a.hprev = w + ws.hprev; a.s = w + ws.S; a.cells = w + ws.cells; a.gates = w + ws.gates;
+    a.alpha_c = w + ws.alpha_c; a.alpha_s = w + ws.alpha_s;
+    a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
+    TRY(decoder_run(false, B, H, cond, a, st));
+
+    // ---- output head hoisted out of the loop (seq2seq_model.py:421-424), W_o2h columns = [e|h|ctx_t|ctx_v]
+    TRY(mm(st, B * T, H, H, w + ws.S, 4 * H, 1, p.out2hid_w, 1, 4 * H, w + ws.preo, H));
+    TRY(mm(st, B * T, H, 2 * H, w + ws.S + H, 4 * H, 1, p.out2hid_w + 2 * H, 1, 4 * H, w + ws.preo, H, 1.f));
+    TRY(mm(st, B * T, H, H, w + ws.S + 3 * H, 4 * H, 1, p.out2hid_w + H, 1, 4 * H, w + ws.preo, H, 1.f));
+    TRY(mm(st, B * T, V, H, w + ws.preo, H, 1, p.hid2out_w, 1, H, w + ws.logits, V));
+    // log_softmax (model.py:203, :166-170); a copy stays in the workspace for the backward pass
+    TRY(log_softmax_rows(w + ws.logits, w + ws.logp_saved, B * T, V, st));
+    GSCAN_HIP(hipMemcpyAsync(logp, w + ws.logp_saved, sizeof(float) * B * T * V, hipMemcpyDeviceToDevice, st));
+    if (d.auxiliary) {
+        TRY(log_softmax_rows(w + ws.att_sum, w + ws.aux_saved, B, M, st));
+        GSCAN_HIP(hipMemcpyAsync(aux_logp, w + ws.aux_saved, sizeof(float) * B * M, hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------
+// backward
+// --------------------------------------------------------------------------------------
+int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
+                  const float *dlogp, const float *daux, const gscan_params &g, hipStream_t st) {
+    TRY(check_dims(d));
+    Workspace ws;
+    TRY(workspace_layout(d, &ws));
+    const int B = d.B, L = d.L, T = d.T, M = d.G * d.G, C = d.C, Co = d.Co, F = 3 * Co, E = d.E, He = d.He, H = d.H,
+              V = d.V, D = d.bidirectional ? 2 : 1;
+    const int Ktot = C * (1 + 25 + d.K3 * d.K3);
+    const int BT = B * T, BL = B * L, BM_ = B * M;
+    const bool cond = d.conditional != 0;
+    GSCAN_CHECK(dlogp, "backward: dlogp is NULL");
+    float *S = w + ws.S, *dS = w + ws.dS;
+    const float *logp = w + ws.logp_saved, *aux_logp = w + ws.aux_saved;
+
+    // ---- head: log_softmax, hidden_to_output, output_to_hidden
+    TRY(log_softmax_rows_backward(logp, dlogp, w + ws.dlogits, BT, V, st));
+    TRY(mm_grad(st, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H));
+    TRY(mm(st, BT, H, V, w + ws.dlogits, V, 1, p.hid2out_w, H, 1, w + ws.dpreo, H));
+    TRY(mm_grad(st, H, H, BT, w + ws.dpreo, 1, H, S, 4 * H, 1, g.out2hid_w, 4 * H));
+    TRY(mm_grad(st, H, 2 * H, BT, w + ws.dpreo, 1, H, S + H, 4 * H, 1, g.out2hid_w + 2 * H, 4 * H));
+    TRY(mm_grad(st, H, H, BT, w + ws.dpreo, 1, H, S + 3 * H, 4 * H, 1, g.out2hid_w + H, 4 * H));
+    TRY(mm(st, BT, H, H, w + ws.dpreo, H, 1, p.out2hid_w, 4 * H, 1, dS, 4 * H));
+    TRY(mm(st, BT, 2 * H, H, w + ws.dpreo, H, 1, p.out2hid_w + 2 * H, 4 * H, 1, dS + H, 4 * H));
+    TRY(mm(st, BT, H, H, w + ws.dpreo, H, 1, p.out2hid_w + H, 4 * H, 1, dS + 3 * H, 4 * H));
+    const bool use_aux = d.auxiliary && daux;
+    if (use_aux) TRY(log_softmax_rows_backward(aux_logp, daux, w + ws.datt, B, M, st));
+
+    // ---- reverse recurrence
+    DecoderArgs a{};
+    a.T = T; a.L = L; a.M = M;
+    a.cmd_lengths = bt.cmd_lengths;
+    a.pk_t = w + ws.pkt; a.u_t = w + ws.ut; a.u2_t = w + ws.u2t;
+    a.pk_v = w + ws.pkv; a.u_v = w + ws.uv;
+    a.ge = w + ws.ge;
+    a.w_hh = p.dec_w_hh; a.w_qt = p.txt_query_w; a.w_qv = p.vis_query_w; a.w_q2k = p.q2k_w; a.b_q2k = p.q2k_b;
+    a.v_t = p.txt_energy_w; a.v_v = p.vis_energy_w;
+    a.hprev = w + ws.hprev; a.s = S; a.cells = w + ws.cells; a.gates = w + ws.gates;
+    a.alpha_c = w + ws.alpha_c; a.alpha_s = w + ws.alpha_s;
+    a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
+    a.ds = dS; a.datt = use_aux ? w + ws.datt : nullptr;
+    a.delta = w + ws.delta; a.dzq = w + ws.dzq; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
+    a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = w + ws.dv_t; a.dv_v = w + ws.dv_v; a.dh0 = w + ws.dh0;
+    TRY(decoder_run(true, B, H, cond, a, st));
+
+    // ---- decoder parameter gradients: dense products over the B*T saved rows
+    const float *delta = w + ws.delta, *hprev = w + ws.hprev;
+    TRY(mm_grad(st, 4 * H, 3 * H, BT, delta, 1, 4 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H));
+    TRY(mm_grad(st, 4 * H, H, BT, delta, 1, 4 * H, hprev, H, 1, g.dec_w_hh, H));
+    TRY(colsum_add(delta, 4 * H, BT, 4 * H, g.dec_b_ih, g.dec_b_hh, st));
+    TRY(mm_grad(st, H, H, BT, w + ws.dqt, 1, H, hprev, H, 1, g.txt_query_w, H));
+    if (cond) {
+        TRY(mm_grad(st, H, H, BT, w + ws.dzq, 1, H, hprev, H, 1, g.q2k_w, 2 * H));
+        TRY(mm_grad(st, H, H, BT, w + ws.dzq, 1, H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H));
+        TRY(colsum_add(w + ws.dzq, H, BT, H, g.q2k_b, nullptr, st));
+        TRY(mm_grad(st, H, H, BT, w + ws.dqv, 1, H, w + ws.q2, H, 1, g.vis_query_w, H));
+    } else {
+        TRY(mm_grad(st, H, H, BT, w + ws.dqv, 1, H, hprev, H, 1, g.vis_query_w, H));
+    }
+    TRY(colsum_add(w + ws.dv_t, H, B, H, g.txt_energy_w, nullptr, st));
+    TRY(colsum_add(w + ws.dv_v, H, B, H, g.vis_energy_w, nullptr, st));
+
+    // ---- gradients wrt [e | ctx_text | ctx_vis] through the LSTM input and the conditional query
+    TRY(mm(st, BT, 3 * H, 4 * H, delta, 4 * H, 1, p.dec_w_ih, 3 * H, 1, dS, 4 * H, 1.f));
+    if (cond) TRY(mm(st, BT, H, H, w + ws.dzq, H, 1, p.q2k_w + H, 2 * H, 1, dS + H, 4 * H, 1.f));
+    TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, st));
+    // value path of both attentions: dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]
+    TRY(attn_value_grad(w + ws.alpha_c, L, dS + H, 4 * H, B, T, L, H, w + ws.dpk_t, 1, st));
+    TRY(attn_value_grad(w + ws.alpha_s, M, dS + 2 * H, 4 * H, B, T, M, H, w + ws.dpk_v, 1, st));
+
+    // ---- textual keys and bridge -> encoder outputs / final state
+    TRY(mm_grad(st, H, He, BL, w + ws.dpk_t, 1, H, w + ws.enc_out, He, 1, g.txt_key_w, He));
+    TRY(mm(st, BL, He, H, w + ws.dpk_t, H, 1, p.txt_key_w, He, 1, w + ws.denc, He));
+    TRY(mm_grad(st, H, He, B, w + ws.dh0, 1, H, w + ws.hN, He, 1, g.bridge_w, He));
+    TRY(colsum_add(w + ws.dh0, H, B, H, g.bridge_b, nullptr, st));
+    TRY(mm(st, B, He, H, w + ws.dh0, H, 1, p.bridge_w, He, 1, w + ws.dhN, He));
+
+    // ---- command encoder BPTT and its parameter gradients
+    TRY(encoder_lstm_backward(B, L, He, D, bt.cmd_lengths, p.enc_w_hh, p.enc_w_hh_rev, w + ws.enc_gates,
+                              w + ws.enc_cells, w + ws.denc, w + ws.dhN, w + ws.enc_delta, st));
+    for (int dir = 0; dir < D; ++dir) {
+        const float *dl = w + ws.enc_delta + dir * 4 * He;
+        const int64_t ldd = (int64_t)D * 4 * He;
+        float *gw_ih = dir ? g.enc_w_ih_rev : g.enc_w_ih, *gw_hh = dir ? g.enc_w_hh_rev : g.enc_w_hh;
+        float *gb_ih = dir ? g.enc_b_ih_rev : g.enc_b_ih, *gb_hh = dir ? g.enc_b_hh_rev : g.enc_b_hh;
+        const float *w_ih = dir ? p.enc_w_ih_rev : p.enc_w_ih;
+        TRY(mm_grad(st, 4 * He, He, BL, dl, 1, ldd, w + ws.enc_hprev + dir * He, (int64_t)D * He, 1, gw_hh, He));
+        TRY(mm_grad(st, 4 * He, E, BL, dl, 1, ldd, w + ws.xe, E, 1, gw_ih, E));
+        TRY(colsum_add(dl, ldd, BL, 4 * He, gb_ih, gb_hh, st));
+        TRY(mm(st, BL, E, 4 * He, dl, ldd, 1, w_ih, E, 1, w + ws.dxe, E, dir ? 1.f : 0.f));
+    }
+    TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));
+
+    // ---- visual keys -> conv features -> conv weights (the world tensor itself needs no gradient)
+    TRY(mm_grad(st, H, F, BM_, w + ws.dpk_v, 1, H, w + ws.feat, F, 1, g.vis_key_w, F));
+    TRY(mm(st, BM_, F, H, w + ws.dpk_v, H, 1, p.vis_key_w, F, 1, w + ws.dfeat, F));
+    TRY(relu_mask_backward(w + ws.dfeat, w + ws.feat, mk.cnn, (int64_t)BM_ * F, st));
+    {
+        float *gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
+        float *gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
+        const int kk[3] = {C, 25 * C, d.K3 * d.K3 * C};
+        int off = 0;
+        for (int i = 0; i < 3; ++i) {
+            TRY(mm_grad(st, Co, kk[i], BM_, w + ws.dfeat + i * Co, 1, F, w + ws.xcol + off, Ktot, 1, gw[i], kk[i]));
+            TRY(colsum_add(w + ws.dfeat + i * Co, F, BM_, Co, gb[i], nullptr, st));
+            off += kk[i];
+        }
+    }
+    return 0;
+}
+
+}  // namespace gscan

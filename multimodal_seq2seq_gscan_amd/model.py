@@ -1,0 +1,473 @@
+"""`Model`: the reference's model facade (seq2seq/model.py:23-261) on top of libgscan_hip.so.
+
+Same constructor keywords, methods, attributes and `state_dict` keys as the reference class, so
+`seq2seq/train.py` and checkpoints written by the reference work unchanged.  What differs is
+everything underneath: there are no torch.nn forward passes.  The parameter tree below only
+*holds* tensors (created by the same torch.nn constructors in the same order, hence identical
+seeded initialisation, train.py:27,58-64); all arithmetic is two C-ABI calls per step —
+`gscan_forward` and `gscan_backward` — operating on ONE flat fp32 parameter buffer and ONE flat
+gradient buffer that every named parameter / `.grad` is a view of.  The flat buffers are what
+the data-parallel all-reduce and the fused Adam kernel consume (train.py in this package).
+
+There is deliberately no CPU path here: CPU tensors raise.  The CPU restatement used for parity
+checks lives in `oracle/` and is never imported by this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import os
+import shutil
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+logger = logging.getLogger(__name__)
+
+
+# ------------------------------------------------------------------------------------------
+# parameter holders: attribute names = the reference's module names (checkpoint ABI)
+# ------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    def forward(self, *args, **kwargs):  # pragma: no cover - arithmetic lives in the HIP library
+        raise RuntimeError("parameter holder: the forward pass is Model.forward (HIP)")
+
+
+class _WorldEncoderParams(_Holder):
+    """cnn_model.py:7-20 — three same-padded convolutions with kernels 1, 5 and cnn_kernel_size."""
+
+    def __init__(self, channels: int, hidden_channels: int, kernel_size: int):
+        super().__init__()
+        self.conv_1 = nn.Conv2d(channels, hidden_channels, kernel_size=1, padding=0)
+        self.conv_2 = nn.Conv2d(channels, hidden_channels, kernel_size=5, padding=2)
+        self.conv_3 = nn.Conv2d(channels, hidden_channels, kernel_size=kernel_size, padding=kernel_size // 2)
+        self.output_dimension = hidden_channels * 3
+
+
+class _AttentionParams(_Holder):
+    """seq2seq_model.py:99-103 — three bias-free projections."""
+
+    def __init__(self, key_size: int, query_size: int, hidden_size: int):
+        super().__init__()
+        self.key_layer = nn.Linear(key_size, hidden_size, bias=False)
+        self.query_layer = nn.Linear(query_size, hidden_size, bias=False)
+        self.energy_layer = nn.Linear(hidden_size, 1, bias=False)
+
+
+class _CommandEncoderParams(_Holder):
+    """seq2seq_model.py:26-45"""
+
+    def __init__(self, vocab: int, embedding_dim: int, hidden_size: int, num_layers: int, bidirectional: bool,
+                 padding_idx: int):
+        super().__init__()
+        self.embedding = nn.Embedding(vocab, embedding_dim, padding_idx=padding_idx)
+        self.lstm = nn.LSTM(input_size=embedding_dim, hidden_size=hidden_size, num_layers=num_layers,
+                            bidirectional=bidirectional)
+
+
+class _DecoderParams(_Holder):
+    """seq2seq_model.py:333-357; shares the two attention holders with the model (":356-357")."""
+
+    def __init__(self, hidden_size: int, output_size: int, num_layers: int, padding_idx: int,
+                 textual_attention: _AttentionParams, visual_attention: _AttentionParams, conditional: bool):
+        super().__init__()
+        if conditional:
+            self.queries_to_keys = nn.Linear(hidden_size * 2, hidden_size)
+        self.embedding = nn.Embedding(output_size, hidden_size, padding_idx=padding_idx)
+        self.lstm = nn.LSTM(hidden_size * 3, hidden_size, num_layers=num_layers)
+        self.textual_attention = textual_attention
+        self.visual_attention = visual_attention
+        self.output_to_hidden = nn.Linear(hidden_size * 4, hidden_size, bias=False)
+        self.hidden_to_output = nn.Linear(hidden_size, output_size, bias=False)
+
+
+def _as_int32_lengths(lengths, device) -> torch.Tensor:
+    """Lengths arrive as lists, numpy float64 arrays (gSCAN_dataset.py:276) or tensors."""
+    if isinstance(lengths, torch.Tensor):
+        return lengths.to(device=device, dtype=torch.int32)
+    return torch.tensor([int(v) for v in lengths], dtype=torch.int32).to(device, non_blocking=True)
+
+
+# ------------------------------------------------------------------------------------------
+# autograd glue: one node for the whole network, one for each loss
+# ------------------------------------------------------------------------------------------
+class _NetworkFunction(torch.autograd.Function):
+    """logp, aux = f(parameters, batch).  Parameter gradients do not travel through autograd:
+    backward() adds them straight into the model's flat gradient buffer (which every
+    `param.grad` is a view of); the `anchor` input only makes autograd call us."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, commands, lengths, world, targets, masks):
+        logp, aux, call = model._launch_forward(commands, lengths, world, targets, masks)
+        ctx.model, ctx.call = model, call
+        return logp, aux
+
+    @staticmethod
+    def backward(ctx, dlogp, daux):
+        ctx.model._launch_backward(ctx.call, dlogp, daux if ctx.call["dims"].auxiliary else None)
+        return (None,) * 7
+
+
+class _SequenceNLL(torch.autograd.Function):
+    """Model.get_loss (model.py:147-160)."""
+
+    @staticmethod
+    def forward(ctx, logp, targets, pad):
+        lib = _lib.load()
+        B, T, V = logp.shape
+        logp = logp.contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=logp.device)
+        dlogp = torch.empty_like(logp)
+        _lib.check(lib.gscan_sequence_nll(logp.data_ptr(), targets.data_ptr(), B, T, V, pad, out.data_ptr(),
+                                          out.data_ptr() + 4, dlogp.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "gscan_sequence_nll")
+        ctx.save_for_backward(dlogp, out)
+        return out[0] / out[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        dlogp, out = ctx.saved_tensors
+        return dlogp * (g / out[1]), None, None
+
+
+class _PositionNLL(torch.autograd.Function):
+    """Model.get_auxiliary_loss (model.py:162-164): mean over the batch."""
+
+    @staticmethod
+    def forward(ctx, aux_logp, positions):
+        lib = _lib.load()
+        B, M = aux_logp.shape
+        aux_logp = aux_logp.contiguous()
+        out = torch.empty(1, dtype=torch.float32, device=aux_logp.device)
+        daux = torch.empty_like(aux_logp)
+        _lib.check(lib.gscan_position_nll(aux_logp.data_ptr(), positions.data_ptr(), B, M, out.data_ptr(),
+                                          daux.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "gscan_position_nll")
+        ctx.save_for_backward(daux)
+        ctx.batch = B
+        return out[0] / B
+
+    @staticmethod
+    def backward(ctx, g):
+        (daux,) = ctx.saved_tensors
+        return daux * (g / ctx.batch), None
+
+
+# ------------------------------------------------------------------------------------------
+class Model(nn.Module):
+    """Drop-in for `seq2seq.model.Model`.  Only the configuration the reference itself can run is
+    supported: Bahdanau attention, simple situation representation, one encoder/decoder layer."""
+
+    def __init__(self, input_vocabulary_size: int, embedding_dimension: int, encoder_hidden_size: int,
+                 num_encoder_layers: int, target_vocabulary_size: int, encoder_dropout_p: float,
+                 encoder_bidirectional: bool, num_decoder_layers: int, decoder_dropout_p: float,
+                 decoder_hidden_size: int, num_cnn_channels: int, cnn_kernel_size: int,
+                 cnn_dropout_p: float, cnn_hidden_num_channels: int, input_padding_idx: int, target_pad_idx: int,
+                 target_eos_idx: int, output_directory: str, conditional_attention: bool, auxiliary_task: bool,
+                 simple_situation_representation: bool, attention_type: str, **kwargs):
+        super().__init__()
+        if attention_type not in ("bahdanau", "luong"):
+            raise ValueError("Unknown attention type {} specified.".format(attention_type))  # model.py:95-96
+        if attention_type != "bahdanau":
+            raise NotImplementedError("only Bahdanau attention is functional in the reference (SURVEY.md App. B)")
+        if not simple_situation_representation:
+            raise NotImplementedError("image situation representation is rejected by the reference CLI "
+                                      "(__main__.py:112-114)")
+        if num_decoder_layers != 1 or num_encoder_layers != 1:
+            raise NotImplementedError("one encoder layer and one decoder layer are supported")
+
+        # construction order = RNG consumption order of the reference (model.py:47-87)
+        self.situation_encoder = _WorldEncoderParams(num_cnn_channels, cnn_hidden_num_channels, cnn_kernel_size)
+        self.visual_attention = _AttentionParams(cnn_hidden_num_channels * 3, decoder_hidden_size,
+                                                 decoder_hidden_size)
+        self.encoder = _CommandEncoderParams(input_vocabulary_size, embedding_dimension, encoder_hidden_size,
+                                             num_encoder_layers, encoder_bidirectional, input_padding_idx)
+        self.enc_hidden_to_dec_hidden = nn.Linear(encoder_hidden_size, decoder_hidden_size)
+        self.textual_attention = _AttentionParams(encoder_hidden_size, decoder_hidden_size, decoder_hidden_size)
+        self.attention_decoder = _DecoderParams(decoder_hidden_size, target_vocabulary_size, num_decoder_layers,
+                                                target_pad_idx, self.textual_attention, self.visual_attention,
+                                                conditional_attention)
+
+        self.simple_situation_representation = simple_situation_representation
+        self.attention_type = attention_type
+        self.auxiliary_task = auxiliary_task
+        self.conditional_attention = conditional_attention
+        self.encoder_bidirectional = encoder_bidirectional
+        self.target_eos_idx = target_eos_idx
+        self.target_pad_idx = target_pad_idx
+        self.input_padding_idx = input_padding_idx
+        self.output_directory = output_directory
+        self.dropout_p = (float(cnn_dropout_p), float(encoder_dropout_p), float(decoder_dropout_p))
+        self.trained_iterations = 0
+        self.best_iteration = 0
+        self.best_exact_match = 0
+        self.best_accuracy = 0
+        self._hyper = dict(C=num_cnn_channels, Co=cnn_hidden_num_channels, K3=cnn_kernel_size,
+                           E=embedding_dimension, He=encoder_hidden_size, H=decoder_hidden_size,
+                           Vi=input_vocabulary_size, V=target_vocabulary_size)
+
+        self._flat: Optional[torch.Tensor] = None
+        self._flat_grad: Optional[torch.Tensor] = None
+        self._param_struct = self._grad_struct = None
+        self._workspace: Optional[torch.Tensor] = None
+        self._generation = 0
+        self._host_masks = None
+        self._dropout_seed = int(kwargs.get("seed", 42))
+        self._dropout_calls = 0
+        self._anchor = None
+        self._flatten()
+
+    # ---- flat parameter / gradient buffers ------------------------------------------------
+    def _named_unique(self) -> "OrderedDict[str, nn.Parameter]":
+        return OrderedDict(self.named_parameters())
+
+    def _flatten(self) -> None:
+        """Re-home every parameter as a view of one contiguous fp32 buffer (same for .grad)."""
+        params = self._named_unique()
+        some = next(iter(params.values()))
+        device = some.device
+        total = sum(p.numel() for p in params.values())
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self._offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for name, p in params.items():
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1).to(torch.float32))
+            p.data = flat[off:off + n].view(p.shape)
+            p.grad = None
+            self._offsets[name] = (off, n)
+            off += n
+        self._flat, self._flat_grad = flat, grad
+        self._workspace = None
+        self._anchor = torch.zeros((), dtype=torch.float32, device=device, requires_grad=True)
+        self._param_struct = self._make_struct(flat)
+        self._grad_struct = self._make_struct(grad)
+
+    def _make_struct(self, flat: torch.Tensor) -> _lib.Params:
+        s = _lib.Params()
+        base = flat.data_ptr()
+        for field, name in _lib.PARAM_FIELDS:
+            if name in self._offsets:
+                setattr(s, field, base + 4 * self._offsets[name][0])
+            else:
+                setattr(s, field, None)
+        return s
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flatten()
+        return out
+
+    @property
+    def flat_parameters(self) -> torch.Tensor:
+        """All parameters as one fp32 vector (named_parameters() order)."""
+        return self._flat
+
+    @property
+    def flat_gradients(self) -> torch.Tensor:
+        return self._flat_grad
+
+    def attach_gradients(self, zero: bool) -> None:
+        """Make every `param.grad` a view of the flat gradient buffer.  A parameter whose grad was
+        dropped (zero_grad(set_to_none=True), the torch default) has its slice zeroed first."""
+        if zero:
+            self._flat_grad.zero_()
+        for name, p in self._named_unique().items():
+            off, n = self._offsets[name]
+            view = self._flat_grad[off:off + n].view(p.shape)
+            if p.grad is None:
+                if not zero:
+                    view.zero_()
+                p.grad = view
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                p.grad = view
+
+    # ---- dropout ----------------------------------------------------------------------------
+    def set_dropout_masks(self, cnn: Optional[torch.Tensor], enc: Optional[torch.Tensor],
+                          dec: Optional[torch.Tensor]) -> None:
+        """Host-mask parity mode: use these scaled keep-masks ([B,G*G,3Co], [B,L,E], [B,T,H]) for the
+        next forward call instead of drawing them on the device (SURVEY.md §7 hard part 3)."""
+        self._host_masks = (cnn, enc, dec)
+
+    def _draw_masks(self, B: int, L: int, T: int, M: int, device) -> Tuple[Optional[torch.Tensor], ...]:
+        if self._host_masks is not None:
+            masks, self._host_masks = self._host_masks, None
+            return tuple(None if m is None else m.to(device=device, dtype=torch.float32).contiguous()
+                         for m in masks)
+        if not self.training:
+            return (None, None, None)
+        lib = _lib.load()
+        h = self._hyper
+        shapes = ((B, M, 3 * h["Co"]), (B, L, h["E"]), (B, T, h["H"]))
+        out = []
+        stream = torch.cuda.current_stream().cuda_stream
+        for i, (shape, p) in enumerate(zip(shapes, self.dropout_p)):
+            if p <= 0.0:
+                out.append(None)
+                continue
+            m = torch.empty(shape, dtype=torch.float32, device=device)
+            _lib.check(lib.gscan_dropout_mask(m.data_ptr(), m.numel(), p, self._dropout_seed,
+                                              self._dropout_calls * 4 + i, stream), "gscan_dropout_mask")
+            out.append(m)
+        self._dropout_calls += 1
+        return tuple(out)
+
+    # ---- the two launches ---------------------------------------------------------------------
+    def _dims(self, B: int, L: int, T: int, G: int) -> _lib.Dims:
+        h = self._hyper
+        return _lib.Dims(B=B, L=L, T=T, G=G, C=h["C"], Co=h["Co"], K3=h["K3"], E=h["E"], He=h["He"], H=h["H"],
+                         Vi=h["Vi"], V=h["V"], conditional=int(self.conditional_attention),
+                         auxiliary=int(self.auxiliary_task), bidirectional=int(self.encoder_bidirectional),
+                         pad_in=self.input_padding_idx, pad_tgt=self.target_pad_idx)
+
+    def _require_device(self, *tensors) -> None:
+        if not (self._flat.is_cuda and all(t.is_cuda for t in tensors)):
+            raise RuntimeError("Model.forward runs on the HIP device only: move the model and the batch to "
+                               "'cuda' (there is no CPU fallback in this package)")
+
+    def _launch_forward(self, commands, lengths, world, targets, masks):
+        lib = _lib.load()
+        self._require_device(commands, world, targets)
+        B, L = commands.shape
+        _, T = targets.shape
+        G = world.shape[1]
+        if world.shape != (B, G, G, self._hyper["C"]):
+            raise ValueError(f"situations_input must be [B,G,G,{self._hyper['C']}], got {tuple(world.shape)}")
+        assert lengths.numel() == B, "Wrong amount of lengths passed to .forward()"   # seq2seq_model.py:57
+        dims = self._dims(B, L, T, G)
+        need = lib.gscan_workspace_bytes(C.byref(dims))
+        if need == 0:
+            raise _lib.GscanError("unsupported dimensions: " + lib.gscan_last_error().decode())
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=commands.device)
+        commands = commands.contiguous()
+        targets = targets.contiguous()
+        world = world.to(torch.float32).contiguous()
+        batch = _lib.Batch(commands.data_ptr(), lengths.data_ptr(), world.data_ptr(), targets.data_ptr())
+        mstruct = _lib.Masks(*[_lib.ptr(m) for m in masks])
+        logp = torch.empty(B, T, self._hyper["V"], dtype=torch.float32, device=commands.device)
+        aux = torch.empty(B, G * G, dtype=torch.float32, device=commands.device) if self.auxiliary_task else None
+        _lib.check(lib.gscan_forward(C.byref(dims), C.byref(self._param_struct), C.byref(batch), C.byref(mstruct),
+                                     self._workspace.data_ptr(), logp.data_ptr(), _lib.ptr(aux),
+                                     torch.cuda.current_stream().cuda_stream), "gscan_forward")
+        self._generation += 1
+        call = dict(dims=dims, batch=batch, masks=mstruct, generation=self._generation,
+                    keep=(commands, lengths, world, targets, masks))
+        if aux is None:
+            aux = torch.zeros(1, device=commands.device)
+        return logp, aux, call
+
+    def _launch_backward(self, call, dlogp: torch.Tensor, daux: Optional[torch.Tensor]) -> None:
+        lib = _lib.load()
+        if call["generation"] != self._generation:
+            raise RuntimeError("backward() after another forward(): the saved activations were overwritten "
+                               "(one in-flight step per model, as in the reference's training loop)")
+        self.attach_gradients(zero=False)
+        dlogp = dlogp.contiguous()
+        daux = None if daux is None else daux.contiguous()
+        _lib.check(lib.gscan_backward(C.byref(call["dims"]), C.byref(self._param_struct), C.byref(call["batch"]),
+                                      C.byref(call["masks"]), self._workspace.data_ptr(), dlogp.data_ptr(),
+                                      _lib.ptr(daux), C.byref(self._grad_struct),
+                                      torch.cuda.current_stream().cuda_stream), "gscan_backward")
+
+    def workspace_view(self, call_dims: _lib.Dims, name: str) -> torch.Tensor:
+        """A saved activation of the last forward/backward as a flat fp32 tensor (tests, debugging)."""
+        lib = _lib.load()
+        off, cnt = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.gscan_workspace_find(C.byref(call_dims), name.encode(), C.byref(off), C.byref(cnt)),
+                   "gscan_workspace_find")
+        return self._workspace[off.value:off.value + 4 * cnt.value].view(torch.float32)
+
+    # ---- the reference's surface ------------------------------------------------------------
+    def forward(self, commands_input: torch.LongTensor, commands_lengths: List[int],
+                situations_input: torch.Tensor, target_batch: torch.LongTensor,
+                target_lengths: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """model.py:206-219.  Returns (log-probabilities [B,T,V], auxiliary log-scores [B,G*G]); without
+        the auxiliary task the second element is the reference's dummy pair of zeros(1)."""
+        self._require_device(commands_input, situations_input, target_batch)
+        device = commands_input.device
+        lengths = _as_int32_lengths(commands_lengths, device)
+        B, L = commands_input.shape
+        masks = self._draw_masks(B, L, target_batch.shape[1], situations_input.shape[1] ** 2, device)
+        if torch.is_grad_enabled():
+            logp, aux = _NetworkFunction.apply(self._anchor, self, commands_input, lengths, situations_input,
+                                               target_batch, masks)
+        else:
+            logp, aux, _ = self._launch_forward(commands_input, lengths, situations_input, target_batch, masks)
+        if not self.auxiliary_task:
+            return logp, (torch.zeros(1), torch.zeros(1))      # model.py:217
+        return logp, aux
+
+    def get_loss(self, target_scores: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        return _SequenceNLL.apply(target_scores, targets.contiguous(), self.target_pad_idx)
+
+    def get_auxiliary_loss(self, auxiliary_scores_target: torch.Tensor, target_target_positions: torch.Tensor):
+        return _PositionNLL.apply(auxiliary_scores_target, target_target_positions.view(-1).contiguous())
+
+    def auxiliary_task_forward(self, output_scores_target_pos: torch.Tensor) -> torch.Tensor:
+        assert self.auxiliary_task, "Please set auxiliary_task to True if using it."
+        return torch.log_softmax(output_scores_target_pos, -1)
+
+    def get_metrics(self, target_scores: torch.Tensor, targets: torch.Tensor) -> Tuple[float, float]:
+        """model.py:117-137: (token accuracy %, exact match %) under the padding mask."""
+        lib = _lib.load()
+        B, T, V = target_scores.shape
+        out = torch.empty(3, dtype=torch.float32, device=target_scores.device)
+        scores = target_scores.detach().contiguous()
+        _lib.check(lib.gscan_sequence_metrics(scores.data_ptr(), targets.contiguous().data_ptr(), B, T, V,
+                                              self.target_pad_idx, out.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "gscan_sequence_metrics")
+        correct, live, exact = out.tolist()
+        return 100.0 * correct / live, 100.0 * exact / B
+
+    @staticmethod
+    def get_auxiliary_accuracy(target_scores: torch.Tensor, targets: torch.Tensor) -> float:
+        with torch.no_grad():
+            hits = (target_scores.argmax(dim=1) == targets.view(-1)).sum().item()
+        return 100.0 * hits / len(targets)
+
+    @staticmethod
+    def remove_start_of_sequence(input_tensor: torch.Tensor) -> torch.Tensor:
+        """model.py:108-115: drop the SOS column, append a column of zeros."""
+        return torch.cat([input_tensor[:, 1:], input_tensor.new_zeros(input_tensor.shape[0], 1)], dim=1)
+
+    def update_state(self, is_best: bool, accuracy=None, exact_match=None) -> None:
+        self.trained_iterations += 1
+        if is_best:
+            self.best_exact_match, self.best_accuracy = exact_match, accuracy
+            self.best_iteration = self.trained_iterations
+
+    # encode_input / decode_input belong to the greedy-decode path (predict.py), SURVEY.md §8 f2: next
+    def encode_input(self, *args, **kwargs):
+        raise NotImplementedError("greedy decoding (predict.py) is outside the training hot path built so far")
+
+    decode_input = encode_input
+
+    # ---- checkpoints (model.py:228-261): same dictionary keys, same file names ----------------
+    def get_current_state(self) -> dict:
+        return {"iteration": self.trained_iterations, "state_dict": self.state_dict(),
+                "best_iteration": self.best_iteration, "best_accuracy": self.best_accuracy,
+                "best_exact_match": self.best_exact_match}
+
+    def load_model(self, path_to_checkpoint: str) -> dict:
+        checkpoint = torch.load(path_to_checkpoint, map_location=self._flat.device)
+        self.load_state_dict(checkpoint["state_dict"])
+        for key, attr in (("iteration", "trained_iterations"), ("best_iteration", "best_iteration"),
+                          ("best_exact_match", "best_exact_match"), ("best_accuracy", "best_accuracy")):
+            setattr(self, attr, checkpoint[key])
+        return checkpoint["optimizer_state_dict"]
+
+    def save_checkpoint(self, file_name: str, is_best: bool, optimizer_state_dict: dict) -> str:
+        path = os.path.join(self.output_directory, file_name)
+        state = self.get_current_state()
+        state["optimizer_state_dict"] = optimizer_state_dict
+        torch.save(state, path)
+        if is_best:
+            shutil.copyfile(path, os.path.join(self.output_directory, "model_best.pth.tar"))
+        return path

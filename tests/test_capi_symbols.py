@@ -1,0 +1,60 @@
+"""The C-ABI library builds, loads and exports every symbol include/gscan_hip.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from multimodal_seq2seq_gscan_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gscan_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gscan_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    from multimodal_seq2seq_gscan_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in gscan_hip.h but not exported"
+        assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
+    assert sorted(_lib.PROTOTYPES) == names
+
+
+def test_abi_version_and_struct_sizes(lib):
+    from multimodal_seq2seq_gscan_amd import _lib
+    assert lib.gscan_abi_version() == _lib.ABI_VERSION
+    assert ctypes.sizeof(_lib.Dims) == 17 * 4
+    assert ctypes.sizeof(_lib.Params) == 32 * 8
+    assert ctypes.sizeof(_lib.Batch) == 4 * 8 and ctypes.sizeof(_lib.Masks) == 3 * 8
+
+
+def test_workspace_query_and_errors(lib):
+    """Host-only entry points: workspace sizing and the error channel."""
+    from multimodal_seq2seq_gscan_amd import _lib
+    d = _lib.Dims(B=256, L=10, T=20, G=6, C=16, Co=50, K3=7, E=25, He=100, H=100, Vi=21, V=9, conditional=1,
+                  auxiliary=0, bidirectional=1, pad_in=0, pad_tgt=0)
+    n = lib.gscan_workspace_bytes(ctypes.byref(d))
+    assert 50e6 < n < 400e6
+    off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.gscan_workspace_find(ctypes.byref(d), b"S", ctypes.byref(off), ctypes.byref(cnt)) == 0
+    assert cnt.value == 256 * 20 * 400 and off.value % 256 == 0
+    assert lib.gscan_workspace_find(ctypes.byref(d), b"nope", ctypes.byref(off), ctypes.byref(cnt)) != 0
+    assert b"nope" in lib.gscan_last_error()
+    bad = _lib.Dims(B=4, L=10, T=20, G=6, C=16, Co=50, K3=7, E=25, He=100, H=77, Vi=21, V=9, conditional=1,
+                    auxiliary=0, bidirectional=1, pad_in=0, pad_tgt=0)
+    assert lib.gscan_workspace_bytes(ctypes.byref(bad)) == 0
+    assert b"decoder_hidden_size 77" in lib.gscan_last_error()
+    big = _lib.Dims(B=4, L=10, T=20, G=12, C=16, Co=50, K3=7, E=25, He=100, H=100, Vi=21, V=9, conditional=1,
+                    auxiliary=0, bidirectional=1, pad_in=0, pad_tgt=0)
+    assert lib.gscan_workspace_bytes(ctypes.byref(big)) == 0

@@ -1,0 +1,96 @@
+"""Host-side behaviour of the drop-in Model that needs no GPU: seeded initialisation identical to the
+reference's, checkpoint ABI (state_dict keys), flat parameter views, loud failure on CPU tensors."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+from multimodal_seq2seq_gscan_amd.config import PARAMETER_TOTALS, model_kwargs
+from multimodal_seq2seq_gscan_amd.model import Model
+
+
+@pytest.fixture(scope="module")
+def init_fixture():
+    with open(os.path.join(GOLDEN, "init_seed42.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("workload", ["demo", "compositional", "target_length"])
+def test_seeded_init_matches_reference(workload, init_fixture):
+    """torch.manual_seed(42); Model(**cfg) reproduces the reference's parameters bit for bit
+    (train.py:27,58-64): same modules constructed in the same order."""
+    torch.manual_seed(42)
+    model = Model(**model_kwargs(workload))
+    ref = init_fixture[workload]
+    assert sum(p.numel() for p in model.parameters()) == PARAMETER_TOTALS[workload] == ref["total"]
+    assert list(model.state_dict().keys()) == ref["state_dict_keys"]
+    for name, p in model.named_parameters():
+        a = p.detach().numpy()
+        assert list(a.shape) == ref["params"][name]["shape"], name
+        assert hashlib.sha256(a.tobytes()).hexdigest() == ref["params"][name]["sha256"], name
+
+
+def test_parameters_are_views_of_one_buffer():
+    model = Model(**model_kwargs("demo"))
+    flat = model.flat_parameters
+    assert flat.numel() == PARAMETER_TOTALS["demo"]
+    off = 0
+    for _, p in model.named_parameters():
+        assert p.data_ptr() == flat.data_ptr() + 4 * off
+        off += p.numel()
+    model.attach_gradients(zero=True)
+    for _, p in model.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape
+    model.flat_gradients.fill_(2.0)
+    assert all(bool((p.grad == 2.0).all()) for p in model.parameters())
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    before = flat.clone()
+    opt.step()                                   # a stock optimizer updates the flat buffer through the views
+    assert torch.allclose(flat, before - 1.0)
+    opt.zero_grad()                              # set_to_none: views are re-attached (zeroed) on demand
+    model.attach_gradients(zero=False)
+    assert all(p.grad is not None and bool((p.grad == 0).all()) for p in model.parameters())
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """Same dictionary keys and file names as model.py:237-261."""
+    cfg = model_kwargs("demo", output_directory=str(tmp_path))
+    a = Model(**cfg)
+    a.update_state(is_best=False)
+    a.update_state(is_best=True, accuracy=12.5, exact_match=3.0)
+    path = a.save_checkpoint("checkpoint.pth.tar", is_best=True, optimizer_state_dict={"k": 1})
+    assert os.path.exists(os.path.join(str(tmp_path), "model_best.pth.tar"))
+    ckpt = torch.load(path)
+    assert set(ckpt) == {"iteration", "state_dict", "best_iteration", "best_accuracy", "best_exact_match",
+                         "optimizer_state_dict"}
+    b = Model(**cfg)
+    assert b.load_model(path) == {"k": 1}
+    assert b.trained_iterations == 2 and b.best_iteration == 2 and b.best_exact_match == 3.0
+    assert torch.equal(a.flat_parameters, b.flat_parameters)
+    first = next(iter(b.parameters()))
+    assert first.data_ptr() == b.flat_parameters.data_ptr()      # loading keeps the views intact
+
+
+def test_constructor_contract():
+    with pytest.raises(ValueError):
+        Model(**model_kwargs("demo", attention_type="dot"))       # model.py:95-96
+    with pytest.raises(NotImplementedError):
+        Model(**model_kwargs("demo", simple_situation_representation=False))
+    m = Model(**model_kwargs("demo"), some_unrelated_flag=3, seed=1)   # extras are swallowed (model.py:32)
+    assert m.trained_iterations == 0 and m.attention_type == "bahdanau"
+    m.update_state(is_best=False)
+    assert m.trained_iterations == 1
+
+
+def test_cpu_tensors_fail_loudly():
+    """No CPU fallback in the product path."""
+    from multimodal_seq2seq_gscan_amd.synthetic import S0_DEMO, make_batch
+    model = Model(**model_kwargs("demo"))
+    b = make_batch(S0_DEMO)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        model(commands_input=b["commands"], commands_lengths=b["cmd_lengths"].tolist(),
+              situations_input=b["world"], target_batch=b["targets"], target_lengths=b["tgt_lengths"].tolist())
