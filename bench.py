@@ -1,0 +1,201 @@
+"""Benchmark of the training hot path: examples/s of one full training step
+(forward + loss + backward + gradient all-reduce + Adam/LR step) on synthetic compositional_splits
+batches, one process per GPU.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task description): `value` is the whole-job
+examples/s with inputs resident in HBM, weak scaling (256 rows per GPU).  `roofline` describes the
+dominant kernel family, timed with HIP events on its launch stream inside a second pass over the
+same K steps; `cpu_baseline` is the CPU oracle (a port of the reference's CPU path) timed on the
+host cores of the same box on the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# fp32 matrix peak of MI355X (v_mfma_f32_*_f32 = the fp32 vector rate), MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP32_TFLOPS = 157.3
+PROBES = ("decoder_forward", "decoder_backward", "encoder_forward", "encoder_backward", "gemm")
+
+
+def algorithmic_mflop_per_example(cfg: dict, G: int, L: int, T: int) -> float:
+    """F_train of SURVEY.md §8(d): 6 x forward MACs, valid convolution taps only."""
+    C_, Co, k3 = cfg["num_cnn_channels"], cfg["cnn_hidden_num_channels"], cfg["cnn_kernel_size"]
+    E, He, H, V = cfg["embedding_dimension"], cfg["encoder_hidden_size"], cfg["decoder_hidden_size"], \
+        cfg["target_vocabulary_size"]
+    valid = lambda k: sum(1 for i in range(G) for j in range(G) if abs(i - j) <= k // 2)
+    mac = C_ * Co * sum(valid(k) ** 2 for k in (1, 5, k3))
+    mac += G * G * 3 * Co * H + 2 * L * 4 * He * (E + He) + L * He * H + He * H
+    step = H * H + 2 * L * H + (2 * H * H if cfg["conditional_attention"] else 0) + H * H + 2 * G * G * H \
+        + 4 * H * 4 * H + 4 * H * H + H * V
+    return 6.0 * (mac + T * step) / 1e6
+
+
+def cpu_baseline(cfg: dict, shape, budget_s: float) -> dict:
+    """The CPU oracle (oracle/seq2seq_oracle.py, a restatement of the reference's CPU path) on this box's cores:
+    the same step definition (forward, loss, backward, Adam + LR) on the same synthetic workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from multimodal_seq2seq_gscan_amd.synthetic import make_batch
+    from oracle import seq2seq_oracle as oracle
+    from weights import golden_weights
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    params = {k: torch.from_numpy(v) for k, v in golden_weights(cfg, 1).items()}
+    names = list(params)
+    m = [torch.zeros_like(params[k]) for k in names]
+    v = [torch.zeros_like(params[k]) for k in names]
+    batch = make_batch(shape, 1234)
+    p = (cfg["cnn_dropout_p"], cfg["encoder_dropout_p"], cfg["decoder_dropout_p"])
+    B, L = batch["commands"].shape
+    T = batch["targets"].shape[1]
+    G = batch["world"].shape[1]
+
+    def one(step):
+        masks = (torch.nn.functional.dropout(torch.ones(B, G * G, 3 * cfg["cnn_hidden_num_channels"]), p[0]),
+                 torch.nn.functional.dropout(torch.ones(B, L, cfg["embedding_dimension"]), p[1]),
+                 torch.nn.functional.dropout(torch.ones(B, T, cfg["decoder_hidden_size"]), p[2]))
+        _, g, _ = oracle.loss_and_grads(params, batch, conditional=cfg["conditional_attention"],
+                                        auxiliary=cfg["auxiliary_task"], masks=masks)
+        oracle.adam_step([params[k] for k in names], [g[k] for k in names], m, v, step, 1e-3)
+
+    one(1)                                   # warm-up (thread pools, allocator)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(n + 2)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {"value": round(n * B / el, 1), "unit": "examples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of the same workload (B={B}, T={T}) after 1 warm-up step, torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="rows per GPU")
+    ap.add_argument("--target-length", type=int, default=20)
+    ap.add_argument("--command-length", type=int, default=10)
+    ap.add_argument("--workload", default="compositional", choices=["compositional", "target_length", "demo"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs the HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group(backend="nccl")          # RCCL over xGMI
+
+    from multimodal_seq2seq_gscan_amd import _lib
+    from multimodal_seq2seq_gscan_amd.config import model_kwargs
+    from multimodal_seq2seq_gscan_amd.model import Model
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+    from multimodal_seq2seq_gscan_amd.train import TrainStep
+
+    lib = _lib.load()
+    cfg = model_kwargs(args.workload)
+    grid = 4 if args.workload == "demo" else 6
+    shape = Shape(batch=args.batch, grid=grid, channels=cfg["num_cnn_channels"],
+                  input_vocab=cfg["input_vocabulary_size"], target_vocab=cfg["target_vocabulary_size"],
+                  max_command=args.command_length, max_target=args.target_length, ragged=False)
+    torch.manual_seed(42)                                 # identical initialisation on every rank (train.py:27)
+    model = Model(**cfg).cuda()
+    batch = {k: v.cuda() for k, v in make_batch(shape, seed=1234 + rank).items()}   # resident in HBM
+    batch["cmd_lengths"] = batch["cmd_lengths"].to(torch.int32)
+    step = TrainStep(model, learning_rate=1e-3)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(batch)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(batch)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    loss = float(out["loss"].item())
+
+    # second pass over the same K steps with HIP-event probes around each kernel family
+    lib.gscan_probe_reset()
+    lib.gscan_probe_enable(1)
+    for _ in range(args.steps):
+        step(batch)
+    torch.cuda.synchronize()
+    lib.gscan_probe_enable(0)
+    families = {}
+    for name in PROBES:
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(lib.gscan_probe_read(name.encode(), C.byref(ms), C.byref(fl), C.byref(n)), "gscan_probe_read")
+        if n.value:
+            families[name] = {"ms_per_step": ms.value / args.steps, "launches_per_step": n.value / args.steps,
+                              "avg_us": 1e3 * ms.value / n.value,
+                              "tflops": fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0}
+    fence()
+
+    if rank == 0:
+        B, L, T = args.batch, args.command_length, args.target_length
+        ex_per_s = world * B * args.steps / elapsed
+        dominant = max(families, key=lambda k: families[k]["ms_per_step"])
+        d = families[dominant]
+        mflop = algorithmic_mflop_per_example(cfg, grid, L, T)
+        result = {
+            "metric": "training examples/sec (forward+backward) on compositional_splits, 1/2/4/8 GPUs",
+            "value": round(ex_per_s, 1), "unit": "examples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"S1 {args.workload}: {B} rows/GPU, {grid}x{grid}x{cfg['num_cnn_channels']} grid, "
+                                   f"k={cfg['cnn_kernel_size']}, hidden {cfg['decoder_hidden_size']}, L={L}, T={T} dense, "
+                                   f"dropout {cfg['encoder_dropout_p']}/{cfg['decoder_dropout_p']}/{cfg['cnn_dropout_p']}, "
+                                   f"conditional attention, Adam+LR step included",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "parameters": model.flat_parameters.numel()},
+            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(d["tflops"], 3),
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_FP32_TFLOPS, 4),
+                         "traffic": None, "avg_launch_us": round(d["avg_us"], 2),
+                         "note": "fp32 matrix peak = fp32 vector peak on gfx950; algorithmic flops per launch in DESIGN.md"},
+            "kernel_families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in families.items()},
+            "step_algorithmic_tflops": round(ex_per_s * mflop / 1e6, 3),
+            "final_loss": round(loss, 4),
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            result["cpu_baseline"] = cpu_baseline(cfg, shape, args.cpu_seconds)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,6 +138,15 @@ int gscan_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
 /* Counter-based (Philox-4x32-10) scaled dropout mask: out[i] = keep ? 1/(1-p) : 0. */
 int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, void *stream);
 
+/* Per-kernel-family timing for roofline reports: when enabled, every launch of a family
+ * ("decoder_forward", "decoder_backward", "encoder_forward", "encoder_backward", "gemm") is
+ * bracketed by HIP events on its launch stream.  gscan_probe_read synchronises on those events
+ * and returns the summed duration, the summed ALGORITHMIC flops (DESIGN.md states the per-launch
+ * formulas) and the launch count since the last reset.  Do not enable during graph capture. */
+int gscan_probe_enable(int on);
+int gscan_probe_reset(void);
+int gscan_probe_read(const char *name, double *total_ms, double *flops, int64_t *launches);
+
 /* ---- building blocks, exported so that each kernel can be parity-tested on its own ---- */
 
 /* C[M,N] = act(alpha * A.B + beta * C + bias[n]) * mask[m,n]

@@ -1,0 +1,133 @@
+"""Command line of the reference (`python -m seq2seq --mode=train ...`, seq2seq/__main__.py:21-167).
+
+Flag names, defaults and the paired on/off switches are the reference's; two flags are additive:
+`--synthetic_data` trains on seeded synthetic batches of the data set's shape (no dataset file ships
+with the reference checkout, .MISSING_LARGE_BLOBS) and `--synthetic_batches` bounds that run.
+Data-parallel runs are launched with `python -m torch.distributed.run --nproc-per-node N -m seq2seq ...`;
+each rank then trains on its shard of every global batch (train.py in this package).
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+
+import torch
+
+logger = logging.getLogger(__name__)
+
+# The reference's flag surface (seq2seq/__main__.py:21-102) as a table: (name, type, default).
+_VALUE_FLAGS = [
+    ("mode", str, None), ("output_directory", str, "output"), ("resume_from_file", str, ""),
+    ("split", str, "test"), ("data_directory", str, "data/uniform_dataset"),
+    ("input_vocab_path", str, "training_input_vocab.txt"), ("target_vocab_path", str, "training_target_vocab.txt"),
+    ("training_batch_size", int, 50), ("k", int, 0), ("test_batch_size", int, 1),
+    ("max_training_examples", int, None), ("learning_rate", float, 0.001), ("lr_decay", float, 0.9),
+    ("lr_decay_steps", float, 20000), ("adam_beta_1", float, 0.9), ("adam_beta_2", float, 0.999),
+    ("print_every", int, 100), ("evaluate_every", int, 1000), ("max_training_iterations", int, 100000),
+    ("weight_target_loss", float, 0.3), ("max_testing_examples", int, None), ("splits", str, "test"),
+    ("max_decoding_steps", int, 30), ("output_file_name", str, "predict.json"),
+    ("cnn_hidden_num_channels", int, 50), ("cnn_kernel_size", int, 7), ("cnn_dropout_p", float, 0.1),
+    ("embedding_dimension", int, 25), ("num_encoder_layers", int, 1), ("encoder_hidden_size", int, 100),
+    ("encoder_dropout_p", float, 0.3), ("num_decoder_layers", int, 1), ("decoder_dropout_p", float, 0.3),
+    ("decoder_hidden_size", int, 100), ("seed", int, 42),
+    # additive: synthetic data (no dataset file ships with the reference checkout)
+    ("synthetic_batches", int, 1000),
+]
+# paired switches: (destination, flag that sets True, flag that sets False, default)
+_SWITCHES = [
+    ("generate_vocabularies", "generate_vocabularies", "load_vocabularies", False),
+    ("simple_situation_representation", "simple_situation_representation", "image_situation_representation", True),
+    ("auxiliary_task", "auxiliary_task", "no_auxiliary_task", False),
+    ("encoder_bidirectional", "encoder_bidirectional", "encoder_unidirectional", True),
+    ("conditional_attention", "conditional_attention", "no_conditional_attention", True),
+    ("synthetic_data", "synthetic_data", "dataset_file", False),
+]
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="gSCAN seq2seq training on MI355X (flags of the reference CLI)")
+    for name, kind, default in _VALUE_FLAGS:
+        p.add_argument("--" + name, type=kind, default=default, required=(name == "mode"))
+    p.add_argument("--attention_type", type=str, default="bahdanau", choices=["bahdanau", "luong"])
+    for dest, on, off, default in _SWITCHES:
+        p.add_argument("--" + on, dest=dest, action="store_true", default=default)
+        p.add_argument("--" + off, dest=dest, action="store_false")
+    return p
+
+
+parser = build_parser()
+
+
+def _init_distributed():
+    """One process per GPU when launched through torch.distributed.run; single process otherwise."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend="nccl")     # RCCL on ROCm
+    return rank, world
+
+
+def _synthetic_batches(flags, rank: int, world: int):
+    from .synthetic import Shape, make_batch
+    from .train import shard_batch
+    shape = Shape(batch=flags["training_batch_size"], ragged=True)
+    for i in range(flags["synthetic_batches"]):
+        cpu = make_batch(shape, seed=flags["seed"] * 100003 + i)       # same global batch on every rank
+        yield {k: v.cuda(non_blocking=True) for k, v in shard_batch(cpu, rank, world).items()}
+
+
+def main(flags):
+    logging.basicConfig(format="%(asctime)-15s %(message)s", level=logging.DEBUG, datefmt="%Y-%m-%d %H:%M")
+    for argument, value in flags.items():
+        logger.info("{}: {}".format(argument, value))
+    if not os.path.exists(flags["output_directory"]):
+        os.makedirs(flags["output_directory"], exist_ok=True)
+    if not flags["simple_situation_representation"]:
+        raise NotImplementedError("Full RGB input image not implemented. Implement or set "
+                                  "--simple_situation_representation")
+    if flags["generate_vocabularies"]:
+        assert flags["input_vocab_path"] and flags["target_vocab_path"], "Please specify paths to vocabularies to save."
+    if flags["test_batch_size"] > 1:
+        raise NotImplementedError("Test batch size larger than 1 not implemented.")
+
+    if flags["mode"] == "train":
+        from .config import model_kwargs
+        from .model import Model
+        from .train import train
+        if not torch.cuda.is_available():
+            raise RuntimeError("training runs on the HIP device only (no CPU fallback in this package)")
+        rank, world = _init_distributed()
+        torch.manual_seed(flags["seed"])                      # train.py:27 (identical init on every rank)
+        if not flags["synthetic_data"]:
+            raise NotImplementedError(
+                "reading data/<split>/dataset.txt is the next row of the scope table (SURVEY.md §8 f1/f3); "
+                "pass --synthetic_data to run the training hot path on synthetic batches")
+        cfg = model_kwargs("compositional")
+        cfg.update({k: flags[k] for k in cfg if k in flags})
+        model = Model(**cfg).cuda()
+        if flags["resume_from_file"]:
+            assert os.path.isfile(flags["resume_from_file"]), "No checkpoint found at {}".format(flags["resume_from_file"])
+            model.load_model(flags["resume_from_file"])
+        step = train(_synthetic_batches(flags, rank, world), model, flags["max_training_iterations"],
+                     print_every=flags["print_every"], weight_target_loss=flags["weight_target_loss"], rank=rank,
+                     learning_rate=flags["learning_rate"], adam_beta_1=flags["adam_beta_1"],
+                     adam_beta_2=flags["adam_beta_2"], lr_decay=flags["lr_decay"],
+                     lr_decay_steps=flags["lr_decay_steps"])
+        if rank == 0:
+            model.save_checkpoint("checkpoint.pth.tar", is_best=False, optimizer_state_dict=step.optimizer.state_dict())
+        logger.info("Finished training.")
+    elif flags["mode"] == "test":
+        raise NotImplementedError("greedy decoding (predict.py) is outside the training hot path built so far "
+                                  "(SURVEY.md §8 f2)")
+    elif flags["mode"] == "predict":
+        raise NotImplementedError()
+    else:
+        raise ValueError("Wrong value for parameters --mode ({}).".format(flags["mode"]))
+
+
+if __name__ == "__main__":
+    main(flags=vars(parser.parse_args()))

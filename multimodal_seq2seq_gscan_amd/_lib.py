@@ -76,6 +76,9 @@ PROTOTYPES = {
     "gscan_sequence_metrics": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gscan_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i64, _vp, _vp]),
     "gscan_dropout_mask": (_i, [_vp, _sz, _f, _u64, _u64, _vp]),
+    "gscan_probe_enable": (_i, [_i]),
+    "gscan_probe_reset": (_i, []),
+    "gscan_probe_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "gscan_gemm_f32": (_i, [_i, _i, _i, _f, _vp, _i64, _i64, _vp, _i64, _i64, _f, _vp, _i64, _vp, _i, _vp, _i, _vp]),
     "gscan_world_im2col": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "gscan_encoder_lstm_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

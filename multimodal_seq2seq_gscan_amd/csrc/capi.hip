@@ -94,6 +94,13 @@ int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t st
     return dropout_mask(out, n, p, seed, stream_id, (hipStream_t)stream);
 }
 
+int gscan_probe_enable(int on) { return probe_enable(on); }
+int gscan_probe_reset(void) { return probe_reset(); }
+int gscan_probe_read(const char *name, double *total_ms, double *flops, int64_t *launches) {
+    ARG(name && total_ms && flops && launches, "probe_read: NULL argument");
+    return probe_read(name, total_ms, flops, launches);
+}
+
 int gscan_gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
                    int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
                    const float *mask, int split_k, void *stream) {

@@ -460,6 +460,12 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
     GSCAN_CHECK(bytes <= kLdsLimit,
                 "decoder: a row's memories need %zu bytes of LDS (> 160 KiB): grid cells=%d command length=%d hidden=%d",
                 bytes, a.M, a.L, H);
+    // Algorithmic MACs of one decoder step that this kernel owns (SURVEY.md §8d MAC_step minus the
+    // embedding part of the LSTM input and the output head, which run as GEMMs outside the loop):
+    // query projections, both score/context reductions, and the [ctx_text|ctx_vis|h] part of the LSTM.
+    const double macs = (double)H * H + 2.0 * a.L * H + (COND ? 2.0 * H * H : 0.0) + (double)H * H +
+                        2.0 * a.M * H + 4.0 * H * 3.0 * H;
+    ProbeScope probe(backward ? P_DECODER_BWD : P_DECODER_FWD, stream, 2.0 * macs * B * a.T);
     if (backward) {
         static bool attr_set = false;
         if (!attr_set) {

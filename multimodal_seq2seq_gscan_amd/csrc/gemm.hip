@@ -144,6 +144,7 @@ int gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int6
                     "gemm: split-K needs beta=1 and no epilogue (got beta=%g act=%d)", beta, act);
     GemmArgs g{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, chunk, split_k > 1 ? 1 : 0};
     dim3 grid(cdiv(N, BN), cdiv(M, BM), split_k);
+    ProbeScope probe(P_GEMM, stream, 2.0 * M * N * K);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
     GSCAN_LAUNCHED("gemm_f32_kernel");
     return 0;

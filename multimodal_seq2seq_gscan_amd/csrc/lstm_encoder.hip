@@ -160,6 +160,8 @@ static int launch_fwd(int B, int L, int D, const float *gx, const int32_t *lengt
                       const float *wr, const float *br, float *out, float *hfin, float *gates, float *cells,
                       float *hprev, hipStream_t stream) {
     const int nt = cdiv(4 * HE, 64) * 64;
+    // algorithmic work: the recurrent product h.W_hh^T per (row, step, direction); padded steps counted
+    ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * HE * HE);
     hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B), dim3(nt), 0, stream, L, D, gx, lengths, wf, bf, wr, br,
                        out, hfin, gates, cells, hprev);
     GSCAN_LAUNCHED("encoder_lstm_fwd_kernel");
@@ -170,6 +172,7 @@ static int launch_bwd(int B, int L, int D, const int32_t *lengths, const float *
                       const float *gates, const float *cells, const float *d_out, const float *d_hfin, float *delta,
                       hipStream_t stream) {
     const int nt = cdiv(4 * HE, 64) * 64;
+    ProbeScope probe(P_ENCODER_BWD, stream, 2.0 * B * L * D * 4 * HE * HE);
     hipLaunchKernelGGL(encoder_lstm_bwd_kernel<HE>, dim3(B, D), dim3(nt), 0, stream, L, D, lengths, wf, wr, gates,
                        cells, d_out, d_hfin, delta);
     GSCAN_LAUNCHED("encoder_lstm_bwd_kernel");

@@ -71,6 +71,18 @@ bool decoder_hidden_supported(int h);
 size_t decoder_lds_bytes(int H, int L, int M, bool cond, bool backward);
 int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
 
+// probe.hip
+enum ProbeId { P_DECODER_FWD = 0, P_DECODER_BWD, P_ENCODER_FWD, P_ENCODER_BWD, P_GEMM, P_COUNT };
+struct ProbeScope {
+    ProbeScope(int id, hipStream_t st, double flops);
+    ~ProbeScope();
+    int id_;
+    hipStream_t st_;
+};
+int probe_enable(int on);
+int probe_reset();
+int probe_read(const char *name, double *total_ms, double *flops, int64_t *launches);
+
 // step.hip
 struct WorkspaceSlot { const char *name; int64_t offset, count; };
 struct Workspace {

@@ -44,25 +44,25 @@ def test_gemm_epilogues_and_split_k(lib):
     bias, mask = torch.randn(N, generator=g), (torch.rand(M, N, generator=g) > 0.3).float() * 1.25
     C0 = torch.randn(M, N, generator=g)
     for act, fn in ((0, lambda x: x), (1, torch.relu), (2, torch.tanh)):
-        Cd = dev(C0.clone())
-        gpu_ops.gemm((dev(A), 0, K, 1), (dev(B), 0, N, 1), (Cd, 0, N), M, N, K, alpha=0.5, beta=2.0, bias=dev(bias),
-                     act=act, mask=dev(mask))
+        Cd, Ad, Bd, bias_d, mask_d = dev(C0.clone()), dev(A), dev(B), dev(bias), dev(mask)
+        gpu_ops.gemm((Ad, 0, K, 1), (Bd, 0, N, 1), (Cd, 0, N), M, N, K, alpha=0.5, beta=2.0, bias=bias_d,
+                     act=act, mask=mask_d)
         ref = fn(0.5 * (A @ B) + 2.0 * C0 + bias) * mask
         assert (Cd.cpu() - ref).abs().max().item() < 1e-4, f"act {act}"
     # split-K accumulates into C with atomics (weight-gradient form: K is the long dimension)
     M, N, K = 100, 130, 4000
     A, B = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
     C0 = torch.randn(M, N, generator=g)
-    Cd = dev(C0.clone())
-    gpu_ops.gemm((dev(A), 0, 1, M), (dev(B), 0, N, 1), (Cd, 0, N), M, N, K, beta=1.0, split_k=16)
+    Cd, Ad, Bd = dev(C0.clone()), dev(A), dev(B)
+    gpu_ops.gemm((Ad, 0, 1, M), (Bd, 0, N, 1), (Cd, 0, N), M, N, K, beta=1.0, split_k=16)
     ref = C0.double() + A.t().double() @ B.double()
     assert (Cd.cpu().double() - ref).abs().max().item() < 2e-3
     # column-sliced operands (the step addresses slices of wider buffers in place)
     M, N, K, ld = 50, 40, 30, 100
     Abig, Bbig = torch.randn(M, ld, generator=g), torch.randn(N, ld, generator=g)
     Cbig = torch.zeros(M, ld)
-    Cd = dev(Cbig)
-    gpu_ops.gemm((dev(Abig), 10, ld, 1), (dev(Bbig), 20, 1, ld), (Cd, 5, ld), M, N, K)
+    Cd, Ad, Bd = dev(Cbig), dev(Abig), dev(Bbig)
+    gpu_ops.gemm((Ad, 10, ld, 1), (Bd, 20, 1, ld), (Cd, 5, ld), M, N, K)
     ref = Abig[:, 10:10 + K] @ Bbig[:, 20:20 + K].t()
     got = Cd.cpu()
     assert (got[:, 5:5 + N] - ref).abs().max().item() < 1e-4
@@ -78,14 +78,16 @@ def test_world_im2col_and_conv(lib):
     world = (torch.rand(B, G, G, Cc, generator=g) > 0.8).float()
     Ktot = Cc * (1 + 25 + K3 * K3)
     xcol = torch.empty(B * G * G, Ktot, device="cuda")
-    _lib.check(lib.gscan_world_im2col(dev(world).data_ptr(), B, G, Cc, K3, xcol.data_ptr(), gpu_ops.stream()), "im2col")
+    world_d = dev(world)                       # keep device tensors referenced while kernels use their pointers
+    _lib.check(lib.gscan_world_im2col(world_d.data_ptr(), B, G, Cc, K3, xcol.data_ptr(), gpu_ops.stream()), "im2col")
     off = 0
     for k in (1, 5, K3):
         W = torch.randn(Co, Cc, k, k, generator=g) * 0.1
         bias = torch.randn(Co, generator=g) * 0.1
         kk = Cc * k * k
         out = torch.zeros(B * G * G, Co, device="cuda")
-        gpu_ops.gemm((xcol, off, Ktot, 1), (dev(W), 0, 1, kk), (out, 0, Co), B * G * G, Co, kk, bias=dev(bias))
+        W_d, bias_d = dev(W), dev(bias)
+        gpu_ops.gemm((xcol, off, Ktot, 1), (W_d, 0, 1, kk), (out, 0, Co), B * G * G, Co, kk, bias=bias_d)
         ref = torch.nn.functional.conv2d(world.transpose(1, 3), W, bias, padding=k // 2).transpose(1, 3)
         assert (out.cpu().view(B, G, G, Co) - ref).abs().max().item() < 1e-4, f"kernel {k}"
         off += kk
@@ -130,7 +132,8 @@ def test_encoder_lstm_forward_backward(lib, He, bidir):
     len_d = dev(lengths.int())
     wd = [dev(w) for w in w_hh] + [None]
     bd = [dev(b) for b in b_hh] + [None]
-    _lib.check(lib.gscan_encoder_lstm_forward(B, L, He, D, dev(gx).data_ptr(), len_d.data_ptr(), wd[0].data_ptr(),
+    gx_d, d_out_d, d_h_d = dev(gx), dev(d_out * live), dev(d_h)
+    _lib.check(lib.gscan_encoder_lstm_forward(B, L, He, D, gx_d.data_ptr(), len_d.data_ptr(), wd[0].data_ptr(),
                                               bd[0].data_ptr(), _lib.ptr(wd[1]), _lib.ptr(bd[1]),
                                               c["out"].data_ptr(), c["hf"].data_ptr(), c["gates"].data_ptr(),
                                               c["cells"].data_ptr(), c["hprev"].data_ptr(), gpu_ops.stream()), "fwd")
@@ -138,7 +141,7 @@ def test_encoder_lstm_forward_backward(lib, He, bidir):
     assert (c["hf"].cpu() - h_ref.detach()).abs().max().item() < 2e-5
     _lib.check(lib.gscan_encoder_lstm_backward(B, L, He, D, len_d.data_ptr(), wd[0].data_ptr(), _lib.ptr(wd[1]),
                                                c["gates"].data_ptr(), c["cells"].data_ptr(),
-                                               dev(d_out * live).data_ptr(), dev(d_h).data_ptr(),
+                                               d_out_d.data_ptr(), d_h_d.data_ptr(),
                                                c["delta"].data_ptr(), gpu_ops.stream()), "bwd")
     delta = c["delta"].cpu()
     assert torch.isfinite(delta).all()
@@ -170,7 +173,8 @@ def test_losses_metrics_adam_dropout(lib):
         targets[b, n:] = 0
     out = torch.zeros(2, device="cuda")
     dl = torch.empty(B, T, V, device="cuda")
-    _lib.check(lib.gscan_sequence_nll(dev(logp).data_ptr(), dev(targets).data_ptr(), B, T, V, 0, out.data_ptr(),
+    logp_d, targets_d = dev(logp), dev(targets)
+    _lib.check(lib.gscan_sequence_nll(logp_d.data_ptr(), targets_d.data_ptr(), B, T, V, 0, out.data_ptr(),
                                       out.data_ptr() + 4, dl.data_ptr(), gpu_ops.stream()), "nll")
     total, n = oracle.sequence_loss(logp, targets, 0, reduction="sum")
     assert abs(out[0].item() - total.item()) < 1e-4 and out[1].item() == n.item()
@@ -178,7 +182,7 @@ def test_losses_metrics_adam_dropout(lib):
     oracle.sequence_loss(lp, targets, 0, reduction="sum")[0].backward()
     assert torch.equal(dl.cpu(), lp.grad)
     m = torch.zeros(3, device="cuda")
-    _lib.check(lib.gscan_sequence_metrics(dev(logp).data_ptr(), dev(targets).data_ptr(), B, T, V, 0, m.data_ptr(),
+    _lib.check(lib.gscan_sequence_metrics(logp_d.data_ptr(), targets_d.data_ptr(), B, T, V, 0, m.data_ptr(),
                                           gpu_ops.stream()), "metrics")
     acc, exact = oracle.metrics(logp, targets)
     c, live, ex = m.tolist()
@@ -188,7 +192,8 @@ def test_losses_metrics_adam_dropout(lib):
     pos = torch.randint(0, 16, (B,), generator=g)
     o1 = torch.zeros(1, device="cuda")
     da = torch.empty(B, 16, device="cuda")
-    _lib.check(lib.gscan_position_nll(dev(aux).data_ptr(), dev(pos).data_ptr(), B, 16, o1.data_ptr(), da.data_ptr(),
+    aux_d, pos_d = dev(aux), dev(pos)
+    _lib.check(lib.gscan_position_nll(aux_d.data_ptr(), pos_d.data_ptr(), B, 16, o1.data_ptr(), da.data_ptr(),
                                       gpu_ops.stream()), "pos nll")
     assert abs(o1.item() / B - oracle.auxiliary_loss(aux, pos).item()) < 1e-5
     assert da.cpu().sum().item() == -B
@@ -200,13 +205,15 @@ def test_losses_metrics_adam_dropout(lib):
     for step in (1, 2, 3):
         gs = g0 * step
         oracle.adam_step(p_ref, [gs], m_ref, v_ref, step, 1e-3, lr_decay=0.9, lr_decay_steps=2.0)
-        _lib.check(lib.gscan_adam_step(pd.data_ptr(), dev(gs).data_ptr(), md.data_ptr(), vd.data_ptr(), n, 1e-3, 0.9,
+        gs_d = dev(gs)
+        _lib.check(lib.gscan_adam_step(pd.data_ptr(), gs_d.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 1e-3, 0.9,
                                        0.999, 1e-8, 0.9, 2.0, step, None, gpu_ops.stream()), "adam")
     assert (pd.cpu() - p_ref[0]).abs().max().item() < 2e-6
     # grad_scale read from device memory
     pd2, md2, vd2 = dev(p0.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     scale = torch.tensor([0.25], device="cuda")
-    _lib.check(lib.gscan_adam_step(pd2.data_ptr(), dev(g0 * 4).data_ptr(), md2.data_ptr(), vd2.data_ptr(), n, 1e-3,
+    g4_d = dev(g0 * 4)
+    _lib.check(lib.gscan_adam_step(pd2.data_ptr(), g4_d.data_ptr(), md2.data_ptr(), vd2.data_ptr(), n, 1e-3,
                                    0.9, 0.999, 1e-8, 0.9, 2.0, 1, scale.data_ptr(), gpu_ops.stream()), "adam")
     p_one = [p0.clone()]
     oracle.adam_step(p_one, [g0], [torch.zeros(n)], [torch.zeros(n)], 1, 1e-3, lr_decay=0.9, lr_decay_steps=2.0)
