@@ -52,7 +52,9 @@ def cpu_baseline(cfg: dict, shape, budget_s: float) -> dict:
     from multimodal_seq2seq_gscan_amd.synthetic import make_batch
     from oracle import seq2seq_oracle as oracle
     from weights import golden_weights
-    cores = len(os.sched_getaffinity(0))
+    # The path issues ~20k small ATen ops per step: beyond a few dozen threads it gets slower, not faster
+    # (256 threads: 0.9 examples/s on the MI355X host).  Use at most 32 of the cores we are allowed to run on.
+    cores = min(len(os.sched_getaffinity(0)), 32)
     torch.set_num_threads(cores)
     params = {k: torch.from_numpy(v) for k, v in golden_weights(cfg, 1).items()}
     names = list(params)

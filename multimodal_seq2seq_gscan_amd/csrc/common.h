@@ -49,15 +49,32 @@ __device__ __forceinline__ float tanhf_(float x) {
     return copysignf(t, x);
 }
 
+// Wave-wide (64-lane) reductions on the DPP datapath instead of ds_bpermute shuffles: four in-row steps
+// (quad_perm, quad_perm, row_ror:4, row_ror:8) leave each 16-lane row holding its own total, row_bcast:15 /
+// row_bcast:31 fold the rows into lane 63, and v_readlane broadcasts it.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_move<0xb1, 0xf>(v);
+    v += dpp_move<0x4e, 0xf>(v);
+    v += dpp_move<0x124, 0xf>(v);
+    v += dpp_move<0x128, 0xf>(v);
+    v += dpp_move<0x142, 0xa>(v);
+    v += dpp_move<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, dpp_move<0xb1, 0xf>(v));
+    v = fmaxf(v, dpp_move<0x4e, 0xf>(v));
+    v = fmaxf(v, dpp_move<0x124, 0xf>(v));
+    v = fmaxf(v, dpp_move<0x128, 0xf>(v));
+    // rows masked out of a row_bcast step receive 0 and may be wrong for negative inputs; lane 63's row
+    // takes part in both steps, and lane 63 is the only lane read back
+    v = fmaxf(v, dpp_move<0x142, 0xa>(v));
+    v = fmaxf(v, dpp_move<0x143, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 #endif
 

@@ -46,6 +46,45 @@ __device__ __forceinline__ float dot_reg_lds(const float (&w)[H], const float *v
 }
 
 
+// sum_{m<n} al[m] * mat[m*stride]: four independent chains so the LDS reads issue back to back
+__device__ __forceinline__ float weighted_sum(const float *al, const float *mat, int stride, int n) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int m = 0;
+    for (; m + 4 <= n; m += 4) {
+        a0 = fmaf(al[m + 0], mat[(m + 0) * stride], a0);
+        a1 = fmaf(al[m + 1], mat[(m + 1) * stride], a1);
+        a2 = fmaf(al[m + 2], mat[(m + 2) * stride], a2);
+        a3 = fmaf(al[m + 3], mat[(m + 3) * stride], a3);
+    }
+    for (; m < n; ++m) a0 = fmaf(al[m], mat[m * stride], a0);
+    return (a0 + a1) + (a2 + a3);
+}
+
+// Additive-attention scores s_m = v . tanh(q + PK_m) for m < n: each wave takes m = wave, wave+nwave, ...
+// four at a time (partials first, then four independent DPP reductions).
+template <int H>
+__device__ __forceinline__ void attention_scores(const float *v_s, const float *q_s, const float *pk, int n,
+                                                 float *sc_s, int wave, int nwave, int lane) {
+    for (int m0 = wave; m0 < n; m0 += 4 * nwave) {
+        float p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + i * nwave;
+            p[i] = 0.f;
+            if (m < n)
+                for (int kk = lane; kk < H; kk += 64) p[i] += v_s[kk] * tanhf_(q_s[kk] + pk[m * H + kk]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + i * nwave;
+            if (m < n) {                      // wave-uniform
+                const float t = wave_sum(p[i]);
+                if (lane == 0) sc_s[m] = t;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // LDS carve shared by both kernels (floats).  Everything is in the dynamic region so the base
 // stays 16-byte aligned (all offsets are multiples of 4 floats).
@@ -124,7 +163,7 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
-        const int64_t bt = (int64_t)b * T + t;
+        const unsigned bt = (unsigned)b * T + t;       // 32-bit offsets: B*T*4H < 2^31 is checked on the host
         // gate input from the embedding (global, issued early; consumed in phase G)
         const float ge = (role < 4) ? a.ge[bt * 4 * H + tid] : 0.f;
 
@@ -140,12 +179,7 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
         __syncthreads();
 
         // ---- B: textual scores s_m = v . tanh(q + PK_m), m < len (seq2seq_model.py:129-135) --
-        for (int m = wave; m < len; m += nwave) {
-            float p = 0.f;
-            for (int kk = lane; kk < H; kk += 64) p += vt_s[kk] * tanhf_(qt_s[kk] + PKt[m * H + kk]);
-            p = wave_sum(p);
-            if (lane == 0) sc_s[m] = p;
-        }
+        attention_scores<H>(vt_s, qt_s, PKt, len, sc_s, wave, nwave, lane);
         __syncthreads();
         if (wave == 0) {
             const float x = (lane < len) ? sc_s[lane] : -INFINITY;
@@ -160,14 +194,11 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
         // ---- C: textual context and its images under W_ih / W_q2k ----------------------------
         float uc = 0.f;
         if (role < 4) {
-            for (int m = 0; m < len; ++m) uc = fmaf(al_s[m], Ut[m * 4 * H + tid], uc);
+            uc = weighted_sum(al_s, Ut + tid, 4 * H, len);
         } else if (role == 4) {
-            float cc = 0.f;
-            for (int m = 0; m < len; ++m) cc = fmaf(al_s[m], PKt[m * H + k], cc);
-            a.s[bt * 4 * H + H + k] = cc;
+            a.s[bt * 4 * H + H + k] = weighted_sum(al_s, PKt + k, H, len);
         } else if (COND && role == 5) {
-            float u2 = 0.f;
-            for (int m = 0; m < len; ++m) u2 = fmaf(al_s[m], U2t[m * H + k], u2);
+            const float u2 = weighted_sum(al_s, U2t + k, H, len);
             const float q = tanhf_(zq_s[k] + u2 + bq);        // seq2seq_model.py:394-396
             q2_s[k] = q;
             a.q2[bt * H + k] = q;
@@ -184,12 +215,7 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
         __syncthreads();
 
         // ---- E: visual scores over all M cells (no mask: every row has M memories) -----------
-        for (int m = wave; m < M; m += nwave) {
-            float p = 0.f;
-            for (int kk = lane; kk < H; kk += 64) p += vv_s[kk] * tanhf_(qv_s[kk] + PKv[m * H + kk]);
-            p = wave_sum(p);
-            if (lane == 0) sc_s[m] = p;
-        }
+        attention_scores<H>(vv_s, qv_s, PKv, M, sc_s, wave, nwave, lane);
         __syncthreads();
         if (wave == 0) {
             const float x = (lane < M) ? sc_s[lane] : -INFINITY;
@@ -204,16 +230,13 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
 
         // ---- F+G: visual context, gate pre-activations, activations --------------------------
         if (role < 4) {
-            float us = 0.f;
-            for (int m = 0; m < M; ++m) us = fmaf(al_s[m], Uv[m * 4 * H + tid], us);
+            const float us = weighted_sum(al_s, Uv + tid, 4 * H, M);
             const float pre = ge + gh + uc + us;
             const float g = (role == 2) ? tanhf_(pre) : sigmoidf_(pre);
             gate_s[tid] = g;
             a.gates[bt * 4 * H + tid] = g;
         } else if (role == 4) {
-            float cs = 0.f;
-            for (int m = 0; m < M; ++m) cs = fmaf(al_s[m], PKv[m * H + k], cs);
-            a.s[bt * 4 * H + 2 * H + k] = cs;
+            a.s[bt * 4 * H + 2 * H + k] = weighted_sum(al_s, PKv + k, H, M);
         }
         __syncthreads();
 
@@ -288,7 +311,7 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
     __syncthreads();
 
     for (int t = T - 1; t >= 0; --t) {
-        const int64_t bt = (int64_t)b * T + t;
+        const unsigned bt = (unsigned)b * T + t;
         // ---- 1: LSTM cell backward -----------------------------------------------------------
         if (tid < H) {
             const float dh = dh_s[tid] + a.ds[bt * 4 * H + 3 * H + tid];
@@ -316,12 +339,25 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
         __syncthreads();
 
         // ---- 2: d alpha_vis[m] = delta . U_vis[m] + dctx_vis(ext) . PK_vis[m] + d att_sum[m] ---
-        for (int m = wave; m < M; m += nwave) {
-            float p = 0.f;
-            for (int j = lane; j < 4 * H; j += 64) p += d_s[j] * Uv[m * 4 * H + j];
-            for (int kk = lane; kk < H; kk += 64) p += exs_s[kk] * PKv[m * H + kk];
-            p = wave_sum(p);
-            if (lane == 0) sc_s[m] = p + datt_s[m];
+        for (int m0 = wave; m0 < M; m0 += 4 * nwave) {
+            float p[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + i * nwave;
+                p[i] = 0.f;
+                if (m < M) {
+                    for (int j = lane; j < 4 * H; j += 64) p[i] = fmaf(d_s[j], Uv[m * 4 * H + j], p[i]);
+                    for (int kk = lane; kk < H; kk += 64) p[i] = fmaf(exs_s[kk], PKv[m * H + kk], p[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + i * nwave;
+                if (m < M) {
+                    const float tsum = wave_sum(p[i]);
+                    if (lane == 0) sc_s[m] = tsum + datt_s[m];
+                }
+            }
         }
         __syncthreads();
         if (wave == 0) {   // softmax backward: ds = alpha * (dalpha - sum alpha dalpha)
@@ -367,15 +403,28 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
         }
 
         // ---- 5: d alpha_text[m] = delta . U_text[m] + dzq . U2_text[m] + dctx_text(ext) . PK_text[m]
-        for (int m = wave; m < len; m += nwave) {
-            float p = 0.f;
-            for (int j = lane; j < 4 * H; j += 64) p += d_s[j] * Ut[m * 4 * H + j];
-            for (int kk = lane; kk < H; kk += 64) {
-                p += exc_s[kk] * PKt[m * H + kk];
-                if (COND) p += d_s[5 * H + kk] * U2t[m * H + kk];
+        for (int m0 = wave; m0 < len; m0 += 4 * nwave) {
+            float p[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + i * nwave;
+                p[i] = 0.f;
+                if (m < len) {
+                    for (int j = lane; j < 4 * H; j += 64) p[i] = fmaf(d_s[j], Ut[m * 4 * H + j], p[i]);
+                    for (int kk = lane; kk < H; kk += 64) {
+                        p[i] = fmaf(exc_s[kk], PKt[m * H + kk], p[i]);
+                        if (COND) p[i] = fmaf(d_s[5 * H + kk], U2t[m * H + kk], p[i]);
+                    }
+                }
             }
-            p = wave_sum(p);
-            if (lane == 0) sc_s[m] = p;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + i * nwave;
+                if (m < len) {
+                    const float tsum = wave_sum(p[i]);
+                    if (lane == 0) sc_s[m] = tsum;
+                }
+            }
         }
         __syncthreads();
         if (wave == 0) {
@@ -434,7 +483,7 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
     if (tid < H) {
         float x = 0.f;
         for (int cch = 0; cch < nchunk; ++cch) x += part_s[cch * H + tid];
-        a.dv_v[(int64_t)b * H + tid] = x;
+        atomicAdd(&a.dv_v[tid], x);
     }
     __syncthreads();
     if (seg < nchunk) part_s[seg * H + k] = dvt_acc;
@@ -442,7 +491,7 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
     if (tid < H) {
         float x = 0.f;
         for (int cch = 0; cch < nchunk; ++cch) x += part_s[cch * H + tid];
-        a.dv_t[(int64_t)b * H + tid] = x;
+        atomicAdd(&a.dv_t[tid], x);
     }
 }
 

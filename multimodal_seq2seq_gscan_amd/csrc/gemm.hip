@@ -1,7 +1,7 @@
 // Strided fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, one
 // rounding per product, so results track an fp32 fmaf chain).
 //
-//   C[M,N] = act(alpha * A.B + beta * C + bias[n]) * mask[m,n]
+//   C[M,N] = act(alpha * A.B + beta * C + bias[n]) * mask[m,n]           (+ optional  asum[m] += sum_k A(m,k))
 //
 // Every dense contraction of the training step that is not inside a time loop goes through
 // this kernel: the im2col convolutions, key/value projections, LSTM input projections, the
@@ -9,19 +9,24 @@
 // Operands are addressed with (row, col) strides so the reference's [out,in] parameter
 // layout and its transposes are consumed in place; nothing is re-packed in HBM.
 //
-// Tile: 64x64x16 per 256-thread workgroup, 4 waves as 2x2, each wave 32x32 = 2x2 MFMA tiles.
-// LDS image per operand is chosen from the operand's unit-stride dimension so both the
-// global read (64-B segments) and the ds_read_b32 fragment reads are (near) conflict-free.
+// These products are small (K <= 400 or M,N <= 400), so a workgroup's time is a chain of
+// K/BK dependent "load tile -> MFMA" rounds, not FLOPs.  Hence: BK = 32 (few rounds), the next
+// tile's global loads are issued into registers BEFORE the current tile's MFMAs and written to
+// the other LDS buffer after them (one barrier per round), and the long-K weight-gradient
+// products are split over blockIdx.z with float-atomic accumulation into the zeroed gradient.
+// Tile: 64x64x32 per 256-thread workgroup, 4 waves as 2x2, each wave 32x32 = 2x2 MFMA tiles.
+// The LDS image of an operand follows its unit-stride dimension, so both the global read
+// (128-B segments) and the ds_read_b32 fragment reads are conflict-free.
 #include "step.h"
 
 namespace gscan {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int BM = 64, BN = 64, BK = 16;
-constexpr int LD_CONTIG_K = BK + 1;   // image [row][k], k contiguous, padded
-constexpr int LD_CONTIG_R = BM + 16;  // image [k][row], row contiguous, stride = 16 mod 32 banks
-constexpr int TILE_FLOATS = (BK * LD_CONTIG_R > BM * LD_CONTIG_K) ? BK * LD_CONTIG_R : BM * LD_CONTIG_K;
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LD_K = BK + 2;    // image [row][k]: fragment read banks (2*row + k) mod 32 are distinct
+constexpr int LD_R = BM + 16;   // image [k][row]: k rows 16 banks apart -> 32-lane halves conflict-free
+constexpr int TILE_FLOATS = (BK * LD_R > BM * LD_K) ? BK * LD_R : BM * LD_K;
 
 struct GemmArgs {
     int M, N, K;
@@ -30,39 +35,44 @@ struct GemmArgs {
     const float *b; int64_t sbk, sbn;
     float *c; int64_t ldc;
     const float *bias; int act; const float *mask;
-    int k_chunk;   // K range per blockIdx.z
-    int atomic;    // split-K: accumulate with atomics
+    int k_chunk;        // K range per blockIdx.z
+    int atomic;         // split-K: accumulate with atomics
+    float *asum1, *asum2;   // optional: += sum over k of A(m,k) (bias gradients), done by blockIdx.x == 0
 };
 
-// Stage a [64 rows x 16 k] panel.  element(row,k) = src[row*s_row + k*s_k].
-// k_contig: the k stride is 1 -> threads run along k first (coalesced), image [row][k];
-// otherwise threads run along rows first, image [k][row].
-__device__ __forceinline__ void stage_panel(float *lds, const float *src, int64_t s_row, int64_t s_k,
-                                            int row0, int nrows, int k0, int kend, bool k_contig, int tid) {
+// One [64 rows x 32 k] panel = 8 elements per thread.  element(row,k) = src[row*s_row + k*s_k].
+// k_contig (k stride 1): threads run along k first, image [row][k]; else along rows, image [k][row].
+__device__ __forceinline__ void panel_load(float (&v)[8], const float *src, int64_t s_row, int64_t s_k, int row0,
+                                           int nrows, int k0, int kend, bool k_contig, int tid) {
     if (k_contig) {
-        const int k = tid & 15;
+        const int k = k0 + (tid & 31);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (tid >> 4) + 16 * i;
-            float v = 0.f;
-            if (row0 + r < nrows && k0 + k < kend) v = src[(int64_t)(row0 + r) * s_row + (int64_t)(k0 + k) * s_k];
-            lds[r * LD_CONTIG_K + k] = v;
+        for (int i = 0; i < 8; ++i) {
+            const int r = row0 + (tid >> 5) + 8 * i;
+            v[i] = (r < nrows && k < kend) ? src[(int64_t)r * s_row + (int64_t)k * s_k] : 0.f;
         }
     } else {
-        const int r = tid & 63;
+        const int r = row0 + (tid & 63);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = (tid >> 6) + 4 * i;
-            float v = 0.f;
-            if (row0 + r < nrows && k0 + k < kend) v = src[(int64_t)(row0 + r) * s_row + (int64_t)(k0 + k) * s_k];
-            lds[k * LD_CONTIG_R + r] = v;
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + (tid >> 6) + 4 * i;
+            v[i] = (r < nrows && k < kend) ? src[(int64_t)r * s_row + (int64_t)k * s_k] : 0.f;
         }
+    }
+}
+__device__ __forceinline__ void panel_store(float *lds, const float (&v)[8], bool k_contig, int tid) {
+    if (k_contig) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds[((tid >> 5) + 8 * i) * LD_K + (tid & 31)] = v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds[((tid >> 6) + 4 * i) * LD_R + (tid & 63)] = v[i];
     }
 }
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ float lds_a[TILE_FLOATS];
-    __shared__ float lds_b[TILE_FLOATS];
+    __shared__ float lds_a[2][TILE_FLOATS];
+    __shared__ float lds_b[2][TILE_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -70,36 +80,63 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int kbeg = blockIdx.z * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
     const bool a_kc = (g.sak == 1), b_kc = (g.sbk == 1);
-    const int a_sr = a_kc ? LD_CONTIG_K : 1, a_sk = a_kc ? 1 : LD_CONTIG_R;
-    const int b_sr = b_kc ? LD_CONTIG_K : 1, b_sk = b_kc ? 1 : LD_CONTIG_R;
+    const int a_sr = a_kc ? LD_K : 1, a_sk = a_kc ? 1 : LD_R;
+    const int b_sr = b_kc ? LD_K : 1, b_sk = b_kc ? 1 : LD_R;
+    const bool do_asum = g.asum1 != nullptr && blockIdx.x == 0;
 
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float asum = 0.f;
 
     const int fr = lane & 15;   // fragment row (A) / column (B)
     const int fk = lane >> 4;   // fragment k within a 4-deep MFMA step
 
+    float ra[8], rb[8];
+    panel_load(ra, g.a, g.sam, g.sak, m0, g.M, kbeg, kend, a_kc, tid);
+    panel_load(rb, g.b, g.sbn, g.sbk, n0, g.N, kbeg, kend, b_kc, tid);
+    panel_store(lds_a[0], ra, a_kc, tid);
+    panel_store(lds_b[0], rb, b_kc, tid);
+    __syncthreads();
+
+    int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stage_panel(lds_a, g.a, g.sam, g.sak, m0, g.M, k0, kend, a_kc, tid);
-        stage_panel(lds_b, g.b, g.sbn, g.sbk, n0, g.N, k0, kend, b_kc, tid);
-        __syncthreads();
+        const bool more = k0 + BK < kend;
+        if (more) {   // next tile's loads fly while this tile's MFMAs run
+            panel_load(ra, g.a, g.sam, g.sak, m0, g.M, k0 + BK, kend, a_kc, tid);
+            panel_load(rb, g.b, g.sbn, g.sbk, n0, g.N, k0 + BK, kend, b_kc, tid);
+        }
+        const float *la = lds_a[buf], *lb = lds_b[buf];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             float af[2], bf[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = lds_a[(wm * 32 + i * 16 + fr) * a_sr + (kk + fk) * a_sk];
+            for (int i = 0; i < 2; ++i) af[i] = la[(wm * 32 + i * 16 + fr) * a_sr + (kk + fk) * a_sk];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = lds_b[(wn * 32 + j * 16 + fr) * b_sr + (kk + fk) * b_sk];
+            for (int j = 0; j < 2; ++j) bf[j] = lb[(wn * 32 + j * 16 + fr) * b_sr + (kk + fk) * b_sk];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        if (do_asum && tid < BM) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) asum += la[tid * a_sr + kk * a_sk];
+        }
+        if (more) {
+            panel_store(lds_a[buf ^ 1], ra, a_kc, tid);
+            panel_store(lds_b[buf ^ 1], rb, b_kc, tid);
+        }
         __syncthreads();
+        buf ^= 1;
+    }
+
+    if (do_asum && tid < BM && m0 + tid < g.M) {
+        atomicAdd(&g.asum1[m0 + tid], asum);
+        if (g.asum2) atomicAdd(&g.asum2[m0 + tid], asum);
     }
 
     // C/D fragment: column = lane & 15, row = (lane >> 4) * 4 + reg
@@ -129,9 +166,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
-int gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
-             int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
-             const float *mask, int split_k, hipStream_t stream) {
+int gemm_f32_ex(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
+                int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
+                const float *mask, int split_k, float *asum1, float *asum2, hipStream_t stream) {
     GSCAN_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem %dx%dx%d", M, N, K);
     GSCAN_CHECK(a && b && c, "gemm: null operand");
     GSCAN_CHECK(act >= 0 && act <= 2, "gemm: unknown activation %d", act);
@@ -142,12 +179,20 @@ int gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int6
     if (split_k > 1)
         GSCAN_CHECK(beta == 1.f && act == 0 && !bias && !mask,
                     "gemm: split-K needs beta=1 and no epilogue (got beta=%g act=%d)", beta, act);
-    GemmArgs g{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, chunk, split_k > 1 ? 1 : 0};
+    GemmArgs g{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, chunk, split_k > 1 ? 1 : 0,
+               asum1, asum2};
     dim3 grid(cdiv(N, BN), cdiv(M, BM), split_k);
     ProbeScope probe(P_GEMM, stream, 2.0 * M * N * K);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
     GSCAN_LAUNCHED("gemm_f32_kernel");
     return 0;
+}
+
+int gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
+             int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
+             const float *mask, int split_k, hipStream_t stream) {
+    return gemm_f32_ex(M, N, K, alpha, a, sam, sak, b, sbk, sbn, beta, c, ldc, bias, act, mask, split_k, nullptr,
+                       nullptr, stream);
 }
 
 }  // namespace gscan

@@ -10,6 +10,10 @@ int gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int6
              int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
              const float *mask, int split_k, hipStream_t stream);
 
+int gemm_f32_ex(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
+                int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
+                const float *mask, int split_k, float *asum1, float *asum2, hipStream_t stream);
+
 // elementwise.hip
 int world_im2col(const float *world, int B, int G, int C, int K3, float *xcol, hipStream_t stream);
 int embed_rows(const int64_t *tok, const float *table, int vocab, const float *mask, int rows, int D, float *out,
@@ -64,7 +68,7 @@ struct DecoderArgs {
     const float *datt;                 // [B,M] grad wrt att_sum or NULL
     float *delta, *dzq, *dqt, *dqv;    // [B,T,4H] [B,T,H] [B,T,H] [B,T,H]
     float *dpk_t, *dpk_v;              // [B,L,H] [B,M,H]  score-path key gradients
-    float *dv_t, *dv_v;                // [B,H] per-row energy-vector gradients
+    float *dv_t, *dv_v;                // [H] energy-vector gradients, accumulated with atomics
     float *dh0;                        // [B,H] gradient wrt the bridge pre-activation
 };
 bool decoder_hidden_supported(int h);

@@ -94,6 +94,8 @@ int check_dims(const gscan_dims &d) {
                 d.He);
     GSCAN_CHECK(decoder_hidden_supported(d.H), "dims: decoder_hidden_size %d has no compiled kernel (20 32 64 100)",
                 d.H);
+    GSCAN_CHECK((int64_t)d.B * d.T * 4 * d.H < (1ll << 31) && (int64_t)d.B * d.G * d.G * 4 * d.H < (1ll << 31),
+                "dims: batch too large for 32-bit activation offsets (B=%d T=%d H=%d)", d.B, d.T, d.H);
     GSCAN_CHECK(d.L <= 64, "dims: commands longer than 64 tokens are not supported (L=%d)", d.L);
     GSCAN_CHECK(d.G * d.G <= 64, "dims: grids larger than 8x8 are not supported (G=%d)", d.G);
     const size_t lds = decoder_lds_bytes(d.H, d.L, d.G * d.G, d.conditional != 0, true);
@@ -116,9 +118,12 @@ static inline int mm(hipStream_t st, int M, int N, int K, const float *a, int64_
     return gemm_f32(M, N, K, 1.f, a, sam, sak, b, sbk, sbn, beta, c, ldc, bias, act, mask, 1, st);
 }
 // weight gradient: C[M,N] += A^T . B with the long dimension (rows of the activations) as K
+// bias1/bias2 (optional) += column sums of the activation gradient = sum over K of A(m,k)
 static inline int mm_grad(hipStream_t st, int M, int N, int K, const float *a, int64_t sam, int64_t sak,
-                          const float *b, int64_t sbk, int64_t sbn, float *c, int64_t ldc) {
-    return gemm_f32(M, N, K, 1.f, a, sam, sak, b, sbk, sbn, 1.f, c, ldc, nullptr, 0, nullptr, pick_split(M, N, K), st);
+                          const float *b, int64_t sbk, int64_t sbn, float *c, int64_t ldc, float *bias1 = nullptr,
+                          float *bias2 = nullptr) {
+    return gemm_f32_ex(M, N, K, 1.f, a, sam, sak, b, sbk, sbn, 1.f, c, ldc, nullptr, 0, nullptr, pick_split(M, N, K),
+                       bias1, bias2, st);
 }
 
 #define TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
@@ -253,25 +258,22 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
     a.ds = dS; a.datt = use_aux ? w + ws.datt : nullptr;
     a.delta = w + ws.delta; a.dzq = w + ws.dzq; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
-    a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = w + ws.dv_t; a.dv_v = w + ws.dv_v; a.dh0 = w + ws.dh0;
+    a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = g.txt_energy_w; a.dv_v = g.vis_energy_w;
+    a.dh0 = w + ws.dh0;
     TRY(decoder_run(true, B, H, cond, a, st));
 
     // ---- decoder parameter gradients: dense products over the B*T saved rows
     const float *delta = w + ws.delta, *hprev = w + ws.hprev;
     TRY(mm_grad(st, 4 * H, 3 * H, BT, delta, 1, 4 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H));
-    TRY(mm_grad(st, 4 * H, H, BT, delta, 1, 4 * H, hprev, H, 1, g.dec_w_hh, H));
-    TRY(colsum_add(delta, 4 * H, BT, 4 * H, g.dec_b_ih, g.dec_b_hh, st));
+    TRY(mm_grad(st, 4 * H, H, BT, delta, 1, 4 * H, hprev, H, 1, g.dec_w_hh, H, g.dec_b_ih, g.dec_b_hh));
     TRY(mm_grad(st, H, H, BT, w + ws.dqt, 1, H, hprev, H, 1, g.txt_query_w, H));
     if (cond) {
-        TRY(mm_grad(st, H, H, BT, w + ws.dzq, 1, H, hprev, H, 1, g.q2k_w, 2 * H));
+        TRY(mm_grad(st, H, H, BT, w + ws.dzq, 1, H, hprev, H, 1, g.q2k_w, 2 * H, g.q2k_b));
         TRY(mm_grad(st, H, H, BT, w + ws.dzq, 1, H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H));
-        TRY(colsum_add(w + ws.dzq, H, BT, H, g.q2k_b, nullptr, st));
         TRY(mm_grad(st, H, H, BT, w + ws.dqv, 1, H, w + ws.q2, H, 1, g.vis_query_w, H));
     } else {
         TRY(mm_grad(st, H, H, BT, w + ws.dqv, 1, H, hprev, H, 1, g.vis_query_w, H));
     }
-    TRY(colsum_add(w + ws.dv_t, H, B, H, g.txt_energy_w, nullptr, st));
-    TRY(colsum_add(w + ws.dv_v, H, B, H, g.vis_energy_w, nullptr, st));
 
     // ---- gradients wrt [e | ctx_text | ctx_vis] through the LSTM input and the conditional query
     TRY(mm(st, BT, 3 * H, 4 * H, delta, 4 * H, 1, p.dec_w_ih, 3 * H, 1, dS, 4 * H, 1.f));
@@ -284,8 +286,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     // ---- textual keys and bridge -> encoder outputs / final state
     TRY(mm_grad(st, H, He, BL, w + ws.dpk_t, 1, H, w + ws.enc_out, He, 1, g.txt_key_w, He));
     TRY(mm(st, BL, He, H, w + ws.dpk_t, H, 1, p.txt_key_w, He, 1, w + ws.denc, He));
-    TRY(mm_grad(st, H, He, B, w + ws.dh0, 1, H, w + ws.hN, He, 1, g.bridge_w, He));
-    TRY(colsum_add(w + ws.dh0, H, B, H, g.bridge_b, nullptr, st));
+    TRY(mm_grad(st, H, He, B, w + ws.dh0, 1, H, w + ws.hN, He, 1, g.bridge_w, He, g.bridge_b));
     TRY(mm(st, B, He, H, w + ws.dh0, H, 1, p.bridge_w, He, 1, w + ws.dhN, He));
 
     // ---- command encoder BPTT and its parameter gradients
@@ -297,9 +298,9 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         float *gw_ih = dir ? g.enc_w_ih_rev : g.enc_w_ih, *gw_hh = dir ? g.enc_w_hh_rev : g.enc_w_hh;
         float *gb_ih = dir ? g.enc_b_ih_rev : g.enc_b_ih, *gb_hh = dir ? g.enc_b_hh_rev : g.enc_b_hh;
         const float *w_ih = dir ? p.enc_w_ih_rev : p.enc_w_ih;
-        TRY(mm_grad(st, 4 * He, He, BL, dl, 1, ldd, w + ws.enc_hprev + dir * He, (int64_t)D * He, 1, gw_hh, He));
+        TRY(mm_grad(st, 4 * He, He, BL, dl, 1, ldd, w + ws.enc_hprev + dir * He, (int64_t)D * He, 1, gw_hh, He, gb_ih,
+                    gb_hh));
         TRY(mm_grad(st, 4 * He, E, BL, dl, 1, ldd, w + ws.xe, E, 1, gw_ih, E));
-        TRY(colsum_add(dl, ldd, BL, 4 * He, gb_ih, gb_hh, st));
         TRY(mm(st, BL, E, 4 * He, dl, ldd, 1, w_ih, E, 1, w + ws.dxe, E, dir ? 1.f : 0.f));
     }
     TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));
@@ -314,8 +315,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         const int kk[3] = {C, 25 * C, d.K3 * d.K3 * C};
         int off = 0;
         for (int i = 0; i < 3; ++i) {
-            TRY(mm_grad(st, Co, kk[i], BM_, w + ws.dfeat + i * Co, 1, F, w + ws.xcol + off, Ktot, 1, gw[i], kk[i]));
-            TRY(colsum_add(w + ws.dfeat + i * Co, F, BM_, Co, gb[i], nullptr, st));
+            TRY(mm_grad(st, Co, kk[i], BM_, w + ws.dfeat + i * Co, 1, F, w + ws.xcol + off, Ktot, 1, gw[i], kk[i],
+                        gb[i]));
             off += kk[i];
         }
     }
