@@ -49,6 +49,15 @@ __device__ __forceinline__ float tanhf_(float x) {
     return copysignf(t, x);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)), i.e. every barrier would wait for the global STORES of saved activations issued in
+// that phase (hundreds of cycles each, several times per time step in the recurrent kernels).  Data that
+// crosses threads inside those kernels goes through LDS, so lgkmcnt(0) + s_barrier is sufficient; values
+// loaded from global memory are still guarded by the compiler's own waits at their first use.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Wave-wide (64-lane) reductions on the DPP datapath instead of ds_bpermute shuffles: four in-row steps
 // (quad_perm, quad_perm, row_ror:4, row_ror:8) leave each 16-lane row holding its own total, row_bcast:15 /
 // row_bcast:31 fold the rows into lane 63, and v_readlane broadcasts it.  All 64 lanes must be active.

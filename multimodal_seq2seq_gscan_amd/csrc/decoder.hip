@@ -46,6 +46,15 @@ __device__ __forceinline__ float dot_reg_lds(const float (&w)[H], const float *v
 }
 
 
+// Diagnostic phase stamps (off unless DecoderArgs::stamps is set): thread 0 of workgroup 0 adds the cycles since
+// the previous stamp to slot i.  Shares, not absolute times, are what to read from them.
+#define GSCAN_STAMP(i)                                                         \
+    if (a.stamps && blockIdx.x == 0 && tid == 0) {                             \
+        const long long now_ = clock64();                                      \
+        stamp_acc[i] += (float)(now_ - stamp_prev);                            \
+        stamp_prev = now_;                                                     \
+    }
+
 // sum_{m<n} al[m] * mat[m*stride]: four independent chains so the LDS reads issue back to back
 __device__ __forceinline__ float weighted_sum(const float *al, const float *mat, int stride, int n) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -124,7 +133,9 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
     float *vec = smem + o.vec;
     float *h_s = vec + V_H * H, *qt_s = vec + V_QT * H, *zq_s = vec + V_ZQ * H, *q2_s = vec + V_Q2 * H,
           *qv_s = vec + V_QV * H, *vt_s = vec + V_VT * H, *vv_s = vec + V_VV * H, *gate_s = vec + V_GATE * H;
-    float *sc_s = vec + V_END * H, *al_s = vec + V_END * H + 64;
+    float *sc_s = vec + V_END * H, *al_s = vec + V_END * H + 64, *stamp_acc = vec + V_END * H + 192;
+    long long stamp_prev = a.stamps ? clock64() : 0;
+    if (tid < 16) stamp_acc[tid] = 0.f;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
 
@@ -160,9 +171,10 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
     }
     float c = (tid < H) ? a.hprev[(int64_t)b * T * H + tid] : 0.f;   // c0 = h0 (seq2seq_model.py:494-504)
     float att_acc = 0.f;                                              // wave 0, lane m
-    __syncthreads();
+    lds_barrier();
 
     for (int t = 0; t < T; ++t) {
+        GSCAN_STAMP(0)
         const unsigned bt = (unsigned)b * T + t;       // 32-bit offsets: B*T*4H < 2^31 is checked on the host
         // gate input from the embedding (global, issued early; consumed in phase G)
         const float ge = (role < 4) ? a.ge[bt * 4 * H + tid] : 0.f;
@@ -176,11 +188,13 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
             else if (COND) zq_s[k] = acc;
             else { qv_s[k] = acc; a.qv[bt * H + k] = acc; }
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(1)
 
         // ---- B: textual scores s_m = v . tanh(q + PK_m), m < len (seq2seq_model.py:129-135) --
         attention_scores<H>(vt_s, qt_s, PKt, len, sc_s, wave, nwave, lane);
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(2)
         if (wave == 0) {
             const float x = (lane < len) ? sc_s[lane] : -INFINITY;
             const float mx = wave_max(x);
@@ -189,7 +203,8 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
             al_s[lane] = al;
             if (lane < L) a.alpha_c[bt * L + lane] = al;
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(3)
 
         // ---- C: textual context and its images under W_ih / W_q2k ----------------------------
         float uc = 0.f;
@@ -204,7 +219,8 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
             a.q2[bt * H + k] = q;
         }
         if (COND) {
-            __syncthreads();
+            lds_barrier();
+            GSCAN_STAMP(4)
             // ---- D: visual query from the conditional query ---------------------------------
             if (role == 6) {
                 const float acc = dot_reg_lds<H>(w, q2_s);
@@ -212,11 +228,13 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
                 a.qv[bt * H + k] = acc;
             }
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(5)
 
         // ---- E: visual scores over all M cells (no mask: every row has M memories) -----------
         attention_scores<H>(vv_s, qv_s, PKv, M, sc_s, wave, nwave, lane);
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(6)
         if (wave == 0) {
             const float x = (lane < M) ? sc_s[lane] : -INFINITY;
             const float mx = wave_max(x);
@@ -226,7 +244,8 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
             if (lane < M) a.alpha_s[bt * M + lane] = al;
             att_acc += al;                                     // seq2seq_model.py:479,490
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(7)
 
         // ---- F+G: visual context, gate pre-activations, activations --------------------------
         if (role < 4) {
@@ -238,7 +257,8 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
         } else if (role == 4) {
             a.s[bt * 4 * H + 2 * H + k] = weighted_sum(al_s, PKv + k, H, M);
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(8)
 
         // ---- H: cell update (seq2seq_model.py:414) ---------------------------------------------
         if (tid < H) {
@@ -250,9 +270,11 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
             a.s[bt * 4 * H + 3 * H + tid] = h;
             if (t + 1 < T) a.hprev[(bt + 1) * H + tid] = h;
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(9)
     }
     if (wave == 0 && lane < M) a.att_sum[(int64_t)b * M + lane] = att_acc;
+    if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_acc[tid];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -275,7 +297,10 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
     float *dh_s = vec + V_H * H, *qt_s = vec + V_QT * H, *q2_s = vec + V_Q2 * H, *qv_s = vec + V_QV * H,
           *vt_s = vec + V_VT * H, *vv_s = vec + V_VV * H, *dqv_s = vec + V_ZQ * H, *d_s = vec + V_D * H,
           *exc_s = vec + V_EXC * H, *exs_s = vec + V_EXS * H, *part_s = vec + V_PART * H;
-    float *sc_s = vec + V_END * H, *al_s = vec + V_END * H + 64, *datt_s = vec + V_END * H + 128;
+    float *sc_s = vec + V_END * H, *al_s = vec + V_END * H + 64, *datt_s = vec + V_END * H + 128,
+          *stamp_acc = vec + V_END * H + 192;
+    long long stamp_prev = a.stamps ? clock64() : 0;
+    if (tid < 16) stamp_acc[tid] = 0.f;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
     const int nchunk = min(6, (int)blockDim.x / H);        // (chunk, k) ownership of key pairs; part_s holds 6H
@@ -308,9 +333,10 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
         }
     }
     float dc = 0.f, dvv_acc = 0.f, dvt_acc = 0.f;
-    __syncthreads();
+    lds_barrier();
 
     for (int t = T - 1; t >= 0; --t) {
+        GSCAN_STAMP(0)
         const unsigned bt = (unsigned)b * T + t;
         // ---- 1: LSTM cell backward -----------------------------------------------------------
         if (tid < H) {
@@ -336,7 +362,8 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
             qv_s[tid] = a.qv[bt * H + tid];
             if (COND) q2_s[tid] = a.q2[bt * H + tid];
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(1)
 
         // ---- 2: d alpha_vis[m] = delta . U_vis[m] + dctx_vis(ext) . PK_vis[m] + d att_sum[m] ---
         for (int m0 = wave; m0 < M; m0 += 4 * nwave) {
@@ -359,14 +386,16 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(2)
         if (wave == 0) {   // softmax backward: ds = alpha * (dalpha - sum alpha dalpha)
             const float al = (lane < M) ? a.alpha_s[bt * M + lane] : 0.f;
             const float da = (lane < M) ? sc_s[lane] : 0.f;
             const float dot = wave_sum(al * da);
             al_s[lane] = al * (da - dot);
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(3)
 
         // ---- 3: through tanh(q + PK) of the visual scores; (chunk,k) owns pairs (m,k) ----------
         if (seg < nchunk) {
@@ -380,7 +409,8 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
             }
             part_s[seg * H + k] = pdq;
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(4)
         if (tid < H) {
             float dq = 0.f;
             for (int cch = 0; cch < nchunk; ++cch) dq += part_s[cch * H + tid];
@@ -388,7 +418,8 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
             a.dqv[bt * H + tid] = dq;
             if (!COND) d_s[5 * H + tid] = dq;               // visual query came straight from h
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(5)
 
         // ---- 4: conditional query: dq2 = W_qv^T dqv, through tanh ------------------------------
         if (COND) {
@@ -399,7 +430,8 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
                 d_s[5 * H + k] = dz;
                 a.dzq[bt * H + k] = dz;
             }
-            __syncthreads();
+            lds_barrier();
+            GSCAN_STAMP(6)
         }
 
         // ---- 5: d alpha_text[m] = delta . U_text[m] + dzq . U2_text[m] + dctx_text(ext) . PK_text[m]
@@ -426,14 +458,16 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(7)
         if (wave == 0) {
             const float al = (lane < len) ? a.alpha_c[bt * L + lane] : 0.f;
             const float da = (lane < len) ? sc_s[lane] : 0.f;
             const float dot = wave_sum(al * da);
             al_s[lane] = al * (da - dot);
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(8)
 
         // ---- 6: through tanh(q + PK) of the textual scores -------------------------------------
         if (seg < nchunk) {
@@ -447,27 +481,31 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
             }
             part_s[seg * H + k] = pdq;
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(9)
         if (tid < H) {
             float dq = 0.f;
             for (int cch = 0; cch < nchunk; ++cch) dq += part_s[cch * H + tid];
             d_s[4 * H + tid] = dq;
             a.dqt[bt * H + tid] = dq;
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(10)
 
         // ---- 7: dh_{t-1} = [W_hh | W_qt | W_q2k_h or W_qv]^T . [delta | dqt | dzq or dqv] ------
         float part = 0.f;
         if (seg < 6) part = dot_reg_lds<H>(wt, d_s + seg * H);
         if (seg < 6) part_s[seg * H + k] = part;            // phase 6's partials were consumed before the last barrier
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(11)
         if (tid < H) {
             float dh = 0.f;
 #pragma unroll
             for (int sgi = 0; sgi < 6; ++sgi) dh += part_s[sgi * H + tid];
             dh_s[tid] = dh;
         }
-        __syncthreads();
+        lds_barrier();
+        GSCAN_STAMP(12)
     }
 
     // ---- epilogue: initial-state gradient through the bridge tanh, key and energy gradients ----
@@ -477,22 +515,23 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
     }
     for (int i = tid; i < M * H; i += blockDim.x) a.dpk_v[(int64_t)b * M * H + i] = dPKv[i];
     for (int i = tid; i < L * H; i += blockDim.x) a.dpk_t[(int64_t)b * L * H + i] = (i / H < len) ? dPKt[i] : 0.f;
-    __syncthreads();
+    lds_barrier();
     if (seg < nchunk) part_s[seg * H + k] = dvv_acc;
-    __syncthreads();
+    lds_barrier();
     if (tid < H) {
         float x = 0.f;
         for (int cch = 0; cch < nchunk; ++cch) x += part_s[cch * H + tid];
         atomicAdd(&a.dv_v[tid], x);
     }
-    __syncthreads();
+    lds_barrier();
     if (seg < nchunk) part_s[seg * H + k] = dvt_acc;
-    __syncthreads();
+    lds_barrier();
     if (tid < H) {
         float x = 0.f;
         for (int cch = 0; cch < nchunk; ++cch) x += part_s[cch * H + tid];
         atomicAdd(&a.dv_t[tid], x);
     }
+    if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_acc[tid];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_fwd_ke
         }
         float c = 0.f;
         if (is_unit) h_s[j] = 0.f;
-        __syncthreads();
+        lds_barrier();
         for (int s = 0; s < len; ++s) {
             const int t = dir ? (len - 1 - s) : s;
             const int64_t row = ((int64_t)b * L + t) * D + dir;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_fwd_ke
                 gates[row * 4 * HE + j] = a;
             }
             if (is_unit) hprev[row * HE + j] = h_s[j];
-            __syncthreads();
+            lds_barrier();
             if (is_unit) {
                 const float ig = gate_s[j], fg = gate_s[HE + j], gg = gate_s[2 * HE + j], og = gate_s[3 * HE + j];
                 c = fg * c + ig * gg;
@@ -86,13 +86,13 @@ __global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_fwd_ke
                 float *o = out + ((int64_t)b * L + t) * HE + j;
                 *o = dir ? (*o + h) : h;          // directions are summed (seq2seq_model.py:77-79)
             }
-            __syncthreads();
+            lds_barrier();
         }
         if (is_unit) {
             float *hf = h_final + (int64_t)b * HE + j;
             *hf = dir ? (*hf + h_s[j]) : h_s[j];  // final states are summed too (:80-81)
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_bwd_ke
     }
     float dc = 0.f;
     if (is_unit) dh_s[tid] = d_h_final[(int64_t)b * HE + tid];
-    __syncthreads();
+    lds_barrier();
     for (int s = len - 1; s >= 0; --s) {
         const int t = dir ? (len - 1 - s) : s;
         const int64_t row = ((int64_t)b * L + t) * D + dir;
@@ -147,11 +147,11 @@ __global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_bwd_ke
             float *dg_out = delta + row * 4 * HE;
             dg_out[tid] = di; dg_out[HE + tid] = df; dg_out[2 * HE + tid] = dg; dg_out[3 * HE + tid] = d_o;
         }
-        __syncthreads();
+        lds_barrier();
         if (active) part_s[tid] = dot_lds<HE>(wt, delta_s + seg * HE);
-        __syncthreads();
+        lds_barrier();
         if (is_unit) dh_s[tid] = (part_s[tid] + part_s[HE + tid]) + (part_s[2 * HE + tid] + part_s[3 * HE + tid]);
-        __syncthreads();
+        lds_barrier();
     }
 }
 

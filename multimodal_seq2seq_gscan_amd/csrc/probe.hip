@@ -17,6 +17,7 @@ struct ProbeState {
     double flops = 0.0;
 };
 static bool g_probe_on = false;
+static bool g_stamps_on = false;
 static ProbeState g_probe[P_COUNT];
 constexpr size_t kMaxPairs = 1 << 15;
 
@@ -41,8 +42,12 @@ ProbeScope::~ProbeScope() {
     ++p.used;
 }
 
+bool probe_stamps_enabled() { return g_stamps_on; }
+
+// bit 0: HIP-event probes around kernel families; bit 1: in-kernel phase stamps of the decoder kernels
 int probe_enable(int on) {
-    g_probe_on = on != 0;
+    g_probe_on = (on & 1) != 0;
+    g_stamps_on = (on & 2) != 0;
     return 0;
 }
 int probe_reset() {

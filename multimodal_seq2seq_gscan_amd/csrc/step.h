@@ -70,6 +70,7 @@ struct DecoderArgs {
     float *dpk_t, *dpk_v;              // [B,L,H] [B,M,H]  score-path key gradients
     float *dv_t, *dv_v;                // [H] energy-vector gradients, accumulated with atomics
     float *dh0;                        // [B,H] gradient wrt the bridge pre-activation
+    float *stamps;                     // diagnostics: [2][16] per-phase cycle sums of workgroup 0, or NULL
 };
 bool decoder_hidden_supported(int h);
 size_t decoder_lds_bytes(int H, int L, int M, bool cond, bool backward);
@@ -84,6 +85,7 @@ struct ProbeScope {
     hipStream_t st_;
 };
 int probe_enable(int on);
+bool probe_stamps_enabled();
 int probe_reset();
 int probe_read(const char *name, double *total_ms, double *flops, int64_t *launches);
 
@@ -92,7 +94,7 @@ struct WorkspaceSlot { const char *name; int64_t offset, count; };
 struct Workspace {
     int64_t xcol, feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, dlogits, dpreo,
-        dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat;
+        dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps;
     WorkspaceSlot slot[64];
     int nslots;
     int64_t total_floats;

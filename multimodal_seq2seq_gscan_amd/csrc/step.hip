@@ -79,6 +79,7 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(enc_delta, B * L * D * 4 * He);
     SLOT(dxe, B * L * E);
     SLOT(dfeat, B * M * F);
+    SLOT(stamps, 64);
 #undef SLOT
     ws->nslots = n;
     ws->total_floats = p;
@@ -197,6 +198,7 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     a.hprev = w + ws.hprev; a.s = w + ws.S; a.cells = w + ws.cells; a.gates = w + ws.gates;
     a.alpha_c = w + ws.alpha_c; a.alpha_s = w + ws.alpha_s;
     a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
+    a.stamps = probe_stamps_enabled() ? w + ws.stamps : nullptr;
     TRY(decoder_run(false, B, H, cond, a, st));
 
     // ---- output head hoisted out of the loop (seq2seq_model.py:421-424), W_o2h columns = [e|h|ctx_t|ctx_v]
@@ -260,6 +262,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     a.delta = w + ws.delta; a.dzq = w + ws.dzq; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
     a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = g.txt_energy_w; a.dv_v = g.vis_energy_w;
     a.dh0 = w + ws.dh0;
+    a.stamps = probe_stamps_enabled() ? w + ws.stamps + 16 : nullptr;
     TRY(decoder_run(true, B, H, cond, a, st));
 
     // ---- decoder parameter gradients: dense products over the B*T saved rows
