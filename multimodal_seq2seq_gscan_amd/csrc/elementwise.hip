@@ -74,33 +74,42 @@ int embed_rows(const int64_t *tok, const float *table, int vocab, const float *m
 // ------------------------------------------------------------------------------------------
 // dtable[v, :] += sum over rows with tok[row] == v, v != pad of g[row, :] * mask[row, :]
 // (the padding row of nn.Embedding(padding_idx=...) never receives gradient).
-// One workgroup per (vocab entry, row chunk); in-register sum, one atomic per column.
+// Vocabularies are tiny (6..21 entries), so each workgroup sums its 64 rows into a private
+// [vocab, D] table in LDS (ds_add_f32; a wave works on ONE row at a time, so its 64 lanes hit
+// 64 different columns) and flushes the table with one global atomic per touched entry.
 // ------------------------------------------------------------------------------------------
+constexpr int kEmbedRows = 64;
 __global__ void embed_grad_kernel(const int64_t *__restrict__ tok, const float *__restrict__ g, int64_t ldg,
-                                  const float *__restrict__ mask, int rows, int D, int pad,
-                                  float *__restrict__ dtable, int rows_per_block) {
-    const int v = blockIdx.x;
-    if (v == pad) return;
-    const int r0 = blockIdx.y * rows_per_block;
-    const int r1 = min(rows, r0 + rows_per_block);
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float acc = 0.f;
-        for (int r = r0; r < r1; ++r) {
-            if (tok[r] == v) {
-                float x = g[(int64_t)r * ldg + d];
-                if (mask) x *= mask[(int64_t)r * D + d];
-                acc += x;
-            }
+                                  const float *__restrict__ mask, int rows, int D, int vocab, int pad,
+                                  float *__restrict__ dtable) {
+    extern __shared__ float table[];
+    const int n = vocab * D;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) table[i] = 0.f;
+    __syncthreads();
+    const int r0 = blockIdx.x * kEmbedRows, r1 = min(rows, r0 + kEmbedRows);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    for (int r = r0 + wave; r < r1; r += nwave) {
+        const int64_t t = tok[r];
+        if (t < 0 || t >= vocab || t == pad) continue;
+        for (int d = lane; d < D; d += 64) {
+            float x = g[(int64_t)r * ldg + d];
+            if (mask) x *= mask[(int64_t)r * D + d];
+            atomicAdd(&table[t * D + d], x);
         }
-        if (acc != 0.f) atomicAdd(&dtable[(int64_t)v * D + d], acc);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float x = table[i];
+        if (x != 0.f) atomicAdd(&dtable[i], x);
     }
 }
 
 int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mask, int rows, int D, int vocab,
                int pad, float *dtable, hipStream_t stream) {
-    const int rpb = 256;
-    hipLaunchKernelGGL(embed_grad_kernel, dim3(vocab, cdiv(rows, rpb)), dim3(128), 0, stream, tok, g, ldg, mask,
-                       rows, D, pad, dtable, rpb);
+    const size_t lds = (size_t)vocab * D * sizeof(float);
+    GSCAN_CHECK(lds <= 64 * 1024, "embed_grad: vocabulary table of %d x %d floats does not fit in LDS", vocab, D);
+    hipLaunchKernelGGL(embed_grad_kernel, dim3(cdiv(rows, kEmbedRows)), dim3(256), lds, stream, tok, g, ldg, mask,
+                       rows, D, vocab, pad, dtable);
     GSCAN_LAUNCHED("embed_grad_kernel");
     return 0;
 }
@@ -161,28 +170,59 @@ int colsum_add(const float *x, int64_t ld, int rows, int N, float *out1, float *
 }
 
 // ------------------------------------------------------------------------------------------
-// Value-path gradient of additive attention (seq2seq_model.py:138, values = projected keys):
-//   dkeys[b, m, :] (+)= sum_t alpha[b, t, m] * dctx[b, t, :]
-// alpha [B,T,Mld] (first M used), dctx rows at dctx[(b*T+t)*ldd + 0:H], dkeys [B,M,H].
-// One workgroup per batch row; thread owns (m, k) pairs and walks t.
+// Value-path gradient of additive attention (seq2seq_model.py:138, values = projected keys), both
+// attentions in one launch:   dkeys[b, m, :] += sum_t alpha[b, t, m] * dctx[b, t, :]
+// blockIdx.y = 0: textual (alpha_c [B,T,L], dctx = dS[:, H:2H]); 1: visual (alpha_s [B,T,M], dS[:, 2H:3H]).
+// One workgroup per (row, attention); alpha[b] and dctx[b] are staged in LDS in chunks of 32 steps.
 // ------------------------------------------------------------------------------------------
-__global__ void attn_value_grad_kernel(const float *__restrict__ alpha, int Mld, const float *__restrict__ dctx,
-                                       int64_t ldd, int T, int M, int H, float *__restrict__ dkeys, int accumulate) {
-    const int b = blockIdx.x;
-    for (int idx = threadIdx.x; idx < M * H; idx += blockDim.x) {
-        const int m = idx / H, k = idx % H;
-        float acc = 0.f;
-        for (int t = 0; t < T; ++t)
-            acc += alpha[((int64_t)b * T + t) * Mld + m] * dctx[((int64_t)b * T + t) * ldd + k];
-        float *p = dkeys + ((int64_t)b * M + m) * H + k;
-        *p = accumulate ? (*p + acc) : acc;
+constexpr int kAvgSteps = 32;
+__global__ void attn_value_grad_kernel(const float *__restrict__ alpha_c, const float *__restrict__ alpha_s,
+                                       const float *__restrict__ ds, int T, int L, int M, int H,
+                                       float *__restrict__ dpk_t, float *__restrict__ dpk_v) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, which = blockIdx.y;
+    const int Mx = which ? M : L;
+    const float *alpha = (which ? alpha_s : alpha_c) + (int64_t)b * T * Mx;
+    const float *dctx = ds + (int64_t)b * T * 4 * H + (which ? 2 * H : H);
+    float *dkeys = (which ? dpk_v : dpk_t) + (int64_t)b * Mx * H;
+    float *al_s = sm, *dc_s = sm + kAvgSteps * Mx;
+    const int npair = Mx * H;
+    constexpr int kPerThread = 16;                   // pairs per thread (host checks Mx*H <= 16*blockDim)
+    float acc[kPerThread];
+#pragma unroll
+    for (int i = 0; i < kPerThread; ++i) acc[i] = 0.f;
+    for (int t0 = 0; t0 < T; t0 += kAvgSteps) {
+        const int nt = min(kAvgSteps, T - t0);
+        for (int i = threadIdx.x; i < nt * Mx; i += blockDim.x) al_s[i] = alpha[(int64_t)t0 * Mx + i];
+        for (int i = threadIdx.x; i < nt * H; i += blockDim.x)
+            dc_s[i] = dctx[(int64_t)(t0 + i / H) * 4 * H + i % H];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            const int idx = threadIdx.x + i * blockDim.x;
+            if (idx < npair) {
+                const int m = idx / H, k = idx % H;
+                float a = acc[i];
+                for (int t = 0; t < nt; ++t) a = fmaf(al_s[t * Mx + m], dc_s[t * H + k], a);
+                acc[i] = a;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < kPerThread; ++i) {
+        const int idx = threadIdx.x + i * blockDim.x;
+        if (idx < npair) dkeys[idx] += acc[i];
     }
 }
 
-int attn_value_grad(const float *alpha, int Mld, const float *dctx, int64_t ldd, int B, int T, int M, int H,
-                    float *dkeys, int accumulate, hipStream_t stream) {
-    hipLaunchKernelGGL(attn_value_grad_kernel, dim3(B), dim3(256), 0, stream, alpha, Mld, dctx, ldd, T, M, H, dkeys,
-                       accumulate);
+int attn_value_grad(const float *alpha_c, const float *alpha_s, const float *ds, int B, int T, int L, int M, int H,
+                    float *dpk_t, float *dpk_v, hipStream_t stream) {
+    const int mx = std::max(L, M);
+    GSCAN_CHECK(mx * H <= 16 * 256, "attn_value_grad: %d x %d key elements per row exceed the kernel's tile", mx, H);
+    const size_t lds = (size_t)kAvgSteps * (mx + H) * sizeof(float);
+    hipLaunchKernelGGL(attn_value_grad_kernel, dim3(B, 2), dim3(256), lds, stream, alpha_c, alpha_s, ds, T, L, M, H,
+                       dpk_t, dpk_v);
     GSCAN_LAUNCHED("attn_value_grad_kernel");
     return 0;
 }
@@ -264,6 +304,80 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)std::min<size_t>(cdiv((n + 3) / 4, 256), 2048)), dim3(256), 0,
                        stream, out, n, p, 1.0f / (1.0f - p), seed, stream_id);
     GSCAN_LAUNCHED("dropout_mask_kernel");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Step prologue: everything that only rearranges parameters or gathers embeddings, in ONE launch.
+//   seg 0  bsum[4H]            = dec_b_ih + dec_b_hh
+//   seg 1  wo_perm[H,4H]       = W_o2h with its columns [e|h|ctx_t|ctx_v] reordered to S order [e|ctx_t|ctx_v|h]
+//   seg 2  wih_stack[D*4He,E]  = [W_ih_fwd ; W_ih_rev]   (one GEMM then gives dXe for both directions)
+//   seg 3  dwo_perm[H,4H]      = 0   (gradient scratch of wo_perm, filled by a split-K GEMM in backward)
+//   seg 4  xe[B*L,E]           = dropout(Emb_enc[commands])      seq2seq_model.py:58-59
+//   seg 5  S[:, 0:H]           = dropout(Emb_dec[targets])       seq2seq_model.py:383-384
+// ------------------------------------------------------------------------------------------
+
+__global__ void prologue_kernel(PrologueArgs a) {
+    const int64_t total = a.end[5];
+    const int H = a.H;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        if (idx < a.end[0]) {
+            a.bsum[idx] = a.b_ih[idx] + a.b_hh[idx];
+        } else if (idx < a.end[1]) {
+            const int64_t i = idx - a.end[0];
+            const int row = (int)(i / (4 * H)), col = (int)(i % (4 * H));     // col in S order
+            const int seg = col / H, k = col % H;
+            const int src = (seg == 0 ? 0 : seg == 1 ? 2 * H : seg == 2 ? 3 * H : H) + k;
+            a.wo_perm[i] = a.w_o2h[(int64_t)row * 4 * H + src];
+        } else if (idx < a.end[2]) {
+            const int64_t i = idx - a.end[1];
+            const int64_t per = (int64_t)4 * a.He * a.E;
+            a.wih_stack[i] = (i < per) ? a.w_ih_f[i] : a.w_ih_r[i - per];
+        } else if (idx < a.end[3]) {
+            a.dwo_perm[idx - a.end[2]] = 0.f;
+        } else if (idx < a.end[4]) {
+            const int64_t i = idx - a.end[3];
+            const int64_t row = i / a.E;
+            const int d = (int)(i % a.E);
+            const int64_t t = a.commands[row];
+            float v = (t >= 0 && t < a.Vi) ? a.enc_emb[t * a.E + d] : 0.f;
+            if (a.mask_enc) v *= a.mask_enc[i];
+            a.xe[i] = v;
+        } else {
+            const int64_t i = idx - a.end[4];
+            const int64_t row = i / H;
+            const int d = (int)(i % H);
+            const int64_t t = a.targets[row];
+            float v = (t >= 0 && t < a.V) ? a.dec_emb[t * H + d] : 0.f;
+            if (a.mask_dec) v *= a.mask_dec[i];
+            a.S[row * 4 * H + d] = v;
+        }
+    }
+}
+
+int step_prologue(const PrologueArgs &args, hipStream_t stream) {
+    const int64_t total = args.end[5];
+    hipLaunchKernelGGL(prologue_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, stream,
+                       args);
+    GSCAN_LAUNCHED("prologue_kernel");
+    return 0;
+}
+
+// g_w_o2h[row, original column] += dwo_perm[row, S-order column]
+__global__ void unpermute_add_kernel(const float *__restrict__ dwo_perm, float *__restrict__ g_w_o2h, int H) {
+    const int n = H * 4 * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int row = i / (4 * H), col = i % (4 * H);
+        const int seg = col / H, k = col % H;
+        const int dst = (seg == 0 ? 0 : seg == 1 ? 2 * H : seg == 2 ? 3 * H : H) + k;
+        g_w_o2h[(int64_t)row * 4 * H + dst] += dwo_perm[i];
+    }
+}
+
+int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream) {
+    hipLaunchKernelGGL(unpermute_add_kernel, dim3(cdiv(H * 4 * H, 256)), dim3(256), 0, stream, dwo_perm, g_w_o2h, H);
+    GSCAN_LAUNCHED("unpermute_add_kernel");
     return 0;
 }
 

@@ -28,17 +28,9 @@ constexpr int LD_K = BK + 2;    // image [row][k]: fragment read banks (2*row + 
 constexpr int LD_R = BM + 16;   // image [k][row]: k rows 16 banks apart -> 32-lane halves conflict-free
 constexpr int TILE_FLOATS = (BK * LD_R > BM * LD_K) ? BK * LD_R : BM * LD_K;
 
-struct GemmArgs {
-    int M, N, K;
-    float alpha, beta;
-    const float *a; int64_t sam, sak;
-    const float *b; int64_t sbk, sbn;
-    float *c; int64_t ldc;
-    const float *bias; int act; const float *mask;
-    int k_chunk;        // K range per blockIdx.z
-    int atomic;         // split-K: accumulate with atomics
-    float *asum1, *asum2;   // optional: += sum over k of A(m,k) (bias gradients), done by blockIdx.x == 0
-};
+// Independent products are launched together as one grid ("grouped GEMM"): the step issues ~45 small
+// products, each of which alone cannot fill 256 CUs and costs a launch; workgroup -> (problem, tile, k-slice)
+// is a scan over at most kMaxGroup prefix sums held in kernel arguments.
 
 // One [64 rows x 32 k] panel = 8 elements per thread.  element(row,k) = src[row*s_row + k*s_k].
 // k_contig (k stride 1): threads run along k first, image [row][k]; else along rows, image [k][row].
@@ -70,19 +62,27 @@ __device__ __forceinline__ void panel_store(float *lds, const float (&v)[8], boo
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxGroup; ++i)
+        if (i < grp.count && (int)blockIdx.x >= grp.p[i].tile_begin) pi = i;
+    const GemmProblem &g = grp.p[pi];
+    const int local = blockIdx.x - g.tile_begin;
+    const int bz = local / g.tiles_mn, rem = local % g.tiles_mn;
+    const int by = rem / g.tiles_n, bx = rem % g.tiles_n;
     __shared__ float lds_a[2][TILE_FLOATS];
     __shared__ float lds_b[2][TILE_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.k_chunk;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
     const bool a_kc = (g.sak == 1), b_kc = (g.sbk == 1);
     const int a_sr = a_kc ? LD_K : 1, a_sk = a_kc ? 1 : LD_R;
     const int b_sr = b_kc ? LD_K : 1, b_sk = b_kc ? 1 : LD_R;
-    const bool do_asum = g.asum1 != nullptr && blockIdx.x == 0;
+    const bool do_asum = g.asum1 != nullptr && bx == 0;
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                     if (g.bias) v += g.bias[col];
                     if (g.act == 1) v = fmaxf(v, 0.f);
                     else if (g.act == 2) v = tanhf_(v);
+                    else if (g.act == 3 && g.gate[(int64_t)row * g.ldc + col] == 0.f) v = 0.f;   // ReLU backward
                     if (g.mask) v *= g.mask[(int64_t)row * g.ldc + col];
                     *cp = v;
                 }
@@ -166,33 +167,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
-int gemm_f32_ex(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
-                int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
-                const float *mask, int split_k, float *asum1, float *asum2, hipStream_t stream) {
-    GSCAN_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem %dx%dx%d", M, N, K);
-    GSCAN_CHECK(a && b && c, "gemm: null operand");
-    GSCAN_CHECK(act >= 0 && act <= 2, "gemm: unknown activation %d", act);
+void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sak, const float *b, int64_t sbk,
+                    int64_t sbn, float *c, int64_t ldc, float beta, const float *bias, int act, const float *mask,
+                    int split_k, float *asum1, float *asum2, const float *gate, float alpha) {
+    if (bad_) return;
+    if (grp_.count >= kMaxGroup || M <= 0 || N <= 0 || K <= 0 || !a || !b || !c || act < 0 || act > 3 ||
+        (act == 3 && !gate)) {
+        bad_ = true;
+        set_error("gemm batch: bad problem %d (%dx%dx%d act=%d) or more than %d problems", grp_.count, M, N, K, act,
+                  kMaxGroup);
+        return;
+    }
     if (split_k < 1) split_k = 1;
     int chunk = cdiv(K, split_k);
     chunk = cdiv(chunk, BK) * BK;
     split_k = cdiv(K, chunk);
-    if (split_k > 1)
-        GSCAN_CHECK(beta == 1.f && act == 0 && !bias && !mask,
-                    "gemm: split-K needs beta=1 and no epilogue (got beta=%g act=%d)", beta, act);
-    GemmArgs g{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, chunk, split_k > 1 ? 1 : 0,
-               asum1, asum2};
-    dim3 grid(cdiv(N, BN), cdiv(M, BM), split_k);
-    ProbeScope probe(P_GEMM, stream, 2.0 * M * N * K);
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
-    GSCAN_LAUNCHED("gemm_f32_kernel");
+    if (split_k > 1 && !(beta == 1.f && act == 0 && !bias && !mask)) {
+        bad_ = true;
+        set_error("gemm batch: split-K needs beta=1 and no epilogue (problem %d, beta=%g act=%d)", grp_.count, beta, act);
+        return;
+    }
+    GemmProblem &p = grp_.p[grp_.count++];
+    p = GemmProblem{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, gate, chunk,
+                    split_k > 1 ? 1 : 0, asum1, asum2, cdiv(N, BN), cdiv(N, BN) * cdiv(M, BM), tiles_};
+    tiles_ += p.tiles_mn * split_k;
+    flops_ += 2.0 * M * N * K;
+}
+
+int GemmBatch::launch(hipStream_t stream) {
+    if (bad_) return 1;
+    if (grp_.count == 0) return 0;
+    ProbeScope probe(P_GEMM, stream, flops_);
+    hipLaunchKernelGGL(gemm_group_kernel, dim3(tiles_), dim3(256), 0, stream, grp_);
+    GSCAN_LAUNCHED("gemm_group_kernel");
     return 0;
 }
 
 int gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
              int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
              const float *mask, int split_k, hipStream_t stream) {
-    return gemm_f32_ex(M, N, K, alpha, a, sam, sak, b, sbk, sbn, beta, c, ldc, bias, act, mask, split_k, nullptr,
-                       nullptr, stream);
+    GSCAN_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem %dx%dx%d", M, N, K);
+    GSCAN_CHECK(a && b && c, "gemm: null operand");
+    GSCAN_CHECK(act >= 0 && act <= 2, "gemm: unknown activation %d", act);
+    GemmBatch batch;
+    batch.add(M, N, K, a, sam, sak, b, sbk, sbn, c, ldc, beta, bias, act, mask, split_k, nullptr, nullptr, nullptr,
+              alpha);
+    return batch.launch(stream);
 }
 
 }  // namespace gscan

@@ -8,7 +8,8 @@
 namespace gscan {
 
 
-__global__ void log_softmax_kernel(const float *__restrict__ x, float *__restrict__ y, int rows, int n) {
+__global__ void log_softmax_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ y2,
+                                   int rows, int n) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const float *xr = x + (int64_t)r * n;
@@ -19,6 +20,10 @@ __global__ void log_softmax_kernel(const float *__restrict__ x, float *__restric
     const float lse = mx + logf(s);
     float *yr = y + (int64_t)r * n;
     for (int j = 0; j < n; ++j) yr[j] = xr[j] - lse;
+    if (y2) {                                    // second copy (the caller's output next to the saved one)
+        float *y2r = y2 + (int64_t)r * n;
+        for (int j = 0; j < n; ++j) y2r[j] = xr[j] - lse;
+    }
 }
 
 // dx = dy - exp(y) * sum(dy)
@@ -33,9 +38,9 @@ __global__ void log_softmax_bwd_kernel(const float *__restrict__ y, const float 
     for (int j = 0; j < n; ++j) xr[j] = dr[j] - expf(yr[j]) * s;
 }
 
-int log_softmax_rows(const float *x, float *y, int rows, int n, hipStream_t stream) {
+int log_softmax_rows(const float *x, float *y, float *y2, int rows, int n, hipStream_t stream) {
     GSCAN_CHECK(n >= 1 && n <= 4096, "log_softmax: row length %d unsupported", n);
-    hipLaunchKernelGGL(log_softmax_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, x, y, rows, n);
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, x, y, y2, rows, n);
     GSCAN_LAUNCHED("log_softmax_kernel");
     return 0;
 }

@@ -10,9 +10,35 @@ int gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int6
              int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
              const float *mask, int split_k, hipStream_t stream);
 
-int gemm_f32_ex(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
-                int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
-                const float *mask, int split_k, float *asum1, float *asum2, hipStream_t stream);
+constexpr int kMaxGroup = 12;
+struct GemmProblem {
+    int M, N, K;
+    float alpha, beta;
+    const float *a; int64_t sam, sak;     // A(m,k) = a[m*sam + k*sak]
+    const float *b; int64_t sbk, sbn;     // B(k,n) = b[k*sbk + n*sbn]
+    float *c; int64_t ldc;
+    const float *bias; int act;           // act: 0 none, 1 relu, 2 tanh, 3 relu-backward (zero where gate == 0)
+    const float *mask, *gate;             // elementwise, same indexing as C
+    int k_chunk, atomic;                  // K range per k-slice; split-K accumulates with atomics
+    float *asum1, *asum2;                 // optional: += sum_k A(m,k) (bias gradients)
+    int tiles_n, tiles_mn, tile_begin;    // grid bookkeeping
+};
+struct GemmGroup { int count; GemmProblem p[kMaxGroup]; };
+
+// Builder for one grouped launch of independent products.
+class GemmBatch {
+public:
+    void add(int M, int N, int K, const float *a, int64_t sam, int64_t sak, const float *b, int64_t sbk, int64_t sbn,
+             float *c, int64_t ldc, float beta = 0.f, const float *bias = nullptr, int act = 0,
+             const float *mask = nullptr, int split_k = 1, float *asum1 = nullptr, float *asum2 = nullptr,
+             const float *gate = nullptr, float alpha = 1.f);
+    int launch(hipStream_t stream);
+private:
+    GemmGroup grp_{};
+    int tiles_ = 0;
+    double flops_ = 0.0;
+    bool bad_ = false;
+};
 
 // elementwise.hip
 int world_im2col(const float *world, int B, int G, int C, int K3, float *xcol, hipStream_t stream);
@@ -23,15 +49,24 @@ int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mas
 int relu_mask_backward(float *dfeat, const float *feat, const float *mask, int64_t n, hipStream_t stream);
 int vec_add(const float *a, const float *b, float *out, int n, hipStream_t stream);
 int colsum_add(const float *x, int64_t ld, int rows, int N, float *out1, float *out2, hipStream_t stream);
-int attn_value_grad(const float *alpha, int Mld, const float *dctx, int64_t ldd, int B, int T, int M, int H,
-                    float *dkeys, int accumulate, hipStream_t stream);
+int attn_value_grad(const float *alpha_c, const float *alpha_s, const float *ds, int B, int T, int L, int M, int H,
+                    float *dpk_t, float *dpk_v, hipStream_t stream);
+struct PrologueArgs {
+    const float *b_ih, *b_hh, *w_o2h, *w_ih_f, *w_ih_r, *enc_emb, *dec_emb, *mask_enc, *mask_dec;
+    const int64_t *commands, *targets;
+    float *bsum, *wo_perm, *wih_stack, *dwo_perm, *xe, *S;
+    int H, He, E, D, BL, BT, Vi, V;
+    int64_t end[6];
+};
+int step_prologue(const PrologueArgs &args, hipStream_t stream);
+int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream);
 int adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
               float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
               hipStream_t stream);
 int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream);
 
 // loss.hip
-int log_softmax_rows(const float *x, float *y, int rows, int n, hipStream_t stream);
+int log_softmax_rows(const float *x, float *y, float *y2, int rows, int n, hipStream_t stream);
 int log_softmax_rows_backward(const float *y, const float *dy, float *dx, int rows, int n, hipStream_t stream);
 int sequence_nll(const float *logp, const int64_t *targets, int B, int T, int V, int pad, float *loss_sum,
                  float *count, float *dlogp, hipStream_t stream);
@@ -94,8 +129,9 @@ struct WorkspaceSlot { const char *name; int64_t offset, count; };
 struct Workspace {
     int64_t xcol, feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, dlogits, dpreo,
-        dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps;
-    WorkspaceSlot slot[64];
+        dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
+        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk;
+    WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;
 };

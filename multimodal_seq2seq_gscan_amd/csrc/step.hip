@@ -45,6 +45,12 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(ut, B * L * 4 * H);
     SLOT(u2t, B * L * H);
     SLOT(bsum, 4 * H);
+    SLOT(wo_perm, H * 4 * H);
+    SLOT(dwo_perm, H * 4 * H);
+    SLOT(wih_stack, D * 4 * He * E);
+    SLOT(w_sk, 4 * H * F);
+    SLOT(w_ck, 4 * H * He);
+    SLOT(w_2kk, H * He);
     SLOT(hprev, B * T * H);
     SLOT(S, B * T * 4 * H);
     SLOT(ge, B * T * 4 * H);
@@ -107,30 +113,39 @@ int check_dims(const gscan_dims &d) {
 
 static int pick_split(int M, int N, int K) {
     const int tiles = cdiv(M, 64) * cdiv(N, 64);
-    int s = cdiv(1024, tiles);
+    int s = cdiv(512, tiles);
     s = std::min(s, std::max(1, K / 128));
     return std::max(1, s);
 }
 
-// C[M,N] (+)= A[M,K] . B[K,N], every operand described by (pointer, row stride, col stride)
-static inline int mm(hipStream_t st, int M, int N, int K, const float *a, int64_t sam, int64_t sak, const float *b,
-                     int64_t sbk, int64_t sbn, float *c, int64_t ldc, float beta = 0.f, const float *bias = nullptr,
-                     int act = 0, const float *mask = nullptr) {
-    return gemm_f32(M, N, K, 1.f, a, sam, sak, b, sbk, sbn, beta, c, ldc, bias, act, mask, 1, st);
-}
-// weight gradient: C[M,N] += A^T . B with the long dimension (rows of the activations) as K
-// bias1/bias2 (optional) += column sums of the activation gradient = sum over K of A(m,k)
-static inline int mm_grad(hipStream_t st, int M, int N, int K, const float *a, int64_t sam, int64_t sak,
-                          const float *b, int64_t sbk, int64_t sbn, float *c, int64_t ldc, float *bias1 = nullptr,
-                          float *bias2 = nullptr) {
-    return gemm_f32_ex(M, N, K, 1.f, a, sam, sak, b, sbk, sbn, 1.f, c, ldc, nullptr, 0, nullptr, pick_split(M, N, K),
-                       bias1, bias2, st);
+// weight gradient: C[M,N] += A^T . B with the long dimension (rows of the activations) as K, split over
+// workgroups; bias1/bias2 (optional) += column sums of the activation gradient = sum over K of A(m,k)
+static inline void add_grad(GemmBatch &g, int M, int N, int K, const float *a, int64_t sam, int64_t sak, const float *b,
+                            int64_t sbk, int64_t sbn, float *c, int64_t ldc, float *bias1 = nullptr,
+                            float *bias2 = nullptr) {
+    g.add(M, N, K, a, sam, sak, b, sbk, sbn, c, ldc, 1.f, nullptr, 0, nullptr, pick_split(M, N, K), bias1, bias2);
 }
 
 #define TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 
+static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, float *w,
+                                const Workspace &ws) {
+    DecoderArgs a{};
+    a.T = d.T; a.L = d.L; a.M = d.G * d.G;
+    a.cmd_lengths = bt.cmd_lengths;
+    a.pk_t = w + ws.pkt; a.u_t = w + ws.ut; a.u2_t = w + ws.u2t;
+    a.pk_v = w + ws.pkv; a.u_v = w + ws.uv;
+    a.ge = w + ws.ge;
+    a.w_hh = p.dec_w_hh; a.w_qt = p.txt_query_w; a.w_qv = p.vis_query_w; a.w_q2k = p.q2k_w; a.b_q2k = p.q2k_b;
+    a.v_t = p.txt_energy_w; a.v_v = p.vis_energy_w;
+    a.hprev = w + ws.hprev; a.s = w + ws.S; a.cells = w + ws.cells; a.gates = w + ws.gates;
+    a.alpha_c = w + ws.alpha_c; a.alpha_s = w + ws.alpha_s;
+    a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
+    return a;
+}
+
 // --------------------------------------------------------------------------------------
-// forward
+// forward: 10 launches (prologue, im2col, 5 grouped GEMMs, 2 recurrences, log_softmax)
 // --------------------------------------------------------------------------------------
 int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk,
                  float *w, float *logp, float *aux_logp, hipStream_t st) {
@@ -147,77 +162,87 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     GSCAN_CHECK(logp != nullptr, "forward: logp is NULL");
     GSCAN_CHECK(!d.auxiliary || aux_logp, "forward: auxiliary task set but aux_logp is NULL");
 
-    // ---- world encoder (cnn_model.py:22-36): im2col + 3 GEMMs with bias/ReLU/dropout epilogue
-    TRY(world_im2col(bt.world, B, d.G, C, d.K3, w + ws.xcol, st));
+    // ---- prologue: bias sum, permuted / stacked weight images, both embedding gathers (one launch)
     {
+        PrologueArgs a{};
+        a.b_ih = p.dec_b_ih; a.b_hh = p.dec_b_hh; a.w_o2h = p.out2hid_w;
+        a.w_ih_f = p.enc_w_ih; a.w_ih_r = p.enc_w_ih_rev; a.enc_emb = p.enc_emb; a.dec_emb = p.dec_emb;
+        a.mask_enc = mk.enc; a.mask_dec = mk.dec; a.commands = bt.commands; a.targets = bt.targets;
+        a.bsum = w + ws.bsum; a.wo_perm = w + ws.wo_perm; a.wih_stack = w + ws.wih_stack;
+        a.dwo_perm = w + ws.dwo_perm; a.xe = w + ws.xe; a.S = w + ws.S;
+        a.H = H; a.He = He; a.E = E; a.D = D; a.BL = B * L; a.BT = B * T; a.Vi = d.Vi; a.V = V;
+        const int64_t n[6] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
+                              (int64_t)B * L * E, (int64_t)B * T * H};
+        int64_t acc = 0;
+        for (int i = 0; i < 6; ++i) { acc += n[i]; a.end[i] = acc; }
+        TRY(step_prologue(a, st));
+    }
+    TRY(world_im2col(bt.world, B, d.G, C, d.K3, w + ws.xcol, st));
+
+    // ---- level 1: everything that depends only on inputs and parameters
+    {
+        GemmBatch g;
         const float *cw[3] = {p.conv1_w, p.conv2_w, p.conv3_w};
         const float *cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
         const int kk[3] = {C, 25 * C, d.K3 * d.K3 * C};
         int off = 0;
-        for (int i = 0; i < 3; ++i) {
-            TRY(mm(st, B * M, Co, kk[i], w + ws.xcol + off, Ktot, 1, cw[i], 1, kk[i], w + ws.feat + i * Co, F, 0.f,
-                   cb[i], 1, mk.cnn ? mk.cnn + i * Co : nullptr));
+        for (int i = 0; i < 3; ++i) {   // world encoder (cnn_model.py:22-36): bias + ReLU + dropout in the epilogue
+            g.add(B * M, Co, kk[i], w + ws.xcol + off, Ktot, 1, cw[i], 1, kk[i], w + ws.feat + i * Co, F, 0.f, cb[i], 1,
+                  mk.cnn ? mk.cnn + i * Co : nullptr);
             off += kk[i];
         }
+        // encoder input projections W_ih x + b_ih, both directions (seq2seq_model.py:70)
+        g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih, 1, E, w + ws.gx, (int64_t)D * 4 * He, 0.f, p.enc_b_ih);
+        if (D == 2)
+            g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih_rev, 1, E, w + ws.gx + 4 * He, (int64_t)D * 4 * He, 0.f,
+                  p.enc_b_ih_rev);
+        // decoder: embedding part of the gate pre-activations for all t (teacher forcing)
+        g.add(B * T, 4 * H, H, w + ws.S, 4 * H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge, 4 * H, 0.f, w + ws.bsum);
+        // composite weights: images of the key projections under W_ih[:, ctx] / W_q2k[:, ctx], so that the
+        // per-memory vectors U = PK . W^T come straight from the features in the next level
+        g.add(4 * H, F, H, p.dec_w_ih + 2 * H, 3 * H, 1, p.vis_key_w, F, 1, w + ws.w_sk, F);
+        g.add(4 * H, He, H, p.dec_w_ih + H, 3 * H, 1, p.txt_key_w, He, 1, w + ws.w_ck, He);
+        if (cond) g.add(H, He, H, p.q2k_w + H, 2 * H, 1, p.txt_key_w, He, 1, w + ws.w_2kk, He);
+        TRY(g.launch(st));
     }
-    // projected visual keys (seq2seq_model.py:466-467) and their image under W_ih[:, ctx_vis]
-    TRY(mm(st, B * M, H, F, w + ws.feat, F, 1, p.vis_key_w, 1, F, w + ws.pkv, H));
-    TRY(mm(st, B * M, 4 * H, H, w + ws.pkv, H, 1, p.dec_w_ih + 2 * H, 1, 3 * H, w + ws.uv, 4 * H));
-
-    // ---- command encoder (seq2seq_model.py:47-89)
-    TRY(embed_rows(bt.commands, p.enc_emb, d.Vi, mk.enc, B * L, E, w + ws.xe, E, st));
-    TRY(mm(st, B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih, 1, E, w + ws.gx, (int64_t)D * 4 * He, 0.f, p.enc_b_ih));
-    if (D == 2)
-        TRY(mm(st, B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih_rev, 1, E, w + ws.gx + 4 * He, (int64_t)D * 4 * He,
-               0.f, p.enc_b_ih_rev));
+    // ---- level 2: projected visual keys (seq2seq_model.py:466-467) and their gate images
+    {
+        GemmBatch g;
+        g.add(B * M, H, F, w + ws.feat, F, 1, p.vis_key_w, 1, F, w + ws.pkv, H);
+        g.add(B * M, 4 * H, F, w + ws.feat, F, 1, w + ws.w_sk, 1, F, w + ws.uv, 4 * H);
+        TRY(g.launch(st));
+    }
+    // ---- command encoder recurrence (seq2seq_model.py:62-88)
     TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, p.enc_w_hh, p.enc_b_hh, p.enc_w_hh_rev,
                              p.enc_b_hh_rev, w + ws.enc_out, w + ws.hN, w + ws.enc_gates, w + ws.enc_cells,
                              w + ws.enc_hprev, st));
-    // projected textual keys (:468-469) and their images under W_ih[:, ctx_text] and W_q2k[:, ctx_text]
-    TRY(mm(st, B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H));
-    TRY(mm(st, B * L, 4 * H, H, w + ws.pkt, H, 1, p.dec_w_ih + H, 1, 3 * H, w + ws.ut, 4 * H));
-    if (cond) TRY(mm(st, B * L, H, H, w + ws.pkt, H, 1, p.q2k_w + H, 1, 2 * H, w + ws.u2t, H));
-
-    // ---- bridge (model.py:195): h0 = c0 = tanh(W hN + b), written as row t=0 of hprev
-    TRY(mm(st, B, H, He, w + ws.hN, He, 1, p.bridge_w, 1, He, w + ws.hprev, (int64_t)T * H, 0.f, p.bridge_b, 2));
-
-    // ---- decoder inputs known for all t (teacher forcing): embeddings and their gate image
-    TRY(embed_rows(bt.targets, p.dec_emb, V, mk.dec, B * T, H, w + ws.S, 4 * H, st));
-    TRY(vec_add(p.dec_b_ih, p.dec_b_hh, w + ws.bsum, 4 * H, st));
-    TRY(mm(st, B * T, 4 * H, H, w + ws.S, 4 * H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge, 4 * H, 0.f, w + ws.bsum));
-
+    // ---- level 3: projected textual keys (:468-469), their images, and the bridge (model.py:195)
+    {
+        GemmBatch g;
+        g.add(B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H);
+        g.add(B * L, 4 * H, He, w + ws.enc_out, He, 1, w + ws.w_ck, 1, He, w + ws.ut, 4 * H);
+        if (cond) g.add(B * L, H, He, w + ws.enc_out, He, 1, w + ws.w_2kk, 1, He, w + ws.u2t, H);
+        g.add(B, H, He, w + ws.hN, He, 1, p.bridge_w, 1, He, w + ws.hprev, (int64_t)T * H, 0.f, p.bridge_b, 2);
+        TRY(g.launch(st));
+    }
     // ---- the T-step recurrence
-    DecoderArgs a{};
-    a.T = T; a.L = L; a.M = M;
-    a.cmd_lengths = bt.cmd_lengths;
-    a.pk_t = w + ws.pkt; a.u_t = w + ws.ut; a.u2_t = w + ws.u2t;
-    a.pk_v = w + ws.pkv; a.u_v = w + ws.uv;
-    a.ge = w + ws.ge;
-    a.w_hh = p.dec_w_hh; a.w_qt = p.txt_query_w; a.w_qv = p.vis_query_w; a.w_q2k = p.q2k_w; a.b_q2k = p.q2k_b;
-    a.v_t = p.txt_energy_w; a.v_v = p.vis_energy_w;
-    a.hprev = w + ws.hprev; a.s = w + ws.S; a.cells = w + ws.cells; a.gates = w + ws.gates;
-    a.alpha_c = w + ws.alpha_c; a.alpha_s = w + ws.alpha_s;
-    a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
+    DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.stamps = probe_stamps_enabled() ? w + ws.stamps : nullptr;
     TRY(decoder_run(false, B, H, cond, a, st));
 
-    // ---- output head hoisted out of the loop (seq2seq_model.py:421-424), W_o2h columns = [e|h|ctx_t|ctx_v]
-    TRY(mm(st, B * T, H, H, w + ws.S, 4 * H, 1, p.out2hid_w, 1, 4 * H, w + ws.preo, H));
-    TRY(mm(st, B * T, H, 2 * H, w + ws.S + H, 4 * H, 1, p.out2hid_w + 2 * H, 1, 4 * H, w + ws.preo, H, 1.f));
-    TRY(mm(st, B * T, H, H, w + ws.S + 3 * H, 4 * H, 1, p.out2hid_w + H, 1, 4 * H, w + ws.preo, H, 1.f));
-    TRY(mm(st, B * T, V, H, w + ws.preo, H, 1, p.hid2out_w, 1, H, w + ws.logits, V));
+    // ---- output head hoisted out of the loop (seq2seq_model.py:421-424): S . wo_perm^T, then W_h2o
+    TRY(gemm_f32(B * T, H, 4 * H, 1.f, w + ws.S, 4 * H, 1, w + ws.wo_perm, 1, 4 * H, 0.f, w + ws.preo, H, nullptr, 0,
+                 nullptr, 1, st));
+    TRY(gemm_f32(B * T, V, H, 1.f, w + ws.preo, H, 1, p.hid2out_w, 1, H, 0.f, w + ws.logits, V, nullptr, 0, nullptr,
+                 1, st));
     // log_softmax (model.py:203, :166-170); a copy stays in the workspace for the backward pass
-    TRY(log_softmax_rows(w + ws.logits, w + ws.logp_saved, B * T, V, st));
-    GSCAN_HIP(hipMemcpyAsync(logp, w + ws.logp_saved, sizeof(float) * B * T * V, hipMemcpyDeviceToDevice, st));
-    if (d.auxiliary) {
-        TRY(log_softmax_rows(w + ws.att_sum, w + ws.aux_saved, B, M, st));
-        GSCAN_HIP(hipMemcpyAsync(aux_logp, w + ws.aux_saved, sizeof(float) * B * M, hipMemcpyDeviceToDevice, st));
-    }
+    TRY(log_softmax_rows(w + ws.logits, w + ws.logp_saved, logp, B * T, V, st));
+    if (d.auxiliary) TRY(log_softmax_rows(w + ws.att_sum, w + ws.aux_saved, aux_logp, B, M, st));
     return 0;
 }
 
 // --------------------------------------------------------------------------------------
-// backward
+// backward: 13 launches
 // --------------------------------------------------------------------------------------
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                   const float *dlogp, const float *daux, const gscan_params &g, hipStream_t st) {
@@ -232,32 +257,27 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     GSCAN_CHECK(dlogp, "backward: dlogp is NULL");
     float *S = w + ws.S, *dS = w + ws.dS;
     const float *logp = w + ws.logp_saved, *aux_logp = w + ws.aux_saved;
+    const float *delta = w + ws.delta, *hprev = w + ws.hprev;
 
     // ---- head: log_softmax, hidden_to_output, output_to_hidden
     TRY(log_softmax_rows_backward(logp, dlogp, w + ws.dlogits, BT, V, st));
-    TRY(mm_grad(st, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H));
-    TRY(mm(st, BT, H, V, w + ws.dlogits, V, 1, p.hid2out_w, H, 1, w + ws.dpreo, H));
-    TRY(mm_grad(st, H, H, BT, w + ws.dpreo, 1, H, S, 4 * H, 1, g.out2hid_w, 4 * H));
-    TRY(mm_grad(st, H, 2 * H, BT, w + ws.dpreo, 1, H, S + H, 4 * H, 1, g.out2hid_w + 2 * H, 4 * H));
-    TRY(mm_grad(st, H, H, BT, w + ws.dpreo, 1, H, S + 3 * H, 4 * H, 1, g.out2hid_w + H, 4 * H));
-    TRY(mm(st, BT, H, H, w + ws.dpreo, H, 1, p.out2hid_w, 4 * H, 1, dS, 4 * H));
-    TRY(mm(st, BT, 2 * H, H, w + ws.dpreo, H, 1, p.out2hid_w + 2 * H, 4 * H, 1, dS + H, 4 * H));
-    TRY(mm(st, BT, H, H, w + ws.dpreo, H, 1, p.out2hid_w + H, 4 * H, 1, dS + 3 * H, 4 * H));
     const bool use_aux = d.auxiliary && daux;
     if (use_aux) TRY(log_softmax_rows_backward(aux_logp, daux, w + ws.datt, B, M, st));
+    {
+        GemmBatch b;
+        add_grad(b, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H);
+        b.add(BT, H, V, w + ws.dlogits, V, 1, p.hid2out_w, H, 1, w + ws.dpreo, H);
+        TRY(b.launch(st));
+    }
+    {
+        GemmBatch b;   // gradient of the permuted head weight (scattered back at the end) and of S
+        add_grad(b, H, 4 * H, BT, w + ws.dpreo, 1, H, S, 4 * H, 1, w + ws.dwo_perm, 4 * H);
+        b.add(BT, 4 * H, H, w + ws.dpreo, H, 1, w + ws.wo_perm, 4 * H, 1, dS, 4 * H);
+        TRY(b.launch(st));
+    }
 
     // ---- reverse recurrence
-    DecoderArgs a{};
-    a.T = T; a.L = L; a.M = M;
-    a.cmd_lengths = bt.cmd_lengths;
-    a.pk_t = w + ws.pkt; a.u_t = w + ws.ut; a.u2_t = w + ws.u2t;
-    a.pk_v = w + ws.pkv; a.u_v = w + ws.uv;
-    a.ge = w + ws.ge;
-    a.w_hh = p.dec_w_hh; a.w_qt = p.txt_query_w; a.w_qv = p.vis_query_w; a.w_q2k = p.q2k_w; a.b_q2k = p.q2k_b;
-    a.v_t = p.txt_energy_w; a.v_v = p.vis_energy_w;
-    a.hprev = w + ws.hprev; a.s = S; a.cells = w + ws.cells; a.gates = w + ws.gates;
-    a.alpha_c = w + ws.alpha_c; a.alpha_s = w + ws.alpha_s;
-    a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
+    DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.ds = dS; a.datt = use_aux ? w + ws.datt : nullptr;
     a.delta = w + ws.delta; a.dzq = w + ws.dzq; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
     a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = g.txt_energy_w; a.dv_v = g.vis_energy_w;
@@ -265,64 +285,71 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     a.stamps = probe_stamps_enabled() ? w + ws.stamps + 16 : nullptr;
     TRY(decoder_run(true, B, H, cond, a, st));
 
-    // ---- decoder parameter gradients: dense products over the B*T saved rows
-    const float *delta = w + ws.delta, *hprev = w + ws.hprev;
-    TRY(mm_grad(st, 4 * H, 3 * H, BT, delta, 1, 4 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H));
-    TRY(mm_grad(st, 4 * H, H, BT, delta, 1, 4 * H, hprev, H, 1, g.dec_w_hh, H, g.dec_b_ih, g.dec_b_hh));
-    TRY(mm_grad(st, H, H, BT, w + ws.dqt, 1, H, hprev, H, 1, g.txt_query_w, H));
-    if (cond) {
-        TRY(mm_grad(st, H, H, BT, w + ws.dzq, 1, H, hprev, H, 1, g.q2k_w, 2 * H, g.q2k_b));
-        TRY(mm_grad(st, H, H, BT, w + ws.dzq, 1, H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H));
-        TRY(mm_grad(st, H, H, BT, w + ws.dqv, 1, H, w + ws.q2, H, 1, g.vis_query_w, H));
-    } else {
-        TRY(mm_grad(st, H, H, BT, w + ws.dqv, 1, H, hprev, H, 1, g.vis_query_w, H));
+    // ---- decoder parameter gradients (dense products over the B*T saved rows) and the gradient wrt
+    //      [e | ctx_text | ctx_vis] through the LSTM input
+    {
+        GemmBatch b;
+        add_grad(b, 4 * H, 3 * H, BT, delta, 1, 4 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
+        add_grad(b, 4 * H, H, BT, delta, 1, 4 * H, hprev, H, 1, g.dec_w_hh, H, g.dec_b_ih, g.dec_b_hh);
+        add_grad(b, H, H, BT, w + ws.dqt, 1, H, hprev, H, 1, g.txt_query_w, H);
+        if (cond) {
+            add_grad(b, H, H, BT, w + ws.dzq, 1, H, hprev, H, 1, g.q2k_w, 2 * H, g.q2k_b);
+            add_grad(b, H, H, BT, w + ws.dzq, 1, H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H);
+            add_grad(b, H, H, BT, w + ws.dqv, 1, H, w + ws.q2, H, 1, g.vis_query_w, H);
+        } else {
+            add_grad(b, H, H, BT, w + ws.dqv, 1, H, hprev, H, 1, g.vis_query_w, H);
+        }
+        b.add(BT, 3 * H, 4 * H, delta, 4 * H, 1, p.dec_w_ih, 3 * H, 1, dS, 4 * H, 1.f);
+        TRY(b.launch(st));
     }
-
-    // ---- gradients wrt [e | ctx_text | ctx_vis] through the LSTM input and the conditional query
-    TRY(mm(st, BT, 3 * H, 4 * H, delta, 4 * H, 1, p.dec_w_ih, 3 * H, 1, dS, 4 * H, 1.f));
-    if (cond) TRY(mm(st, BT, H, H, w + ws.dzq, H, 1, p.q2k_w + H, 2 * H, 1, dS + H, 4 * H, 1.f));
+    if (cond)   // ... and through the conditional query (same output columns as above: a second launch)
+        TRY(gemm_f32(BT, H, H, 1.f, w + ws.dzq, H, 1, p.q2k_w + H, 2 * H, 1, 1.f, dS + H, 4 * H, nullptr, 0, nullptr, 1,
+                     st));
     TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, st));
     // value path of both attentions: dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]
-    TRY(attn_value_grad(w + ws.alpha_c, L, dS + H, 4 * H, B, T, L, H, w + ws.dpk_t, 1, st));
-    TRY(attn_value_grad(w + ws.alpha_s, M, dS + 2 * H, 4 * H, B, T, M, H, w + ws.dpk_v, 1, st));
+    TRY(attn_value_grad(w + ws.alpha_c, w + ws.alpha_s, dS, B, T, L, M, H, w + ws.dpk_t, w + ws.dpk_v, st));
 
-    // ---- textual keys and bridge -> encoder outputs / final state
-    TRY(mm_grad(st, H, He, BL, w + ws.dpk_t, 1, H, w + ws.enc_out, He, 1, g.txt_key_w, He));
-    TRY(mm(st, BL, He, H, w + ws.dpk_t, H, 1, p.txt_key_w, He, 1, w + ws.denc, He));
-    TRY(mm_grad(st, H, He, B, w + ws.dh0, 1, H, w + ws.hN, He, 1, g.bridge_w, He, g.bridge_b));
-    TRY(mm(st, B, He, H, w + ws.dh0, H, 1, p.bridge_w, He, 1, w + ws.dhN, He));
-
-    // ---- command encoder BPTT and its parameter gradients
+    // ---- keys and bridge -> encoder outputs / final state / conv features
+    {
+        GemmBatch b;
+        add_grad(b, H, He, BL, w + ws.dpk_t, 1, H, w + ws.enc_out, He, 1, g.txt_key_w, He);
+        b.add(BL, He, H, w + ws.dpk_t, H, 1, p.txt_key_w, He, 1, w + ws.denc, He);
+        add_grad(b, H, He, B, w + ws.dh0, 1, H, w + ws.hN, He, 1, g.bridge_w, He, g.bridge_b);
+        b.add(B, He, H, w + ws.dh0, H, 1, p.bridge_w, He, 1, w + ws.dhN, He);
+        add_grad(b, H, F, BM_, w + ws.dpk_v, 1, H, w + ws.feat, F, 1, g.vis_key_w, F);
+        // d feat with the ReLU/dropout backward fused: feat = relu(x) * mask  =>  dx = (feat != 0) ? dfeat * mask : 0
+        b.add(BM_, F, H, w + ws.dpk_v, H, 1, p.vis_key_w, F, 1, w + ws.dfeat, F, 0.f, nullptr, 3, mk.cnn, 1, nullptr,
+              nullptr, w + ws.feat);
+        TRY(b.launch(st));
+    }
+    // ---- command encoder BPTT
     TRY(encoder_lstm_backward(B, L, He, D, bt.cmd_lengths, p.enc_w_hh, p.enc_w_hh_rev, w + ws.enc_gates,
                               w + ws.enc_cells, w + ws.denc, w + ws.dhN, w + ws.enc_delta, st));
-    for (int dir = 0; dir < D; ++dir) {
-        const float *dl = w + ws.enc_delta + dir * 4 * He;
-        const int64_t ldd = (int64_t)D * 4 * He;
-        float *gw_ih = dir ? g.enc_w_ih_rev : g.enc_w_ih, *gw_hh = dir ? g.enc_w_hh_rev : g.enc_w_hh;
-        float *gb_ih = dir ? g.enc_b_ih_rev : g.enc_b_ih, *gb_hh = dir ? g.enc_b_hh_rev : g.enc_b_hh;
-        const float *w_ih = dir ? p.enc_w_ih_rev : p.enc_w_ih;
-        TRY(mm_grad(st, 4 * He, He, BL, dl, 1, ldd, w + ws.enc_hprev + dir * He, (int64_t)D * He, 1, gw_hh, He, gb_ih,
-                    gb_hh));
-        TRY(mm_grad(st, 4 * He, E, BL, dl, 1, ldd, w + ws.xe, E, 1, gw_ih, E));
-        TRY(mm(st, BL, E, 4 * He, dl, ldd, 1, w_ih, E, 1, w + ws.dxe, E, dir ? 1.f : 0.f));
-    }
-    TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));
-
-    // ---- visual keys -> conv features -> conv weights (the world tensor itself needs no gradient)
-    TRY(mm_grad(st, H, F, BM_, w + ws.dpk_v, 1, H, w + ws.feat, F, 1, g.vis_key_w, F));
-    TRY(mm(st, BM_, F, H, w + ws.dpk_v, H, 1, p.vis_key_w, F, 1, w + ws.dfeat, F));
-    TRY(relu_mask_backward(w + ws.dfeat, w + ws.feat, mk.cnn, (int64_t)BM_ * F, st));
     {
+        GemmBatch b;   // conv weights (the world tensor itself needs no gradient) and encoder LSTM weights
         float *gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
         float *gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
         const int kk[3] = {C, 25 * C, d.K3 * d.K3 * C};
         int off = 0;
         for (int i = 0; i < 3; ++i) {
-            TRY(mm_grad(st, Co, kk[i], BM_, w + ws.dfeat + i * Co, 1, F, w + ws.xcol + off, Ktot, 1, gw[i], kk[i],
-                        gb[i]));
+            add_grad(b, Co, kk[i], BM_, w + ws.dfeat + i * Co, 1, F, w + ws.xcol + off, Ktot, 1, gw[i], kk[i], gb[i]);
             off += kk[i];
         }
+        const int64_t ldd = (int64_t)D * 4 * He;
+        for (int dir = 0; dir < D; ++dir) {
+            const float *dl = w + ws.enc_delta + dir * 4 * He;
+            float *gw_ih = dir ? g.enc_w_ih_rev : g.enc_w_ih, *gw_hh = dir ? g.enc_w_hh_rev : g.enc_w_hh;
+            float *gb_ih = dir ? g.enc_b_ih_rev : g.enc_b_ih, *gb_hh = dir ? g.enc_b_hh_rev : g.enc_b_hh;
+            add_grad(b, 4 * He, He, BL, dl, 1, ldd, w + ws.enc_hprev + dir * He, (int64_t)D * He, 1, gw_hh, He, gb_ih,
+                     gb_hh);
+            add_grad(b, 4 * He, E, BL, dl, 1, ldd, w + ws.xe, E, 1, gw_ih, E);
+        }
+        // d(embedded command) for both directions at once: [delta_f | delta_r] . [W_ih_f ; W_ih_r]
+        b.add(BL, E, D * 4 * He, w + ws.enc_delta, ldd, 1, w + ws.wih_stack, E, 1, w + ws.dxe, E);
+        TRY(b.launch(st));
     }
+    TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));
+    TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, st));
     return 0;
 }
 
