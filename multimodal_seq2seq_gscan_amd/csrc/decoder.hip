@@ -6,9 +6,12 @@
 // (SURVEY.md §7 hard part 1).  With a row per workgroup, 256 rows fill the 256 CUs and a
 // step needs no inter-workgroup traffic at all:
 //   * every matrix that multiplies the recurrent state ( W_hh | W_query_text | W_q2k[:, :H]
-//     and W_query_vis: 7*H*H floats = 280 KB at H=100) stays in VGPRs for all T steps, one
-//     row (forward) or one column segment (backward) per thread — 2 MB of registers per CU
-//     is the largest on-chip store, LDS (160 KB) could not hold them;
+//     and W_query_vis: 7*H*H floats = 280 KB at H=100) stays in VGPRs for all T steps — 2 MB of
+//     registers per CU is the largest on-chip store, LDS (160 KB) could not hold them.  A weight
+//     row is split over a LANE PAIR (each lane holds half of it, up to three rows per pair), so
+//     the workgroup is 8 waves = 2 per SIMD with a 256-VGPR budget: room to keep a dozen LDS
+//     reads in flight, which is what the 100-deep dot products need.  The two halves are added
+//     with one DPP quad_perm, not through LDS;
 //   * the row's memories stay in LDS for all T steps: projected keys PK_text [L,H] and
 //     PK_vis [G*G,H], plus U = PK . W_ih[:, ctx]^T ([L,4H] and [G*G,4H]).  Because an attention
 //     context is a convex combination of projected keys, W_ih[:,ctx] . ctx = sum_m alpha_m U[m]:
@@ -19,32 +22,15 @@
 //     (46*H floats per step per row would make the path HBM-bound).
 // The output head does not feed back, so it is hoisted out of the loop (host side).
 //
-// Thread roles (forward), H = hidden size, tid in [0, 7H):
-//   [0,4H)  gate row j: W_hh[j,:] in registers, also owns column j of U_text / U_vis
-//   [4H,5H) text query row k: W_query_text[k,:]; owns ctx_text[k], ctx_vis[k]
-//   [5H,6H) conditional: W_q2k[k, 0:H] (and U2_text column k);  else W_query_vis[k,:]
-//   [6H,7H) conditional only: W_query_vis[k,:] applied to the conditional query
-// Backward uses the transposed ownership (thread (s,k): rows s*H..s*H+H-1, column k).
+// Weight rows ("tasks") r = slot*256 + pair, H = hidden size:
+//   forward   [0,4H) W_hh[r,:] -> gate r      [4H,5H) W_query_text[k,:]      [5H,6H) W_q2k[k,:H] (conditional)
+//             or W_query_vis[k,:];            [6H,7H) W_query_vis[k,:] applied to the conditional query
+//   backward  the transposes: task (seg,k) holds column k of block seg of [W_hh (4 blocks) | W_query_text |
+//             W_q2k[:, :H] or W_query_vis] and of W_query_vis; dh_{t-1}[k] = sum over the six blocks.
+// decoder_weight_images() writes both register images once per step ([slot][i][thread], coalesced).
 #include "step.h"
 
 namespace gscan {
-
-template <int H>
-__device__ __forceinline__ float dot_reg_lds(const float (&w)[H], const float *v) {
-    static_assert(H % 4 == 0, "hidden size must be a multiple of 4");
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float4 *v4 = reinterpret_cast<const float4 *>(v);
-#pragma unroll
-    for (int i = 0; i < H / 4; ++i) {
-        const float4 x = v4[i];
-        a0 = fmaf(w[4 * i + 0], x.x, a0);
-        a1 = fmaf(w[4 * i + 1], x.y, a1);
-        a2 = fmaf(w[4 * i + 2], x.z, a2);
-        a3 = fmaf(w[4 * i + 3], x.w, a3);
-    }
-    return (a0 + a1) + (a2 + a3);
-}
-
 
 // Diagnostic phase stamps (off unless DecoderArgs::stamps is set): thread 0 of workgroup 0 adds the cycles since
 // the previous stamp to slot i.  Shares, not absolute times, are what to read from them.
@@ -55,18 +41,73 @@ __device__ __forceinline__ float dot_reg_lds(const float (&w)[H], const float *v
         stamp_prev = now_;                                                     \
     }
 
-// sum_{m<n} al[m] * mat[m*stride]: four independent chains so the LDS reads issue back to back
-__device__ __forceinline__ float weighted_sum(const float *al, const float *mat, int stride, int n) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int m = 0;
-    for (; m + 4 <= n; m += 4) {
-        a0 = fmaf(al[m + 0], mat[(m + 0) * stride], a0);
-        a1 = fmaf(al[m + 1], mat[(m + 1) * stride], a1);
-        a2 = fmaf(al[m + 2], mat[(m + 2) * stride], a2);
-        a3 = fmaf(al[m + 3], mat[(m + 3) * stride], a3);
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// lane <-> lane^1 exchange on the DPP datapath (quad_perm [1,0,3,2]); both lanes of a pair must be active
+__device__ __forceinline__ float pair_sum(float v) { return v + dpp_move<0xb1, 0xf>(v); }
+
+// Dot products of register-resident half rows with an LDS vector (K0 % 4 == 0), as packed FMAs
+// (v_pk_fma_f32).  The vector is read in chunks of four float4; the next chunk's reads are issued before the
+// current chunk's FMAs, so the LDS latency is paid about once per dot instead of once per read.
+constexpr int kDotChunk = 4;
+
+template <int K0>
+__device__ __forceinline__ void load_chunk(float4 (&x)[kDotChunk], const float4 *v4, int c) {
+#pragma unroll
+    for (int j = 0; j < kDotChunk; ++j)
+        if (c * kDotChunk + j < K0 / 4) x[j] = v4[c * kDotChunk + j];
+}
+
+// NS dots that share the same vector: out[s] = sum_i w[s][i] * v[i]
+template <int NS, int K0>
+__device__ __forceinline__ void shared_dots(const float (&w)[NS][K0], const float *v, float (&out)[NS]) {
+    constexpr int NQ = K0 / 4, NC = (NQ + kDotChunk - 1) / kDotChunk;
+    const float4 *v4 = reinterpret_cast<const float4 *>(v);
+    f32x2 a01[NS], a23[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { a01[s] = f32x2{0.f, 0.f}; a23[s] = f32x2{0.f, 0.f}; }
+    float4 xa[kDotChunk], xb[kDotChunk];
+    load_chunk<K0>(xa, v4, 0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float4 (&cur)[kDotChunk] = (c & 1) ? xb : xa;
+        float4 (&nxt)[kDotChunk] = (c & 1) ? xa : xb;
+        if (c + 1 < NC) load_chunk<K0>(nxt, v4, c + 1);
+#pragma unroll
+        for (int j = 0; j < kDotChunk; ++j) {
+            const int q = c * kDotChunk + j;
+            if (q < NQ) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    a01[s] += f32x2{w[s][4 * q + 0], w[s][4 * q + 1]} * f32x2{cur[j].x, cur[j].y};
+                    a23[s] += f32x2{w[s][4 * q + 2], w[s][4 * q + 3]} * f32x2{cur[j].z, cur[j].w};
+                }
+            }
+        }
     }
-    for (; m < n; ++m) a0 = fmaf(al[m], mat[m * stride], a0);
-    return (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) out[s] = (a01[s].x + a01[s].y) + (a23[s].x + a23[s].y);
+}
+
+template <int K0>
+__device__ __forceinline__ float half_dot(const float (&w)[K0], const float *v) {
+    const float(&w1)[1][K0] = reinterpret_cast<const float(&)[1][K0]>(w);
+    float out[1];
+    shared_dots<1, K0>(w1, v, out);
+    return out[0];
+}
+
+// this lane's share of sum_{m<n} al[m] * mat[m*stride]: m = half, half+2, ... (the pair adds the two shares)
+__device__ __forceinline__ float split_weighted_sum(const float *al, const float *mat, int stride, int n, int half) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    int m = half;
+    for (; m + 4 < n; m += 6) {
+        a0 = fmaf(al[m + 0], mat[(m + 0) * stride], a0);
+        a1 = fmaf(al[m + 2], mat[(m + 2) * stride], a1);
+        a2 = fmaf(al[m + 4], mat[(m + 4) * stride], a2);
+    }
+    for (; m < n; m += 2) a0 = fmaf(al[m], mat[m * stride], a0);
+    return a0 + (a1 + a2);
 }
 
 // Additive-attention scores s_m = v . tanh(q + PK_m) for m < n: each wave takes m = wave, wave+nwave, ...
@@ -94,14 +135,36 @@ __device__ __forceinline__ void attention_scores(const float *v_s, const float *
     }
 }
 
+// global -> LDS copy of n floats (n % 4 == 0, both 16-byte aligned), four 16-byte loads in flight per thread
+__device__ __forceinline__ void stage(float *dst, const float *src, int n, int tid, int nthreads) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    const int n4 = n >> 2;
+    int i = tid;
+    for (; i + 3 * nthreads < n4; i += 4 * nthreads) {
+        const float4 x0 = s4[i], x1 = s4[i + nthreads], x2 = s4[i + 2 * nthreads], x3 = s4[i + 3 * nthreads];
+        d4[i] = x0; d4[i + nthreads] = x1; d4[i + 2 * nthreads] = x2; d4[i + 3 * nthreads] = x3;
+    }
+    for (; i < n4; i += nthreads) d4[i] = s4[i];
+}
+
 // ------------------------------------------------------------------------------------------
-// LDS carve shared by both kernels (floats).  Everything is in the dynamic region so the base
-// stays 16-byte aligned (all offsets are multiples of 4 floats).
+// geometry shared by the kernels, the weight-image kernel and the host
 // ------------------------------------------------------------------------------------------
+DecoderGeometry decoder_geometry(int H, bool cond) {
+    DecoderGeometry g;
+    g.rows = (cond ? 7 : 6) * H;
+    g.slots = (g.rows + kDecPairs - 1) / kDecPairs;
+    g.k0 = ((H / 2 + 3) / 4) * 4;
+    g.image_floats = (int64_t)g.slots * g.k0 * kDecThreads;
+    return g;
+}
+
 struct DecoderLds {
     int uv, pkv, ut, pkt, u2t, dpkv, dpkt, vec, total;
 };
 __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, bool cond, bool backward) {
+    const int HP = 2 * (((H / 2 + 3) / 4) * 4);       // padded length of every vector a half_dot reads
     DecoderLds o;
     int p = 0;
     o.uv = p;  p += M * 4 * H;
@@ -112,81 +175,83 @@ __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, bool cond
     o.dpkv = p; p += backward ? M * H : 0;
     o.dpkt = p; p += backward ? L * H : 0;
     o.vec = p;
-    p += 26 * H + 256;               // small vectors (V_* below) + three 64-float slots
+    p += (backward ? 7 * HP + 14 * H : 2 * HP + 8 * H) + 256;
     o.total = p;
     return o;
 }
-// offsets inside the small-vector region, in units of H floats (then two 64-float slots)
-enum { V_H = 0, V_QT = 1, V_ZQ = 2, V_Q2 = 3, V_QV = 4, V_VT = 5, V_VV = 6, V_GATE = 7 /*4H*/, V_D = 11 /*6H*/,
-       V_EXC = 17, V_EXS = 18, V_PART = 19 /* 6H: partial sums */, V_END = 26 };
 
+// ------------------------------------------------------------------------------------------
 template <int H, bool COND>
-constexpr int decoder_threads() { return (((COND ? 7 : 6) * H + 63) / 64) * 64; }
-
-template <int H, bool COND>
-__global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kernel(DecoderArgs a) {
+__global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a) {
+    constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
+                  HP = 2 * K0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = kDecThreads / 64;
+    const int pair = tid >> 1, half = tid & 1;
     const int T = a.T, L = a.L, M = a.M;
     const DecoderLds o = decoder_lds(H, L, M, COND, false);
     float *Uv = smem + o.uv, *PKv = smem + o.pkv, *Ut = smem + o.ut, *PKt = smem + o.pkt, *U2t = smem + o.u2t;
     float *vec = smem + o.vec;
-    float *h_s = vec + V_H * H, *qt_s = vec + V_QT * H, *zq_s = vec + V_ZQ * H, *q2_s = vec + V_Q2 * H,
-          *qv_s = vec + V_QV * H, *vt_s = vec + V_VT * H, *vv_s = vec + V_VV * H, *gate_s = vec + V_GATE * H;
-    float *sc_s = vec + V_END * H, *al_s = vec + V_END * H + 64, *stamp_acc = vec + V_END * H + 192;
+    float *h_s = vec, *q2_s = vec + HP;                     // dot inputs, zero-padded to HP
+    float *qt_s = vec + 2 * HP, *qv_s = qt_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H, *gate_s = vv_s + H;
+    float *sc_s = gate_s + 4 * H, *al_s = sc_s + 64, *stamp_acc = sc_s + 192;
     long long stamp_prev = a.stamps ? clock64() : 0;
-    if (tid < 16) stamp_acc[tid] = 0.f;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
 
-    // ---- one-time loads: memories -> LDS, weights -> registers ------------------------------
-    for (int i = tid; i < M * 4 * H; i += blockDim.x) Uv[i] = a.u_v[(int64_t)b * M * 4 * H + i];
-    for (int i = tid; i < M * H; i += blockDim.x) PKv[i] = a.pk_v[(int64_t)b * M * H + i];
-    for (int i = tid; i < L * 4 * H; i += blockDim.x) Ut[i] = a.u_t[(int64_t)b * L * 4 * H + i];
-    for (int i = tid; i < L * H; i += blockDim.x) PKt[i] = a.pk_t[(int64_t)b * L * H + i];
-    if (COND)
-        for (int i = tid; i < L * H; i += blockDim.x) U2t[i] = a.u2_t[(int64_t)b * L * H + i];
+    // ---- one-time loads: register image of the weights (coalesced), memories -> LDS -----------
+    float w[NS][K0];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int i = 0; i < K0; ++i) w[s][i] = a.w_image[(s * K0 + i) * kDecThreads + tid];
+    stage(Uv, a.u_v + (int64_t)b * M * 4 * H, M * 4 * H, tid, kDecThreads);
+    stage(PKv, a.pk_v + (int64_t)b * M * H, M * H, tid, kDecThreads);
+    stage(Ut, a.u_t + (int64_t)b * L * 4 * H, L * 4 * H, tid, kDecThreads);
+    stage(PKt, a.pk_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
+    if (COND) stage(U2t, a.u2_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
+    if (tid < 2 * HP) vec[tid] = 0.f;                       // zero the padding of h_s / q2_s
+    if (tid < 16) stamp_acc[tid] = 0.f;
+    lds_barrier();
+    float c = 0.f;
     if (tid < H) {
-        h_s[tid] = a.hprev[(int64_t)b * T * H + tid];
+        c = a.hprev[(int64_t)b * T * H + tid];              // c0 = h0 (seq2seq_model.py:494-504)
+        h_s[tid] = c;
         vt_s[tid] = a.v_t[tid];
         vv_s[tid] = a.v_v[tid];
     }
-    const int role = tid / H, k = tid % H;     // role 0..3 gates, 4 text query, 5 q2k|vis, 6 vis (cond)
-    float w[H];
-    float bq = 0.f;
-    {
-        const float *src = nullptr;
-        if (role < 4) src = a.w_hh + (int64_t)tid * H;
-        else if (role == 4) src = a.w_qt + (int64_t)k * H;
-        else if (role == 5) src = COND ? a.w_q2k + (int64_t)k * 2 * H : a.w_qv + (int64_t)k * H;
-        else if (role == 6 && COND) src = a.w_qv + (int64_t)k * H;
-        if (src) {
+    float bq[NS];
 #pragma unroll
-            for (int i = 0; i < H; ++i) w[i] = src[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < H; ++i) w[i] = 0.f;
-        }
-        if (COND && role == 5) bq = a.b_q2k[k];
+    for (int s = 0; s < NS; ++s) {
+        const int r = s * kDecPairs + pair;
+        bq[s] = (COND && r >= 5 * H && r < 6 * H) ? a.b_q2k[r - 5 * H] : 0.f;
     }
-    float c = (tid < H) ? a.hprev[(int64_t)b * T * H + tid] : 0.f;   // c0 = h0 (seq2seq_model.py:494-504)
-    float att_acc = 0.f;                                              // wave 0, lane m
+    float att_acc = 0.f;                                    // wave 0, lane m
     lds_barrier();
 
     for (int t = 0; t < T; ++t) {
         GSCAN_STAMP(0)
-        const unsigned bt = (unsigned)b * T + t;       // 32-bit offsets: B*T*4H < 2^31 is checked on the host
-        // gate input from the embedding (global, issued early; consumed in phase G)
-        const float ge = (role < 4) ? a.ge[bt * 4 * H + tid] : 0.f;
+        const unsigned bt = (unsigned)b * T + t;            // 32-bit offsets: B*T*4H < 2^31 is checked on the host
+        float ge[NS], gh[NS], uc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {                      // embedding part of the gates: issued early, used in F
+            const int r = s * kDecPairs + pair;
+            ge[s] = (r < 4 * H) ? a.ge[bt * 4 * H + r] : 0.f;
+        }
 
         // ---- A: everything that multiplies h_{t-1} -------------------------------------------
-        float gh = 0.f;
-        if (role < 6) {
-            const float acc = dot_reg_lds<H>(w, h_s);
-            if (role < 4) gh = acc;
-            else if (role == 4) { qt_s[k] = acc; a.qt[bt * H + k] = acc; }
-            else if (COND) zq_s[k] = acc;
-            else { qv_s[k] = acc; a.qv[bt * H + k] = acc; }
+        shared_dots<NS, K0>(w, h_s + half * K0, gh);        // rows >= 6H (phase D rows) compute an unused value
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int r = s * kDecPairs + pair;
+            {
+                const float acc = pair_sum(gh[s]);
+                gh[s] = acc;                                // gate rows keep it; q2k rows reuse the register in C
+                if (r >= 4 * H && r < 6 * H && half == 0) {
+                    if (r < 5 * H) { qt_s[r - 4 * H] = acc; a.qt[bt * H + r - 4 * H] = acc; }
+                    else if (!COND) { qv_s[r - 5 * H] = acc; a.qv[bt * H + r - 5 * H] = acc; }
+                }
+            }
         }
         lds_barrier();
         GSCAN_STAMP(1)
@@ -207,25 +272,32 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
         GSCAN_STAMP(3)
 
         // ---- C: textual context and its images under W_ih / W_q2k ----------------------------
-        float uc = 0.f;
-        if (role < 4) {
-            uc = weighted_sum(al_s, Ut + tid, 4 * H, len);
-        } else if (role == 4) {
-            a.s[bt * 4 * H + H + k] = weighted_sum(al_s, PKt + k, H, len);
-        } else if (COND && role == 5) {
-            const float u2 = weighted_sum(al_s, U2t + k, H, len);
-            const float q = tanhf_(zq_s[k] + u2 + bq);        // seq2seq_model.py:394-396
-            q2_s[k] = q;
-            a.q2[bt * H + k] = q;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int r = s * kDecPairs + pair;
+            uc[s] = 0.f;
+            if (r < 4 * H) {
+                uc[s] = pair_sum(split_weighted_sum(al_s, Ut + r, 4 * H, len, half));
+            } else if (r < 5 * H) {
+                const float cc = pair_sum(split_weighted_sum(al_s, PKt + (r - 4 * H), H, len, half));
+                if (half == 0) a.s[bt * 4 * H + H + (r - 4 * H)] = cc;
+            } else if (COND && r < 6 * H) {
+                const float u2 = pair_sum(split_weighted_sum(al_s, U2t + (r - 5 * H), H, len, half));
+                const float q = tanhf_(gh[s] + u2 + bq[s]);   // seq2seq_model.py:394-396
+                if (half == 0) { q2_s[r - 5 * H] = q; a.q2[bt * H + r - 5 * H] = q; }
+            }
         }
         if (COND) {
             lds_barrier();
             GSCAN_STAMP(4)
             // ---- D: visual query from the conditional query ---------------------------------
-            if (role == 6) {
-                const float acc = dot_reg_lds<H>(w, q2_s);
-                qv_s[k] = acc;
-                a.qv[bt * H + k] = acc;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int r = s * kDecPairs + pair;
+                if (r >= 6 * H && r < 7 * H) {
+                    const float acc = pair_sum(half_dot<K0>(w[s], q2_s + half * K0));
+                    if (half == 0) { qv_s[r - 6 * H] = acc; a.qv[bt * H + r - 6 * H] = acc; }
+                }
             }
         }
         lds_barrier();
@@ -248,14 +320,18 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
         GSCAN_STAMP(7)
 
         // ---- F+G: visual context, gate pre-activations, activations --------------------------
-        if (role < 4) {
-            const float us = weighted_sum(al_s, Uv + tid, 4 * H, M);
-            const float pre = ge + gh + uc + us;
-            const float g = (role == 2) ? tanhf_(pre) : sigmoidf_(pre);
-            gate_s[tid] = g;
-            a.gates[bt * 4 * H + tid] = g;
-        } else if (role == 4) {
-            a.s[bt * 4 * H + 2 * H + k] = weighted_sum(al_s, PKv + k, H, M);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int r = s * kDecPairs + pair;
+            if (r < 4 * H) {
+                const float us = pair_sum(split_weighted_sum(al_s, Uv + r, 4 * H, M, half));
+                const float pre = ge[s] + gh[s] + uc[s] + us;
+                const float g = (r >= 2 * H && r < 3 * H) ? tanhf_(pre) : sigmoidf_(pre);
+                if (half == 0) { gate_s[r] = g; a.gates[bt * 4 * H + r] = g; }
+            } else if (r < 5 * H) {
+                const float cs = pair_sum(split_weighted_sum(al_s, PKv + (r - 4 * H), H, M, half));
+                if (half == 0) a.s[bt * 4 * H + 2 * H + (r - 4 * H)] = cs;
+            }
         }
         lds_barrier();
         GSCAN_STAMP(8)
@@ -286,52 +362,45 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_fwd_kern
 // which is again a dense GEMM).
 // ------------------------------------------------------------------------------------------
 template <int H, bool COND>
-__global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kernel(DecoderArgs a) {
+__global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a) {
+    constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
+                  HP = 2 * K0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = kDecThreads / 64;
+    const int pair = tid >> 1, half = tid & 1;
     const int T = a.T, L = a.L, M = a.M;
     const DecoderLds o = decoder_lds(H, L, M, COND, true);
     float *Uv = smem + o.uv, *PKv = smem + o.pkv, *Ut = smem + o.ut, *PKt = smem + o.pkt, *U2t = smem + o.u2t;
     float *dPKv = smem + o.dpkv, *dPKt = smem + o.dpkt;
     float *vec = smem + o.vec;
-    float *dh_s = vec + V_H * H, *qt_s = vec + V_QT * H, *q2_s = vec + V_Q2 * H, *qv_s = vec + V_QV * H,
-          *vt_s = vec + V_VT * H, *vv_s = vec + V_VV * H, *dqv_s = vec + V_ZQ * H, *d_s = vec + V_D * H,
-          *exc_s = vec + V_EXC * H, *exs_s = vec + V_EXS * H, *part_s = vec + V_PART * H;
-    float *sc_s = vec + V_END * H, *al_s = vec + V_END * H + 64, *datt_s = vec + V_END * H + 128,
-          *stamp_acc = vec + V_END * H + 192;
+    float *d_s = vec;                 // [6][HP]: delta (4 blocks) | dqt | dzq or dqv, each zero-padded to HP
+    float *dqv_s = vec + 6 * HP;      // [HP]
+    float *dh_s = vec + 7 * HP, *qt_s = dh_s + H, *q2_s = qt_s + H, *qv_s = q2_s + H, *vt_s = qv_s + H,
+          *vv_s = vt_s + H, *exc_s = vv_s + H, *exs_s = exc_s + H, *part_s = exs_s + H;    // part_s: 6H
+    float *sc_s = part_s + 6 * H, *al_s = sc_s + 64, *datt_s = sc_s + 128, *stamp_acc = sc_s + 192;
     long long stamp_prev = a.stamps ? clock64() : 0;
-    if (tid < 16) stamp_acc[tid] = 0.f;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
-    const int nchunk = min(6, (int)blockDim.x / H);        // (chunk, k) ownership of key pairs; part_s holds 6H
-
-    for (int i = tid; i < M * 4 * H; i += blockDim.x) Uv[i] = a.u_v[(int64_t)b * M * 4 * H + i];
-    for (int i = tid; i < M * H; i += blockDim.x) { PKv[i] = a.pk_v[(int64_t)b * M * H + i]; dPKv[i] = 0.f; }
-    for (int i = tid; i < L * 4 * H; i += blockDim.x) Ut[i] = a.u_t[(int64_t)b * L * 4 * H + i];
-    for (int i = tid; i < L * H; i += blockDim.x) { PKt[i] = a.pk_t[(int64_t)b * L * H + i]; dPKt[i] = 0.f; }
-    if (COND)
-        for (int i = tid; i < L * H; i += blockDim.x) U2t[i] = a.u2_t[(int64_t)b * L * H + i];
-    if (tid < H) { dh_s[tid] = 0.f; vt_s[tid] = a.v_t[tid]; vv_s[tid] = a.v_v[tid]; }
-    if (tid < 64) datt_s[tid] = (a.datt && tid < M) ? a.datt[(int64_t)b * M + tid] : 0.f;
-
-    // transposed weights: thread (seg, k) holds rows seg*H.. of [W_hh(4H) | W_qt | W_q2k_h or W_qv], column k
+    const int nchunk = min(6, kDecThreads / H);            // (chunk, k) ownership of key pairs; part_s holds 6H
     const int seg = tid / H, k = tid % H;
-    float wt[H];
-    {
-        const float *src = nullptr;
-        int64_t stride = H;
-        if (seg < 4) src = a.w_hh + (int64_t)seg * H * H + k;
-        else if (seg == 4) src = a.w_qt + k;
-        else if (seg == 5) { src = COND ? a.w_q2k + k : a.w_qv + k; stride = COND ? 2 * H : H; }
-        else if (seg == 6 && COND) src = a.w_qv + k;
-        if (src) {
+
+    float wt[NS][K0];
 #pragma unroll
-            for (int j = 0; j < H; ++j) wt[j] = src[(int64_t)j * stride];
-        } else {
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int j = 0; j < H; ++j) wt[j] = 0.f;
-        }
-    }
+        for (int i = 0; i < K0; ++i) wt[s][i] = a.w_image[(s * K0 + i) * kDecThreads + tid];
+    stage(Uv, a.u_v + (int64_t)b * M * 4 * H, M * 4 * H, tid, kDecThreads);
+    stage(PKv, a.pk_v + (int64_t)b * M * H, M * H, tid, kDecThreads);
+    stage(Ut, a.u_t + (int64_t)b * L * 4 * H, L * 4 * H, tid, kDecThreads);
+    stage(PKt, a.pk_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
+    if (COND) stage(U2t, a.u2_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
+    for (int i = tid; i < M * H; i += kDecThreads) dPKv[i] = 0.f;
+    for (int i = tid; i < L * H; i += kDecThreads) dPKt[i] = 0.f;
+    for (int i = tid; i < 7 * HP + H; i += kDecThreads) vec[i] = 0.f;    // d_s / dqv_s incl. padding, and dh_s
+    lds_barrier();
+    if (tid < H) { vt_s[tid] = a.v_t[tid]; vv_s[tid] = a.v_v[tid]; }
+    if (tid < 64) datt_s[tid] = (a.datt && tid < M) ? a.datt[(int64_t)b * M + tid] : 0.f;
+    if (tid >= 64 && tid < 80) stamp_acc[tid - 64] = 0.f;
     float dc = 0.f, dvv_acc = 0.f, dvt_acc = 0.f;
     lds_barrier();
 
@@ -352,15 +421,17 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
             const float dg = dct * ig * (1.f - gg * gg);
             const float d_o = dh * tc * og * (1.f - og);
             dc = dct * fg;
-            d_s[tid] = di; d_s[H + tid] = df; d_s[2 * H + tid] = dg; d_s[3 * H + tid] = d_o;
+            d_s[tid] = di; d_s[HP + tid] = df; d_s[2 * HP + tid] = dg; d_s[3 * HP + tid] = d_o;
             float *dp = a.delta + bt * 4 * H;
             dp[tid] = di; dp[H + tid] = df; dp[2 * H + tid] = dg; dp[3 * H + tid] = d_o;
+        } else if (tid >= 128 && tid < 128 + H) {
             // external gradients wrt the two contexts (output head) and the saved queries
-            exc_s[tid] = a.ds[bt * 4 * H + H + tid];
-            exs_s[tid] = a.ds[bt * 4 * H + 2 * H + tid];
-            qt_s[tid] = a.qt[bt * H + tid];
-            qv_s[tid] = a.qv[bt * H + tid];
-            if (COND) q2_s[tid] = a.q2[bt * H + tid];
+            const int kk = tid - 128;
+            exc_s[kk] = a.ds[bt * 4 * H + H + kk];
+            exs_s[kk] = a.ds[bt * 4 * H + 2 * H + kk];
+            qt_s[kk] = a.qt[bt * H + kk];
+            qv_s[kk] = a.qv[bt * H + kk];
+            if (COND) q2_s[kk] = a.q2[bt * H + kk];
         }
         lds_barrier();
         GSCAN_STAMP(1)
@@ -373,7 +444,9 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
                 const int m = m0 + i * nwave;
                 p[i] = 0.f;
                 if (m < M) {
-                    for (int j = lane; j < 4 * H; j += 64) p[i] = fmaf(d_s[j], Uv[m * 4 * H + j], p[i]);
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg)
+                        for (int j = lane; j < H; j += 64) p[i] = fmaf(d_s[sg * HP + j], Uv[m * 4 * H + sg * H + j], p[i]);
                     for (int kk = lane; kk < H; kk += 64) p[i] = fmaf(exs_s[kk], PKv[m * H + kk], p[i]);
                 }
             }
@@ -416,23 +489,26 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
             for (int cch = 0; cch < nchunk; ++cch) dq += part_s[cch * H + tid];
             dqv_s[tid] = dq;
             a.dqv[bt * H + tid] = dq;
-            if (!COND) d_s[5 * H + tid] = dq;               // visual query came straight from h
+            if (!COND) d_s[5 * HP + tid] = dq;               // visual query came straight from h
         }
         lds_barrier();
         GSCAN_STAMP(5)
 
         // ---- 4: conditional query: dq2 = W_qv^T dqv, through tanh ------------------------------
         if (COND) {
-            if (seg == 6) {
-                const float dq2 = dot_reg_lds<H>(wt, dqv_s);
-                const float q = q2_s[k];
-                const float dz = dq2 * (1.f - q * q);
-                d_s[5 * H + k] = dz;
-                a.dzq[bt * H + k] = dz;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int r = s * kDecPairs + pair;
+                if (r >= 6 * H && r < 7 * H) {
+                    const float dq2 = pair_sum(half_dot<K0>(wt[s], dqv_s + half * K0));
+                    const float q = q2_s[r - 6 * H];
+                    const float dz = dq2 * (1.f - q * q);
+                    if (half == 0) { d_s[5 * HP + r - 6 * H] = dz; a.dzq[bt * H + r - 6 * H] = dz; }
+                }
             }
             lds_barrier();
-            GSCAN_STAMP(6)
         }
+        GSCAN_STAMP(6)
 
         // ---- 5: d alpha_text[m] = delta . U_text[m] + dzq . U2_text[m] + dctx_text(ext) . PK_text[m]
         for (int m0 = wave; m0 < len; m0 += 4 * nwave) {
@@ -442,10 +518,12 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
                 const int m = m0 + i * nwave;
                 p[i] = 0.f;
                 if (m < len) {
-                    for (int j = lane; j < 4 * H; j += 64) p[i] = fmaf(d_s[j], Ut[m * 4 * H + j], p[i]);
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg)
+                        for (int j = lane; j < H; j += 64) p[i] = fmaf(d_s[sg * HP + j], Ut[m * 4 * H + sg * H + j], p[i]);
                     for (int kk = lane; kk < H; kk += 64) {
                         p[i] = fmaf(exc_s[kk], PKt[m * H + kk], p[i]);
-                        if (COND) p[i] = fmaf(d_s[5 * H + kk], U2t[m * H + kk], p[i]);
+                        if (COND) p[i] = fmaf(d_s[5 * HP + kk], U2t[m * H + kk], p[i]);
                     }
                 }
             }
@@ -486,16 +564,22 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
         if (tid < H) {
             float dq = 0.f;
             for (int cch = 0; cch < nchunk; ++cch) dq += part_s[cch * H + tid];
-            d_s[4 * H + tid] = dq;
+            d_s[4 * HP + tid] = dq;
             a.dqt[bt * H + tid] = dq;
         }
         lds_barrier();
         GSCAN_STAMP(10)
 
         // ---- 7: dh_{t-1} = [W_hh | W_qt | W_q2k_h or W_qv]^T . [delta | dqt | dzq or dqv] ------
-        float part = 0.f;
-        if (seg < 6) part = dot_reg_lds<H>(wt, d_s + seg * H);
-        if (seg < 6) part_s[seg * H + k] = part;            // phase 6's partials were consumed before the last barrier
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int r = s * kDecPairs + pair;
+            if (r < 6 * H) {
+                const int sg = r / H;
+                const float part = pair_sum(half_dot<K0>(wt[s], d_s + sg * HP + half * K0));
+                if (half == 0) part_s[r] = part;             // r = sg*H + k
+            }
+        }
         lds_barrier();
         GSCAN_STAMP(11)
         if (tid < H) {
@@ -513,8 +597,8 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
         const float h0 = a.hprev[(int64_t)b * T * H + tid];
         a.dh0[(int64_t)b * H + tid] = (dh_s[tid] + dc) * (1.f - h0 * h0);   // h0 = c0 = tanh(.) (model.py:195)
     }
-    for (int i = tid; i < M * H; i += blockDim.x) a.dpk_v[(int64_t)b * M * H + i] = dPKv[i];
-    for (int i = tid; i < L * H; i += blockDim.x) a.dpk_t[(int64_t)b * L * H + i] = (i / H < len) ? dPKt[i] : 0.f;
+    for (int i = tid; i < M * H; i += kDecThreads) a.dpk_v[(int64_t)b * M * H + i] = dPKv[i];
+    for (int i = tid; i < L * H; i += kDecThreads) a.dpk_t[(int64_t)b * L * H + i] = (i / H < len) ? dPKt[i] : 0.f;
     lds_barrier();
     if (seg < nchunk) part_s[seg * H + k] = dvv_acc;
     lds_barrier();
@@ -535,19 +619,63 @@ __global__ __launch_bounds__((decoder_threads<H, COND>())) void decoder_bwd_kern
 }
 
 // ------------------------------------------------------------------------------------------
+// Register images of the decoder weights, written once per step (both directions of use):
+//   image[(slot*K0 + i)*512 + tid] = element i of the half-row that thread tid keeps in slot `slot`.
+// forward image: task r -> row of the stacked matrix; backward image: task (seg,k) -> column k of block seg.
+// ------------------------------------------------------------------------------------------
+__global__ void decoder_weight_image_kernel(const float *__restrict__ w_hh, const float *__restrict__ w_qt,
+                                            const float *__restrict__ w_qv, const float *__restrict__ w_q2k, int H,
+                                            int cond, int slots, int k0, float *__restrict__ fwd_image,
+                                            float *__restrict__ bwd_image) {
+    const int total = slots * k0 * kDecThreads;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * total; idx += gridDim.x * blockDim.x) {
+        const bool bwd = idx >= total;
+        const int e = bwd ? idx - total : idx;
+        const int tid = e % kDecThreads, i = (e / kDecThreads) % k0, s = e / (kDecThreads * k0);
+        const int r = s * kDecPairs + (tid >> 1), kk = (tid & 1) * k0 + i;       // kk: position along the dot
+        float v = 0.f;
+        const int rows = (cond ? 7 : 6) * H;
+        if (r < rows && kk < H) {
+            const int sg = r / H, q = r % H;                                      // block, index inside it
+            if (!bwd) {          // row q of block sg, element kk
+                if (sg < 4) v = w_hh[(int64_t)r * H + kk];
+                else if (sg == 4) v = w_qt[(int64_t)q * H + kk];
+                else if (sg == 5) v = cond ? w_q2k[(int64_t)q * 2 * H + kk] : w_qv[(int64_t)q * H + kk];
+                else v = w_qv[(int64_t)q * H + kk];
+            } else {             // column q of block sg, element (row) kk
+                if (sg < 4) v = w_hh[(int64_t)(sg * H + kk) * H + q];
+                else if (sg == 4) v = w_qt[(int64_t)kk * H + q];
+                else if (sg == 5) v = cond ? w_q2k[(int64_t)kk * 2 * H + q] : w_qv[(int64_t)kk * H + q];
+                else v = w_qv[(int64_t)kk * H + q];
+            }
+        }
+        (bwd ? bwd_image : fwd_image)[e] = v;
+    }
+}
+
+int decoder_weight_images(const float *w_hh, const float *w_qt, const float *w_qv, const float *w_q2k, int H,
+                          bool cond, float *fwd_image, float *bwd_image, hipStream_t stream) {
+    const DecoderGeometry g = decoder_geometry(H, cond);
+    const int total = 2 * (int)g.image_floats;
+    hipLaunchKernelGGL(decoder_weight_image_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, stream, w_hh,
+                       w_qt, w_qv, w_q2k, H, cond ? 1 : 0, g.slots, g.k0, fwd_image, bwd_image);
+    GSCAN_LAUNCHED("decoder_weight_image_kernel");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 constexpr size_t kLdsLimit = 160 * 1024;
 
 template <int H, bool COND>
 static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_t stream) {
-    constexpr int nt = decoder_threads<H, COND>();
-    GSCAN_CHECK(nt <= 1024, "decoder: hidden size %d needs %d threads per row (> 1024)", H, nt);
     const DecoderLds o = decoder_lds(H, a.L, a.M, COND, backward);
     const size_t bytes = (size_t)o.total * sizeof(float);
     GSCAN_CHECK(bytes <= kLdsLimit,
                 "decoder: a row's memories need %zu bytes of LDS (> 160 KiB): grid cells=%d command length=%d hidden=%d",
                 bytes, a.M, a.L, H);
+    GSCAN_CHECK(a.w_image != nullptr, "decoder: weight image missing");
     // Algorithmic MACs of one decoder step that this kernel owns (SURVEY.md §8d MAC_step minus the
     // embedding part of the LSTM input and the output head, which run as GEMMs outside the loop):
     // query projections, both score/context reductions, and the [ctx_text|ctx_vis|h] part of the LSTM.
@@ -561,7 +689,7 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
             attr_set = true;
         }
-        hipLaunchKernelGGL((decoder_bwd_kernel<H, COND>), dim3(B), dim3(nt), bytes, stream, a);
+        hipLaunchKernelGGL((decoder_bwd_kernel<H, COND>), dim3(B), dim3(kDecThreads), bytes, stream, a);
         GSCAN_LAUNCHED("decoder_bwd_kernel");
     } else {
         static bool attr_set = false;
@@ -570,7 +698,7 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
             attr_set = true;
         }
-        hipLaunchKernelGGL((decoder_fwd_kernel<H, COND>), dim3(B), dim3(nt), bytes, stream, a);
+        hipLaunchKernelGGL((decoder_fwd_kernel<H, COND>), dim3(B), dim3(kDecThreads), bytes, stream, a);
         GSCAN_LAUNCHED("decoder_fwd_kernel");
     }
     return 0;

@@ -85,13 +85,21 @@ int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, c
                           const float *d_h_final, float *delta, hipStream_t stream);
 
 // decoder.hip
+constexpr int kDecThreads = 512;   // 8 waves: 2 per SIMD, 256-VGPR budget
+constexpr int kDecPairs = 256;     // lane pairs; a weight row lives in one pair
+struct DecoderGeometry { int rows, slots, k0; int64_t image_floats; };
+DecoderGeometry decoder_geometry(int H, bool cond);
+int decoder_weight_images(const float *w_hh, const float *w_qt, const float *w_qv, const float *w_q2k, int H,
+                          bool cond, float *fwd_image, float *bwd_image, hipStream_t stream);
+
 struct DecoderArgs {
     int T, L, M;                       // target steps, command memories, grid memories (G*G)
     const int32_t *cmd_lengths;        // [B]
     const float *pk_t, *u_t, *u2_t;    // [B,L,H] [B,L,4H] [B,L,H]
     const float *pk_v, *u_v;           // [B,M,H] [B,M,4H]
     const float *ge;                   // [B,T,4H] embedding part of the gates + both biases
-    const float *w_hh, *w_qt, *w_qv, *w_q2k, *b_q2k, *v_t, *v_v;
+    const float *w_image;              // register image of the recurrent weights (decoder_weight_images)
+    const float *b_q2k, *v_t, *v_v;
     float *hprev;                      // [B,T,H]  hprev[b,0] = h0 = c0 on entry; kernel fills t+1
     float *s;                          // [B,T,4H] = [e | ctx_text | ctx_vis | h_t]; kernel fills 3 parts
     float *cells, *gates;              // [B,T,H] [B,T,4H]
@@ -130,7 +138,7 @@ struct Workspace {
     int64_t xcol, feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
-        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk;
+        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd;
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;

@@ -51,6 +51,8 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(w_sk, 4 * H * F);
     SLOT(w_ck, 4 * H * He);
     SLOT(w_2kk, H * He);
+    SLOT(dec_w_fwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
+    SLOT(dec_w_bwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
     SLOT(hprev, B * T * H);
     SLOT(S, B * T * 4 * H);
     SLOT(ge, B * T * 4 * H);
@@ -136,8 +138,7 @@ static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, cons
     a.pk_t = w + ws.pkt; a.u_t = w + ws.ut; a.u2_t = w + ws.u2t;
     a.pk_v = w + ws.pkv; a.u_v = w + ws.uv;
     a.ge = w + ws.ge;
-    a.w_hh = p.dec_w_hh; a.w_qt = p.txt_query_w; a.w_qv = p.vis_query_w; a.w_q2k = p.q2k_w; a.b_q2k = p.q2k_b;
-    a.v_t = p.txt_energy_w; a.v_v = p.vis_energy_w;
+    a.b_q2k = p.q2k_b; a.v_t = p.txt_energy_w; a.v_v = p.vis_energy_w;
     a.hprev = w + ws.hprev; a.s = w + ws.S; a.cells = w + ws.cells; a.gates = w + ws.gates;
     a.alpha_c = w + ws.alpha_c; a.alpha_s = w + ws.alpha_s;
     a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
@@ -177,6 +178,8 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
         for (int i = 0; i < 6; ++i) { acc += n[i]; a.end[i] = acc; }
         TRY(step_prologue(a, st));
     }
+    TRY(decoder_weight_images(p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, H, cond, w + ws.dec_w_fwd,
+                              w + ws.dec_w_bwd, st));
     TRY(world_im2col(bt.world, B, d.G, C, d.K3, w + ws.xcol, st));
 
     // ---- level 1: everything that depends only on inputs and parameters
@@ -227,6 +230,7 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     }
     // ---- the T-step recurrence
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
+    a.w_image = w + ws.dec_w_fwd;
     a.stamps = probe_stamps_enabled() ? w + ws.stamps : nullptr;
     TRY(decoder_run(false, B, H, cond, a, st));
 
@@ -282,6 +286,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     a.delta = w + ws.delta; a.dzq = w + ws.dzq; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
     a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = g.txt_energy_w; a.dv_v = g.vis_energy_w;
     a.dh0 = w + ws.dh0;
+    a.w_image = w + ws.dec_w_bwd;
     a.stamps = probe_stamps_enabled() ? w + ws.stamps + 16 : nullptr;
     TRY(decoder_run(true, B, H, cond, a, st));
 
