@@ -163,6 +163,7 @@ DecoderGeometry decoder_geometry(int H, bool cond) {
 struct DecoderLds {
     int uv, pkv, ut, pkt, u2t, dpkv, dpkt, vec, total;
 };
+constexpr int kPartStride = 512;   // columns per m-group slab of partial sums (>= 5H)
 __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, bool cond, bool backward) {
     const int HP = 2 * (((H / 2 + 3) / 4) * 4);       // padded length of every vector a half_dot reads
     DecoderLds o;
@@ -175,9 +176,27 @@ __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, bool cond
     o.dpkv = p; p += backward ? M * H : 0;
     o.dpkt = p; p += backward ? L * H : 0;
     o.vec = p;
-    p += (backward ? 7 * HP + 14 * H : 2 * HP + 8 * H) + 256;
+    p += (backward ? 7 * HP + 14 * H : 2 * HP + 14 * H + 4 * kPartStride) + 256;
     o.total = p;
     return o;
+}
+
+// float4 helpers
+__device__ __forceinline__ float4 fma4(float a, const float4 &x, const float4 &acc) {
+    return float4{fmaf(a, x.x, acc.x), fmaf(a, x.y, acc.y), fmaf(a, x.z, acc.z), fmaf(a, x.w, acc.w)};
+}
+__device__ __forceinline__ float dot4(const float4 &a, const float4 &b, float acc) {
+    return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, fmaf(a.w, b.w, acc))));
+}
+
+// Column quad q of the row-memory images for one attention: [U (4H cols) | PK (H cols) | U2 (H cols, optional)].
+// Returns the address of columns 4q..4q+3 of memory m.
+__device__ __forceinline__ const float4 *quad_ptr(const float *U, const float *PK, const float *U2, int H, int m,
+                                                  int q) {
+    const int col = 4 * q;
+    if (col < 4 * H) return reinterpret_cast<const float4 *>(U + m * 4 * H + col);
+    if (col < 5 * H) return reinterpret_cast<const float4 *>(PK + m * H + (col - 4 * H));
+    return reinterpret_cast<const float4 *>(U2 + m * H + (col - 5 * H));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -185,6 +204,9 @@ template <int H, bool COND>
 __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a) {
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
                   HP = 2 * K0;
+    constexpr int NQT = (COND ? 6 : 5) * H / 4;   // column quads of the textual images [U_t | PK_t | U2_t]
+    constexpr int NQV = 5 * H / 4;                // column quads of the visual images [U_v | PK_v]
+    static_assert(4 * NQV <= kDecThreads && 5 * H <= kPartStride, "hidden size too large for the m-group split");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = kDecThreads / 64;
     const int pair = tid >> 1, half = tid & 1;
@@ -193,11 +215,15 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     float *Uv = smem + o.uv, *PKv = smem + o.pkv, *Ut = smem + o.ut, *PKt = smem + o.pkt, *U2t = smem + o.u2t;
     float *vec = smem + o.vec;
     float *h_s = vec, *q2_s = vec + HP;                     // dot inputs, zero-padded to HP
-    float *qt_s = vec + 2 * HP, *qv_s = qt_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H, *gate_s = vv_s + H;
-    float *sc_s = gate_s + 4 * H, *al_s = sc_s + 64, *stamp_acc = sc_s + 192;
+    float *qt_s = vec + 2 * HP, *qv_s = qt_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H;
+    float *gsum_s = vv_s + H;                               // [4H] ge + gh + uc per gate row
+    float *col_s = gsum_s + 4 * H;                          // [6H] textual column sums
+    float *part_s = col_s + 6 * H;                          // [4][kPartStride] visual partial column sums
+    float *sc_s = part_s + 4 * kPartStride, *al_s = sc_s + 64, *stamp_acc = sc_s + 192;
     long long stamp_prev = a.stamps ? clock64() : 0;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
+    const int mg = (M + 3) / 4;                             // memories per visual m-group
 
     // ---- one-time loads: register image of the weights (coalesced), memories -> LDS -----------
     float w[NS][K0];
@@ -232,9 +258,9 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     for (int t = 0; t < T; ++t) {
         GSCAN_STAMP(0)
         const unsigned bt = (unsigned)b * T + t;            // 32-bit offsets: B*T*4H < 2^31 is checked on the host
-        float ge[NS], gh[NS], uc[NS];
+        float ge[NS], gh[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {                      // embedding part of the gates: issued early, used in F
+        for (int s = 0; s < NS; ++s) {                      // embedding part of the gates: issued early, used in C2
             const int r = s * kDecPairs + pair;
             ge[s] = (r < 4 * H) ? a.ge[bt * 4 * H + r] : 0.f;
         }
@@ -244,13 +270,11 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int r = s * kDecPairs + pair;
-            {
-                const float acc = pair_sum(gh[s]);
-                gh[s] = acc;                                // gate rows keep it; q2k rows reuse the register in C
-                if (r >= 4 * H && r < 6 * H && half == 0) {
-                    if (r < 5 * H) { qt_s[r - 4 * H] = acc; a.qt[bt * H + r - 4 * H] = acc; }
-                    else if (!COND) { qv_s[r - 5 * H] = acc; a.qv[bt * H + r - 5 * H] = acc; }
-                }
+            const float acc = pair_sum(gh[s]);
+            gh[s] = acc;                                    // gate rows and q2k rows keep it for phase C2
+            if (r >= 4 * H && r < 6 * H && half == 0) {
+                if (r < 5 * H) { qt_s[r - 4 * H] = acc; a.qt[bt * H + r - 4 * H] = acc; }
+                else if (!COND) { qv_s[r - 5 * H] = acc; a.qv[bt * H + r - 5 * H] = acc; }
             }
         }
         lds_barrier();
@@ -271,25 +295,34 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         lds_barrier();
         GSCAN_STAMP(3)
 
-        // ---- C: textual context and its images under W_ih / W_q2k ----------------------------
+        // ---- C1: textual column sums sum_m alpha_m [U_t | PK_t | U2_t][m, :], one column quad per thread --
+        if (tid < NQT) {
+            float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int m = 0; m < len; ++m) acc = fma4(al_s[m], *quad_ptr(Ut, PKt, U2t, H, m, tid), acc);
+            *reinterpret_cast<float4 *>(col_s + 4 * tid) = acc;
+        }
+        lds_barrier();
+        GSCAN_STAMP(4)
+        // ---- C2: hand the sums to their owners: gate rows, textual context, conditional query ------
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int r = s * kDecPairs + pair;
-            uc[s] = 0.f;
-            if (r < 4 * H) {
-                uc[s] = pair_sum(split_weighted_sum(al_s, Ut + r, 4 * H, len, half));
-            } else if (r < 5 * H) {
-                const float cc = pair_sum(split_weighted_sum(al_s, PKt + (r - 4 * H), H, len, half));
-                if (half == 0) a.s[bt * 4 * H + H + (r - 4 * H)] = cc;
-            } else if (COND && r < 6 * H) {
-                const float u2 = pair_sum(split_weighted_sum(al_s, U2t + (r - 5 * H), H, len, half));
-                const float q = tanhf_(gh[s] + u2 + bq[s]);   // seq2seq_model.py:394-396
-                if (half == 0) { q2_s[r - 5 * H] = q; a.q2[bt * H + r - 5 * H] = q; }
+            if (half == 0) {
+                if (r < 4 * H) {
+                    gsum_s[r] = ge[s] + gh[s] + col_s[r];
+                } else if (r < 5 * H) {
+                    a.s[bt * 4 * H + H + (r - 4 * H)] = col_s[r];
+                } else if (COND && r < 6 * H) {
+                    const float q = tanhf_(gh[s] + col_s[r] + bq[s]);   // seq2seq_model.py:394-396
+                    q2_s[r - 5 * H] = q;
+                    a.q2[bt * H + r - 5 * H] = q;
+                }
             }
         }
         if (COND) {
             lds_barrier();
-            GSCAN_STAMP(4)
+            GSCAN_STAMP(5)
             // ---- D: visual query from the conditional query ---------------------------------
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -301,12 +334,12 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             }
         }
         lds_barrier();
-        GSCAN_STAMP(5)
+        GSCAN_STAMP(6)
 
         // ---- E: visual scores over all M cells (no mask: every row has M memories) -----------
         attention_scores<H>(vv_s, qv_s, PKv, M, sc_s, wave, nwave, lane);
         lds_barrier();
-        GSCAN_STAMP(6)
+        GSCAN_STAMP(7)
         if (wave == 0) {
             const float x = (lane < M) ? sc_s[lane] : -INFINITY;
             const float mx = wave_max(x);
@@ -317,40 +350,88 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             att_acc += al;                                     // seq2seq_model.py:479,490
         }
         lds_barrier();
-        GSCAN_STAMP(7)
-
-        // ---- F+G: visual context, gate pre-activations, activations --------------------------
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int r = s * kDecPairs + pair;
-            if (r < 4 * H) {
-                const float us = pair_sum(split_weighted_sum(al_s, Uv + r, 4 * H, M, half));
-                const float pre = ge[s] + gh[s] + uc[s] + us;
-                const float g = (r >= 2 * H && r < 3 * H) ? tanhf_(pre) : sigmoidf_(pre);
-                if (half == 0) { gate_s[r] = g; a.gates[bt * 4 * H + r] = g; }
-            } else if (r < 5 * H) {
-                const float cs = pair_sum(split_weighted_sum(al_s, PKv + (r - 4 * H), H, M, half));
-                if (half == 0) a.s[bt * 4 * H + 2 * H + (r - 4 * H)] = cs;
-            }
-        }
-        lds_barrier();
         GSCAN_STAMP(8)
 
-        // ---- H: cell update (seq2seq_model.py:414) ---------------------------------------------
+        // ---- F1: visual column sums over four m-groups: thread = (group, column quad) -----------
+        if (tid < 4 * NQV) {
+            const int grp = tid / NQV, q = tid % NQV;
+            const int m_lo = grp * mg, m_hi = min(M, m_lo + mg);
+            float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 3
+            for (int m = m_lo; m < m_hi; ++m) acc = fma4(al_s[m], *quad_ptr(Uv, PKv, PKv, H, m, q), acc);
+            *reinterpret_cast<float4 *>(part_s + grp * kPartStride + 4 * q) = acc;
+        }
+        lds_barrier();
+        GSCAN_STAMP(9)
+
+        // ---- H: gates, cell update (seq2seq_model.py:414) and visual context -----------------------
         if (tid < H) {
-            const float ig = gate_s[tid], fg = gate_s[H + tid], gg = gate_s[2 * H + tid], og = gate_s[3 * H + tid];
-            c = fg * c + ig * gg;
-            const float h = og * tanhf_(c);
+            float g4[4];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                const int r = gi * H + tid;
+                const float pre = gsum_s[r] + (part_s[r] + part_s[kPartStride + r]) +
+                                  (part_s[2 * kPartStride + r] + part_s[3 * kPartStride + r]);
+                g4[gi] = (gi == 2) ? tanhf_(pre) : sigmoidf_(pre);
+                a.gates[bt * 4 * H + r] = g4[gi];
+            }
+            c = g4[1] * c + g4[0] * g4[2];
+            const float h = g4[3] * tanhf_(c);
             h_s[tid] = h;
             a.cells[bt * H + tid] = c;
             a.s[bt * 4 * H + 3 * H + tid] = h;
             if (t + 1 < T) a.hprev[(bt + 1) * H + tid] = h;
+        } else if (tid >= 128 && tid < 128 + H) {
+            const int r = 4 * H + (tid - 128);
+            a.s[bt * 4 * H + 2 * H + (tid - 128)] = (part_s[r] + part_s[kPartStride + r]) +
+                                                    (part_s[2 * kPartStride + r] + part_s[3 * kPartStride + r]);
         }
         lds_barrier();
-        GSCAN_STAMP(9)
+        GSCAN_STAMP(10)
     }
     if (wave == 0 && lane < M) a.att_sum[(int64_t)b * M + lane] = att_acc;
     if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_acc[tid];
+}
+
+// d alpha[m] = delta . U[m] (+ dzq . U2[m]) + dctx(ext) . PK[m] for the memories of one attention, one wave per
+// memory, 16-byte LDS reads: float4 index i < H covers the four delta blocks, then H/4 for PK, then H/4 for U2.
+template <int H, int HP, bool WITH_U2>
+__device__ __forceinline__ void dalpha_rows(const float *d_s, const float *ext_s, const float *U, const float *PK,
+                                            const float *U2, int n, const float *add, float *sc_s, int wave,
+                                            int nwave, int lane) {
+    constexpr int Q = H / 4, NQ = (WITH_U2 ? 6 : 5) * Q;
+    for (int m0 = wave; m0 < n; m0 += 4 * nwave) {
+        float p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + i * nwave;
+            p[i] = 0.f;
+            if (m < n) {
+                for (int idx = lane; idx < NQ; idx += 64) {
+                    float4 x, y;
+                    if (idx < 4 * Q) {
+                        x = *reinterpret_cast<const float4 *>(d_s + (idx / Q) * HP + 4 * (idx % Q));
+                        y = *reinterpret_cast<const float4 *>(U + m * 4 * H + 4 * idx);
+                    } else if (idx < 5 * Q) {
+                        x = *reinterpret_cast<const float4 *>(ext_s + 4 * (idx - 4 * Q));
+                        y = *reinterpret_cast<const float4 *>(PK + m * H + 4 * (idx - 4 * Q));
+                    } else {
+                        x = *reinterpret_cast<const float4 *>(d_s + 5 * HP + 4 * (idx - 5 * Q));
+                        y = *reinterpret_cast<const float4 *>(U2 + m * H + 4 * (idx - 5 * Q));
+                    }
+                    p[i] = dot4(x, y, p[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + i * nwave;
+            if (m < n) {
+                const float tsum = wave_sum(p[i]);
+                if (lane == 0) sc_s[m] = tsum + (add ? add[m] : 0.f);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -375,9 +456,9 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     float *vec = smem + o.vec;
     float *d_s = vec;                 // [6][HP]: delta (4 blocks) | dqt | dzq or dqv, each zero-padded to HP
     float *dqv_s = vec + 6 * HP;      // [HP]
-    float *dh_s = vec + 7 * HP, *qt_s = dh_s + H, *q2_s = qt_s + H, *qv_s = q2_s + H, *vt_s = qv_s + H,
-          *vv_s = vt_s + H, *exc_s = vv_s + H, *exs_s = exc_s + H, *part_s = exs_s + H;    // part_s: 6H
-    float *sc_s = part_s + 6 * H, *al_s = sc_s + 64, *datt_s = sc_s + 128, *stamp_acc = sc_s + 192;
+    float *qt_s = vec + 7 * HP, *q2_s = qt_s + H, *qv_s = q2_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H,
+          *exc_s = vv_s + H, *exs_s = exc_s + H, *part_s = exs_s + H;    // part_s: 6H (+H spare)
+    float *sc_s = part_s + 7 * H, *al_s = sc_s + 64, *datt_s = sc_s + 128, *stamp_acc = sc_s + 192;
     long long stamp_prev = a.stamps ? clock64() : 0;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
@@ -396,7 +477,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     if (COND) stage(U2t, a.u2_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
     for (int i = tid; i < M * H; i += kDecThreads) dPKv[i] = 0.f;
     for (int i = tid; i < L * H; i += kDecThreads) dPKt[i] = 0.f;
-    for (int i = tid; i < 7 * HP + H; i += kDecThreads) vec[i] = 0.f;    // d_s / dqv_s incl. padding, and dh_s
+    for (int i = tid; i < 7 * HP; i += kDecThreads) vec[i] = 0.f;        // d_s / dqv_s incl. padding
+    for (int i = tid; i < 7 * H; i += kDecThreads) part_s[i] = 0.f;      // dh_T = 0 (summed at the top of the loop)
     lds_barrier();
     if (tid < H) { vt_s[tid] = a.v_t[tid]; vv_s[tid] = a.v_v[tid]; }
     if (tid < 64) datt_s[tid] = (a.datt && tid < M) ? a.datt[(int64_t)b * M + tid] : 0.f;
@@ -407,9 +489,11 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     for (int t = T - 1; t >= 0; --t) {
         GSCAN_STAMP(0)
         const unsigned bt = (unsigned)b * T + t;
-        // ---- 1: LSTM cell backward -----------------------------------------------------------
+        // ---- 1: dh_t = sum of the six partial products of step t+1; LSTM cell backward ------------
         if (tid < H) {
-            const float dh = dh_s[tid] + a.ds[bt * 4 * H + 3 * H + tid];
+            float dh = a.ds[bt * 4 * H + 3 * H + tid];
+#pragma unroll
+            for (int sgi = 0; sgi < 6; ++sgi) dh += part_s[sgi * H + tid];
             const float *g = a.gates + bt * 4 * H;
             const float ig = g[tid], fg = g[H + tid], gg = g[2 * H + tid], og = g[3 * H + tid];
             const float c = a.cells[bt * H + tid];
@@ -437,28 +521,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         GSCAN_STAMP(1)
 
         // ---- 2: d alpha_vis[m] = delta . U_vis[m] + dctx_vis(ext) . PK_vis[m] + d att_sum[m] ---
-        for (int m0 = wave; m0 < M; m0 += 4 * nwave) {
-            float p[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + i * nwave;
-                p[i] = 0.f;
-                if (m < M) {
-#pragma unroll
-                    for (int sg = 0; sg < 4; ++sg)
-                        for (int j = lane; j < H; j += 64) p[i] = fmaf(d_s[sg * HP + j], Uv[m * 4 * H + sg * H + j], p[i]);
-                    for (int kk = lane; kk < H; kk += 64) p[i] = fmaf(exs_s[kk], PKv[m * H + kk], p[i]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + i * nwave;
-                if (m < M) {
-                    const float tsum = wave_sum(p[i]);
-                    if (lane == 0) sc_s[m] = tsum + datt_s[m];
-                }
-            }
-        }
+        dalpha_rows<H, HP, false>(d_s, exs_s, Uv, PKv, PKv, M, datt_s, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(2)
         if (wave == 0) {   // softmax backward: ds = alpha * (dalpha - sum alpha dalpha)
@@ -473,9 +536,11 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         // ---- 3: through tanh(q + PK) of the visual scores; (chunk,k) owns pairs (m,k) ----------
         if (seg < nchunk) {
             float pdq = 0.f;
+            const float qk = qv_s[k], vk = vv_s[k];
+#pragma unroll 2
             for (int m = seg; m < M; m += nchunk) {
-                const float th = tanhf_(qv_s[k] + PKv[m * H + k]);
-                const float term = al_s[m] * vv_s[k] * (1.f - th * th);
+                const float th = tanhf_(qk + PKv[m * H + k]);
+                const float term = al_s[m] * vk * (1.f - th * th);
                 dPKv[m * H + k] += term;
                 pdq += term;
                 dvv_acc = fmaf(al_s[m], th, dvv_acc);
@@ -511,31 +576,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         GSCAN_STAMP(6)
 
         // ---- 5: d alpha_text[m] = delta . U_text[m] + dzq . U2_text[m] + dctx_text(ext) . PK_text[m]
-        for (int m0 = wave; m0 < len; m0 += 4 * nwave) {
-            float p[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + i * nwave;
-                p[i] = 0.f;
-                if (m < len) {
-#pragma unroll
-                    for (int sg = 0; sg < 4; ++sg)
-                        for (int j = lane; j < H; j += 64) p[i] = fmaf(d_s[sg * HP + j], Ut[m * 4 * H + sg * H + j], p[i]);
-                    for (int kk = lane; kk < H; kk += 64) {
-                        p[i] = fmaf(exc_s[kk], PKt[m * H + kk], p[i]);
-                        if (COND) p[i] = fmaf(d_s[5 * HP + kk], U2t[m * H + kk], p[i]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + i * nwave;
-                if (m < len) {
-                    const float tsum = wave_sum(p[i]);
-                    if (lane == 0) sc_s[m] = tsum;
-                }
-            }
-        }
+        dalpha_rows<H, HP, COND>(d_s, exc_s, Ut, PKt, U2t, len, nullptr, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(7)
         if (wave == 0) {
@@ -550,9 +591,10 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         // ---- 6: through tanh(q + PK) of the textual scores -------------------------------------
         if (seg < nchunk) {
             float pdq = 0.f;
+            const float qk = qt_s[k], vk = vt_s[k];
             for (int m = seg; m < len; m += nchunk) {
-                const float th = tanhf_(qt_s[k] + PKt[m * H + k]);
-                const float term = al_s[m] * vt_s[k] * (1.f - th * th);
+                const float th = tanhf_(qk + PKt[m * H + k]);
+                const float term = al_s[m] * vk * (1.f - th * th);
                 dPKt[m * H + k] += term;
                 pdq += term;
                 dvt_acc = fmaf(al_s[m], th, dvt_acc);
@@ -571,6 +613,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         GSCAN_STAMP(10)
 
         // ---- 7: dh_{t-1} = [W_hh | W_qt | W_q2k_h or W_qv]^T . [delta | dqt | dzq or dqv] ------
+        //         (six partial products per unit; they are summed at the top of the next iteration)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int r = s * kDecPairs + pair;
@@ -582,20 +625,15 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         }
         lds_barrier();
         GSCAN_STAMP(11)
-        if (tid < H) {
-            float dh = 0.f;
-#pragma unroll
-            for (int sgi = 0; sgi < 6; ++sgi) dh += part_s[sgi * H + tid];
-            dh_s[tid] = dh;
-        }
-        lds_barrier();
-        GSCAN_STAMP(12)
     }
 
     // ---- epilogue: initial-state gradient through the bridge tanh, key and energy gradients ----
     if (tid < H) {
+        float dh = 0.f;
+#pragma unroll
+        for (int sgi = 0; sgi < 6; ++sgi) dh += part_s[sgi * H + tid];
         const float h0 = a.hprev[(int64_t)b * T * H + tid];
-        a.dh0[(int64_t)b * H + tid] = (dh_s[tid] + dc) * (1.f - h0 * h0);   // h0 = c0 = tanh(.) (model.py:195)
+        a.dh0[(int64_t)b * H + tid] = (dh + dc) * (1.f - h0 * h0);   // h0 = c0 = tanh(.) (model.py:195)
     }
     for (int i = tid; i < M * H; i += kDecThreads) a.dpk_v[(int64_t)b * M * H + i] = dPKv[i];
     for (int i = tid; i < L * H; i += kDecThreads) a.dpk_t[(int64_t)b * L * H + i] = (i / H < len) ? dPKt[i] : 0.f;
