@@ -111,24 +111,29 @@ __device__ __forceinline__ float split_weighted_sum(const float *al, const float
 }
 
 // Additive-attention scores s_m = v . tanh(q + PK_m) for m < n: each wave takes m = wave, wave+nwave, ...
-// four at a time (partials first, then four independent DPP reductions).
+// four at a time (all key reads first, then the tanh's, then four independent DPP reductions).  A lane owns the
+// feature indices lane and lane+64; v and q for them are read once.
 template <int H>
 __device__ __forceinline__ void attention_scores(const float *v_s, const float *q_s, const float *pk, int n,
                                                  float *sc_s, int wave, int nwave, int lane) {
+    static_assert(H <= 128, "two feature indices per lane");
+    const bool has2 = lane + 64 < H, has1 = lane < H;
+    const int k1 = has1 ? lane : 0, k2 = has2 ? lane + 64 : 0;
+    const float v1 = has1 ? v_s[k1] : 0.f, v2 = has2 ? v_s[k2] : 0.f;
+    const float q1 = q_s[k1], q2 = q_s[k2];
     for (int m0 = wave; m0 < n; m0 += 4 * nwave) {
-        float p[4];
+        float x1[4], x2[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m0 + i * nwave;
-            p[i] = 0.f;
-            if (m < n)
-                for (int kk = lane; kk < H; kk += 64) p[i] += v_s[kk] * tanhf_(q_s[kk] + pk[m * H + kk]);
+            const int m = min(m0 + i * nwave, n - 1);
+            x1[i] = pk[m * H + k1];
+            x2[i] = pk[m * H + k2];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + i * nwave;
             if (m < n) {                      // wave-uniform
-                const float t = wave_sum(p[i]);
+                const float t = wave_sum(fmaf(v1, tanhf_(q1 + x1[i]), v2 * tanhf_(q2 + x2[i])));
                 if (lane == 0) sc_s[m] = t;
             }
         }
@@ -189,14 +194,13 @@ __device__ __forceinline__ float dot4(const float4 &a, const float4 &b, float ac
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, fmaf(a.w, b.w, acc))));
 }
 
-// Column quad q of the row-memory images for one attention: [U (4H cols) | PK (H cols) | U2 (H cols, optional)].
-// Returns the address of columns 4q..4q+3 of memory m.
-__device__ __forceinline__ const float4 *quad_ptr(const float *U, const float *PK, const float *U2, int H, int m,
-                                                  int q) {
+// Column quad q (columns 4q..4q+3) of the row-memory images of one attention, [U (4H cols) | PK (H) | U2 (H)]:
+// LDS float offset of memory 0 and the stride between memories.
+__device__ __forceinline__ void quad_offset(int u_off, int pk_off, int u2_off, int H, int q, int &off, int &stride) {
     const int col = 4 * q;
-    if (col < 4 * H) return reinterpret_cast<const float4 *>(U + m * 4 * H + col);
-    if (col < 5 * H) return reinterpret_cast<const float4 *>(PK + m * H + (col - 4 * H));
-    return reinterpret_cast<const float4 *>(U2 + m * H + (col - 5 * H));
+    if (col < 4 * H) { off = u_off + col; stride = 4 * H; }
+    else if (col < 5 * H) { off = pk_off + (col - 4 * H); stride = H; }
+    else { off = u2_off + (col - 5 * H); stride = H; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -224,6 +228,9 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
     const int mg = (M + 3) / 4;                             // memories per visual m-group
+    int qt_off = o.ut, qt_stride = 0, qv_off = o.uv, qv_stride = 0;   // this thread's column quads (C1 / F1)
+    if (tid < NQT) quad_offset(o.ut, o.pkt, o.u2t, H, tid, qt_off, qt_stride);
+    if (tid < 4 * NQV) quad_offset(o.uv, o.pkv, o.pkv, H, tid % NQV, qv_off, qv_stride);
 
     // ---- one-time loads: register image of the weights (coalesced), memories -> LDS -----------
     float w[NS][K0];
@@ -298,8 +305,9 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         // ---- C1: textual column sums sum_m alpha_m [U_t | PK_t | U2_t][m, :], one column quad per thread --
         if (tid < NQT) {
             float4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float *src = smem + qt_off;
 #pragma unroll 4
-            for (int m = 0; m < len; ++m) acc = fma4(al_s[m], *quad_ptr(Ut, PKt, U2t, H, m, tid), acc);
+            for (int m = 0; m < len; ++m) acc = fma4(al_s[m], *reinterpret_cast<const float4 *>(src + m * qt_stride), acc);
             *reinterpret_cast<float4 *>(col_s + 4 * tid) = acc;
         }
         lds_barrier();
@@ -357,8 +365,9 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             const int grp = tid / NQV, q = tid % NQV;
             const int m_lo = grp * mg, m_hi = min(M, m_lo + mg);
             float4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float *src = smem + qv_off;
 #pragma unroll 3
-            for (int m = m_lo; m < m_hi; ++m) acc = fma4(al_s[m], *quad_ptr(Uv, PKv, PKv, H, m, q), acc);
+            for (int m = m_lo; m < m_hi; ++m) acc = fma4(al_s[m], *reinterpret_cast<const float4 *>(src + m * qv_stride), acc);
             *reinterpret_cast<float4 *>(part_s + grp * kPartStride + 4 * q) = acc;
         }
         lds_barrier();
@@ -394,34 +403,42 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
 }
 
 // d alpha[m] = delta . U[m] (+ dzq . U2[m]) + dctx(ext) . PK[m] for the memories of one attention, one wave per
-// memory, 16-byte LDS reads: float4 index i < H covers the four delta blocks, then H/4 for PK, then H/4 for U2.
+// memory, 16-byte LDS reads.  float4 index idx < H covers the four delta blocks against U, the next H/4 the
+// external context gradient against PK, the last H/4 (conditional, textual only) dzq against U2.  The left-hand
+// vectors do not depend on m: each lane reads its (up to three) float4 of them once.
 template <int H, int HP, bool WITH_U2>
-__device__ __forceinline__ void dalpha_rows(const float *d_s, const float *ext_s, const float *U, const float *PK,
-                                            const float *U2, int n, const float *add, float *sc_s, int wave,
+__device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s, const float *ext_s, int u_off,
+                                            int pk_off, int u2_off, int n, const float *add, float *sc_s, int wave,
                                             int nwave, int lane) {
-    constexpr int Q = H / 4, NQ = (WITH_U2 ? 6 : 5) * Q;
+    constexpr int Q = H / 4, NQ = (WITH_U2 ? 6 : 5) * Q, NI = (NQ + 63) / 64;
+    float4 x[NI];
+    int yoff[NI], ystr[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = lane + 64 * i;
+        x[i] = float4{0.f, 0.f, 0.f, 0.f};
+        yoff[i] = u_off;
+        ystr[i] = 0;
+        if (idx < 4 * Q) {
+            x[i] = *reinterpret_cast<const float4 *>(d_s + (idx / Q) * HP + 4 * (idx % Q));
+            yoff[i] = u_off + 4 * idx; ystr[i] = 4 * H;
+        } else if (idx < 5 * Q) {
+            x[i] = *reinterpret_cast<const float4 *>(ext_s + 4 * (idx - 4 * Q));
+            yoff[i] = pk_off + 4 * (idx - 4 * Q); ystr[i] = H;
+        } else if (idx < NQ) {
+            x[i] = *reinterpret_cast<const float4 *>(d_s + 5 * HP + 4 * (idx - 5 * Q));
+            yoff[i] = u2_off + 4 * (idx - 5 * Q); ystr[i] = H;
+        }
+    }
     for (int m0 = wave; m0 < n; m0 += 4 * nwave) {
         float p[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m0 + i * nwave;
+            const int m = min(m0 + i * nwave, n - 1);
             p[i] = 0.f;
-            if (m < n) {
-                for (int idx = lane; idx < NQ; idx += 64) {
-                    float4 x, y;
-                    if (idx < 4 * Q) {
-                        x = *reinterpret_cast<const float4 *>(d_s + (idx / Q) * HP + 4 * (idx % Q));
-                        y = *reinterpret_cast<const float4 *>(U + m * 4 * H + 4 * idx);
-                    } else if (idx < 5 * Q) {
-                        x = *reinterpret_cast<const float4 *>(ext_s + 4 * (idx - 4 * Q));
-                        y = *reinterpret_cast<const float4 *>(PK + m * H + 4 * (idx - 4 * Q));
-                    } else {
-                        x = *reinterpret_cast<const float4 *>(d_s + 5 * HP + 4 * (idx - 5 * Q));
-                        y = *reinterpret_cast<const float4 *>(U2 + m * H + 4 * (idx - 5 * Q));
-                    }
-                    p[i] = dot4(x, y, p[i]);
-                }
-            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                p[i] = dot4(x[j], *reinterpret_cast<const float4 *>(smem + yoff[j] + m * ystr[j]), p[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -484,6 +501,26 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     if (tid < 64) datt_s[tid] = (a.datt && tid < M) ? a.datt[(int64_t)b * M + tid] : 0.f;
     if (tid >= 64 && tid < 80) stamp_acc[tid - 64] = 0.f;
     float dc = 0.f, dvv_acc = 0.f, dvt_acc = 0.f;
+    // saved activations of step t are fetched one iteration ahead (their HBM/L2 latency hides behind step t+1)
+    float pf[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto prefetch = [&](int t) {
+        const unsigned bt = (unsigned)b * T + t;
+        if (tid < H) {
+            const float *g = a.gates + bt * 4 * H;
+            pf[0] = g[tid]; pf[1] = g[H + tid]; pf[2] = g[2 * H + tid]; pf[3] = g[3 * H + tid];
+            pf[4] = a.cells[bt * H + tid];
+            pf[5] = (t > 0) ? a.cells[(bt - 1) * H + tid] : a.hprev[(int64_t)b * T * H + tid];
+            pf[6] = a.ds[bt * 4 * H + 3 * H + tid];
+        } else if (tid >= 128 && tid < 128 + H) {
+            const int kk = tid - 128;
+            pf[0] = a.ds[bt * 4 * H + H + kk];
+            pf[1] = a.ds[bt * 4 * H + 2 * H + kk];
+            pf[2] = a.qt[bt * H + kk];
+            pf[3] = a.qv[bt * H + kk];
+            if (COND) pf[4] = a.q2[bt * H + kk];
+        }
+    };
+    prefetch(T - 1);
     lds_barrier();
 
     for (int t = T - 1; t >= 0; --t) {
@@ -491,13 +528,12 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         const unsigned bt = (unsigned)b * T + t;
         // ---- 1: dh_t = sum of the six partial products of step t+1; LSTM cell backward ------------
         if (tid < H) {
-            float dh = a.ds[bt * 4 * H + 3 * H + tid];
+            float dh = pf[6];
 #pragma unroll
             for (int sgi = 0; sgi < 6; ++sgi) dh += part_s[sgi * H + tid];
-            const float *g = a.gates + bt * 4 * H;
-            const float ig = g[tid], fg = g[H + tid], gg = g[2 * H + tid], og = g[3 * H + tid];
-            const float c = a.cells[bt * H + tid];
-            const float c_prev = (t > 0) ? a.cells[(bt - 1) * H + tid] : a.hprev[(int64_t)b * T * H + tid];
+            const float ig = pf[0], fg = pf[1], gg = pf[2], og = pf[3];
+            const float c = pf[4];
+            const float c_prev = pf[5];
             const float tc = tanhf_(c);
             const float dct = dc + dh * og * (1.f - tc * tc);
             const float di = dct * gg * ig * (1.f - ig);
@@ -511,17 +547,18 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         } else if (tid >= 128 && tid < 128 + H) {
             // external gradients wrt the two contexts (output head) and the saved queries
             const int kk = tid - 128;
-            exc_s[kk] = a.ds[bt * 4 * H + H + kk];
-            exs_s[kk] = a.ds[bt * 4 * H + 2 * H + kk];
-            qt_s[kk] = a.qt[bt * H + kk];
-            qv_s[kk] = a.qv[bt * H + kk];
-            if (COND) q2_s[kk] = a.q2[bt * H + kk];
+            exc_s[kk] = pf[0];
+            exs_s[kk] = pf[1];
+            qt_s[kk] = pf[2];
+            qv_s[kk] = pf[3];
+            if (COND) q2_s[kk] = pf[4];
         }
+        if (t > 0) prefetch(t - 1);
         lds_barrier();
         GSCAN_STAMP(1)
 
         // ---- 2: d alpha_vis[m] = delta . U_vis[m] + dctx_vis(ext) . PK_vis[m] + d att_sum[m] ---
-        dalpha_rows<H, HP, false>(d_s, exs_s, Uv, PKv, PKv, M, datt_s, sc_s, wave, nwave, lane);
+        dalpha_rows<H, HP, false>(smem, d_s, exs_s, o.uv, o.pkv, o.pkv, M, datt_s, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(2)
         if (wave == 0) {   // softmax backward: ds = alpha * (dalpha - sum alpha dalpha)
@@ -576,7 +613,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         GSCAN_STAMP(6)
 
         // ---- 5: d alpha_text[m] = delta . U_text[m] + dzq . U2_text[m] + dctx_text(ext) . PK_text[m]
-        dalpha_rows<H, HP, COND>(d_s, exc_s, Ut, PKt, U2t, len, nullptr, sc_s, wave, nwave, lane);
+        dalpha_rows<H, HP, COND>(smem, d_s, exc_s, o.ut, o.pkt, o.u2t, len, nullptr, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(7)
         if (wave == 0) {
