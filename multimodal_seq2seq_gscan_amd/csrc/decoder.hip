@@ -129,11 +129,16 @@ __device__ __forceinline__ void attention_scores(const float *v_s, const float *
             x1[i] = pk[m * H + k1];
             x2[i] = pk[m * H + k2];
         }
+        float p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (m0 + i * nwave < n)           // wave-uniform: a short last round costs only its own tanh's
+                p[i] = fmaf(v1, tanhf_(q1 + x1[i]), v2 * tanhf_(q2 + x2[i]));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + i * nwave;
-            if (m < n) {                      // wave-uniform
-                const float t = wave_sum(fmaf(v1, tanhf_(q1 + x1[i]), v2 * tanhf_(q2 + x2[i])));
+            if (m < n) {
+                const float t = wave_sum(p[i]);
                 if (lane == 0) sc_s[m] = t;
             }
         }
@@ -181,7 +186,7 @@ __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, bool cond
     o.dpkv = p; p += backward ? M * H : 0;
     o.dpkt = p; p += backward ? L * H : 0;
     o.vec = p;
-    p += (backward ? 7 * HP + 14 * H : 2 * HP + 14 * H + 4 * kPartStride) + 256;
+    p += (backward ? 7 * HP + 15 * H : 2 * HP + 14 * H + 4 * kPartStride) + 256;
     o.total = p;
     return o;
 }
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
                   HP = 2 * K0;
     constexpr int NQT = (COND ? 6 : 5) * H / 4;   // column quads of the textual images [U_t | PK_t | U2_t]
     constexpr int NQV = 5 * H / 4;                // column quads of the visual images [U_v | PK_v]
-    static_assert(4 * NQV <= kDecThreads && 5 * H <= kPartStride, "hidden size too large for the m-group split");
+    static_assert(NQV <= 128 && 5 * H <= kPartStride, "hidden size too large for the m-group split");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = kDecThreads / 64;
     const int pair = tid >> 1, half = tid & 1;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     const int mg = (M + 3) / 4;                             // memories per visual m-group
     int qt_off = o.ut, qt_stride = 0, qv_off = o.uv, qv_stride = 0;   // this thread's column quads (C1 / F1)
     if (tid < NQT) quad_offset(o.ut, o.pkt, o.u2t, H, tid, qt_off, qt_stride);
-    if (tid < 4 * NQV) quad_offset(o.uv, o.pkv, o.pkv, H, tid % NQV, qv_off, qv_stride);
+    if ((tid & 127) < NQV) quad_offset(o.uv, o.pkv, o.pkv, H, tid & 127, qv_off, qv_stride);
 
     // ---- one-time loads: register image of the weights (coalesced), memories -> LDS -----------
     float w[NS][K0];
@@ -291,27 +296,29 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         attention_scores<H>(vt_s, qt_s, PKt, len, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(2)
-        if (wave == 0) {
+        // softmax over the command (seq2seq_model.py:136-137) in every wave's registers: lane m holds alpha_m,
+        // consumers fetch it with v_readlane — no LDS round trip, no serial single-wave phase
+        float alpha;
+        {
             const float x = (lane < len) ? sc_s[lane] : -INFINITY;
             const float mx = wave_max(x);
-            const float e = (lane < len) ? expf(x - mx) : 0.f;
-            const float al = e / wave_sum(e);
-            al_s[lane] = al;
-            if (lane < L) a.alpha_c[bt * L + lane] = al;
+            const float e = (lane < len) ? __expf(x - mx) : 0.f;
+            alpha = e * __builtin_amdgcn_rcpf(wave_sum(e));
+            if (wave == 0 && lane < L) a.alpha_c[bt * L + lane] = alpha;
         }
-        lds_barrier();
-        GSCAN_STAMP(3)
-
         // ---- C1: textual column sums sum_m alpha_m [U_t | PK_t | U2_t][m, :], one column quad per thread --
-        if (tid < NQT) {
+        if (wave < (NQT + 63) / 64) {
             float4 acc = {0.f, 0.f, 0.f, 0.f};
             const float *src = smem + qt_off;
 #pragma unroll 4
-            for (int m = 0; m < len; ++m) acc = fma4(al_s[m], *reinterpret_cast<const float4 *>(src + m * qt_stride), acc);
-            *reinterpret_cast<float4 *>(col_s + 4 * tid) = acc;
+            for (int m = 0; m < len; ++m) {
+                const float am = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), m));
+                acc = fma4(am, *reinterpret_cast<const float4 *>(src + m * qt_stride), acc);
+            }
+            if (tid < NQT) *reinterpret_cast<float4 *>(col_s + 4 * tid) = acc;
         }
         lds_barrier();
-        GSCAN_STAMP(4)
+        GSCAN_STAMP(3)
         // ---- C2: hand the sums to their owners: gate rows, textual context, conditional query ------
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         }
         if (COND) {
             lds_barrier();
-            GSCAN_STAMP(5)
+            GSCAN_STAMP(4)
             // ---- D: visual query from the conditional query ---------------------------------
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -342,36 +349,37 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             }
         }
         lds_barrier();
-        GSCAN_STAMP(6)
+        GSCAN_STAMP(5)
 
         // ---- E: visual scores over all M cells (no mask: every row has M memories) -----------
         attention_scores<H>(vv_s, qv_s, PKv, M, sc_s, wave, nwave, lane);
         lds_barrier();
-        GSCAN_STAMP(7)
-        if (wave == 0) {
+        GSCAN_STAMP(6)
+        {
             const float x = (lane < M) ? sc_s[lane] : -INFINITY;
             const float mx = wave_max(x);
-            const float e = (lane < M) ? expf(x - mx) : 0.f;
-            const float al = e / wave_sum(e);
-            al_s[lane] = al;
-            if (lane < M) a.alpha_s[bt * M + lane] = al;
-            att_acc += al;                                     // seq2seq_model.py:479,490
+            const float e = (lane < M) ? __expf(x - mx) : 0.f;
+            alpha = e * __builtin_amdgcn_rcpf(wave_sum(e));
+            if (wave == 0) {
+                if (lane < M) a.alpha_s[bt * M + lane] = alpha;
+                att_acc += alpha;                              // seq2seq_model.py:479,490
+            }
         }
-        lds_barrier();
-        GSCAN_STAMP(8)
-
-        // ---- F1: visual column sums over four m-groups: thread = (group, column quad) -----------
-        if (tid < 4 * NQV) {
-            const int grp = tid / NQV, q = tid % NQV;
+        // ---- F1: visual column sums over four m-groups of two waves each: thread = (group, column quad) ---
+        {
+            const int grp = wave >> 1, q = tid & 127;          // the m range is wave-uniform
             const int m_lo = grp * mg, m_hi = min(M, m_lo + mg);
             float4 acc = {0.f, 0.f, 0.f, 0.f};
             const float *src = smem + qv_off;
 #pragma unroll 3
-            for (int m = m_lo; m < m_hi; ++m) acc = fma4(al_s[m], *reinterpret_cast<const float4 *>(src + m * qv_stride), acc);
-            *reinterpret_cast<float4 *>(part_s + grp * kPartStride + 4 * q) = acc;
+            for (int m = m_lo; m < m_hi; ++m) {
+                const float am = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), m));
+                acc = fma4(am, *reinterpret_cast<const float4 *>(src + m * qv_stride), acc);
+            }
+            if (q < NQV) *reinterpret_cast<float4 *>(part_s + grp * kPartStride + 4 * q) = acc;
         }
         lds_barrier();
-        GSCAN_STAMP(9)
+        GSCAN_STAMP(7)
 
         // ---- H: gates, cell update (seq2seq_model.py:414) and visual context -----------------------
         if (tid < H) {
@@ -396,10 +404,39 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
                                                     (part_s[2 * kPartStride + r] + part_s[3 * kPartStride + r]);
         }
         lds_barrier();
-        GSCAN_STAMP(10)
+        GSCAN_STAMP(8)
     }
     if (wave == 0 && lane < M) a.att_sum[(int64_t)b * M + lane] = att_acc;
     if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_acc[tid];
+}
+
+// Backward of s_m = v . tanh(q + PK_m) for one attention.  Lane m of `dsm` holds d s_m.  Wave w owns the memories
+// w, w+nwave, ...; a lane owns features (lane, lane+64):  dPK[m][k] += ds_m v_k (1 - th^2)  (accumulated over the
+// T steps in LDS), the same term summed over this wave's memories goes to part_s[wave][k] (-> d q_k after the
+// cross-wave sum), and dv_k += ds_m th is kept per lane.
+template <int H>
+__device__ __forceinline__ void score_backward(float dsm, const float *q_s, const float *v_s, const float *pk,
+                                               float *dpk, int n, float *part_s, f32x2 &dv_acc, int wave, int nwave,
+                                               int lane) {
+    const bool has2 = lane + 64 < H, has1 = lane < H;
+    const int k1 = has1 ? lane : 0, k2 = has2 ? lane + 64 : 0;
+    const float v1 = has1 ? v_s[k1] : 0.f, v2 = has2 ? v_s[k2] : 0.f;
+    const float q1 = q_s[k1], q2 = q_s[k2];
+    float pdq1 = 0.f, pdq2 = 0.f;
+#pragma unroll 2
+    for (int m = wave; m < n; m += nwave) {
+        const float ds = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dsm), m));
+        const float th1 = tanhf_(q1 + pk[m * H + k1]), th2 = tanhf_(q2 + pk[m * H + k2]);
+        const float t1 = ds * v1 * (1.f - th1 * th1), t2 = ds * v2 * (1.f - th2 * th2);
+        if (has1) dpk[m * H + k1] += t1;
+        if (has2) dpk[m * H + k2] += t2;
+        pdq1 += t1;
+        pdq2 += t2;
+        dv_acc.x = fmaf(ds, th1, dv_acc.x);
+        dv_acc.y = fmaf(ds, th2, dv_acc.y);
+    }
+    if (has1) part_s[wave * H + k1] = pdq1;
+    if (has2) part_s[wave * H + k2] = pdq2;
 }
 
 // d alpha[m] = delta . U[m] (+ dzq . U2[m]) + dctx(ext) . PK[m] for the memories of one attention, one wave per
@@ -430,10 +467,10 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
             yoff[i] = u2_off + 4 * (idx - 5 * Q); ystr[i] = H;
         }
     }
-    for (int m0 = wave; m0 < n; m0 += 4 * nwave) {
-        float p[4];
+    for (int m0 = wave; m0 < n; m0 += 2 * nwave) {
+        float p[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int m = min(m0 + i * nwave, n - 1);
             p[i] = 0.f;
 #pragma unroll
@@ -441,7 +478,7 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
                 p[i] = dot4(x[j], *reinterpret_cast<const float4 *>(smem + yoff[j] + m * ystr[j]), p[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int m = m0 + i * nwave;
             if (m < n) {
                 const float tsum = wave_sum(p[i]);
@@ -474,13 +511,11 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     float *d_s = vec;                 // [6][HP]: delta (4 blocks) | dqt | dzq or dqv, each zero-padded to HP
     float *dqv_s = vec + 6 * HP;      // [HP]
     float *qt_s = vec + 7 * HP, *q2_s = qt_s + H, *qv_s = q2_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H,
-          *exc_s = vv_s + H, *exs_s = exc_s + H, *part_s = exs_s + H;    // part_s: 6H (+H spare)
-    float *sc_s = part_s + 7 * H, *al_s = sc_s + 64, *datt_s = sc_s + 128, *stamp_acc = sc_s + 192;
+          *exc_s = vv_s + H, *exs_s = exc_s + H, *part_s = exs_s + H;    // part_s: 8H
+    float *sc_s = part_s + 8 * H, *al_s = sc_s + 64, *datt_s = sc_s + 128, *stamp_acc = sc_s + 192;
     long long stamp_prev = a.stamps ? clock64() : 0;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
-    const int nchunk = min(6, kDecThreads / H);            // (chunk, k) ownership of key pairs; part_s holds 6H
-    const int seg = tid / H, k = tid % H;
 
     float wt[NS][K0];
 #pragma unroll
@@ -495,16 +530,20 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     for (int i = tid; i < M * H; i += kDecThreads) dPKv[i] = 0.f;
     for (int i = tid; i < L * H; i += kDecThreads) dPKt[i] = 0.f;
     for (int i = tid; i < 7 * HP; i += kDecThreads) vec[i] = 0.f;        // d_s / dqv_s incl. padding
-    for (int i = tid; i < 7 * H; i += kDecThreads) part_s[i] = 0.f;      // dh_T = 0 (summed at the top of the loop)
+    for (int i = tid; i < 8 * H; i += kDecThreads) part_s[i] = 0.f;      // dh_T = 0 (summed at the top of the loop)
     lds_barrier();
     if (tid < H) { vt_s[tid] = a.v_t[tid]; vv_s[tid] = a.v_v[tid]; }
     if (tid < 64) datt_s[tid] = (a.datt && tid < M) ? a.datt[(int64_t)b * M + tid] : 0.f;
     if (tid >= 64 && tid < 80) stamp_acc[tid - 64] = 0.f;
-    float dc = 0.f, dvv_acc = 0.f, dvt_acc = 0.f;
+    float dc = 0.f;
+    f32x2 dvv_acc = {0.f, 0.f}, dvt_acc = {0.f, 0.f};
     // saved activations of step t are fetched one iteration ahead (their HBM/L2 latency hides behind step t+1)
     float pf[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float alpha_v_pf = 0.f, alpha_c_pf = 0.f, alpha_v_nx = 0.f, alpha_c_nx = 0.f;   // lane m of every wave
     auto prefetch = [&](int t) {
         const unsigned bt = (unsigned)b * T + t;
+        alpha_v_nx = (lane < M) ? a.alpha_s[bt * M + lane] : 0.f;
+        alpha_c_nx = (lane < L) ? a.alpha_c[bt * L + lane] : 0.f;
         if (tid < H) {
             const float *g = a.gates + bt * 4 * H;
             pf[0] = g[tid]; pf[1] = g[H + tid]; pf[2] = g[2 * H + tid]; pf[3] = g[3 * H + tid];
@@ -526,6 +565,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     for (int t = T - 1; t >= 0; --t) {
         GSCAN_STAMP(0)
         const unsigned bt = (unsigned)b * T + t;
+        alpha_v_pf = alpha_v_nx;
+        alpha_c_pf = alpha_c_nx;
         // ---- 1: dh_t = sum of the six partial products of step t+1; LSTM cell backward ------------
         if (tid < H) {
             float dh = pf[6];
@@ -561,40 +602,26 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         dalpha_rows<H, HP, false>(smem, d_s, exs_s, o.uv, o.pkv, o.pkv, M, datt_s, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(2)
-        if (wave == 0) {   // softmax backward: ds = alpha * (dalpha - sum alpha dalpha)
-            const float al = (lane < M) ? a.alpha_s[bt * M + lane] : 0.f;
+        // ---- 3: softmax backward in every wave's registers (lane m: ds_m = alpha_m (dalpha_m - sum alpha dalpha)),
+        //         then through tanh(q + PK): wave w owns memories w, w+8, ...; a lane owns features lane, lane+64
+        {
+            const float al = (lane < M) ? alpha_v_pf : 0.f;
             const float da = (lane < M) ? sc_s[lane] : 0.f;
-            const float dot = wave_sum(al * da);
-            al_s[lane] = al * (da - dot);
+            const float dsm = al * (da - wave_sum(al * da));
+            score_backward<H>(dsm, qv_s, vv_s, PKv, dPKv, M, part_s, dvv_acc, wave, nwave, lane);
         }
         lds_barrier();
         GSCAN_STAMP(3)
-
-        // ---- 3: through tanh(q + PK) of the visual scores; (chunk,k) owns pairs (m,k) ----------
-        if (seg < nchunk) {
-            float pdq = 0.f;
-            const float qk = qv_s[k], vk = vv_s[k];
-#pragma unroll 2
-            for (int m = seg; m < M; m += nchunk) {
-                const float th = tanhf_(qk + PKv[m * H + k]);
-                const float term = al_s[m] * vk * (1.f - th * th);
-                dPKv[m * H + k] += term;
-                pdq += term;
-                dvv_acc = fmaf(al_s[m], th, dvv_acc);
-            }
-            part_s[seg * H + k] = pdq;
-        }
-        lds_barrier();
-        GSCAN_STAMP(4)
         if (tid < H) {
             float dq = 0.f;
-            for (int cch = 0; cch < nchunk; ++cch) dq += part_s[cch * H + tid];
+#pragma unroll
+            for (int cch = 0; cch < kDecThreads / 64; ++cch) dq += part_s[cch * H + tid];
             dqv_s[tid] = dq;
             a.dqv[bt * H + tid] = dq;
             if (!COND) d_s[5 * HP + tid] = dq;               // visual query came straight from h
         }
         lds_barrier();
-        GSCAN_STAMP(5)
+        GSCAN_STAMP(4)
 
         // ---- 4: conditional query: dq2 = W_qv^T dqv, through tanh ------------------------------
         if (COND) {
@@ -610,44 +637,30 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             }
             lds_barrier();
         }
-        GSCAN_STAMP(6)
+        GSCAN_STAMP(5)
 
         // ---- 5: d alpha_text[m] = delta . U_text[m] + dzq . U2_text[m] + dctx_text(ext) . PK_text[m]
         dalpha_rows<H, HP, COND>(smem, d_s, exc_s, o.ut, o.pkt, o.u2t, len, nullptr, sc_s, wave, nwave, lane);
         lds_barrier();
-        GSCAN_STAMP(7)
-        if (wave == 0) {
-            const float al = (lane < len) ? a.alpha_c[bt * L + lane] : 0.f;
+        GSCAN_STAMP(6)
+        // ---- 6: the same for the textual attention -----------------------------------------------
+        {
+            const float al = (lane < len) ? alpha_c_pf : 0.f;
             const float da = (lane < len) ? sc_s[lane] : 0.f;
-            const float dot = wave_sum(al * da);
-            al_s[lane] = al * (da - dot);
+            const float dsm = al * (da - wave_sum(al * da));
+            score_backward<H>(dsm, qt_s, vt_s, PKt, dPKt, len, part_s, dvt_acc, wave, nwave, lane);
         }
         lds_barrier();
-        GSCAN_STAMP(8)
-
-        // ---- 6: through tanh(q + PK) of the textual scores -------------------------------------
-        if (seg < nchunk) {
-            float pdq = 0.f;
-            const float qk = qt_s[k], vk = vt_s[k];
-            for (int m = seg; m < len; m += nchunk) {
-                const float th = tanhf_(qk + PKt[m * H + k]);
-                const float term = al_s[m] * vk * (1.f - th * th);
-                dPKt[m * H + k] += term;
-                pdq += term;
-                dvt_acc = fmaf(al_s[m], th, dvt_acc);
-            }
-            part_s[seg * H + k] = pdq;
-        }
-        lds_barrier();
-        GSCAN_STAMP(9)
+        GSCAN_STAMP(7)
         if (tid < H) {
             float dq = 0.f;
-            for (int cch = 0; cch < nchunk; ++cch) dq += part_s[cch * H + tid];
+#pragma unroll
+            for (int cch = 0; cch < kDecThreads / 64; ++cch) dq += part_s[cch * H + tid];
             d_s[4 * HP + tid] = dq;
             a.dqt[bt * H + tid] = dq;
         }
         lds_barrier();
-        GSCAN_STAMP(10)
+        GSCAN_STAMP(8)
 
         // ---- 7: dh_{t-1} = [W_hh | W_qt | W_q2k_h or W_qv]^T . [delta | dqt | dzq or dqv] ------
         //         (six partial products per unit; they are summed at the top of the next iteration)
@@ -661,7 +674,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             }
         }
         lds_barrier();
-        GSCAN_STAMP(11)
+        GSCAN_STAMP(9)
     }
 
     // ---- epilogue: initial-state gradient through the bridge tanh, key and energy gradients ----
@@ -674,20 +687,23 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     }
     for (int i = tid; i < M * H; i += kDecThreads) a.dpk_v[(int64_t)b * M * H + i] = dPKv[i];
     for (int i = tid; i < L * H; i += kDecThreads) a.dpk_t[(int64_t)b * L * H + i] = (i / H < len) ? dPKt[i] : 0.f;
+    // energy-vector gradients: every wave holds partial sums for features (lane, lane+64)
     lds_barrier();
-    if (seg < nchunk) part_s[seg * H + k] = dvv_acc;
+    if (lane < H) part_s[wave * H + lane] = dvv_acc.x;
+    if (lane + 64 < H) part_s[wave * H + lane + 64] = dvv_acc.y;
     lds_barrier();
     if (tid < H) {
         float x = 0.f;
-        for (int cch = 0; cch < nchunk; ++cch) x += part_s[cch * H + tid];
+        for (int cch = 0; cch < kDecThreads / 64; ++cch) x += part_s[cch * H + tid];
         atomicAdd(&a.dv_v[tid], x);
     }
     lds_barrier();
-    if (seg < nchunk) part_s[seg * H + k] = dvt_acc;
+    if (lane < H) part_s[wave * H + lane] = dvt_acc.x;
+    if (lane + 64 < H) part_s[wave * H + lane + 64] = dvt_acc.y;
     lds_barrier();
     if (tid < H) {
         float x = 0.f;
-        for (int cch = 0; cch < nchunk; ++cch) x += part_s[cch * H + tid];
+        for (int cch = 0; cch < kDecThreads / 64; ++cch) x += part_s[cch * H + tid];
         atomicAdd(&a.dv_t[tid], x);
     }
     if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_acc[tid];
