@@ -14,51 +14,103 @@
 // tile's global loads are issued into registers BEFORE the current tile's MFMAs and written to
 // the other LDS buffer after them (one barrier per round), and the long-K weight-gradient
 // products are split over blockIdx.z with float-atomic accumulation into the zeroed gradient.
-// Tile: 64x64x32 per 256-thread workgroup, 4 waves as 2x2, each wave 32x32 = 2x2 MFMA tiles.
-// The LDS image of an operand follows its unit-stride dimension, so both the global read
-// (128-B segments) and the ds_read_b32 fragment reads are conflict-free.
+// Tile geometry and LDS images are described next to the kernel below.
 #include "step.h"
 
 namespace gscan {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int BM = 64, BN = 64, BK = 32;
-constexpr int LD_K = BK + 2;    // image [row][k]: fragment read banks (2*row + k) mod 32 are distinct
-constexpr int LD_R = BM + 16;   // image [k][row]: k rows 16 banks apart -> 32-lane halves conflict-free
-constexpr int TILE_FLOATS = (BK * LD_R > BM * LD_K) ? BK * LD_R : BM * LD_K;
+constexpr int TMW = 2, TNW = 2;  // MFMA tiles per wave along M / N
+constexpr int BM = 2 * 16 * TMW, BN = 2 * 16 * TNW, BK = 32;
+constexpr int LDK = BK + 4;      // k-contiguous image [row][LDK]: 16-byte rows, b128 fragment reads 2-way at worst
+constexpr int LDR_A = BM + 4;    // row-contiguous image [k][LDR]: b64 reads of 2 adjacent rows, conflict-free
+constexpr int LDR_B = BN + 4;    // b64 reads of 2 adjacent columns, conflict-free
+constexpr int A_FLOATS = (BM * LDK > BK * LDR_A) ? BM * LDK : BK * LDR_A;
+constexpr int B_FLOATS = (BN * LDK > BK * LDR_B) ? BN * LDK : BK * LDR_B;
 
 // Independent products are launched together as one grid ("grouped GEMM"): the step issues ~45 small
 // products, each of which alone cannot fill 256 CUs and costs a launch; workgroup -> (problem, tile, k-slice)
 // is a scan over at most kMaxGroup prefix sums held in kernel arguments.
+//
+// Tile geometry.  Workgroup 64 x 64 x 32, 4 waves as 2 x 2, each wave 32 x 32 = 2 x 2 MFMA tiles of 16 x 16
+// (many small tiles: these products are latency-bound, occupancy hides more than a bigger tile saves).
+// Within a 32-deep tile the MFMA k index of lane group g (= lane >> 4) at step s (0..7) is k = 8 g + s, so a lane
+// of a k-contiguous operand reads its 8 values with two ds_read_b128.  A row-contiguous operand interleaves its
+// MFMA tiles instead (row = 2 i + tile for A, col = 2 i + tile for B), so one ds_read_b64 per k feeds both
+// of a wave's tiles.  Either way a wave issues ~1 LDS read per 4-8 MFMAs instead of 1 per MFMA.
+// Global loads are 16-byte whenever the operand's pointer, strides and extent allow, else 4-byte.
 
-// One [64 rows x 32 k] panel = 8 elements per thread.  element(row,k) = src[row*s_row + k*s_k].
-// k_contig (k stride 1): threads run along k first, image [row][k]; else along rows, image [k][row].
-__device__ __forceinline__ void panel_load(float (&v)[8], const float *src, int64_t s_row, int64_t s_k, int row0,
-                                           int nrows, int k0, int kend, bool k_contig, int tid) {
-    if (k_contig) {
-        const int k = k0 + (tid & 31);
+struct Panel {                  // how one operand's [rows x 32] panel moves global -> registers -> LDS
+    const float *src;
+    int64_t s_row, s_k;         // element (row, k) = src[row * s_row + k * s_k]
+    int nrows, row0;
+    bool kc, vec;               // k-contiguous image?  16-byte global loads?
+};
+
+template <int ROWS>
+__device__ __forceinline__ void panel_load(float (&v)[ROWS / 8], const Panel &p, int k0, int kend, int tid) {
+    constexpr int N = ROWS / 8;             // floats per thread
+    if (p.kc) {
+        if (p.vec) {                        // 8 float4 per row: q = tid & 7, row = (tid >> 3) + 32 i
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = row0 + (tid >> 5) + 8 * i;
-            v[i] = (r < nrows && k < kend) ? src[(int64_t)r * s_row + (int64_t)k * s_k] : 0.f;
+            for (int i = 0; i < N / 4; ++i) {
+                const int r = p.row0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
+                float4 x = {0.f, 0.f, 0.f, 0.f};
+                if (r < p.nrows && k < kend) x = *reinterpret_cast<const float4 *>(p.src + (int64_t)r * p.s_row + k);
+                v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+            }
+        } else {                            // k = tid & 31, row = (tid >> 5) + 8 i
+            const int k = k0 + (tid & 31);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int r = p.row0 + (tid >> 5) + 8 * i;
+                v[i] = (r < p.nrows && k < kend) ? p.src[(int64_t)r * p.s_row + (int64_t)k * p.s_k] : 0.f;
+            }
         }
     } else {
-        const int r = row0 + (tid & 63);
+        if (p.vec) {                        // 4 adjacent rows per load
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = k0 + (tid >> 6) + 4 * i;
-            v[i] = (r < nrows && k < kend) ? src[(int64_t)r * s_row + (int64_t)k * s_k] : 0.f;
+            for (int i = 0; i < N / 4; ++i) {
+                const int r = p.row0 + 4 * (tid % (ROWS / 4)), k = k0 + tid / (ROWS / 4) + (1024 / ROWS) * i;
+                float4 x = {0.f, 0.f, 0.f, 0.f};
+                if (r < p.nrows && k < kend) x = *reinterpret_cast<const float4 *>(p.src + (int64_t)k * p.s_k + r);
+                v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+            }
+        } else {                            // row = tid % ROWS, k = tid / ROWS + (256/ROWS) i
+            const int r = p.row0 + tid % ROWS;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int k = k0 + tid / ROWS + (256 / ROWS) * i;
+                v[i] = (r < p.nrows && k < kend) ? p.src[(int64_t)r * p.s_row + (int64_t)k * p.s_k] : 0.f;
+            }
         }
     }
 }
-__device__ __forceinline__ void panel_store(float *lds, const float (&v)[8], bool k_contig, int tid) {
-    if (k_contig) {
+
+template <int ROWS, int LDR>
+__device__ __forceinline__ void panel_store(float *lds, const float (&v)[ROWS / 8], const Panel &p, int tid) {
+    constexpr int N = ROWS / 8;
+    if (p.kc) {
+        if (p.vec) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lds[((tid >> 5) + 8 * i) * LD_K + (tid & 31)] = v[i];
+            for (int i = 0; i < N / 4; ++i)
+                *reinterpret_cast<float4 *>(lds + ((tid >> 3) + 32 * i) * LDK + 4 * (tid & 7)) =
+                    float4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) lds[((tid >> 5) + 8 * i) * LDK + (tid & 31)] = v[i];
+        }
     } else {
+        if (p.vec) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lds[((tid >> 6) + 4 * i) * LD_R + (tid & 63)] = v[i];
+            for (int i = 0; i < N / 4; ++i)
+                *reinterpret_cast<float4 *>(lds + (tid / (ROWS / 4) + (1024 / ROWS) * i) * LDR + 4 * (tid % (ROWS / 4))) =
+                    float4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) lds[(tid / ROWS + (256 / ROWS) * i) * LDR + tid % ROWS] = v[i];
+        }
     }
 }
 
@@ -71,64 +123,93 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
     const int local = blockIdx.x - g.tile_begin;
     const int bz = local / g.tiles_mn, rem = local % g.tiles_mn;
     const int by = rem / g.tiles_n, bx = rem % g.tiles_n;
-    __shared__ float lds_a[2][TILE_FLOATS];
-    __shared__ float lds_b[2][TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds_a[2][A_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds_b[2][B_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = bz * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
-    const bool a_kc = (g.sak == 1), b_kc = (g.sbk == 1);
-    const int a_sr = a_kc ? LD_K : 1, a_sk = a_kc ? 1 : LD_R;
-    const int b_sr = b_kc ? LD_K : 1, b_sk = b_kc ? 1 : LD_R;
+    const Panel pa{g.a, g.sam, g.sak, g.M, m0, g.sak == 1, (g.flags & 1) != 0};
+    const Panel pb{g.b, g.sbn, g.sbk, g.N, n0, g.sbk == 1, (g.flags & 2) != 0};
     const bool do_asum = g.asum1 != nullptr && bx == 0;
 
-    f32x4 acc[2][2];
+    f32x4 acc[TMW][TNW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
 
-    const int fr = lane & 15;   // fragment row (A) / column (B)
-    const int fk = lane >> 4;   // fragment k within a 4-deep MFMA step
+    const int fr = lane & 15;   // MFMA row (A) / column (B) index
+    const int fg = lane >> 4;   // lane group: k = 8*fg + step
 
-    float ra[8], rb[8];
-    panel_load(ra, g.a, g.sam, g.sak, m0, g.M, kbeg, kend, a_kc, tid);
-    panel_load(rb, g.b, g.sbn, g.sbk, n0, g.N, kbeg, kend, b_kc, tid);
-    panel_store(lds_a[0], ra, a_kc, tid);
-    panel_store(lds_b[0], rb, b_kc, tid);
+    float ra[BM / 8], rb[BN / 8];
+    panel_load<BM>(ra, pa, kbeg, kend, tid);
+    panel_load<BN>(rb, pb, kbeg, kend, tid);
+    panel_store<BM, LDR_A>(lds_a[0], ra, pa, tid);
+    panel_store<BN, LDR_B>(lds_b[0], rb, pb, tid);
     __syncthreads();
 
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) {   // next tile's loads fly while this tile's MFMAs run
-            panel_load(ra, g.a, g.sam, g.sak, m0, g.M, k0 + BK, kend, a_kc, tid);
-            panel_load(rb, g.b, g.sbn, g.sbk, n0, g.N, k0 + BK, kend, b_kc, tid);
+            panel_load<BM>(ra, pa, k0 + BK, kend, tid);
+            panel_load<BN>(rb, pb, k0 + BK, kend, tid);
         }
         const float *la = lds_a[buf], *lb = lds_b[buf];
+        float af[TMW][8], bf[TNW][8];        // [tile][step]
+        if (pa.kc) {                         // natural tiles: row = 16 t + fr
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
-            float af[2], bf[2];
+            for (int t = 0; t < TMW; ++t) {
+                const float4 *q = reinterpret_cast<const float4 *>(la + (wm * 16 * TMW + 16 * t + fr) * LDK + 8 * fg);
+                const float4 x = q[0], y = q[1];
+                af[t][0] = x.x; af[t][1] = x.y; af[t][2] = x.z; af[t][3] = x.w;
+                af[t][4] = y.x; af[t][5] = y.y; af[t][6] = y.z; af[t][7] = y.w;
+            }
+        } else {                             // interleaved tiles: row = 2 fr + t
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = la[(wm * 32 + i * 16 + fr) * a_sr + (kk + fk) * a_sk];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = lb[(wn * 32 + j * 16 + fr) * b_sr + (kk + fk) * b_sk];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int s = 0; s < 8; ++s) {
+                const float2 x = *reinterpret_cast<const float2 *>(la + (8 * fg + s) * LDR_A + wm * 16 * TMW + 2 * fr);
+                af[0][s] = x.x; af[1][s] = x.y;
+            }
         }
-        if (do_asum && tid < BM) {
+        if (pb.kc) {                         // natural tiles: col = 16 t + fr
 #pragma unroll
-            for (int kk = 0; kk < BK; ++kk) asum += la[tid * a_sr + kk * a_sk];
+            for (int t = 0; t < TNW; ++t) {
+                const float4 *q = reinterpret_cast<const float4 *>(lb + (wn * 16 * TNW + 16 * t + fr) * LDK + 8 * fg);
+                const float4 x = q[0], y = q[1];
+                bf[t][0] = x.x; bf[t][1] = x.y; bf[t][2] = x.z; bf[t][3] = x.w;
+                bf[t][4] = y.x; bf[t][5] = y.y; bf[t][6] = y.z; bf[t][7] = y.w;
+            }
+        } else {                             // interleaved tiles: col = 2 fr + t
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float2 x = *reinterpret_cast<const float2 *>(lb + (8 * fg + s) * LDR_B + wn * 16 * TNW + 2 * fr);
+                bf[0][s] = x.x; bf[1][s] = x.y;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        if (do_asum && tid < BM) {           // column sums of A (bias gradients): sum over this tile's 32 k
+            if (pa.kc) {
+#pragma unroll
+                for (int kk = 0; kk < BK; ++kk) asum += la[tid * LDK + kk];
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < BK; ++kk) asum += la[kk * LDR_A + tid];
+            }
         }
         if (more) {
-            panel_store(lds_a[buf ^ 1], ra, a_kc, tid);
-            panel_store(lds_b[buf ^ 1], rb, b_kc, tid);
+            panel_store<BM, LDR_A>(lds_a[buf ^ 1], ra, pa, tid);
+            panel_store<BN, LDR_B>(lds_b[buf ^ 1], rb, pb, tid);
         }
         __syncthreads();
         buf ^= 1;
@@ -139,17 +220,18 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
         if (g.asum2) atomicAdd(&g.asum2[m0 + tid], asum);
     }
 
-    // C/D fragment: column = lane & 15, row = (lane >> 4) * 4 + reg
+    // epilogue.  MFMA C/D fragment: column index = lane & 15, row index = (lane >> 4) * 4 + reg
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 32 + j * 16 + (lane & 15);
-            if (col >= g.N) continue;
+        for (int r = 0; r < 4; ++r) {
+            const int ri = fg * 4 + r;                                        // MFMA row index 0..15
+            const int row = m0 + wm * 16 * TMW + (pa.kc ? 16 * i + ri : TMW * ri + i);
+            if (row >= g.M) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
-                if (row >= g.M) continue;
+            for (int j = 0; j < TNW; ++j) {
+                const int col = n0 + wn * 16 * TNW + (pb.kc ? 16 * j + fr : TNW * fr + j);
+                if (col >= g.N) continue;
                 float *cp = g.c + (int64_t)row * g.ldc + col;
                 float v = g.alpha * acc[i][j][r];
                 if (g.atomic) {
@@ -166,6 +248,8 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
             }
         }
 }
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sak, const float *b, int64_t sbk,
                     int64_t sbn, float *c, int64_t ldc, float beta, const float *bias, int act, const float *mask,
@@ -187,9 +271,15 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
         set_error("gemm batch: split-K needs beta=1 and no epilogue (problem %d, beta=%g act=%d)", grp_.count, beta, act);
         return;
     }
+    // 16-byte global loads need: unit stride along the load direction, the other stride a multiple of 4 floats,
+    // a 16-byte aligned base, and an extent along the load direction that is a multiple of 4 (tile edges included:
+    // K slices start at multiples of 32)
+    int flags = 0;
+    if (aligned16(a) && ((sak == 1 && sam % 4 == 0 && K % 4 == 0) || (sam == 1 && sak % 4 == 0 && M % 4 == 0))) flags |= 1;
+    if (aligned16(b) && ((sbk == 1 && sbn % 4 == 0 && K % 4 == 0) || (sbn == 1 && sbk % 4 == 0 && N % 4 == 0))) flags |= 2;
     GemmProblem &p = grp_.p[grp_.count++];
     p = GemmProblem{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, gate, chunk,
-                    split_k > 1 ? 1 : 0, asum1, asum2, cdiv(N, BN), cdiv(N, BN) * cdiv(M, BM), tiles_};
+                    split_k > 1 ? 1 : 0, asum1, asum2, cdiv(N, BN), cdiv(N, BN) * cdiv(M, BM), tiles_, flags};
     tiles_ += p.tiles_mn * split_k;
     flops_ += 2.0 * M * N * K;
 }
