@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--command-length", type=int, default=10)
     ap.add_argument("--workload", default="compositional", choices=["compositional", "target_length", "demo"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay captured HIP graphs instead of launching eagerly (pays off once the host is the limiter)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,7 +128,7 @@ def main():
     model = Model(**cfg).cuda()
     batch = {k: v.cuda() for k, v in make_batch(shape, seed=1234 + rank).items()}   # resident in HBM
     batch["cmd_lengths"] = batch["cmd_lengths"].to(torch.int32)
-    step = TrainStep(model, learning_rate=1e-3)
+    step = TrainStep(model, learning_rate=1e-3, graph=args.graph)
 
     def fence():
         torch.cuda.synchronize()
@@ -148,11 +150,16 @@ def main():
     elapsed = float(t.item())
     loss = float(out["loss"].item())
 
-    # second pass over the same K steps with HIP-event probes around each kernel family
+    # second pass over the same K steps, launched eagerly, with HIP-event probes around each kernel family
+    # (events cannot be read back from inside a captured graph)
+    probe_step = TrainStep(model, learning_rate=1e-3, graph=False)
+    for _ in range(3):
+        probe_step(batch)
+    torch.cuda.synchronize()
     lib.gscan_probe_reset()
     lib.gscan_probe_enable(1)
     for _ in range(args.steps):
-        step(batch)
+        probe_step(batch)
     torch.cuda.synchronize()
     lib.gscan_probe_enable(0)
     families = {}
@@ -180,7 +187,8 @@ def main():
                                    f"k={cfg['cnn_kernel_size']}, hidden {cfg['decoder_hidden_size']}, L={L}, T={T} dense, "
                                    f"dropout {cfg['encoder_dropout_p']}/{cfg['decoder_dropout_p']}/{cfg['cnn_dropout_p']}, "
                                    f"conditional attention, Adam+LR step included",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "parameters": model.flat_parameters.numel()},
+                       "global_batch": world * B, "parallelism": f"dp{world}", "parameters": model.flat_parameters.numel(),
+                       "launch": "hipGraph replay (3 graphs per step)" if args.graph else "eager, 30 launches per step"},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(d["tflops"], 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_FP32_TFLOPS, 4),
                          "traffic": None, "avg_launch_us": round(d["avg_us"], 2),

@@ -135,6 +135,36 @@ int gscan_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
                     float lr, float beta1, float beta2, float eps, float lr_decay, float lr_decay_steps,
                     int64_t step, const float *grad_scale, void *stream);
 
+/* ---- the same loop body for a captured (hipGraph) step: everything that changes from step to step is read from
+ * device memory, so one captured sequence can be replayed unchanged ---- */
+
+/* Both losses in one launch: stats[4] = [sum NLL, tokens, sum aux NLL, rows] and the unit seeds
+ * dlogp = d(sum NLL)/d(logp), daux = d(sum aux NLL)/d(aux_logp).  aux_logp/positions/daux may be NULL. */
+int gscan_step_losses(const float *logp, const int64_t *targets, const float *aux_logp, const int64_t *positions, int B,
+                      int T, int V, int M, int pad, float *stats, float *dlogp, float *daux, void *stream);
+
+/* seeds[0] = 1/stats[1], seeds[1] = w/stats[3] (0 without the auxiliary task), seeds[2] = the reference's loss
+ * (train.py:102-107).  Call after the data-parallel all-reduce of stats. */
+int gscan_loss_seeds(const float *stats, float weight_target_loss, int auxiliary, float *seeds, void *stream);
+
+/* gscan_backward with dlogp multiplied by seeds[0] and daux_logp by seeds[1] (device scalars, may be NULL). */
+int gscan_backward_seeded(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                          const gscan_masks *masks, void *workspace, const float *dlogp, const float *daux_logp,
+                          const float *seeds, const gscan_params *grads, void *stream);
+
+/* Adam with the step-dependent scalars [lr_t / (1 - beta1^t), 1 / sqrt(1 - beta2^t)] read from device memory
+ * (gscan_adam_scalars computes them on the host); zero_grad != 0 also clears the gradient buffer
+ * (optimizer.zero_grad(), train.py:113). */
+int gscan_adam_step_graph(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float beta1,
+                          float beta2, float eps, const float *dev_scalars, int zero_grad, void *stream);
+void gscan_adam_scalars(float lr, float beta1, float beta2, float lr_decay, float lr_decay_steps, int64_t step,
+                        float *scalars2_host);
+
+/* The three dropout masks of one step (contiguous: cnn | enc | dec) in one launch; the Philox stream id is
+ * dev_stream_id[0] when that device pointer is not NULL. */
+int gscan_dropout_masks(float *out, size_t n_cnn, size_t n_enc, size_t n_dec, float p_cnn, float p_enc, float p_dec,
+                        uint64_t seed, uint64_t stream_id, const uint64_t *dev_stream_id, void *stream);
+
 /* Counter-based (Philox-4x32-10) scaled dropout mask: out[i] = keep ? 1/(1-p) : 0. */
 int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, void *stream);
 

@@ -76,6 +76,13 @@ PROTOTYPES = {
     "gscan_sequence_metrics": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gscan_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i64, _vp, _vp]),
     "gscan_dropout_mask": (_i, [_vp, _sz, _f, _u64, _u64, _vp]),
+    "gscan_step_losses": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gscan_loss_seeds": (_i, [_vp, _f, _i, _vp, _vp]),
+    "gscan_backward_seeded": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp,
+                                   _vp, _vp, C.POINTER(Params), _vp]),
+    "gscan_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _vp, _i, _vp]),
+    "gscan_adam_scalars": (None, [_f, _f, _f, _f, _f, _i64, _vp]),
+    "gscan_dropout_masks": (_i, [_vp, _sz, _sz, _sz, _f, _f, _f, _u64, _u64, _vp, _vp]),
     "gscan_probe_enable": (_i, [_i]),
     "gscan_probe_reset": (_i, []),
     "gscan_probe_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),

@@ -59,8 +59,49 @@ int gscan_backward(const gscan_dims *dims, const gscan_params *params, const gsc
                    const gscan_params *grads, void *stream) {
     ARG(dims && params && batch && workspace && grads, "backward: NULL argument");
     gscan_masks none{nullptr, nullptr, nullptr};
-    return step_backward(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, dlogp, daux_logp, *grads,
-                         (hipStream_t)stream);
+    return step_backward(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, dlogp, daux_logp, nullptr,
+                         *grads, (hipStream_t)stream);
+}
+
+int gscan_backward_seeded(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                          const gscan_masks *masks, void *workspace, const float *dlogp, const float *daux_logp,
+                          const float *seeds, const gscan_params *grads, void *stream) {
+    ARG(dims && params && batch && workspace && grads, "backward: NULL argument");
+    gscan_masks none{nullptr, nullptr, nullptr};
+    return step_backward(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, dlogp, daux_logp, seeds,
+                         *grads, (hipStream_t)stream);
+}
+
+int gscan_step_losses(const float *logp, const int64_t *targets, const float *aux_logp, const int64_t *positions, int B,
+                      int T, int V, int M, int pad, float *stats, float *dlogp, float *daux, void *stream) {
+    ARG(logp && targets && stats && dlogp && B > 0 && T > 0 && V > 0, "step_losses: bad argument");
+    ARG(!aux_logp || (positions && daux && M > 0), "step_losses: auxiliary arrays incomplete");
+    return step_losses(logp, targets, aux_logp, positions, B, T, V, M, pad, stats, dlogp, daux, (hipStream_t)stream);
+}
+
+int gscan_loss_seeds(const float *stats, float weight_target_loss, int auxiliary, float *seeds, void *stream) {
+    ARG(stats && seeds, "loss_seeds: NULL argument");
+    return loss_seeds(stats, weight_target_loss, auxiliary, seeds, (hipStream_t)stream);
+}
+
+int gscan_adam_step_graph(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float beta1,
+                          float beta2, float eps, const float *dev_scalars, int zero_grad, void *stream) {
+    ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && dev_scalars, "adam_step_graph: bad argument");
+    return adam_step(param, grad, exp_avg, exp_avg_sq, n, 0.f, beta1, beta2, eps, 0.f, 1.f, 0, nullptr, dev_scalars,
+                     zero_grad, (hipStream_t)stream);
+}
+
+void gscan_adam_scalars(float lr, float beta1, float beta2, float lr_decay, float lr_decay_steps, int64_t step,
+                        float *scalars2_host) {
+    adam_scalars(lr, beta1, beta2, lr_decay, lr_decay_steps, step, scalars2_host, scalars2_host + 1);
+}
+
+int gscan_dropout_masks(float *out, size_t n_cnn, size_t n_enc, size_t n_dec, float p_cnn, float p_enc, float p_dec,
+                        uint64_t seed, uint64_t stream_id, const uint64_t *dev_stream_id, void *stream) {
+    ARG(out, "dropout_masks: NULL output");
+    const size_t n[3] = {n_cnn, n_enc, n_dec};
+    const float p[3] = {p_cnn, p_enc, p_dec};
+    return dropout_masks(out, n, p, seed, stream_id, dev_stream_id, (hipStream_t)stream);
 }
 
 int gscan_sequence_nll(const float *logp, const int64_t *targets, int B, int T, int V, int pad, float *loss_sum,
@@ -85,8 +126,8 @@ int gscan_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
                     float beta1, float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step,
                     const float *grad_scale, void *stream) {
     ARG(param && grad && exp_avg && exp_avg_sq && n > 0, "adam_step: bad argument");
-    return adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, lr_decay, lr_decay_steps, step,
-                     grad_scale, (hipStream_t)stream);
+    return adam_step(param, const_cast<float *>(grad), exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, lr_decay,
+                     lr_decay_steps, step, grad_scale, nullptr, 0, (hipStream_t)stream);
 }
 
 int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, void *stream) {

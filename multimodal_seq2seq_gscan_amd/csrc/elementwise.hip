@@ -230,12 +230,15 @@ int attn_value_grad(const float *alpha_c, const float *alpha_s, const float *ds,
 // ------------------------------------------------------------------------------------------
 // Fused Adam over the flat parameter buffer (torch.optim.Adam semantics, train.py:68,111).
 // ------------------------------------------------------------------------------------------
-__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+__global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                             float *__restrict__ v, size_t n, float step_size, float beta1, float beta2, float eps,
-                            float inv_sqrt_bc2, const float *__restrict__ grad_scale) {
+                            float inv_sqrt_bc2, const float *__restrict__ grad_scale,
+                            const float *__restrict__ dev_scalars, int zero_grad) {
     const float gs = grad_scale ? grad_scale[0] : 1.f;
+    if (dev_scalars) { step_size = dev_scalars[0]; inv_sqrt_bc2 = dev_scalars[1]; }   // graph replay: per-step values
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gs;
+        if (zero_grad) g[i] = 0.f;                 // optimizer.zero_grad() of train.py:113 folded in
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         m[i] = mi;
@@ -245,16 +248,24 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
     }
 }
 
-int adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
-              float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
-              hipStream_t stream) {
-    GSCAN_CHECK(step >= 1, "adam: step is 1-based (got %lld)", (long long)step);
+void adam_scalars(float lr, float beta1, float beta2, float lr_decay, float lr_decay_steps, int64_t step,
+                  float *step_size, float *inv_sqrt_bc2) {
     const double lr_t = (double)lr * pow((double)lr_decay, (double)(step - 1) / (double)lr_decay_steps);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    *step_size = (float)(lr_t / bc1);
+    *inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+}
+
+int adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+              float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
+              const float *dev_scalars, int zero_grad, hipStream_t stream) {
+    GSCAN_CHECK(step >= 1 || dev_scalars, "adam: step is 1-based (got %lld)", (long long)step);
+    float step_size = 0.f, inv_sqrt_bc2 = 0.f;
+    if (!dev_scalars) adam_scalars(lr, beta1, beta2, lr_decay, lr_decay_steps, step, &step_size, &inv_sqrt_bc2);
     hipLaunchKernelGGL(adam_kernel, dim3((int)std::min<size_t>(cdiv(n, 256), 2048)), dim3(256), 0, stream, param, grad,
-                       exp_avg, exp_avg_sq, n, (float)(lr_t / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)),
-                       grad_scale);
+                       exp_avg, exp_avg_sq, n, step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale, dev_scalars,
+                       zero_grad);
     GSCAN_LAUNCHED("adam_kernel");
     return 0;
 }
@@ -274,9 +285,15 @@ __device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
 
-__global__ void dropout_mask_kernel(float *__restrict__ out, size_t n, float p, float scale, uint64_t seed,
-                                    uint64_t stream_id) {
+// Up to three consecutive segments (the CNN / encoder / decoder masks of one step) with their own keep
+// probabilities in one launch; the stream id may come from device memory (graph replay).
+struct MaskSegments { size_t end[3]; float p[3]; };
+
+__global__ void dropout_mask_kernel(float *__restrict__ out, MaskSegments seg, uint64_t seed, uint64_t stream_id,
+                                    const uint64_t *__restrict__ dev_stream_id) {
+    const size_t n = seg.end[2];
     const size_t nquad = (n + 3) / 4;
+    if (dev_stream_id) stream_id = dev_stream_id[0];
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (size_t)gridDim.x * blockDim.x) {
         uint32_t c0 = (uint32_t)q, c1 = (uint32_t)(q >> 32), c2 = (uint32_t)stream_id, c3 = (uint32_t)(stream_id >> 32);
         uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -291,20 +308,35 @@ __global__ void dropout_mask_kernel(float *__restrict__ out, size_t n, float p, 
         for (int j = 0; j < 4; ++j) {
             const size_t i = q * 4 + j;
             if (i < n) {
+                const float p = i < seg.end[0] ? seg.p[0] : (i < seg.end[1] ? seg.p[1] : seg.p[2]);
                 const float u = (float)(rnd[j] >> 8) * (1.0f / 16777216.0f);   // [0,1)
-                out[i] = (u >= p) ? scale : 0.f;
+                out[i] = (u >= p) ? 1.0f / (1.0f - p) : 0.f;
             }
         }
     }
 }
 
-int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream) {
-    GSCAN_CHECK(p >= 0.f && p < 1.f, "dropout: p=%g out of [0,1)", p);
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)std::min<size_t>(cdiv((n + 3) / 4, 256), 2048)), dim3(256), 0,
-                       stream, out, n, p, 1.0f / (1.0f - p), seed, stream_id);
+int dropout_masks(float *out, const size_t (&n)[3], const float (&p)[3], uint64_t seed, uint64_t stream_id,
+                  const uint64_t *dev_stream_id, hipStream_t stream) {
+    MaskSegments seg;
+    size_t acc = 0;
+    for (int i = 0; i < 3; ++i) {
+        GSCAN_CHECK(p[i] >= 0.f && p[i] < 1.f, "dropout: p=%g out of [0,1)", p[i]);
+        acc += n[i];
+        seg.end[i] = acc;
+        seg.p[i] = p[i];
+    }
+    if (acc == 0) return 0;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)std::min<size_t>(cdiv((acc + 3) / 4, 256), 2048)), dim3(256), 0,
+                       stream, out, seg, seed, stream_id, dev_stream_id);
     GSCAN_LAUNCHED("dropout_mask_kernel");
     return 0;
+}
+
+int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream) {
+    const size_t ns[3] = {n, 0, 0};
+    const float ps[3] = {p, 0.f, 0.f};
+    return dropout_masks(out, ns, ps, seed, stream_id, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------

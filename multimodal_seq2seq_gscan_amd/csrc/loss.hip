@@ -27,15 +27,18 @@ __global__ void log_softmax_kernel(const float *__restrict__ x, float *__restric
 }
 
 // dx = dy - exp(y) * sum(dy)
+// dx = scale * (dy - exp(y) * sum(dy));  scale (device scalar, optional) seeds the backward pass with
+// 1/tokens_global or w/rows_global without a host round trip
 __global__ void log_softmax_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy,
-                                       float *__restrict__ dx, int rows, int n) {
+                                       float *__restrict__ dx, int rows, int n, const float *__restrict__ scale) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
+    const float sc = scale ? scale[0] : 1.f;
     const float *yr = y + (int64_t)r * n, *dr = dy + (int64_t)r * n;
     float s = 0.f;
     for (int j = 0; j < n; ++j) s += dr[j];
     float *xr = dx + (int64_t)r * n;
-    for (int j = 0; j < n; ++j) xr[j] = dr[j] - expf(yr[j]) * s;
+    for (int j = 0; j < n; ++j) xr[j] = sc * (dr[j] - expf(yr[j]) * s);
 }
 
 int log_softmax_rows(const float *x, float *y, float *y2, int rows, int n, hipStream_t stream) {
@@ -44,8 +47,9 @@ int log_softmax_rows(const float *x, float *y, float *y2, int rows, int n, hipSt
     GSCAN_LAUNCHED("log_softmax_kernel");
     return 0;
 }
-int log_softmax_rows_backward(const float *y, const float *dy, float *dx, int rows, int n, hipStream_t stream) {
-    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, y, dy, dx, rows, n);
+int log_softmax_rows_backward(const float *y, const float *dy, float *dx, int rows, int n, const float *scale,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, y, dy, dx, rows, n, scale);
     GSCAN_LAUNCHED("log_softmax_bwd_kernel");
     return 0;
 }
@@ -115,6 +119,66 @@ int position_nll(const float *aux, const int64_t *pos, int B, int M, float *loss
                  hipStream_t stream) {
     hipLaunchKernelGGL(position_nll_kernel, dim3(1), dim3(256), 0, stream, aux, pos, B, M, loss_sum, daux);
     GSCAN_LAUNCHED("position_nll_kernel");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Both losses of the training step in one launch (train.py:102-107): stats = [sum NLL, tokens, sum aux NLL, rows],
+// unit seeds d(sum NLL)/d(logp) and d(sum aux NLL)/d(aux_logp).  Single workgroup, fixed reduction order.
+// ------------------------------------------------------------------------------------------
+__global__ void step_losses_kernel(const float *__restrict__ logp, const int64_t *__restrict__ targets,
+                                   const float *__restrict__ aux, const int64_t *__restrict__ pos, int B, int T, int V,
+                                   int M, int pad, float *stats, float *__restrict__ dlogp, float *__restrict__ daux) {
+    __shared__ float s_sum[16], s_cnt[16], s_aux[16];
+    float acc = 0.f, cnt = 0.f, acc_aux = 0.f;
+    const int n = B * T;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int t = i % T;
+        const int64_t tgt = (t + 1 < T) ? targets[i + 1] : (int64_t)0;
+        const bool live = tgt != pad && tgt >= 0 && tgt < V;
+        for (int j = 0; j < V; ++j) dlogp[(int64_t)i * V + j] = (live && j == tgt) ? -1.f : 0.f;
+        if (live) { acc -= logp[(int64_t)i * V + tgt]; cnt += 1.f; }
+    }
+    if (aux) {
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            const int64_t p = pos[b];
+            const bool ok = p >= 0 && p < M;
+            for (int j = 0; j < M; ++j) daux[(int64_t)b * M + j] = (ok && j == p) ? -1.f : 0.f;
+            if (ok) acc_aux -= aux[(int64_t)b * M + p];
+        }
+    }
+    acc = wave_sum(acc); cnt = wave_sum(cnt); acc_aux = wave_sum(acc_aux);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_sum[w] = acc; s_cnt[w] = cnt; s_aux[w] = acc_aux; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, c = 0.f, x = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { a += s_sum[i]; c += s_cnt[i]; x += s_aux[i]; }
+        stats[0] = a; stats[1] = c; stats[2] = x; stats[3] = (float)B;
+    }
+}
+
+int step_losses(const float *logp, const int64_t *targets, const float *aux, const int64_t *pos, int B, int T, int V,
+                int M, int pad, float *stats, float *dlogp, float *daux, hipStream_t stream) {
+    hipLaunchKernelGGL(step_losses_kernel, dim3(1), dim3(1024), 0, stream, logp, targets, aux, pos, B, T, V, M, pad,
+                       stats, dlogp, daux);
+    GSCAN_LAUNCHED("step_losses_kernel");
+    return 0;
+}
+
+// seeds[0] = 1/tokens, seeds[1] = w/rows, seeds[2] = loss = sum NLL / tokens (+ w * sum aux NLL / rows)
+__global__ void loss_seeds_kernel(const float *stats, float w, int auxiliary, float *seeds) {
+    if (threadIdx.x == 0) {
+        const float s0 = 1.f / stats[1];
+        const float s1 = auxiliary ? w / stats[3] : 0.f;
+        seeds[0] = s0;
+        seeds[1] = s1;
+        seeds[2] = stats[0] * s0 + (auxiliary ? stats[2] * s1 : 0.f);
+    }
+}
+int loss_seeds(const float *stats, float w, int auxiliary, float *seeds, hipStream_t stream) {
+    hipLaunchKernelGGL(loss_seeds_kernel, dim3(1), dim3(64), 0, stream, stats, w, auxiliary, seeds);
+    GSCAN_LAUNCHED("loss_seeds_kernel");
     return 0;
 }
 

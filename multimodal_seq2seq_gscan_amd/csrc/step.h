@@ -61,14 +61,22 @@ struct PrologueArgs {
 };
 int step_prologue(const PrologueArgs &args, hipStream_t stream);
 int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream);
-int adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+int adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
               float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
-              hipStream_t stream);
+              const float *dev_scalars, int zero_grad, hipStream_t stream);
+void adam_scalars(float lr, float beta1, float beta2, float lr_decay, float lr_decay_steps, int64_t step,
+                  float *step_size, float *inv_sqrt_bc2);
 int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream);
+int dropout_masks(float *out, const size_t (&n)[3], const float (&p)[3], uint64_t seed, uint64_t stream_id,
+                  const uint64_t *dev_stream_id, hipStream_t stream);
 
 // loss.hip
 int log_softmax_rows(const float *x, float *y, float *y2, int rows, int n, hipStream_t stream);
-int log_softmax_rows_backward(const float *y, const float *dy, float *dx, int rows, int n, hipStream_t stream);
+int log_softmax_rows_backward(const float *y, const float *dy, float *dx, int rows, int n, const float *scale,
+                              hipStream_t stream);
+int step_losses(const float *logp, const int64_t *targets, const float *aux, const int64_t *pos, int B, int T, int V,
+                int M, int pad, float *stats, float *dlogp, float *daux, hipStream_t stream);
+int loss_seeds(const float *stats, float w, int auxiliary, float *seeds, hipStream_t stream);
 int sequence_nll(const float *logp, const int64_t *targets, int B, int T, int V, int pad, float *loss_sum,
                  float *count, float *dlogp, hipStream_t stream);
 int position_nll(const float *aux, const int64_t *pos, int B, int M, float *loss_sum, float *daux,
@@ -149,6 +157,6 @@ int workspace_layout(const gscan_dims &d, Workspace *ws);
 int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                  float *logp, float *aux_logp, hipStream_t st);
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
-                  const float *dlogp, const float *daux, const gscan_params &g, hipStream_t st);
+                  const float *dlogp, const float *daux, const float *seeds, const gscan_params &g, hipStream_t st);
 
 }  // namespace gscan

@@ -250,7 +250,7 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
 // backward: 13 launches
 // --------------------------------------------------------------------------------------
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
-                  const float *dlogp, const float *daux, const gscan_params &g, hipStream_t st) {
+                  const float *dlogp, const float *daux, const float *seeds, const gscan_params &g, hipStream_t st) {
     TRY(check_dims(d));
     Workspace ws;
     TRY(workspace_layout(d, &ws));
@@ -265,9 +265,10 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     const float *delta = w + ws.delta, *hprev = w + ws.hprev;
 
     // ---- head: log_softmax, hidden_to_output, output_to_hidden
-    TRY(log_softmax_rows_backward(logp, dlogp, w + ws.dlogits, BT, V, st));
+    // seeds (optional, device): dlogp is multiplied by seeds[0], daux by seeds[1]
+    TRY(log_softmax_rows_backward(logp, dlogp, w + ws.dlogits, BT, V, seeds, st));
     const bool use_aux = d.auxiliary && daux;
-    if (use_aux) TRY(log_softmax_rows_backward(aux_logp, daux, w + ws.datt, B, M, st));
+    if (use_aux) TRY(log_softmax_rows_backward(aux_logp, daux, w + ws.datt, B, M, seeds ? seeds + 1 : nullptr, st));
     {
         GemmBatch b;
         add_grad(b, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H);

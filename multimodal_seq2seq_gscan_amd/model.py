@@ -218,6 +218,9 @@ class Model(nn.Module):
         self._host_masks = None
         self._dropout_seed = int(kwargs.get("seed", 42))
         self._dropout_calls = 0
+        self._mask_buffer = None
+        self._mask_key = None
+        self._mask_stream_id = None      # device uint64 holding the Philox stream id (graph replay), or None
         self._anchor = None
         self._flatten()
 
@@ -300,22 +303,27 @@ class Model(nn.Module):
             masks, self._host_masks = self._host_masks, None
             return tuple(None if m is None else m.to(device=device, dtype=torch.float32).contiguous()
                          for m in masks)
-        if not self.training:
+        if not self.training or max(self.dropout_p) <= 0.0:
             return (None, None, None)
+        # the three masks of a step are one buffer filled by one Philox launch (cnn | enc | dec)
         lib = _lib.load()
         h = self._hyper
         shapes = ((B, M, 3 * h["Co"]), (B, L, h["E"]), (B, T, h["H"]))
-        out = []
-        stream = torch.cuda.current_stream().cuda_stream
-        for i, (shape, p) in enumerate(zip(shapes, self.dropout_p)):
-            if p <= 0.0:
-                out.append(None)
-                continue
-            m = torch.empty(shape, dtype=torch.float32, device=device)
-            _lib.check(lib.gscan_dropout_mask(m.data_ptr(), m.numel(), p, self._dropout_seed,
-                                              self._dropout_calls * 4 + i, stream), "gscan_dropout_mask")
-            out.append(m)
+        sizes = [s[0] * s[1] * s[2] for s in shapes]
+        key = tuple(sizes)
+        if self._mask_buffer is None or self._mask_key != key:
+            self._mask_buffer = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+            self._mask_key = key
+        buf = self._mask_buffer
+        _lib.check(lib.gscan_dropout_masks(buf.data_ptr(), sizes[0], sizes[1], sizes[2], self.dropout_p[0],
+                                           self.dropout_p[1], self.dropout_p[2], self._dropout_seed,
+                                           self._dropout_calls, _lib.ptr(self._mask_stream_id),
+                                           torch.cuda.current_stream().cuda_stream), "gscan_dropout_masks")
         self._dropout_calls += 1
+        out, off = [], 0
+        for shape, n, p in zip(shapes, sizes, self.dropout_p):
+            out.append(buf[off:off + n].view(shape) if p > 0.0 else None)
+            off += n
         return tuple(out)
 
     # ---- the two launches ---------------------------------------------------------------------
@@ -363,18 +371,21 @@ class Model(nn.Module):
             aux = torch.zeros(1, device=commands.device)
         return logp, aux, call
 
-    def _launch_backward(self, call, dlogp: torch.Tensor, daux: Optional[torch.Tensor]) -> None:
+    def _launch_backward(self, call, dlogp: torch.Tensor, daux: Optional[torch.Tensor],
+                         seeds: Optional[torch.Tensor] = None, attach: bool = True) -> None:
         lib = _lib.load()
         if call["generation"] != self._generation:
             raise RuntimeError("backward() after another forward(): the saved activations were overwritten "
                                "(one in-flight step per model, as in the reference's training loop)")
-        self.attach_gradients(zero=False)
+        if attach:
+            self.attach_gradients(zero=False)
         dlogp = dlogp.contiguous()
         daux = None if daux is None else daux.contiguous()
-        _lib.check(lib.gscan_backward(C.byref(call["dims"]), C.byref(self._param_struct), C.byref(call["batch"]),
-                                      C.byref(call["masks"]), self._workspace.data_ptr(), dlogp.data_ptr(),
-                                      _lib.ptr(daux), C.byref(self._grad_struct),
-                                      torch.cuda.current_stream().cuda_stream), "gscan_backward")
+        _lib.check(lib.gscan_backward_seeded(C.byref(call["dims"]), C.byref(self._param_struct),
+                                             C.byref(call["batch"]), C.byref(call["masks"]),
+                                             self._workspace.data_ptr(), dlogp.data_ptr(), _lib.ptr(daux),
+                                             _lib.ptr(seeds), C.byref(self._grad_struct),
+                                             torch.cuda.current_stream().cuda_stream), "gscan_backward_seeded")
 
     def workspace_view(self, call_dims: _lib.Dims, name: str) -> torch.Tensor:
         """A saved activation of the last forward/backward as a flat fp32 tensor (tests, debugging)."""
@@ -394,6 +405,8 @@ class Model(nn.Module):
         device = commands_input.device
         lengths = _as_int32_lengths(commands_lengths, device)
         B, L = commands_input.shape
+        if self._mask_stream_id is not None:      # a TrainStep owns the device-side Philox stream id: keep it moving
+            self._mask_stream_id.fill_(self._dropout_calls)
         masks = self._draw_masks(B, L, target_batch.shape[1], situations_input.shape[1] ** 2, device)
         if torch.is_grad_enabled():
             logp, aux = _NetworkFunction.apply(self._anchor, self, commands_input, lengths, situations_input,

@@ -32,7 +32,10 @@ logger = logging.getLogger(__name__)
 
 class FlatAdam:
     """torch.optim.Adam(lr, betas) + LambdaLR(lr_decay ** (t / lr_decay_steps)) of train.py:67-70 over
-    the model's flat parameter buffer: one fused HIP kernel per step."""
+    the model's flat parameter buffer: one fused HIP kernel per step.  The step-dependent scalars live in a
+    two-float device buffer refreshed from the host before each step, so the launch itself is identical
+    every step (and can sit inside a captured graph); the kernel also clears the gradient buffer
+    (optimizer.zero_grad(), train.py:113)."""
 
     def __init__(self, model: Model, learning_rate: float, adam_beta_1: float = 0.9, adam_beta_2: float = 0.999,
                  lr_decay: float = 0.9, lr_decay_steps: float = 20000.0, eps: float = 1e-8):
@@ -43,20 +46,33 @@ class FlatAdam:
         flat = model.flat_parameters
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
+        self._host_scalars = torch.zeros(2, dtype=torch.float32).pin_memory() if flat.is_cuda else torch.zeros(2)
+        self._dev_scalars = torch.zeros(2, dtype=torch.float32, device=flat.device)
 
     def current_lr(self) -> float:
         """What scheduler.get_lr()[0] prints at train.py:123 after `steps_taken` scheduler steps."""
         return self.lr * self.lr_decay ** (self.steps_taken / self.lr_decay_steps)
 
-    def step(self, grad_scale: Optional[torch.Tensor] = None) -> None:
+    def stage_scalars(self) -> None:
+        """Host side of one step: advance the counter, push [lr_t/(1-b1^t), 1/sqrt(1-b2^t)] to the device."""
+        lib = _lib.load()
+        self.steps_taken += 1
+        lib.gscan_adam_scalars(self.lr, self.betas[0], self.betas[1], self.lr_decay, self.lr_decay_steps,
+                               self.steps_taken, self._host_scalars.data_ptr())
+        self._dev_scalars.copy_(self._host_scalars, non_blocking=True)
+
+    def launch(self, zero_grad: bool = True) -> None:
         lib = _lib.load()
         m = self.model
-        self.steps_taken += 1
-        _lib.check(lib.gscan_adam_step(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(),
-                                       self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                       m.flat_parameters.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
-                                       self.lr_decay, self.lr_decay_steps, self.steps_taken, _lib.ptr(grad_scale),
-                                       torch.cuda.current_stream().cuda_stream), "gscan_adam_step")
+        _lib.check(lib.gscan_adam_step_graph(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(),
+                                             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                             m.flat_parameters.numel(), self.betas[0], self.betas[1], self.eps,
+                                             self._dev_scalars.data_ptr(), int(zero_grad),
+                                             torch.cuda.current_stream().cuda_stream), "gscan_adam_step_graph")
+
+    def step(self, zero_grad: bool = True) -> None:
+        self.stage_scalars()
+        self.launch(zero_grad)
 
     # ---- checkpoint interop with torch.optim.Adam (model.py:246-261 stores optimizer.state_dict()) ----
     def state_dict(self) -> dict:
@@ -111,56 +127,138 @@ class GradientExchange:
 
 
 class TrainStep:
-    """One iteration of the reference loop (train.py:96-114) for this rank's rows of the minibatch."""
+    """One iteration of the reference loop (train.py:96-114) for this rank's rows of the minibatch.
+
+    `graph=True` captures the launch sequence of a step once per batch shape into HIP graphs
+    (torch.cuda.CUDAGraph is the stream-capture plumbing) and replays it: masks + forward + losses |
+    seeds + backward | Adam, cut only where the data-parallel all-reduces sit.  Everything that differs
+    between steps (Adam scalars, Philox stream id, the batch itself) is read from fixed device buffers."""
 
     def __init__(self, model: Model, learning_rate: float = 1e-3, adam_beta_1: float = 0.9,
                  adam_beta_2: float = 0.999, lr_decay: float = 0.9, lr_decay_steps: float = 20000.0,
-                 weight_target_loss: float = 0.3, process_group=None, **_):
+                 weight_target_loss: float = 0.3, process_group=None, graph: bool = False, **_):
         self.model = model
         self.optimizer = FlatAdam(model, learning_rate, adam_beta_1, adam_beta_2, lr_decay, lr_decay_steps)
         self.weight_target_loss = float(weight_target_loss)
         self.exchange = GradientExchange(process_group)
+        self.graph = bool(graph)
+        device = model.flat_parameters.device
+        self.stats = torch.zeros(4, dtype=torch.float32, device=device)
+        self.seeds = torch.zeros(3, dtype=torch.float32, device=device)
+        self._graphs: Dict[tuple, dict] = {}
+        model.flat_gradients.zero_()
+        model.attach_gradients(zero=False)
+        if device.type == "cuda":
+            if model._mask_stream_id is None:     # one device slot per model: captured graphs keep its address
+                model._mask_stream_id = torch.zeros(1, dtype=torch.int64, device=device)
+            self._host_stream_id = torch.zeros(1, dtype=torch.int64).pin_memory()
 
+    # ---- the three launch sections of a step ------------------------------------------------
+    def _section_forward(self, batch) -> dict:
+        lib = _lib.load()
+        model = self.model
+        stream = torch.cuda.current_stream().cuda_stream
+        commands, world, targets = batch["commands"], batch["world"], batch["targets"]
+        B, L = commands.shape
+        T = targets.shape[1]
+        masks = model._draw_masks(B, L, T, world.shape[1] ** 2, commands.device)
+        logp, aux, call = model._launch_forward(commands, batch["cmd_lengths"], world, targets, masks)
+        dlogp = torch.empty_like(logp)
+        daux = torch.empty_like(aux) if model.auxiliary_task else None
+        pos = batch["target_positions"].view(-1).contiguous() if model.auxiliary_task else None
+        _lib.check(lib.gscan_step_losses(logp.data_ptr(), call["keep"][3].data_ptr(),
+                                         aux.data_ptr() if model.auxiliary_task else None, _lib.ptr(pos), B, T,
+                                         logp.shape[2], aux.shape[1] if model.auxiliary_task else 0,
+                                         model.target_pad_idx, self.stats.data_ptr(), dlogp.data_ptr(),
+                                         _lib.ptr(daux), stream), "gscan_step_losses")
+        return {"logp": logp, "aux": aux, "call": call, "dlogp": dlogp, "daux": daux, "pos": pos}
+
+    def _section_backward(self, fw: dict) -> None:
+        lib = _lib.load()
+        _lib.check(lib.gscan_loss_seeds(self.stats.data_ptr(), self.weight_target_loss,
+                                        int(self.model.auxiliary_task), self.seeds.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "gscan_loss_seeds")
+        self.model._launch_backward(fw["call"], fw["dlogp"], fw["daux"], seeds=self.seeds, attach=False)
+
+    def _host_prologue(self) -> None:
+        """Per-step host work: optimizer scalars and the Philox stream id go to their device slots."""
+        self.optimizer.stage_scalars()
+        self._host_stream_id[0] = self.model._dropout_calls
+        self.model._mask_stream_id.copy_(self._host_stream_id, non_blocking=True)
+        self.model._dropout_calls += 1
+
+    def _result(self, fw: dict) -> Dict[str, torch.Tensor]:
+        self.model.update_state(is_best=False)
+        return {"loss": self.seeds[2], "tokens": self.stats[1], "logp": fw["logp"], "aux": fw["aux"]}
+
+    # ---- eager and captured execution -----------------------------------------------------------
     def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """batch: commands [B,L] i64, cmd_lengths [B], world [B,G,G,C] f32, targets [B,T] i64 and, with the
         auxiliary task, target_positions [B] i64 — all on the HIP device.  Returns device scalars
         `loss` (global mean, as the reference logs it), `tokens` and the local `logp`."""
-        lib = _lib.load()
         model = self.model
         model.train()
-        stream = torch.cuda.current_stream().cuda_stream
-        commands, world, targets = batch["commands"], batch["world"], batch["targets"]
-        device = commands.device
-        B, L = commands.shape
-        T = targets.shape[1]
-        lengths = _as_int32_lengths(batch["cmd_lengths"], device)
-        masks = model._draw_masks(B, L, T, world.shape[1] ** 2, device)
-        logp, aux, call = model._launch_forward(commands, lengths, world, targets, masks)
-
-        # [sum NLL, tokens, sum aux NLL, rows] — the only quantities ranks must agree on before backward
-        stats = torch.zeros(4, dtype=torch.float32, device=device)
-        dlogp = torch.empty_like(logp)
-        _lib.check(lib.gscan_sequence_nll(logp.data_ptr(), call["keep"][3].data_ptr(), B, T, logp.shape[2],
-                                          model.target_pad_idx, stats.data_ptr(), stats.data_ptr() + 4,
-                                          dlogp.data_ptr(), stream), "gscan_sequence_nll")
-        daux = None
-        if model.auxiliary_task:
-            daux = torch.empty_like(aux)
-            pos = batch["target_positions"].view(-1).contiguous()
-            _lib.check(lib.gscan_position_nll(aux.data_ptr(), pos.data_ptr(), B, aux.shape[1],
-                                              stats.data_ptr() + 8, daux.data_ptr(), stream), "gscan_position_nll")
-        stats[3] = float(B)
-        stats, seq_seed, aux_seed, loss = self.exchange.seeds(stats, self.weight_target_loss, model.auxiliary_task)
-        dlogp.mul_(seq_seed)
-        if daux is not None:
-            daux.mul_(aux_seed)
-
-        model.flat_gradients.zero_()
-        model._launch_backward(call, dlogp, daux)
+        device = batch["commands"].device
+        batch = dict(batch, cmd_lengths=_as_int32_lengths(batch["cmd_lengths"], device))
+        if self.graph:
+            return self._replay(batch)
+        self._host_prologue()
+        fw = self._section_forward(batch)
+        self.exchange.all_reduce(self.stats)
+        self._section_backward(fw)
         self.exchange.all_reduce(model.flat_gradients)
-        self.optimizer.step()
-        model.update_state(is_best=False)
-        return {"loss": loss, "tokens": stats[1], "logp": logp, "aux": aux}
+        self.optimizer.launch(zero_grad=True)
+        return self._result(fw)
+
+    def _replay(self, batch) -> Dict[str, torch.Tensor]:
+        key = tuple((k, tuple(v.shape)) for k, v in sorted(batch.items()))
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._capture(batch)
+            self._graphs[key] = entry
+        for k, v in batch.items():
+            if entry["static"][k].data_ptr() != v.data_ptr():
+                entry["static"][k].copy_(v, non_blocking=True)
+        self._host_prologue()
+        entry["g_forward"].replay()
+        self.exchange.all_reduce(self.stats)
+        entry["g_backward"].replay()
+        self.exchange.all_reduce(self.model.flat_gradients)
+        entry["g_adam"].replay()
+        return self._result(entry["fw"])
+
+    def _capture(self, batch) -> dict:
+        static = {k: v.clone() for k, v in batch.items()}
+        # warm-up on a side stream (first launches set kernel attributes, allocate the workspace and masks)
+        saved_steps, saved_calls = self.optimizer.steps_taken, self.model._dropout_calls
+        params = self.model.flat_parameters.clone()
+        m, v = self.optimizer.exp_avg.clone(), self.optimizer.exp_avg_sq.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._host_prologue()
+            fw = self._section_forward(static)
+            self._section_backward(fw)
+            self.optimizer.launch(zero_grad=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        # the warm-up step must not count: restore parameters, moments and counters
+        self.model.flat_parameters.copy_(params)
+        self.optimizer.exp_avg.copy_(m)
+        self.optimizer.exp_avg_sq.copy_(v)
+        self.optimizer.steps_taken, self.model._dropout_calls = saved_steps, saved_calls
+        self.model.flat_gradients.zero_()
+        g_forward, g_backward, g_adam = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g_forward, pool=pool):
+            fw = self._section_forward(static)
+        with torch.cuda.graph(g_backward, pool=pool):
+            self._section_backward(fw)
+        with torch.cuda.graph(g_adam, pool=pool):
+            self.optimizer.launch(zero_grad=True)
+        self.model.flat_gradients.zero_()
+        self.model._dropout_calls = saved_calls
+        return {"static": static, "fw": fw, "g_forward": g_forward, "g_backward": g_backward, "g_adam": g_adam}
 
 
 def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world_size: int) -> Dict[str, torch.Tensor]:

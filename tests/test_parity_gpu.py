@@ -192,3 +192,30 @@ def test_gradient_accumulation_semantics():
     g3 = dict(model.named_parameters())[name].grad.cpu()
     assert torch.allclose(g3, 3 * g1[name], atol=1e-5, rtol=1e-4)
     assert dict(model.named_parameters())[name].grad.data_ptr() >= model.flat_gradients.data_ptr()
+
+
+def test_train_step_matches_reference_adam_steps():
+    """TrainStep (fused losses, seeded backward, device-scalar Adam) for three iterations against the reference's
+    own Adam + LambdaLR run (tests/golden/demo_adam3.npz), eagerly and through captured HIP graphs."""
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+    from multimodal_seq2seq_gscan_amd.train import TrainStep
+    cfg = model_kwargs("demo", cnn_dropout_p=0.0, encoder_dropout_p=0.0, decoder_dropout_p=0.0)
+    fx = load_fixture("demo_adam3.npz")
+    shape = Shape(batch=4, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=7, max_target=10,
+                  ragged=True)
+    for graph in (False, True):
+        model = build_model(cfg, fixture_params(cfg, {"seed_weights": 11}))
+        step = TrainStep(model, learning_rate=float(fx["lr"]), lr_decay=float(fx["lr_decay"]),
+                         lr_decay_steps=float(fx["lr_decay_steps"]), graph=graph)
+        for i in range(3):
+            batch = {k: v.cuda() for k, v in make_batch(shape, 100 + i).items()}
+            if graph:   # one captured shape: pad every batch to the fixture's maximum lengths
+                L, T = 7, 10
+                batch["commands"] = torch.nn.functional.pad(batch["commands"], (0, L - batch["commands"].shape[1]))
+                batch["targets"] = torch.nn.functional.pad(batch["targets"], (0, T - batch["targets"].shape[1]))
+            out = step(batch)
+            assert abs(out["loss"].item() - float(fx["losses"][i])) < TOL, (graph, i)
+        torch.cuda.synchronize()
+        for n, p in model.named_parameters():
+            assert torch.allclose(p.detach().cpu(), torch.from_numpy(fx["param/" + n]), atol=1e-5, rtol=0), (graph, n)
+        assert model.trained_iterations == 3
