@@ -413,4 +413,106 @@ int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stre
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// World encoder as ONE dense product (seq2seq/cnn_model.py:22-36).  The grid is tiny (G*G = 36 cells, 576
+// inputs per example), so the three same-padded convolutions are expanded into a Toeplitz matrix
+//   Wt[(r',c',ch), (r,c,f)] = W_conv(f)[o(f), ch, kh = c'-c+p, kw = r'-r+p]   (0 outside the kernel window)
+// and  features[b, (r,c,f)] = relu(world[b,:] . Wt[:, (r,c,f)] + bias[f]) : no im2col buffer (44 MB at B=256),
+// K = 576 instead of 16*(1+25+49) = 1200 gathered taps, and the output is already [B, G*G, 3*Co].
+// kh walks grid columns and kw grid rows because the reference convolves the transposed image.
+// ------------------------------------------------------------------------------------------
+struct ToeplitzArgs {
+    const float *w[3], *b[3];
+    int G, C, Co, K3;
+};
+__device__ __forceinline__ int conv_kernel_size(int i, int K3) { return i == 0 ? 1 : (i == 1 ? 5 : K3); }
+
+__global__ void toeplitz_build_kernel(ToeplitzArgs a, float *__restrict__ wt, float *__restrict__ bias_rep) {
+    const int G = a.G, C = a.C, Co = a.Co, F = 3 * Co, N = G * G * F, J = G * G * C;
+    const int64_t total = (int64_t)J * N;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + N;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        if (idx >= total) {                                   // bias replicated over the G*G positions
+            const int n = (int)(idx - total), f = n % F;
+            bias_rep[n] = a.b[f / Co][f % Co];
+            continue;
+        }
+        const int n = (int)(idx % N), j = (int)(idx / N);
+        const int f = n % F, pos = n / F, r = pos / G, c = pos % G;
+        const int ch = j % C, cell = j / C, r2 = cell / G, c2 = cell % G;
+        const int i = f / Co, o = f % Co, k = conv_kernel_size(i, a.K3), p = k / 2;
+        const int kw = r2 - r + p, kh = c2 - c + p;
+        float v = 0.f;
+        if (kw >= 0 && kw < k && kh >= 0 && kh < k) v = a.w[i][((o * C + ch) * k + kh) * k + kw];
+        wt[idx] = v;
+    }
+}
+
+int toeplitz_build(const float *const (&w)[3], const float *const (&b)[3], int G, int C, int Co, int K3, float *wt,
+                   float *bias_rep, hipStream_t stream) {
+    ToeplitzArgs a{{w[0], w[1], w[2]}, {b[0], b[1], b[2]}, G, C, Co, K3};
+    const int64_t total = (int64_t)G * G * C * G * G * 3 * Co;
+    hipLaunchKernelGGL(toeplitz_build_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 8192)), dim3(256), 0, stream,
+                       a, wt, bias_rep);
+    GSCAN_LAUNCHED("toeplitz_build_kernel");
+    return 0;
+}
+
+// Fold d(Wt) back onto the three convolution kernels and sum d(features) into the three biases:
+//   dW_i[o,ch,kh,kw] += sum over output cells (r,c) with (r+kw-p, c+kh-p) inside the grid of dWt[(r',c',ch),(r,c,f)]
+//   db_i[o]          += sum over rows b and cells of dfeat[b, (r,c), f]
+// Blocks [0, nw) fold weights (thread -> (o fastest, tap)), the remaining blocks sum 64-row chunks of dfeat.
+struct ToeplitzGradArgs {
+    float *gw[3], *gb[3];
+    int G, C, Co, K3, rows, nw_blocks;
+    int wcount[3];
+};
+__global__ void toeplitz_fold_kernel(ToeplitzGradArgs a, const float *__restrict__ dwt, const float *__restrict__ dfeat) {
+    const int G = a.G, C = a.C, Co = a.Co, F = 3 * Co, N = G * G * F;
+    if ((int)blockIdx.x < a.nw_blocks) {
+        int e = blockIdx.x * blockDim.x + threadIdx.x;
+        int i = 0;
+        while (i < 3 && e >= a.wcount[i]) { e -= a.wcount[i]; ++i; }
+        if (i >= 3) return;
+        const int k = conv_kernel_size(i, a.K3), p = k / 2;
+        const int o = e % Co, tap = e / Co;                    // tap = (ch*k + kh)*k + kw
+        const int kw = tap % k, kh = (tap / k) % k, ch = tap / (k * k);
+        float acc = 0.f;
+        for (int r = 0; r < G; ++r) {
+            const int r2 = r + kw - p;
+            if (r2 < 0 || r2 >= G) continue;
+            for (int c = 0; c < G; ++c) {
+                const int c2 = c + kh - p;
+                if (c2 < 0 || c2 >= G) continue;
+                acc += dwt[(int64_t)((r2 * G + c2) * C + ch) * N + (r * G + c) * F + i * Co + o];
+            }
+        }
+        a.gw[i][((o * C + ch) * k + kh) * k + kw] += acc;
+    } else {
+        const int chunk = blockIdx.x - a.nw_blocks;
+        const int f = threadIdx.x;
+        if (f >= F) return;
+        const int r0 = chunk * 64, r1 = min(a.rows, r0 + 64);     // rows of the [B*G*G, F] view
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) acc += dfeat[(int64_t)r * F + f];
+        atomicAdd(&a.gb[f / Co][f % Co], acc);
+    }
+}
+
+int toeplitz_fold(float *const (&gw)[3], float *const (&gb)[3], int G, int C, int Co, int K3, int B, const float *dwt,
+                  const float *dfeat, hipStream_t stream) {
+    ToeplitzGradArgs a{{gw[0], gw[1], gw[2]}, {gb[0], gb[1], gb[2]}, G, C, Co, K3, B * G * G, 0, {0, 0, 0}};
+    int total = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int k = i == 0 ? 1 : (i == 1 ? 5 : K3);
+        a.wcount[i] = Co * C * k * k;
+        total += a.wcount[i];
+    }
+    GSCAN_CHECK(3 * Co <= 256, "toeplitz_fold: more than 256 feature channels");
+    a.nw_blocks = cdiv(total, 256);
+    hipLaunchKernelGGL(toeplitz_fold_kernel, dim3(a.nw_blocks + cdiv(a.rows, 64)), dim3(256), 0, stream, a, dwt, dfeat);
+    GSCAN_LAUNCHED("toeplitz_fold_kernel");
+    return 0;
+}
+
 }  // namespace gscan

@@ -60,6 +60,10 @@ struct PrologueArgs {
     int64_t end[6];
 };
 int step_prologue(const PrologueArgs &args, hipStream_t stream);
+int toeplitz_build(const float *const (&w)[3], const float *const (&b)[3], int G, int C, int Co, int K3, float *wt,
+                   float *bias_rep, hipStream_t stream);
+int toeplitz_fold(float *const (&gw)[3], float *const (&gb)[3], int G, int C, int Co, int K3, int B, const float *dwt,
+                  const float *dfeat, hipStream_t stream);
 int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream);
 int adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
               float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
@@ -147,7 +151,7 @@ struct Workspace {
     int64_t xcol, feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
-        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd;
+        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, wt, dwt, bias_rep;
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;

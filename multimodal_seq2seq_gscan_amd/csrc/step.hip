@@ -30,7 +30,10 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
         return ws->slot[n - 1].offset;
     };
 #define SLOT(field, count) ws->field = take(#field, (count))
-    SLOT(xcol, B * M * Ktot);
+    SLOT(xcol, 64);                                  // (im2col buffer of the first design; unused)
+    SLOT(wt, M * d.C * M * F);
+    SLOT(dwt, M * d.C * M * F);
+    SLOT(bias_rep, M * F);
     SLOT(feat, B * M * F);
     SLOT(pkv, B * M * H);
     SLOT(uv, B * M * 4 * H);
@@ -181,20 +184,19 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     }
     TRY(decoder_weight_images(p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, H, cond, w + ws.dec_w_fwd,
                               w + ws.dec_w_bwd, st));
-    TRY(world_im2col(bt.world, B, d.G, C, d.K3, w + ws.xcol, st));
+    {   // Toeplitz image of the three convolutions (12.4 MB at G=6, C=16, Co=50), rebuilt from the live weights
+        const float *const cw[3] = {p.conv1_w, p.conv2_w, p.conv3_w};
+        const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
+        TRY(toeplitz_build(cw, cb, d.G, C, Co, d.K3, w + ws.wt, w + ws.bias_rep, st));
+    }
 
     // ---- level 1: everything that depends only on inputs and parameters
     {
         GemmBatch g;
-        const float *cw[3] = {p.conv1_w, p.conv2_w, p.conv3_w};
-        const float *cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
-        const int kk[3] = {C, 25 * C, d.K3 * d.K3 * C};
-        int off = 0;
-        for (int i = 0; i < 3; ++i) {   // world encoder (cnn_model.py:22-36): bias + ReLU + dropout in the epilogue
-            g.add(B * M, Co, kk[i], w + ws.xcol + off, Ktot, 1, cw[i], 1, kk[i], w + ws.feat + i * Co, F, 0.f, cb[i], 1,
-                  mk.cnn ? mk.cnn + i * Co : nullptr);
-            off += kk[i];
-        }
+        // world encoder (cnn_model.py:22-36) as one product world[B, G*G*C] . Wt[G*G*C, G*G*3Co]; bias + ReLU +
+        // dropout in the epilogue; the result IS feat[B, G*G, 3Co]
+        g.add(B, M * F, M * C, bt.world, (int64_t)M * C, 1, w + ws.wt, (int64_t)M * F, 1, w + ws.feat, (int64_t)M * F, 0.f,
+              w + ws.bias_rep, 1, mk.cnn);
         // encoder input projections W_ih x + b_ih, both directions (seq2seq_model.py:70)
         g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih, 1, E, w + ws.gx, (int64_t)D * 4 * He, 0.f, p.enc_b_ih);
         if (D == 2)
@@ -334,14 +336,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
                               w + ws.enc_cells, w + ws.denc, w + ws.dhN, w + ws.enc_delta, st));
     {
         GemmBatch b;   // conv weights (the world tensor itself needs no gradient) and encoder LSTM weights
-        float *gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
-        float *gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
-        const int kk[3] = {C, 25 * C, d.K3 * d.K3 * C};
-        int off = 0;
-        for (int i = 0; i < 3; ++i) {
-            add_grad(b, Co, kk[i], BM_, w + ws.dfeat + i * Co, 1, F, w + ws.xcol + off, Ktot, 1, gw[i], kk[i], gb[i]);
-            off += kk[i];
-        }
+        // d(Wt) = world^T . dfeat  (K = B only: no split, no atomics); folded onto the conv kernels below
+        b.add(M * C, M * F, B, bt.world, 1, (int64_t)M * C, w + ws.dfeat, (int64_t)M * F, 1, w + ws.dwt, (int64_t)M * F);
         const int64_t ldd = (int64_t)D * 4 * He;
         for (int dir = 0; dir < D; ++dir) {
             const float *dl = w + ws.enc_delta + dir * 4 * He;
@@ -354,6 +350,11 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         // d(embedded command) for both directions at once: [delta_f | delta_r] . [W_ih_f ; W_ih_r]
         b.add(BL, E, D * 4 * He, w + ws.enc_delta, ldd, 1, w + ws.wih_stack, E, 1, w + ws.dxe, E);
         TRY(b.launch(st));
+    }
+    {
+        float *const gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
+        float *const gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
+        TRY(toeplitz_fold(gw, gb, d.G, C, Co, d.K3, B, w + ws.dwt, w + ws.dfeat, st));
     }
     TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));
     TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, st));
