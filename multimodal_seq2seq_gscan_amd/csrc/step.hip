@@ -150,7 +150,40 @@ static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, cons
 }
 
 // --------------------------------------------------------------------------------------
-// forward: 10 launches (prologue, im2col, 5 grouped GEMMs, 2 recurrences, log_softmax)
+// Two-stream schedule.  Most launches of the step are small and latency-bound, and the dependency graph has
+// width: in forward the world branch (Toeplitz conv -> visual keys) and the command branch (input projection
+// -> BiLSTM -> textual keys) are independent until the decoder; in backward every weight-gradient product is
+// a leaf that nothing waits for except the optimiser.  The main stream (the caller's) carries the critical
+// chain; a side stream carries the other branch / the leaves, tied together with HIP events.  Event and
+// stream objects are created once per process on first use (the only non-launch work this file ever does) and
+// the same sequence can be captured into a hipGraph (cross-stream capture through the events).
+// --------------------------------------------------------------------------------------
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[16] = {};
+    bool ready = false;
+    int next = 0;
+};
+static SideStream g_side;
+
+static int side_init() {
+    if (g_side.ready) return 0;
+    GSCAN_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+    for (auto &e : g_side.ev) GSCAN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    g_side.ready = true;
+    return 0;
+}
+// `waiter` will not run anything issued after this call until everything issued so far on `signaller` is done
+static int order_after(hipStream_t waiter, hipStream_t signaller) {
+    hipEvent_t e = g_side.ev[g_side.next];
+    g_side.next = (g_side.next + 1) % 16;
+    GSCAN_HIP(hipEventRecord(e, signaller));
+    GSCAN_HIP(hipStreamWaitEvent(waiter, e, 0));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------
+// forward
 // --------------------------------------------------------------------------------------
 int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk,
                  float *w, float *logp, float *aux_logp, hipStream_t st) {
@@ -159,16 +192,41 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     TRY(workspace_layout(d, &ws));
     const int B = d.B, L = d.L, T = d.T, M = d.G * d.G, C = d.C, Co = d.Co, F = 3 * Co, E = d.E, He = d.He, H = d.H,
               V = d.V, D = d.bidirectional ? 2 : 1;
-    const int Ktot = C * (1 + 25 + d.K3 * d.K3);
     const bool cond = d.conditional != 0;
     GSCAN_CHECK(!cond || (p.q2k_w && p.q2k_b), "forward: conditional attention needs queries_to_keys parameters");
     GSCAN_CHECK(D == 1 || (p.enc_w_ih_rev && p.enc_w_hh_rev && p.enc_b_ih_rev && p.enc_b_hh_rev),
                 "forward: bidirectional encoder needs the *_reverse parameters");
     GSCAN_CHECK(logp != nullptr, "forward: logp is NULL");
     GSCAN_CHECK(!d.auxiliary || aux_logp, "forward: auxiliary task set but aux_logp is NULL");
+    TRY(side_init());
+    hipStream_t sd = g_side.stream;
 
-    // ---- prologue: bias sum, permuted / stacked weight images, both embedding gathers (one launch)
+    // ================= side stream: world branch (needs only the batch, the parameters and the CNN mask) ==========
+    TRY(order_after(sd, st));          // whatever produced the inputs / masks on the caller's stream
+    {   // Toeplitz image of the three convolutions (12.4 MB at G=6, C=16, Co=50), rebuilt from the live weights
+        const float *const cw[3] = {p.conv1_w, p.conv2_w, p.conv3_w};
+        const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
+        TRY(toeplitz_build(cw, cb, d.G, C, Co, d.K3, w + ws.wt, w + ws.bias_rep, sd));
+    }
     {
+        GemmBatch g;
+        // world encoder (cnn_model.py:22-36) as one product world[B, G*G*C] . Wt[G*G*C, G*G*3Co]; bias + ReLU +
+        // dropout in the epilogue; the result IS feat[B, G*G, 3Co]
+        g.add(B, M * F, M * C, bt.world, (int64_t)M * C, 1, w + ws.wt, (int64_t)M * F, 1, w + ws.feat, (int64_t)M * F, 0.f,
+              w + ws.bias_rep, 1, mk.cnn);
+        // composite weight W_ih[:, ctx_vis] . W_key_vis, so that U_vis = feat . (.)^T needs no extra level
+        g.add(4 * H, F, H, p.dec_w_ih + 2 * H, 3 * H, 1, p.vis_key_w, F, 1, w + ws.w_sk, F);
+        TRY(g.launch(sd));
+    }
+    {   // projected visual keys (seq2seq_model.py:466-467) and their gate images
+        GemmBatch g;
+        g.add(B * M, H, F, w + ws.feat, F, 1, p.vis_key_w, 1, F, w + ws.pkv, H);
+        g.add(B * M, 4 * H, F, w + ws.feat, F, 1, w + ws.w_sk, 1, F, w + ws.uv, 4 * H);
+        TRY(g.launch(sd));
+    }
+
+    // ================= main stream: command branch and decoder inputs ==========================================
+    {   // prologue: bias sum, permuted / stacked weight images, both embedding gathers (one launch)
         PrologueArgs a{};
         a.b_ih = p.dec_b_ih; a.b_hh = p.dec_b_hh; a.w_o2h = p.out2hid_w;
         a.w_ih_f = p.enc_w_ih; a.w_ih_r = p.enc_w_ih_rev; a.enc_emb = p.enc_emb; a.dec_emb = p.dec_emb;
@@ -184,19 +242,8 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     }
     TRY(decoder_weight_images(p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, H, cond, w + ws.dec_w_fwd,
                               w + ws.dec_w_bwd, st));
-    {   // Toeplitz image of the three convolutions (12.4 MB at G=6, C=16, Co=50), rebuilt from the live weights
-        const float *const cw[3] = {p.conv1_w, p.conv2_w, p.conv3_w};
-        const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
-        TRY(toeplitz_build(cw, cb, d.G, C, Co, d.K3, w + ws.wt, w + ws.bias_rep, st));
-    }
-
-    // ---- level 1: everything that depends only on inputs and parameters
     {
         GemmBatch g;
-        // world encoder (cnn_model.py:22-36) as one product world[B, G*G*C] . Wt[G*G*C, G*G*3Co]; bias + ReLU +
-        // dropout in the epilogue; the result IS feat[B, G*G, 3Co]
-        g.add(B, M * F, M * C, bt.world, (int64_t)M * C, 1, w + ws.wt, (int64_t)M * F, 1, w + ws.feat, (int64_t)M * F, 0.f,
-              w + ws.bias_rep, 1, mk.cnn);
         // encoder input projections W_ih x + b_ih, both directions (seq2seq_model.py:70)
         g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih, 1, E, w + ws.gx, (int64_t)D * 4 * He, 0.f, p.enc_b_ih);
         if (D == 2)
@@ -204,26 +251,16 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
                   p.enc_b_ih_rev);
         // decoder: embedding part of the gate pre-activations for all t (teacher forcing)
         g.add(B * T, 4 * H, H, w + ws.S, 4 * H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge, 4 * H, 0.f, w + ws.bsum);
-        // composite weights: images of the key projections under W_ih[:, ctx] / W_q2k[:, ctx], so that the
-        // per-memory vectors U = PK . W^T come straight from the features in the next level
-        g.add(4 * H, F, H, p.dec_w_ih + 2 * H, 3 * H, 1, p.vis_key_w, F, 1, w + ws.w_sk, F);
+        // composite weights for the textual memories
         g.add(4 * H, He, H, p.dec_w_ih + H, 3 * H, 1, p.txt_key_w, He, 1, w + ws.w_ck, He);
         if (cond) g.add(H, He, H, p.q2k_w + H, 2 * H, 1, p.txt_key_w, He, 1, w + ws.w_2kk, He);
         TRY(g.launch(st));
     }
-    // ---- level 2: projected visual keys (seq2seq_model.py:466-467) and their gate images
-    {
-        GemmBatch g;
-        g.add(B * M, H, F, w + ws.feat, F, 1, p.vis_key_w, 1, F, w + ws.pkv, H);
-        g.add(B * M, 4 * H, F, w + ws.feat, F, 1, w + ws.w_sk, 1, F, w + ws.uv, 4 * H);
-        TRY(g.launch(st));
-    }
-    // ---- command encoder recurrence (seq2seq_model.py:62-88)
+    // command encoder recurrence (seq2seq_model.py:62-88)
     TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, p.enc_w_hh, p.enc_b_hh, p.enc_w_hh_rev,
                              p.enc_b_hh_rev, w + ws.enc_out, w + ws.hN, w + ws.enc_gates, w + ws.enc_cells,
                              w + ws.enc_hprev, st));
-    // ---- level 3: projected textual keys (:468-469), their images, and the bridge (model.py:195)
-    {
+    {   // projected textual keys (:468-469), their images, and the bridge (model.py:195)
         GemmBatch g;
         g.add(B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H);
         g.add(B * L, 4 * H, He, w + ws.enc_out, He, 1, w + ws.w_ck, 1, He, w + ws.ut, 4 * H);
@@ -231,6 +268,8 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
         g.add(B, H, He, w + ws.hN, He, 1, p.bridge_w, 1, He, w + ws.hprev, (int64_t)T * H, 0.f, p.bridge_b, 2);
         TRY(g.launch(st));
     }
+    TRY(order_after(st, sd));          // join: the decoder needs both branches
+
     // ---- the T-step recurrence
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.w_image = w + ws.dec_w_fwd;
@@ -249,7 +288,7 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
 }
 
 // --------------------------------------------------------------------------------------
-// backward: 13 launches
+// backward: main stream = chain of data gradients; side stream = weight-gradient leaves
 // --------------------------------------------------------------------------------------
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                   const float *dlogp, const float *daux, const float *seeds, const gscan_params &g, hipStream_t st) {
@@ -258,10 +297,11 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     TRY(workspace_layout(d, &ws));
     const int B = d.B, L = d.L, T = d.T, M = d.G * d.G, C = d.C, Co = d.Co, F = 3 * Co, E = d.E, He = d.He, H = d.H,
               V = d.V, D = d.bidirectional ? 2 : 1;
-    const int Ktot = C * (1 + 25 + d.K3 * d.K3);
     const int BT = B * T, BL = B * L, BM_ = B * M;
     const bool cond = d.conditional != 0;
     GSCAN_CHECK(dlogp, "backward: dlogp is NULL");
+    TRY(side_init());
+    hipStream_t sd = g_side.stream;
     float *S = w + ws.S, *dS = w + ws.dS;
     const float *logp = w + ws.logp_saved, *aux_logp = w + ws.aux_saved;
     const float *delta = w + ws.delta, *hprev = w + ws.hprev;
@@ -271,20 +311,10 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     TRY(log_softmax_rows_backward(logp, dlogp, w + ws.dlogits, BT, V, seeds, st));
     const bool use_aux = d.auxiliary && daux;
     if (use_aux) TRY(log_softmax_rows_backward(aux_logp, daux, w + ws.datt, B, M, seeds ? seeds + 1 : nullptr, st));
-    {
-        GemmBatch b;
-        add_grad(b, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H);
-        b.add(BT, H, V, w + ws.dlogits, V, 1, p.hid2out_w, H, 1, w + ws.dpreo, H);
-        TRY(b.launch(st));
-    }
-    {
-        GemmBatch b;   // gradient of the permuted head weight (scattered back at the end) and of S
-        add_grad(b, H, 4 * H, BT, w + ws.dpreo, 1, H, S, 4 * H, 1, w + ws.dwo_perm, 4 * H);
-        b.add(BT, 4 * H, H, w + ws.dpreo, H, 1, w + ws.wo_perm, 4 * H, 1, dS, 4 * H);
-        TRY(b.launch(st));
-    }
+    TRY(gemm_f32(BT, H, V, 1.f, w + ws.dlogits, V, 1, p.hid2out_w, H, 1, 0.f, w + ws.dpreo, H, nullptr, 0, nullptr, 1, st));
+    TRY(gemm_f32(BT, 4 * H, H, 1.f, w + ws.dpreo, H, 1, w + ws.wo_perm, 4 * H, 1, 0.f, dS, 4 * H, nullptr, 0, nullptr, 1, st));
 
-    // ---- reverse recurrence
+    // ---- reverse recurrence (occupies every CU: nothing overlaps it)
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.ds = dS; a.datt = use_aux ? w + ws.datt : nullptr;
     a.delta = w + ws.delta; a.dzq = w + ws.dzq; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
@@ -293,11 +323,13 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     a.w_image = w + ws.dec_w_bwd;
     a.stamps = probe_stamps_enabled() ? w + ws.stamps + 16 : nullptr;
     TRY(decoder_run(true, B, H, cond, a, st));
+    TRY(order_after(sd, st));          // the leaves start only now: the recurrence owns every CU while it runs
 
-    // ---- decoder parameter gradients (dense products over the B*T saved rows) and the gradient wrt
-    //      [e | ctx_text | ctx_vis] through the LSTM input
-    {
+    {   // leaves: head weights (the permuted W_o2h gradient is scattered back below) and the decoder parameter
+        // gradients (dense products over the B*T saved rows)
         GemmBatch b;
+        add_grad(b, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H);
+        add_grad(b, H, 4 * H, BT, w + ws.dpreo, 1, H, S, 4 * H, 1, w + ws.dwo_perm, 4 * H);
         add_grad(b, 4 * H, 3 * H, BT, delta, 1, 4 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
         add_grad(b, 4 * H, H, BT, delta, 1, 4 * H, hprev, H, 1, g.dec_w_hh, H, g.dec_b_ih, g.dec_b_hh);
         add_grad(b, H, H, BT, w + ws.dqt, 1, H, hprev, H, 1, g.txt_query_w, H);
@@ -308,37 +340,51 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         } else {
             add_grad(b, H, H, BT, w + ws.dqv, 1, H, hprev, H, 1, g.vis_query_w, H);
         }
-        b.add(BT, 3 * H, 4 * H, delta, 4 * H, 1, p.dec_w_ih, 3 * H, 1, dS, 4 * H, 1.f);
-        TRY(b.launch(st));
+        TRY(b.launch(sd));
+        TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, sd));
     }
-    if (cond)   // ... and through the conditional query (same output columns as above: a second launch)
+    // chain: gradient wrt [e | ctx_text | ctx_vis] through the LSTM input and the conditional query
+    TRY(gemm_f32(BT, 3 * H, 4 * H, 1.f, delta, 4 * H, 1, p.dec_w_ih, 3 * H, 1, 1.f, dS, 4 * H, nullptr, 0, nullptr, 1, st));
+    if (cond)
         TRY(gemm_f32(BT, H, H, 1.f, w + ws.dzq, H, 1, p.q2k_w + H, 2 * H, 1, 1.f, dS + H, 4 * H, nullptr, 0, nullptr, 1,
                      st));
-    TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, st));
+    TRY(order_after(sd, st));
+    TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd));     // leaf
     // value path of both attentions: dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]
     TRY(attn_value_grad(w + ws.alpha_c, w + ws.alpha_s, dS, B, T, L, M, H, w + ws.dpk_t, w + ws.dpk_v, st));
-
-    // ---- keys and bridge -> encoder outputs / final state / conv features
-    {
+    TRY(order_after(sd, st));
+    {   // leaves: key and bridge weights
         GemmBatch b;
         add_grad(b, H, He, BL, w + ws.dpk_t, 1, H, w + ws.enc_out, He, 1, g.txt_key_w, He);
-        b.add(BL, He, H, w + ws.dpk_t, H, 1, p.txt_key_w, He, 1, w + ws.denc, He);
         add_grad(b, H, He, B, w + ws.dh0, 1, H, w + ws.hN, He, 1, g.bridge_w, He, g.bridge_b);
-        b.add(B, He, H, w + ws.dh0, H, 1, p.bridge_w, He, 1, w + ws.dhN, He);
         add_grad(b, H, F, BM_, w + ws.dpk_v, 1, H, w + ws.feat, F, 1, g.vis_key_w, F);
+        TRY(b.launch(sd));
+    }
+    {   // chain: encoder outputs / final state / conv features
+        GemmBatch b;
+        b.add(BL, He, H, w + ws.dpk_t, H, 1, p.txt_key_w, He, 1, w + ws.denc, He);
+        b.add(B, He, H, w + ws.dh0, H, 1, p.bridge_w, He, 1, w + ws.dhN, He);
         // d feat with the ReLU/dropout backward fused: feat = relu(x) * mask  =>  dx = (feat != 0) ? dfeat * mask : 0
         b.add(BM_, F, H, w + ws.dpk_v, H, 1, p.vis_key_w, F, 1, w + ws.dfeat, F, 0.f, nullptr, 3, mk.cnn, 1, nullptr,
               nullptr, w + ws.feat);
         TRY(b.launch(st));
     }
-    // ---- command encoder BPTT
+    TRY(order_after(sd, st));
+    {   // leaf: d(Wt) = world^T . dfeat (K = B only: no split, no atomics), folded onto the conv kernels
+        GemmBatch b;
+        b.add(M * C, M * F, B, bt.world, 1, (int64_t)M * C, w + ws.dfeat, (int64_t)M * F, 1, w + ws.dwt, (int64_t)M * F);
+        TRY(b.launch(sd));
+        float *const gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
+        float *const gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
+        TRY(toeplitz_fold(gw, gb, d.G, C, Co, d.K3, B, w + ws.dwt, w + ws.dfeat, sd));
+    }
+    // ---- command encoder BPTT (chain)
     TRY(encoder_lstm_backward(B, L, He, D, bt.cmd_lengths, p.enc_w_hh, p.enc_w_hh_rev, w + ws.enc_gates,
                               w + ws.enc_cells, w + ws.denc, w + ws.dhN, w + ws.enc_delta, st));
-    {
-        GemmBatch b;   // conv weights (the world tensor itself needs no gradient) and encoder LSTM weights
-        // d(Wt) = world^T . dfeat  (K = B only: no split, no atomics); folded onto the conv kernels below
-        b.add(M * C, M * F, B, bt.world, 1, (int64_t)M * C, w + ws.dfeat, (int64_t)M * F, 1, w + ws.dwt, (int64_t)M * F);
-        const int64_t ldd = (int64_t)D * 4 * He;
+    TRY(order_after(sd, st));
+    const int64_t ldd = (int64_t)D * 4 * He;
+    {   // leaves: encoder LSTM weights
+        GemmBatch b;
         for (int dir = 0; dir < D; ++dir) {
             const float *dl = w + ws.enc_delta + dir * 4 * He;
             float *gw_ih = dir ? g.enc_w_ih_rev : g.enc_w_ih, *gw_hh = dir ? g.enc_w_hh_rev : g.enc_w_hh;
@@ -347,17 +393,13 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
                      gb_hh);
             add_grad(b, 4 * He, E, BL, dl, 1, ldd, w + ws.xe, E, 1, gw_ih, E);
         }
-        // d(embedded command) for both directions at once: [delta_f | delta_r] . [W_ih_f ; W_ih_r]
-        b.add(BL, E, D * 4 * He, w + ws.enc_delta, ldd, 1, w + ws.wih_stack, E, 1, w + ws.dxe, E);
-        TRY(b.launch(st));
+        TRY(b.launch(sd));
     }
-    {
-        float *const gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
-        float *const gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
-        TRY(toeplitz_fold(gw, gb, d.G, C, Co, d.K3, B, w + ws.dwt, w + ws.dfeat, st));
-    }
+    // chain tail: d(embedded command) for both directions at once, then the embedding table
+    TRY(gemm_f32(BL, E, D * 4 * He, 1.f, w + ws.enc_delta, ldd, 1, w + ws.wih_stack, E, 1, 0.f, w + ws.dxe, E, nullptr, 0,
+                 nullptr, 1, st));
     TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));
-    TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, st));
+    TRY(order_after(st, sd));          // join: every gradient is complete when the caller's stream continues
     return 0;
 }
 
