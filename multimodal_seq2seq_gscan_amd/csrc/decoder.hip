@@ -583,7 +583,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             const float d_o = dh * tc * og * (1.f - og);
             dc = dct * fg;
             d_s[tid] = di; d_s[HP + tid] = df; d_s[2 * HP + tid] = dg; d_s[3 * HP + tid] = d_o;
-            float *dp = a.delta + bt * 4 * H;
+            float *dp = a.delta + bt * 5 * H;            // rows of [delta (4H) | dzq (H)]
             dp[tid] = di; dp[H + tid] = df; dp[2 * H + tid] = dg; dp[3 * H + tid] = d_o;
         } else if (tid >= 128 && tid < 128 + H) {
             // external gradients wrt the two contexts (output head) and the saved queries
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
                     const float dq2 = pair_sum(half_dot<K0>(wt[s], dqv_s + half * K0));
                     const float q = q2_s[r - 6 * H];
                     const float dz = dq2 * (1.f - q * q);
-                    if (half == 0) { d_s[5 * HP + r - 6 * H] = dz; a.dzq[bt * H + r - 6 * H] = dz; }
+                    if (half == 0) { d_s[5 * HP + r - 6 * H] = dz; a.delta[bt * 5 * H + 4 * H + r - 6 * H] = dz; }
                 }
             }
             lds_barrier();

@@ -347,10 +347,13 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 //   seg 3  dwo_perm[H,4H]      = 0   (gradient scratch of wo_perm, filled by a split-K GEMM in backward)
 //   seg 4  xe[B*L,E]           = dropout(Emb_enc[commands])      seq2seq_model.py:58-59
 //   seg 5  S[:, 0:H]           = dropout(Emb_dec[targets])       seq2seq_model.py:383-384
+//   seg 6  wcat5[5H,3H]        = [W_ih_dec ; (0 | W_q2k[:, H:2H] | 0)]: one product then carries delta AND dzq back to
+//                                [e | ctx_text | ctx_vis]
+//   seg 7  zero_extra          = 0   (accumulation targets of split-K products: dxe, preo)
 // ------------------------------------------------------------------------------------------
 
 __global__ void prologue_kernel(PrologueArgs a) {
-    const int64_t total = a.end[5];
+    const int64_t total = a.end[7];
     const int H = a.H;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -376,7 +379,7 @@ __global__ void prologue_kernel(PrologueArgs a) {
             float v = (t >= 0 && t < a.Vi) ? a.enc_emb[t * a.E + d] : 0.f;
             if (a.mask_enc) v *= a.mask_enc[i];
             a.xe[i] = v;
-        } else {
+        } else if (idx < a.end[5]) {
             const int64_t i = idx - a.end[4];
             const int64_t row = i / H;
             const int d = (int)(i % H);
@@ -384,12 +387,21 @@ __global__ void prologue_kernel(PrologueArgs a) {
             float v = (t >= 0 && t < a.V) ? a.dec_emb[t * H + d] : 0.f;
             if (a.mask_dec) v *= a.mask_dec[i];
             a.S[row * 4 * H + d] = v;
+        } else if (idx < a.end[6]) {
+            const int64_t i = idx - a.end[5];
+            const int row = (int)(i / (3 * H)), col = (int)(i % (3 * H));
+            float v = 0.f;
+            if (row < 4 * H) v = a.w_ih_dec[i];
+            else if (a.cond && col >= H && col < 2 * H) v = a.w_q2k[(int64_t)(row - 4 * H) * 2 * H + col];
+            a.wcat5[i] = v;
+        } else {
+            a.zero_extra[idx - a.end[6]] = 0.f;
         }
     }
 }
 
 int step_prologue(const PrologueArgs &args, hipStream_t stream) {
-    const int64_t total = args.end[5];
+    const int64_t total = args.end[7];
     hipLaunchKernelGGL(prologue_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, stream,
                        args);
     GSCAN_LAUNCHED("prologue_kernel");

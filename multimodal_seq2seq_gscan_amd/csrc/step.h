@@ -55,9 +55,12 @@ int attn_value_grad(const float *alpha_c, const float *alpha_s, const float *ds,
 struct PrologueArgs {
     const float *b_ih, *b_hh, *w_o2h, *w_ih_f, *w_ih_r, *enc_emb, *dec_emb, *mask_enc, *mask_dec;
     const int64_t *commands, *targets;
-    float *bsum, *wo_perm, *wih_stack, *dwo_perm, *xe, *S;
+    float *bsum, *wo_perm, *wih_stack, *dwo_perm, *xe, *S, *wcat5, *zero_extra;
+    const float *w_ih_dec, *w_q2k;
+    int cond;
+    int64_t zero_extra_count;
     int H, He, E, D, BL, BT, Vi, V;
-    int64_t end[6];
+    int64_t end[8];
 };
 int step_prologue(const PrologueArgs &args, hipStream_t stream);
 int toeplitz_build(const float *const (&w)[3], const float *const (&b)[3], int G, int C, int Co, int K3, float *wt,
@@ -122,7 +125,7 @@ struct DecoderArgs {
     // backward only
     const float *ds;                   // [B,T,4H] external grads wrt [e | ctx_text | ctx_vis | h_t] (head)
     const float *datt;                 // [B,M] grad wrt att_sum or NULL
-    float *delta, *dzq, *dqt, *dqv;    // [B,T,4H] [B,T,H] [B,T,H] [B,T,H]
+    float *delta, *dqt, *dqv;          // [B,T,5H] = [gate deltas (4H) | dzq (H)], [B,T,H], [B,T,H]
     float *dpk_t, *dpk_v;              // [B,L,H] [B,M,H]  score-path key gradients
     float *dv_t, *dv_v;                // [H] energy-vector gradients, accumulated with atomics
     float *dh0;                        // [B,H] gradient wrt the bridge pre-activation
@@ -151,7 +154,7 @@ struct Workspace {
     int64_t xcol, feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
-        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, wt, dwt, bias_rep;
+        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, wt, dwt, bias_rep, wcat5;
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;

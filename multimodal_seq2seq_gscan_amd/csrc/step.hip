@@ -67,7 +67,9 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(qt, B * T * H);
     SLOT(qv, B * T * H);
     SLOT(att_sum, B * M);
-    SLOT(preo, B * T * H);
+    SLOT(wcat5, 5 * H * 3 * H);
+    SLOT(preo, B * T * H);                           // preo | dxe are zeroed together by the prologue (split-K targets)
+    SLOT(dxe, B * L * E);
     SLOT(logits, B * T * V);
     SLOT(logp_saved, B * T * V);
     SLOT(aux_saved, B * M);
@@ -76,8 +78,8 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(dpreo, B * T * H);
     SLOT(dS, B * T * 4 * H);
     SLOT(datt, B * M);
-    SLOT(delta, B * T * 4 * H);
-    SLOT(dzq, B * T * H);
+    SLOT(delta, B * T * 5 * H);                      // [delta (4H) | dzq (H)] per (b,t)
+    SLOT(dzq, 64);
     SLOT(dqt, B * T * H);
     SLOT(dqv, B * T * H);
     SLOT(dpk_t, B * L * H);
@@ -88,7 +90,6 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(denc, B * L * He);
     SLOT(dhN, B * He);
     SLOT(enc_delta, B * L * D * 4 * He);
-    SLOT(dxe, B * L * E);
     SLOT(dfeat, B * M * F);
     SLOT(stamps, 64);
 #undef SLOT
@@ -234,10 +235,13 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
         a.bsum = w + ws.bsum; a.wo_perm = w + ws.wo_perm; a.wih_stack = w + ws.wih_stack;
         a.dwo_perm = w + ws.dwo_perm; a.xe = w + ws.xe; a.S = w + ws.S;
         a.H = H; a.He = He; a.E = E; a.D = D; a.BL = B * L; a.BT = B * T; a.Vi = d.Vi; a.V = V;
-        const int64_t n[6] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
-                              (int64_t)B * L * E, (int64_t)B * T * H};
+        a.wcat5 = w + ws.wcat5; a.w_ih_dec = p.dec_w_ih; a.w_q2k = p.q2k_w; a.cond = cond ? 1 : 0;
+        a.zero_extra = w + ws.preo;                        // preo and dxe are adjacent slots
+        a.zero_extra_count = (ws.dxe + (int64_t)B * L * E) - ws.preo;
+        const int64_t n[8] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
+                              (int64_t)B * L * E, (int64_t)B * T * H, (int64_t)5 * H * 3 * H, a.zero_extra_count};
         int64_t acc = 0;
-        for (int i = 0; i < 6; ++i) { acc += n[i]; a.end[i] = acc; }
+        for (int i = 0; i < 8; ++i) { acc += n[i]; a.end[i] = acc; }
         TRY(step_prologue(a, st));
     }
     TRY(decoder_weight_images(p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, H, cond, w + ws.dec_w_fwd,
@@ -277,6 +281,7 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     TRY(decoder_run(false, B, H, cond, a, st));
 
     // ---- output head hoisted out of the loop (seq2seq_model.py:421-424): S . wo_perm^T, then W_h2o
+    // (no split-K here: the forward pass stays bitwise reproducible — float atomics are used only for gradients)
     TRY(gemm_f32(B * T, H, 4 * H, 1.f, w + ws.S, 4 * H, 1, w + ws.wo_perm, 1, 4 * H, 0.f, w + ws.preo, H, nullptr, 0,
                  nullptr, 1, st));
     TRY(gemm_f32(B * T, V, H, 1.f, w + ws.preo, H, 1, p.hid2out_w, 1, H, 0.f, w + ws.logits, V, nullptr, 0, nullptr,
@@ -317,7 +322,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     // ---- reverse recurrence (occupies every CU: nothing overlaps it)
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.ds = dS; a.datt = use_aux ? w + ws.datt : nullptr;
-    a.delta = w + ws.delta; a.dzq = w + ws.dzq; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
+    a.delta = w + ws.delta; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
     a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = g.txt_energy_w; a.dv_v = g.vis_energy_w;
     a.dh0 = w + ws.dh0;
     a.w_image = w + ws.dec_w_bwd;
@@ -330,12 +335,12 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         GemmBatch b;
         add_grad(b, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H);
         add_grad(b, H, 4 * H, BT, w + ws.dpreo, 1, H, S, 4 * H, 1, w + ws.dwo_perm, 4 * H);
-        add_grad(b, 4 * H, 3 * H, BT, delta, 1, 4 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
-        add_grad(b, 4 * H, H, BT, delta, 1, 4 * H, hprev, H, 1, g.dec_w_hh, H, g.dec_b_ih, g.dec_b_hh);
+        add_grad(b, 4 * H, 3 * H, BT, delta, 1, 5 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
+        add_grad(b, 4 * H, H, BT, delta, 1, 5 * H, hprev, H, 1, g.dec_w_hh, H, g.dec_b_ih, g.dec_b_hh);
         add_grad(b, H, H, BT, w + ws.dqt, 1, H, hprev, H, 1, g.txt_query_w, H);
         if (cond) {
-            add_grad(b, H, H, BT, w + ws.dzq, 1, H, hprev, H, 1, g.q2k_w, 2 * H, g.q2k_b);
-            add_grad(b, H, H, BT, w + ws.dzq, 1, H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H);
+            add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, hprev, H, 1, g.q2k_w, 2 * H, g.q2k_b);
+            add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H);
             add_grad(b, H, H, BT, w + ws.dqv, 1, H, w + ws.q2, H, 1, g.vis_query_w, H);
         } else {
             add_grad(b, H, H, BT, w + ws.dqv, 1, H, hprev, H, 1, g.vis_query_w, H);
@@ -344,10 +349,9 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, sd));
     }
     // chain: gradient wrt [e | ctx_text | ctx_vis] through the LSTM input and the conditional query
-    TRY(gemm_f32(BT, 3 * H, 4 * H, 1.f, delta, 4 * H, 1, p.dec_w_ih, 3 * H, 1, 1.f, dS, 4 * H, nullptr, 0, nullptr, 1, st));
-    if (cond)
-        TRY(gemm_f32(BT, H, H, 1.f, w + ws.dzq, H, 1, p.q2k_w + H, 2 * H, 1, 1.f, dS + H, 4 * H, nullptr, 0, nullptr, 1,
-                     st));
+    // (one product: [delta | dzq] . [W_ih ; (0 | W_q2k[:, ctx] | 0)], K = 5H when conditional)
+    TRY(gemm_f32(BT, 3 * H, cond ? 5 * H : 4 * H, 1.f, delta, 5 * H, 1, w + ws.wcat5, 3 * H, 1, 1.f, dS, 4 * H, nullptr,
+                 0, nullptr, 1, st));
     TRY(order_after(sd, st));
     TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd));     // leaf
     // value path of both attentions: dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]
@@ -396,8 +400,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         TRY(b.launch(sd));
     }
     // chain tail: d(embedded command) for both directions at once, then the embedding table
-    TRY(gemm_f32(BL, E, D * 4 * He, 1.f, w + ws.enc_delta, ldd, 1, w + ws.wih_stack, E, 1, 0.f, w + ws.dxe, E, nullptr, 0,
-                 nullptr, 1, st));
+    TRY(gemm_f32(BL, E, D * 4 * He, 1.f, w + ws.enc_delta, ldd, 1, w + ws.wih_stack, E, 1, 1.f, w + ws.dxe, E, nullptr, 0,
+                 nullptr, 8, st));   // K = 8He split eight ways onto the zeroed buffer
     TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));
     TRY(order_after(st, sd));          // join: every gradient is complete when the caller's stream continues
     return 0;

@@ -219,6 +219,7 @@ class Model(nn.Module):
         self._dropout_seed = int(kwargs.get("seed", 42))
         self._dropout_calls = 0
         self._mask_buffer = None
+        self._dummy_aux = None
         self._mask_key = None
         self._mask_stream_id = None      # device uint64 holding the Philox stream id (graph replay), or None
         self._anchor = None
@@ -368,7 +369,9 @@ class Model(nn.Module):
         call = dict(dims=dims, batch=batch, masks=mstruct, generation=self._generation,
                     keep=(commands, lengths, world, targets, masks))
         if aux is None:
-            aux = torch.zeros(1, device=commands.device)
+            if self._dummy_aux is None or self._dummy_aux.device != commands.device:
+                self._dummy_aux = torch.zeros(1, device=commands.device)
+            aux = self._dummy_aux
         return logp, aux, call
 
     def _launch_backward(self, call, dlogp: torch.Tensor, daux: Optional[torch.Tensor],
