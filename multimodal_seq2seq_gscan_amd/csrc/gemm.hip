@@ -22,7 +22,10 @@ namespace gscan {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int TMW = 2, TNW = 2;  // MFMA tiles per wave along M / N
-constexpr int BM = 2 * 16 * TMW, BN = 2 * 16 * TNW, BK = 32;
+#ifndef GSCAN_GEMM_BK
+#define GSCAN_GEMM_BK 32
+#endif
+constexpr int BM = 2 * 16 * TMW, BN = 2 * 16 * TNW, BK = GSCAN_GEMM_BK;
 constexpr int LDK = BK + 4;      // k-contiguous image [row][LDK]: 16-byte rows, b128 fragment reads 2-way at worst
 constexpr int LDR_A = BM + 4;    // row-contiguous image [k][LDR]: b64 reads of 2 adjacent rows, conflict-free
 constexpr int LDR_B = BN + 4;    // b64 reads of 2 adjacent columns, conflict-free
@@ -49,22 +52,22 @@ struct Panel {                  // how one operand's [rows x 32] panel moves glo
 };
 
 template <int ROWS>
-__device__ __forceinline__ void panel_load(float (&v)[ROWS / 8], const Panel &p, int k0, int kend, int tid) {
-    constexpr int N = ROWS / 8;             // floats per thread
+__device__ __forceinline__ void panel_load(float (&v)[ROWS * BK / 256], const Panel &p, int k0, int kend, int tid) {
+    constexpr int N = ROWS * BK / 256;      // floats per thread
     if (p.kc) {
-        if (p.vec) {                        // 8 float4 per row: q = tid & 7, row = (tid >> 3) + 32 i
+        if (p.vec) {                        // BK/4 float4 per row
 #pragma unroll
             for (int i = 0; i < N / 4; ++i) {
-                const int r = p.row0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
+                const int r = p.row0 + tid / (BK / 4) + (1024 / BK) * i, k = k0 + 4 * (tid % (BK / 4));
                 float4 x = {0.f, 0.f, 0.f, 0.f};
                 if (r < p.nrows && k < kend) x = *reinterpret_cast<const float4 *>(p.src + (int64_t)r * p.s_row + k);
                 v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
             }
-        } else {                            // k = tid & 31, row = (tid >> 5) + 8 i
-            const int k = k0 + (tid & 31);
+        } else {                            // k = tid % BK, row = tid / BK + (256/BK) i
+            const int k = k0 + (tid % BK);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                const int r = p.row0 + (tid >> 5) + 8 * i;
+                const int r = p.row0 + tid / BK + (256 / BK) * i;
                 v[i] = (r < p.nrows && k < kend) ? p.src[(int64_t)r * p.s_row + (int64_t)k * p.s_k] : 0.f;
             }
         }
@@ -89,17 +92,17 @@ __device__ __forceinline__ void panel_load(float (&v)[ROWS / 8], const Panel &p,
 }
 
 template <int ROWS, int LDR>
-__device__ __forceinline__ void panel_store(float *lds, const float (&v)[ROWS / 8], const Panel &p, int tid) {
-    constexpr int N = ROWS / 8;
+__device__ __forceinline__ void panel_store(float *lds, const float (&v)[ROWS * BK / 256], const Panel &p, int tid) {
+    constexpr int N = ROWS * BK / 256;
     if (p.kc) {
         if (p.vec) {
 #pragma unroll
             for (int i = 0; i < N / 4; ++i)
-                *reinterpret_cast<float4 *>(lds + ((tid >> 3) + 32 * i) * LDK + 4 * (tid & 7)) =
+                *reinterpret_cast<float4 *>(lds + (tid / (BK / 4) + (1024 / BK) * i) * LDK + 4 * (tid % (BK / 4))) =
                     float4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
         } else {
 #pragma unroll
-            for (int i = 0; i < N; ++i) lds[((tid >> 5) + 8 * i) * LDK + (tid & 31)] = v[i];
+            for (int i = 0; i < N; ++i) lds[(tid / BK + (256 / BK) * i) * LDK + (tid % BK)] = v[i];
         }
     } else {
         if (p.vec) {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
     const int fr = lane & 15;   // MFMA row (A) / column (B) index
     const int fg = lane >> 4;   // lane group: k = 8*fg + step
 
-    float ra[BM / 8], rb[BN / 8];
+    float ra[BM * BK / 256], rb[BN * BK / 256];
     panel_load<BM>(ra, pa, kbeg, kend, tid);
     panel_load<BN>(rb, pb, kbeg, kend, tid);
     panel_store<BM, LDR_A>(lds_a[0], ra, pa, tid);
@@ -159,7 +162,9 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
             panel_load<BM>(ra, pa, k0 + BK, kend, tid);
             panel_load<BN>(rb, pb, k0 + BK, kend, tid);
         }
-        const float *la = lds_a[buf], *lb = lds_b[buf];
+#pragma unroll
+        for (int kh = 0; kh < BK; kh += 32) {
+        const float *la = lds_a[buf] + (pa.kc ? kh : kh * LDR_A), *lb = lds_b[buf] + (pb.kc ? kh : kh * LDR_B);
         float af[TMW][8], bf[TNW][8];        // [tile][step]
         if (pa.kc) {                         // natural tiles: row = 16 t + fr
 #pragma unroll
@@ -198,14 +203,15 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
 #pragma unroll
                 for (int j = 0; j < TNW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-        if (do_asum && tid < BM) {           // column sums of A (bias gradients): sum over this tile's 32 k
+        if (do_asum && tid < BM) {           // column sums of A (bias gradients): sum over these 32 k
             if (pa.kc) {
 #pragma unroll
-                for (int kk = 0; kk < BK; ++kk) asum += la[tid * LDK + kk];
+                for (int kk = 0; kk < 32; ++kk) asum += la[tid * LDK + kk];
             } else {
 #pragma unroll
-                for (int kk = 0; kk < BK; ++kk) asum += la[kk * LDR_A + tid];
+                for (int kk = 0; kk < 32; ++kk) asum += la[kk * LDR_A + tid];
             }
+        }
         }
         if (more) {
             panel_store<BM, LDR_A>(lds_a[buf ^ 1], ra, pa, tid);
