@@ -20,7 +20,8 @@
 //     LSTM input is known for all t (teacher forcing) and is also a GEMM before the loop;
 //   * tanh(q + PK) score tiles are recomputed in backward instead of being saved
 //     (46*H floats per step per row would make the path HBM-bound).
-// The output head does not feed back, so it is hoisted out of the loop (host side).
+// The output head does not feed back: it runs once for the row's T steps as the epilogue of the forward kernel
+// and its backward as the prologue of the backward kernel (no launches, no HBM round trip in between).
 //
 // Weight rows ("tasks") r = slot*256 + pair, H = hidden size:
 //   forward   [0,4H) W_hh[r,:] -> gate r      [4H,5H) W_query_text[k,:]      [5H,6H) W_q2k[k,:H] (conditional)
@@ -42,6 +43,7 @@ namespace gscan {
     }
 
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // lane <-> lane^1 exchange on the DPP datapath (quad_perm [1,0,3,2]); both lanes of a pair must be active
 __device__ __forceinline__ float pair_sum(float v) { return v + dpp_move<0xb1, 0xf>(v); }
@@ -174,7 +176,7 @@ struct DecoderLds {
     int uv, pkv, ut, pkt, u2t, dpkv, dpkt, vec, total;
 };
 constexpr int kPartStride = 512;   // columns per m-group slab of partial sums (>= 5H)
-__host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, bool cond, bool backward) {
+__host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bool cond, bool backward) {
     const int HP = 2 * (((H / 2 + 3) / 4) * 4);       // padded length of every vector a half_dot reads
     DecoderLds o;
     int p = 0;
@@ -187,7 +189,9 @@ __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, bool cond
     o.dpkt = p; p += backward ? L * H : 0;
     o.vec = p;
     p += (backward ? 7 * HP + 15 * H : 2 * HP + 14 * H + 4 * kPartStride) + 256;
-    o.total = p;
+    // scratch of the fused output head, overlaid on the memories (forward: after the loop; backward: before staging)
+    const int head = backward ? kHeadChunk * (V + H + 4) + V * H : kHeadChunk * (5 * H + 4 + V) + V * H;
+    o.total = p > head ? p : head;
     return o;
 }
 
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = kDecThreads / 64;
     const int pair = tid >> 1, half = tid & 1;
     const int T = a.T, L = a.L, M = a.M;
-    const DecoderLds o = decoder_lds(H, L, M, COND, false);
+    const DecoderLds o = decoder_lds(H, L, M, a.V, COND, false);
     float *Uv = smem + o.uv, *PKv = smem + o.pkv, *Ut = smem + o.ut, *PKt = smem + o.pkt, *U2t = smem + o.u2t;
     float *vec = smem + o.vec;
     float *h_s = vec, *q2_s = vec + HP;                     // dot inputs, zero-padded to HP
@@ -406,8 +410,92 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         lds_barrier();
         GSCAN_STAMP(8)
     }
-    if (wave == 0 && lane < M) a.att_sum[(int64_t)b * M + lane] = att_acc;
+    if (wave == 0) {
+        if (lane < M) a.att_sum[(int64_t)b * M + lane] = att_acc;
+        if (a.aux_saved) {                                   // auxiliary head: log_softmax over the cells (model.py:205)
+            const float x = (lane < M) ? att_acc : -INFINITY;
+            const float mx = wave_max(x);
+            const float lse = mx + logf(wave_sum((lane < M) ? expf(x - mx) : 0.f));
+            if (lane < M) {
+                a.aux_saved[(int64_t)b * M + lane] = x - lse;
+                a.aux_out[(int64_t)b * M + lane] = x - lse;
+            }
+        }
+    }
     if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_acc[tid];
+
+    // ---- output head of the row's T steps (it does not feed back, seq2seq_model.py:421-424):
+    //      preo = S . wo_perm^T  ([T,4H] x [4H,H]) on the matrix cores, logits_t = W_h2o . preo_t,
+    //      logp_t = log_softmax(logits_t) (model.py:203).  Wave w owns output columns 16w..16w+15 and keeps its
+    //      B fragments (H steps of k = 4s + lane/16) in registers; A fragments are single LDS reads of the staged
+    //      S rows (row stride 4H+4: conflict-free across the 16 rows of a tile).
+    __syncthreads();                                         // the row's S is complete and visible to the workgroup
+    {
+        constexpr int SS = 4 * H + 4, NT = (H + 15) / 16;
+        const int V = a.V, fr = lane & 15, fg = lane >> 4;
+        float *S_ch = smem, *preo_ch = S_ch + kHeadChunk * SS, *lg_ch = preo_ch + kHeadChunk * H,
+              *wh_s = lg_ch + kHeadChunk * V;
+        float bw[H];
+        if (wave < NT) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) bw[i] = a.head_image[i * kDecThreads + tid];
+        }
+        for (int i = tid; i < V * H; i += kDecThreads) wh_s[i] = a.w_h2o[i];
+        for (int t0 = 0; t0 < T; t0 += kHeadChunk) {
+            const int n = min(kHeadChunk, T - t0);
+            const unsigned bt0 = (unsigned)b * T + t0;
+            {
+                const float4 *src4 = reinterpret_cast<const float4 *>(a.s + bt0 * 4 * H);
+                for (int idx = tid; idx < n * H; idx += kDecThreads) {
+                    const int row = idx / H, c4 = idx - row * H;
+                    *reinterpret_cast<float4 *>(S_ch + row * SS + 4 * c4) = src4[idx];
+                }
+            }
+            lds_barrier();
+            if (wave < NT) {
+                for (int mt = 0; mt < (n + 15) / 16; ++mt) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const float *ap = S_ch + (16 * mt + fr) * SS + fg;
+#pragma unroll
+                    for (int i = 0; i < H; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * i], bw[i], acc, 0, 0, 0);
+                    const int kk = 16 * wave + fr;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int tt = 16 * mt + 4 * fg + r;
+                        if (tt < n && kk < H) {
+                            preo_ch[tt * H + kk] = acc[r];
+                            a.preo[(bt0 + tt) * H + kk] = acc[r];
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+            for (int idx = tid; idx < n * V; idx += kDecThreads) {
+                const int tt = idx / V, v = idx - tt * V;
+                const float4 *x4 = reinterpret_cast<const float4 *>(preo_ch + tt * H);
+                const float4 *w4 = reinterpret_cast<const float4 *>(wh_s + v * H);
+                float acc = 0.f;
+#pragma unroll 5
+                for (int i = 0; i < H / 4; ++i) acc = dot4(w4[i], x4[i], acc);
+                lg_ch[idx] = acc;
+                a.logits[bt0 * V + idx] = acc;
+            }
+            lds_barrier();
+            if (tid < n) {
+                const float *row = lg_ch + tid * V;
+                float mx = -INFINITY;
+                for (int j = 0; j < V; ++j) mx = fmaxf(mx, row[j]);
+                float sum = 0.f;
+                for (int j = 0; j < V; ++j) sum += expf(row[j] - mx);
+                const float lse = mx + logf(sum);
+                for (int j = 0; j < V; ++j) {
+                    const float y = row[j] - lse;
+                    a.logp_saved[(bt0 + tid) * V + j] = y;
+                    a.logp_out[(bt0 + tid) * V + j] = y;
+                }
+            }
+        }
+    }
 }
 
 // Backward of s_m = v . tanh(q + PK_m) for one attention.  Lane m of `dsm` holds d s_m.  Wave w owns the memories
@@ -504,7 +592,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = kDecThreads / 64;
     const int pair = tid >> 1, half = tid & 1;
     const int T = a.T, L = a.L, M = a.M;
-    const DecoderLds o = decoder_lds(H, L, M, COND, true);
+    const DecoderLds o = decoder_lds(H, L, M, a.V, COND, true);
     float *Uv = smem + o.uv, *PKv = smem + o.pkv, *Ut = smem + o.ut, *PKt = smem + o.pkt, *U2t = smem + o.u2t;
     float *dPKv = smem + o.dpkv, *dPKt = smem + o.dpkt;
     float *vec = smem + o.vec;
@@ -516,6 +604,69 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     long long stamp_prev = a.stamps ? clock64() : 0;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
+
+    // ---- backward of the output head for the row's T steps (log_softmax, hidden_to_output, output_to_hidden):
+    //      dlogits_t = seed * (dlogp_t - exp(logp_t) sum dlogp_t), dpreo_t = W_h2o^T dlogits_t, and
+    //      dS = dpreo . wo_perm ([T,H] x [H,4H]) on the matrix cores: wave w owns column tiles w, w+8, ... and keeps
+    //      their B fragments in registers.  dlogits / dpreo are kept for the weight gradients; dS is what the loop
+    //      below (and the LSTM-input product after it) starts from.
+    {
+        constexpr int HS = (H % 8 == 4) ? H : H + 4, NTB = H / 4, RB = (NTB + 7) / 8, KS = H / 4;
+        const int V = a.V, fr = lane & 15, fg = lane >> 4;
+        float *dl_ch = smem, *dp_ch = dl_ch + kHeadChunk * V, *wh_s = dp_ch + kHeadChunk * HS;
+        float bw[RB][KS];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int nt = wave + 8 * r;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) bw[r][i] = (nt < NTB) ? a.wo_perm[(4 * i + fg) * 4 * H + 16 * nt + fr] : 0.f;
+        }
+        for (int i = tid; i < V * H; i += kDecThreads) wh_s[i] = a.w_h2o[i];
+        const float sc = a.seeds ? a.seeds[0] : 1.f;
+        for (int t0 = 0; t0 < T; t0 += kHeadChunk) {
+            const int n = min(kHeadChunk, T - t0);
+            const unsigned bt0 = (unsigned)b * T + t0;
+            if (tid < n) {
+                const float *y = a.logp_saved + (bt0 + tid) * V, *dy = a.dlogp + (bt0 + tid) * V;
+                float sum = 0.f;
+                for (int j = 0; j < V; ++j) sum += dy[j];
+                for (int j = 0; j < V; ++j) {
+                    const float dl = sc * (dy[j] - expf(y[j]) * sum);
+                    dl_ch[tid * V + j] = dl;
+                    a.dlogits[(bt0 + tid) * V + j] = dl;
+                }
+            }
+            lds_barrier();
+            for (int idx = tid; idx < n * H; idx += kDecThreads) {
+                const int tt = idx / H, kk = idx - tt * H;
+                float acc = 0.f;
+                for (int v = 0; v < V; ++v) acc = fmaf(dl_ch[tt * V + v], wh_s[v * H + kk], acc);
+                dp_ch[tt * HS + kk] = acc;
+                a.dpreo[bt0 * H + idx] = acc;
+            }
+            lds_barrier();
+            for (int mt = 0; mt < (n + 15) / 16; ++mt) {
+                const float *ap = dp_ch + (16 * mt + fr) * HS + fg;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    const int nt = wave + 8 * r;
+                    if (nt < NTB) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < KS; ++i)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * i], bw[r][i], acc, 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int tt = 16 * mt + 4 * fg + i;
+                            if (tt < n) a.ds[(bt0 + tt) * 4 * H + 16 * nt + fr] = acc[i];
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+        }
+        __syncthreads();                                     // the row's dS is visible to the workgroup
+    }
 
     float wt[NS][K0];
 #pragma unroll
@@ -533,7 +684,16 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     for (int i = tid; i < 8 * H; i += kDecThreads) part_s[i] = 0.f;      // dh_T = 0 (summed at the top of the loop)
     lds_barrier();
     if (tid < H) { vt_s[tid] = a.v_t[tid]; vv_s[tid] = a.v_v[tid]; }
-    if (tid < 64) datt_s[tid] = (a.datt && tid < M) ? a.datt[(int64_t)b * M + tid] : 0.f;
+    if (tid < 64) {       // auxiliary head backward: d att_sum = seed1 * (daux - exp(aux_logp) sum daux)  (model.py:205)
+        float da = 0.f;
+        if (a.daux) {
+            const float dy = (tid < M) ? a.daux[(int64_t)b * M + tid] : 0.f;
+            const float sum = wave_sum(dy);
+            const float y = (tid < M) ? a.aux_saved[(int64_t)b * M + tid] : 0.f;
+            da = (tid < M) ? (a.seeds ? a.seeds[1] : 1.f) * (dy - expf(y) * sum) : 0.f;
+        }
+        datt_s[tid] = da;
+    }
     if (tid >= 64 && tid < 80) stamp_acc[tid - 64] = 0.f;
     float dc = 0.f;
     f32x2 dvv_acc = {0.f, 0.f}, dvt_acc = {0.f, 0.f};
@@ -715,11 +875,19 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
 // forward image: task r -> row of the stacked matrix; backward image: task (seg,k) -> column k of block seg.
 // ------------------------------------------------------------------------------------------
 __global__ void decoder_weight_image_kernel(const float *__restrict__ w_hh, const float *__restrict__ w_qt,
-                                            const float *__restrict__ w_qv, const float *__restrict__ w_q2k, int H,
-                                            int cond, int slots, int k0, float *__restrict__ fwd_image,
-                                            float *__restrict__ bwd_image) {
+                                            const float *__restrict__ w_qv, const float *__restrict__ w_q2k,
+                                            const float *__restrict__ wo_perm, int H, int cond, int slots, int k0,
+                                            float *__restrict__ fwd_image, float *__restrict__ bwd_image,
+                                            float *__restrict__ head_image) {
     const int total = slots * k0 * kDecThreads;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * total; idx += gridDim.x * blockDim.x) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * total + H * kDecThreads;
+         idx += gridDim.x * blockDim.x) {
+        if (idx >= 2 * total) {      // head image: MFMA B fragments, lane (fg, fr) of wave w at step i holds
+            const int e = idx - 2 * total, tid = e % kDecThreads, i = e / kDecThreads;   // wo_perm[16w + fr][4i + fg]
+            const int n = 16 * (tid >> 6) + (tid & 15), k = 4 * i + ((tid >> 4) & 3);
+            head_image[e] = (n < H) ? wo_perm[(int64_t)n * 4 * H + k] : 0.f;
+            continue;
+        }
         const bool bwd = idx >= total;
         const int e = bwd ? idx - total : idx;
         const int tid = e % kDecThreads, i = (e / kDecThreads) % k0, s = e / (kDecThreads * k0);
@@ -744,12 +912,13 @@ __global__ void decoder_weight_image_kernel(const float *__restrict__ w_hh, cons
     }
 }
 
-int decoder_weight_images(const float *w_hh, const float *w_qt, const float *w_qv, const float *w_q2k, int H,
-                          bool cond, float *fwd_image, float *bwd_image, hipStream_t stream) {
+int decoder_weight_images(const float *w_hh, const float *w_qt, const float *w_qv, const float *w_q2k,
+                          const float *wo_perm, int H, bool cond, float *fwd_image, float *bwd_image,
+                          float *head_image, hipStream_t stream) {
     const DecoderGeometry g = decoder_geometry(H, cond);
-    const int total = 2 * (int)g.image_floats;
+    const int total = 2 * (int)g.image_floats + H * kDecThreads;
     hipLaunchKernelGGL(decoder_weight_image_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, stream, w_hh,
-                       w_qt, w_qv, w_q2k, H, cond ? 1 : 0, g.slots, g.k0, fwd_image, bwd_image);
+                       w_qt, w_qv, w_q2k, wo_perm, H, cond ? 1 : 0, g.slots, g.k0, fwd_image, bwd_image, head_image);
     GSCAN_LAUNCHED("decoder_weight_image_kernel");
     return 0;
 }
@@ -761,7 +930,7 @@ constexpr size_t kLdsLimit = 160 * 1024;
 
 template <int H, bool COND>
 static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_t stream) {
-    const DecoderLds o = decoder_lds(H, a.L, a.M, COND, backward);
+    const DecoderLds o = decoder_lds(H, a.L, a.M, a.V, COND, backward);
     const size_t bytes = (size_t)o.total * sizeof(float);
     GSCAN_CHECK(bytes <= kLdsLimit,
                 "decoder: a row's memories need %zu bytes of LDS (> 160 KiB): grid cells=%d command length=%d hidden=%d",
@@ -771,7 +940,7 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
     // embedding part of the LSTM input and the output head, which run as GEMMs outside the loop):
     // query projections, both score/context reductions, and the [ctx_text|ctx_vis|h] part of the LSTM.
     const double macs = (double)H * H + 2.0 * a.L * H + (COND ? 2.0 * H * H : 0.0) + (double)H * H +
-                        2.0 * a.M * H + 4.0 * H * 3.0 * H;
+                        2.0 * a.M * H + 4.0 * H * 3.0 * H + 4.0 * H * H + (double)H * a.V;   // + the fused head
     ProbeScope probe(backward ? P_DECODER_BWD : P_DECODER_FWD, stream, 2.0 * macs * B * a.T);
     if (backward) {
         static bool attr_set = false;
@@ -804,8 +973,8 @@ bool decoder_hidden_supported(int h) {
     return false;
 }
 
-size_t decoder_lds_bytes(int H, int L, int M, bool cond, bool backward) {
-    return (size_t)decoder_lds(H, L, M, cond, backward).total * sizeof(float);
+size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward) {
+    return (size_t)decoder_lds(H, L, M, V, cond, backward).total * sizeof(float);
 }
 
 int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream) {

@@ -105,8 +105,10 @@ constexpr int kDecThreads = 512;   // 8 waves: 2 per SIMD, 256-VGPR budget
 constexpr int kDecPairs = 256;     // lane pairs; a weight row lives in one pair
 struct DecoderGeometry { int rows, slots, k0; int64_t image_floats; };
 DecoderGeometry decoder_geometry(int H, bool cond);
-int decoder_weight_images(const float *w_hh, const float *w_qt, const float *w_qv, const float *w_q2k, int H,
-                          bool cond, float *fwd_image, float *bwd_image, hipStream_t stream);
+int decoder_weight_images(const float *w_hh, const float *w_qt, const float *w_qv, const float *w_q2k,
+                          const float *wo_perm, int H, bool cond, float *fwd_image, float *bwd_image,
+                          float *head_image, hipStream_t stream);
+constexpr int kHeadChunk = 32;     // target steps per pass of the fused output head (two 16-row MFMA tiles)
 
 struct DecoderArgs {
     int T, L, M;                       // target steps, command memories, grid memories (G*G)
@@ -122,9 +124,17 @@ struct DecoderArgs {
     float *alpha_c, *alpha_s;          // [B,T,L] [B,T,M]
     float *q2, *qt, *qv;               // [B,T,H] conditional query, projected text / visual query
     float *att_sum;                    // [B,M] sum_t alpha_s (auxiliary head input)
+    // fused output head (seq2seq_model.py:421-424, model.py:203): forward epilogue / backward prologue
+    int V;
+    const float *head_image;           // register image of the permuted output_to_hidden rows [H][512]
+    const float *wo_perm, *w_h2o;      // [H,4H] (columns in S order), [V,H]
+    float *preo, *logits;              // [B,T,H] [B,T,V]
+    float *logp_saved, *logp_out;      // [B,T,V] workspace copy and the caller's output
+    float *aux_saved, *aux_out;        // [B,M] log_softmax(att_sum), or NULL without the auxiliary task
     // backward only
-    const float *ds;                   // [B,T,4H] external grads wrt [e | ctx_text | ctx_vis | h_t] (head)
-    const float *datt;                 // [B,M] grad wrt att_sum or NULL
+    const float *dlogp, *daux, *seeds; // incoming gradients ([B,T,V], [B,M] or NULL) and optional device scales [2]
+    float *dlogits, *dpreo;            // [B,T,V] [B,T,H] saved for the head's weight gradients
+    float *ds;                         // [B,T,4H] head gradient wrt [e | ctx_text | ctx_vis | h_t] (written first)
     float *delta, *dqt, *dqv;          // [B,T,5H] = [gate deltas (4H) | dzq (H)], [B,T,H], [B,T,H]
     float *dpk_t, *dpk_v;              // [B,L,H] [B,M,H]  score-path key gradients
     float *dv_t, *dv_v;                // [H] energy-vector gradients, accumulated with atomics
@@ -132,7 +142,7 @@ struct DecoderArgs {
     float *stamps;                     // diagnostics: [2][16] per-phase cycle sums of workgroup 0, or NULL
 };
 bool decoder_hidden_supported(int h);
-size_t decoder_lds_bytes(int H, int L, int M, bool cond, bool backward);
+size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward);
 int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
 
 // probe.hip
@@ -154,7 +164,7 @@ struct Workspace {
     int64_t xcol, feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
-        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, wt, dwt, bias_rep, wcat5;
+        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, wt, dwt, bias_rep, wcat5;
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;

@@ -56,6 +56,7 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(w_2kk, H * He);
     SLOT(dec_w_fwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
     SLOT(dec_w_bwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
+    SLOT(dec_w_head, H * kDecThreads);
     SLOT(hprev, B * T * H);
     SLOT(S, B * T * 4 * H);
     SLOT(ge, B * T * 4 * H);
@@ -68,7 +69,7 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(qv, B * T * H);
     SLOT(att_sum, B * M);
     SLOT(wcat5, 5 * H * 3 * H);
-    SLOT(preo, B * T * H);                           // preo | dxe are zeroed together by the prologue (split-K targets)
+    SLOT(preo, B * T * H);
     SLOT(dxe, B * L * E);
     SLOT(logits, B * T * V);
     SLOT(logp_saved, B * T * V);
@@ -111,7 +112,7 @@ int check_dims(const gscan_dims &d) {
                 "dims: batch too large for 32-bit activation offsets (B=%d T=%d H=%d)", d.B, d.T, d.H);
     GSCAN_CHECK(d.L <= 64, "dims: commands longer than 64 tokens are not supported (L=%d)", d.L);
     GSCAN_CHECK(d.G * d.G <= 64, "dims: grids larger than 8x8 are not supported (G=%d)", d.G);
-    const size_t lds = decoder_lds_bytes(d.H, d.L, d.G * d.G, d.conditional != 0, true);
+    const size_t lds = decoder_lds_bytes(d.H, d.L, d.G * d.G, d.V, d.conditional != 0, true);
     GSCAN_CHECK(lds <= 160 * 1024, "dims: the decoder needs %zu bytes of LDS per row (limit 163840): L=%d G=%d H=%d", lds,
                 d.L, d.G, d.H);
     return 0;
@@ -147,6 +148,9 @@ static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, cons
     a.hprev = w + ws.hprev; a.s = w + ws.S; a.cells = w + ws.cells; a.gates = w + ws.gates;
     a.alpha_c = w + ws.alpha_c; a.alpha_s = w + ws.alpha_s;
     a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
+    a.V = d.V; a.head_image = w + ws.dec_w_head; a.wo_perm = w + ws.wo_perm; a.w_h2o = p.hid2out_w;
+    a.preo = w + ws.preo; a.logits = w + ws.logits; a.logp_saved = w + ws.logp_saved;
+    a.aux_saved = d.auxiliary ? w + ws.aux_saved : nullptr;
     return a;
 }
 
@@ -236,16 +240,16 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
         a.dwo_perm = w + ws.dwo_perm; a.xe = w + ws.xe; a.S = w + ws.S;
         a.H = H; a.He = He; a.E = E; a.D = D; a.BL = B * L; a.BT = B * T; a.Vi = d.Vi; a.V = V;
         a.wcat5 = w + ws.wcat5; a.w_ih_dec = p.dec_w_ih; a.w_q2k = p.q2k_w; a.cond = cond ? 1 : 0;
-        a.zero_extra = w + ws.preo;                        // preo and dxe are adjacent slots
-        a.zero_extra_count = (ws.dxe + (int64_t)B * L * E) - ws.preo;
+        a.zero_extra = w + ws.dxe;                         // split-K target of the backward tail
+        a.zero_extra_count = (int64_t)B * L * E;
         const int64_t n[8] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
                               (int64_t)B * L * E, (int64_t)B * T * H, (int64_t)5 * H * 3 * H, a.zero_extra_count};
         int64_t acc = 0;
         for (int i = 0; i < 8; ++i) { acc += n[i]; a.end[i] = acc; }
         TRY(step_prologue(a, st));
     }
-    TRY(decoder_weight_images(p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, H, cond, w + ws.dec_w_fwd,
-                              w + ws.dec_w_bwd, st));
+    TRY(decoder_weight_images(p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, w + ws.wo_perm, H, cond,
+                              w + ws.dec_w_fwd, w + ws.dec_w_bwd, w + ws.dec_w_head, st));
     {
         GemmBatch g;
         // encoder input projections W_ih x + b_ih, both directions (seq2seq_model.py:70)
@@ -274,21 +278,15 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     }
     TRY(order_after(st, sd));          // join: the decoder needs both branches
 
-    // ---- the T-step recurrence
+    // ---- the T-step recurrence; its epilogue is the output head, which does not feed back
+    // (seq2seq_model.py:421-424: S . wo_perm^T, then W_h2o) and log_softmax (model.py:203, :166-170) of the row's
+    // T steps, and the auxiliary log_softmax over the summed visual attention (model.py:205)
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.w_image = w + ws.dec_w_fwd;
+    a.logp_out = logp;
+    a.aux_out = d.auxiliary ? aux_logp : nullptr;
     a.stamps = probe_stamps_enabled() ? w + ws.stamps : nullptr;
     TRY(decoder_run(false, B, H, cond, a, st));
-
-    // ---- output head hoisted out of the loop (seq2seq_model.py:421-424): S . wo_perm^T, then W_h2o
-    // (no split-K here: the forward pass stays bitwise reproducible — float atomics are used only for gradients)
-    TRY(gemm_f32(B * T, H, 4 * H, 1.f, w + ws.S, 4 * H, 1, w + ws.wo_perm, 1, 4 * H, 0.f, w + ws.preo, H, nullptr, 0,
-                 nullptr, 1, st));
-    TRY(gemm_f32(B * T, V, H, 1.f, w + ws.preo, H, 1, p.hid2out_w, 1, H, 0.f, w + ws.logits, V, nullptr, 0, nullptr,
-                 1, st));
-    // log_softmax (model.py:203, :166-170); a copy stays in the workspace for the backward pass
-    TRY(log_softmax_rows(w + ws.logits, w + ws.logp_saved, logp, B * T, V, st));
-    if (d.auxiliary) TRY(log_softmax_rows(w + ws.att_sum, w + ws.aux_saved, aux_logp, B, M, st));
     return 0;
 }
 
@@ -308,20 +306,15 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     TRY(side_init());
     hipStream_t sd = g_side.stream;
     float *S = w + ws.S, *dS = w + ws.dS;
-    const float *logp = w + ws.logp_saved, *aux_logp = w + ws.aux_saved;
     const float *delta = w + ws.delta, *hprev = w + ws.hprev;
 
-    // ---- head: log_softmax, hidden_to_output, output_to_hidden
-    // seeds (optional, device): dlogp is multiplied by seeds[0], daux by seeds[1]
-    TRY(log_softmax_rows_backward(logp, dlogp, w + ws.dlogits, BT, V, seeds, st));
+    // ---- reverse recurrence (occupies every CU: nothing overlaps it).  Its prologue is the backward of the head
+    // (log_softmax, hidden_to_output, output_to_hidden) for the row's T steps; seeds (optional, device) multiply
+    // dlogp by seeds[0] and daux by seeds[1]
     const bool use_aux = d.auxiliary && daux;
-    if (use_aux) TRY(log_softmax_rows_backward(aux_logp, daux, w + ws.datt, B, M, seeds ? seeds + 1 : nullptr, st));
-    TRY(gemm_f32(BT, H, V, 1.f, w + ws.dlogits, V, 1, p.hid2out_w, H, 1, 0.f, w + ws.dpreo, H, nullptr, 0, nullptr, 1, st));
-    TRY(gemm_f32(BT, 4 * H, H, 1.f, w + ws.dpreo, H, 1, w + ws.wo_perm, 4 * H, 1, 0.f, dS, 4 * H, nullptr, 0, nullptr, 1, st));
-
-    // ---- reverse recurrence (occupies every CU: nothing overlaps it)
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
-    a.ds = dS; a.datt = use_aux ? w + ws.datt : nullptr;
+    a.dlogp = dlogp; a.daux = use_aux ? daux : nullptr; a.seeds = seeds;
+    a.dlogits = w + ws.dlogits; a.dpreo = w + ws.dpreo; a.ds = dS;
     a.delta = w + ws.delta; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
     a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = g.txt_energy_w; a.dv_v = g.vis_energy_w;
     a.dh0 = w + ws.dh0;
