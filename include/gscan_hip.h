@@ -135,6 +135,12 @@ int gscan_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
                     float lr, float beta1, float beta2, float eps, float lr_decay, float lr_decay_steps,
                     int64_t step, const float *grad_scale, void *stream);
 
+/* optimizer.step() followed by optimizer.zero_grad() (train.py:110-113) in one launch: as gscan_adam_step, and
+ * the gradient buffer is cleared as it is consumed. */
+int gscan_adam_step_zero_grad(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr,
+                              float beta1, float beta2, float eps, float lr_decay, float lr_decay_steps,
+                              int64_t step, const float *grad_scale, void *stream);
+
 /* ---- the same loop body for a captured (hipGraph) step: everything that changes from step to step is read from
  * device memory, so one captured sequence can be replayed unchanged ---- */
 

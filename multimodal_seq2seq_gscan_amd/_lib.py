@@ -75,6 +75,7 @@ PROTOTYPES = {
     "gscan_position_nll": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "gscan_sequence_metrics": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gscan_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i64, _vp, _vp]),
+    "gscan_adam_step_zero_grad": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i64, _vp, _vp]),
     "gscan_dropout_mask": (_i, [_vp, _sz, _f, _u64, _u64, _vp]),
     "gscan_step_losses": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gscan_loss_seeds": (_i, [_vp, _f, _i, _vp, _vp]),

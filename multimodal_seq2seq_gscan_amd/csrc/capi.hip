@@ -130,6 +130,14 @@ int gscan_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
                      lr_decay_steps, step, grad_scale, nullptr, 0, (hipStream_t)stream);
 }
 
+int gscan_adam_step_zero_grad(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr,
+                              float beta1, float beta2, float eps, float lr_decay, float lr_decay_steps,
+                              int64_t step, const float *grad_scale, void *stream) {
+    ARG(param && grad && exp_avg && exp_avg_sq && n > 0, "adam_step_zero_grad: bad argument");
+    return adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, lr_decay, lr_decay_steps, step,
+                     grad_scale, nullptr, 1, (hipStream_t)stream);
+}
+
 int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, void *stream) {
     ARG(out || n == 0, "dropout_mask: NULL output");
     return dropout_mask(out, n, p, seed, stream_id, (hipStream_t)stream);
@@ -160,6 +168,10 @@ int gscan_encoder_lstm_forward(int B, int L, int He, int D, const float *gx, con
                                float *hprev, void *stream) {
     ARG(gx && lengths && w_hh_fwd && b_hh_fwd && out && h_final && gates && cells && hprev,
         "encoder_lstm_forward: NULL argument");
+    ARG(B > 0 && L > 0 && He > 0, "encoder_lstm_forward: bad dims");
+    // the kernel accumulates the direction sums into out / h_final
+    GSCAN_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * L * He, (hipStream_t)stream));
+    GSCAN_HIP(hipMemsetAsync(h_final, 0, sizeof(float) * (size_t)B * He, (hipStream_t)stream));
     return encoder_lstm_forward(B, L, He, D, gx, lengths, w_hh_fwd, b_hh_fwd, w_hh_rev, b_hh_rev, out, h_final, gates,
                                 cells, hprev, (hipStream_t)stream);
 }

@@ -349,7 +349,7 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 //   seg 5  S[:, 0:H]           = dropout(Emb_dec[targets])       seq2seq_model.py:383-384
 //   seg 6  wcat5[5H,3H]        = [W_ih_dec ; (0 | W_q2k[:, H:2H] | 0)]: one product then carries delta AND dzq back to
 //                                [e | ctx_text | ctx_vis]
-//   seg 7  zero_extra          = 0   (accumulation targets of split-K products: dxe, preo)
+//   seg 7  zero_extra          = 0   (accumulation targets: encoder direction sums enc_out / hN, split-K dxe)
 // ------------------------------------------------------------------------------------------
 
 __global__ void prologue_kernel(PrologueArgs a) {
@@ -439,33 +439,34 @@ struct ToeplitzArgs {
 };
 __device__ __forceinline__ int conv_kernel_size(int i, int K3) { return i == 0 ? 1 : (i == 1 ? 5 : K3); }
 
+// grid (G*G output cells, G*G*C + 1): one (row j of Wt, output cell) pair per block, so the cell / channel / tap
+// arithmetic is block-uniform and a thread only selects its feature f; the extra last row of blocks writes the
+// replicated bias
 __global__ void toeplitz_build_kernel(ToeplitzArgs a, float *__restrict__ wt, float *__restrict__ bias_rep) {
     const int G = a.G, C = a.C, Co = a.Co, F = 3 * Co, N = G * G * F, J = G * G * C;
-    const int64_t total = (int64_t)J * N;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + N;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        if (idx >= total) {                                   // bias replicated over the G*G positions
-            const int n = (int)(idx - total), f = n % F;
-            bias_rep[n] = a.b[f / Co][f % Co];
+    const int pos = blockIdx.x, j = blockIdx.y;
+    const int r = pos / G, c = pos - r * G;
+    const int cell = j / C, ch = j - cell * C, r2 = cell / G, c2 = cell - r2 * G;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const int i = (f >= Co) + (f >= 2 * Co), o = f - i * Co;
+        if (j == J) {                                         // bias replicated over the G*G positions
+            bias_rep[pos * F + f] = a.b[i][o];
             continue;
         }
-        const int n = (int)(idx % N), j = (int)(idx / N);
-        const int f = n % F, pos = n / F, r = pos / G, c = pos % G;
-        const int ch = j % C, cell = j / C, r2 = cell / G, c2 = cell % G;
-        const int i = f / Co, o = f % Co, k = conv_kernel_size(i, a.K3), p = k / 2;
+        const int k = conv_kernel_size(i, a.K3), p = k / 2;
         const int kw = r2 - r + p, kh = c2 - c + p;
         float v = 0.f;
         if (kw >= 0 && kw < k && kh >= 0 && kh < k) v = a.w[i][((o * C + ch) * k + kh) * k + kw];
-        wt[idx] = v;
+        wt[(int64_t)j * N + pos * F + f] = v;
     }
 }
 
 int toeplitz_build(const float *const (&w)[3], const float *const (&b)[3], int G, int C, int Co, int K3, float *wt,
                    float *bias_rep, hipStream_t stream) {
     ToeplitzArgs a{{w[0], w[1], w[2]}, {b[0], b[1], b[2]}, G, C, Co, K3};
-    const int64_t total = (int64_t)G * G * C * G * G * 3 * Co;
-    hipLaunchKernelGGL(toeplitz_build_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 8192)), dim3(256), 0, stream,
-                       a, wt, bias_rep);
+    const int F = 3 * Co, J = G * G * C;
+    hipLaunchKernelGGL(toeplitz_build_kernel, dim3(G * G, J + 1), dim3(std::min(256, cdiv(F, 64) * 64)), 0, stream, a,
+                       wt, bias_rep);
     GSCAN_LAUNCHED("toeplitz_build_kernel");
     return 0;
 }

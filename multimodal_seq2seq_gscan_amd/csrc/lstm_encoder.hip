@@ -6,7 +6,7 @@
 // row j), h is broadcast from LDS, and there is no global traffic inside the loop except the
 // precomputed input projection gx[t] coming in and the saved activations going out.  Length
 // masking replaces packing: a row simply stops after its own length (the reverse direction
-// starts at its last real token), outputs at padded positions are written as zeros.
+// starts at its last real token), outputs at padded positions stay zero.
 //
 // Backward keeps the transposed ownership: thread (s, k) holds W_hh[s*He .. s*He+He-1][k], so
 // dh_{t-1}[k] = sum_j W_hh[j][k] * delta[j] is four in-register partial dots plus one LDS sum.
@@ -32,6 +32,9 @@ __device__ __forceinline__ float dot_lds(const float (&w)[HE], const float *v) {
     return (a0 + a1) + (a2 + a3);
 }
 
+// grid (B, D): the two directions of a row run as two workgroups (they only meet in the sums below).
+// `out` and `h_final` must be zero on entry: each direction ADDS its h (0 + h_f + h_r in either order is the same
+// float: two-operand addition commutes), which is how the directions are summed (seq2seq_model.py:77-81).
 template <int HE>
 __global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_fwd_kernel(int L, int D, const float *__restrict__ gx,
                                         const int32_t *__restrict__ lengths, const float *__restrict__ w_hh_f,
@@ -41,59 +44,59 @@ __global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_fwd_ke
                                         float *__restrict__ cells, float *__restrict__ hprev) {
     __shared__ __attribute__((aligned(16))) float h_s[HE];
     __shared__ float gate_s[4 * HE];
-    const int b = blockIdx.x, j = threadIdx.x;
+    const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
     int len = lengths[b];
     len = max(0, min(len, L));
     const bool is_gate = j < 4 * HE, is_unit = j < HE;
     float w[HE];
 
-    // padded positions: zero output, zero saved h_prev (it multiplies delta = 0 in a GEMM later)
+    // padded positions: zero saved h_prev (it multiplies delta = 0 in a GEMM later); out stays zero
     for (int idx = j; idx < (L - len) * HE; idx += blockDim.x) {
         const int t = len + idx / HE, k = idx % HE;
-        out[((int64_t)b * L + t) * HE + k] = 0.f;
-        for (int d = 0; d < D; ++d) hprev[(((int64_t)b * L + t) * D + d) * HE + k] = 0.f;
+        hprev[(((int64_t)b * L + t) * D + dir) * HE + k] = 0.f;
     }
 
-    for (int dir = 0; dir < D; ++dir) {
-        const float *w_hh = dir ? w_hh_r : w_hh_f;
-        const float *b_hh = dir ? b_hh_r : b_hh_f;
-        float bias = 0.f;
-        if (is_gate) {
+    const float *w_hh = dir ? w_hh_r : w_hh_f;
+    const float *b_hh = dir ? b_hh_r : b_hh_f;
+    float bias = 0.f;
+    if (is_gate) {
 #pragma unroll
-            for (int k = 0; k < HE; ++k) w[k] = w_hh[(int64_t)j * HE + k];
-            bias = b_hh[j];
+        for (int k = 0; k < HE; ++k) w[k] = w_hh[(int64_t)j * HE + k];
+        bias = b_hh[j];
+    }
+    float c = 0.f;
+    if (is_unit) h_s[j] = 0.f;
+    // the input projection of step s+1 is fetched while step s computes
+    auto gx_at = [&](int s) {
+        const int t = dir ? (len - 1 - s) : s;
+        return gx[(((int64_t)b * L + t) * D + dir) * 4 * HE + j];
+    };
+    float gx_next = (is_gate && len > 0) ? gx_at(0) + bias : 0.f;
+    lds_barrier();
+    for (int s = 0; s < len; ++s) {
+        const int t = dir ? (len - 1 - s) : s;
+        const int64_t row = ((int64_t)b * L + t) * D + dir;
+        const float gx_cur = gx_next;
+        if (is_gate && s + 1 < len) gx_next = gx_at(s + 1) + bias;
+        if (is_gate) {
+            const float pre = gx_cur + dot_lds<HE>(w, h_s);
+            const float a = (j >= 2 * HE && j < 3 * HE) ? tanhf_(pre) : sigmoidf_(pre);
+            gate_s[j] = a;
+            gates[row * 4 * HE + j] = a;
         }
-        float c = 0.f;
-        if (is_unit) h_s[j] = 0.f;
+        if (is_unit) hprev[row * HE + j] = h_s[j];
         lds_barrier();
-        for (int s = 0; s < len; ++s) {
-            const int t = dir ? (len - 1 - s) : s;
-            const int64_t row = ((int64_t)b * L + t) * D + dir;
-            if (is_gate) {
-                float pre = gx[row * 4 * HE + j] + bias + dot_lds<HE>(w, h_s);
-                const float a = (j >= 2 * HE && j < 3 * HE) ? tanhf_(pre) : sigmoidf_(pre);
-                gate_s[j] = a;
-                gates[row * 4 * HE + j] = a;
-            }
-            if (is_unit) hprev[row * HE + j] = h_s[j];
-            lds_barrier();
-            if (is_unit) {
-                const float ig = gate_s[j], fg = gate_s[HE + j], gg = gate_s[2 * HE + j], og = gate_s[3 * HE + j];
-                c = fg * c + ig * gg;
-                const float h = og * tanhf_(c);
-                cells[row * HE + j] = c;
-                h_s[j] = h;
-                float *o = out + ((int64_t)b * L + t) * HE + j;
-                *o = dir ? (*o + h) : h;          // directions are summed (seq2seq_model.py:77-79)
-            }
-            lds_barrier();
-        }
         if (is_unit) {
-            float *hf = h_final + (int64_t)b * HE + j;
-            *hf = dir ? (*hf + h_s[j]) : h_s[j];  // final states are summed too (:80-81)
+            const float ig = gate_s[j], fg = gate_s[HE + j], gg = gate_s[2 * HE + j], og = gate_s[3 * HE + j];
+            c = fg * c + ig * gg;
+            const float h = og * tanhf_(c);
+            cells[row * HE + j] = c;
+            h_s[j] = h;
+            atomicAdd(out + ((int64_t)b * L + t) * HE + j, h);
         }
         lds_barrier();
     }
+    if (is_unit) atomicAdd(h_final + (int64_t)b * HE + j, h_s[j]);
 }
 
 template <int HE>
@@ -122,20 +125,32 @@ __global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_bwd_ke
     }
     float dc = 0.f;
     if (is_unit) dh_s[tid] = d_h_final[(int64_t)b * HE + tid];
+    // saved activations of the next step to process are fetched while the current one computes
+    float pf[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto prefetch = [&](int s) {
+        const int t = dir ? (len - 1 - s) : s;
+        const int64_t row = ((int64_t)b * L + t) * D + dir;
+        const float *g = gates + row * 4 * HE;
+        pf[0] = g[tid]; pf[1] = g[HE + tid]; pf[2] = g[2 * HE + tid]; pf[3] = g[3 * HE + tid];
+        pf[4] = cells[row * HE + tid];
+        pf[5] = 0.f;
+        if (s > 0) {
+            const int tp = dir ? (t + 1) : (t - 1);
+            pf[5] = cells[(((int64_t)b * L + tp) * D + dir) * HE + tid];
+        }
+        pf[6] = d_out[((int64_t)b * L + t) * HE + tid];
+    };
+    if (is_unit && len > 0) prefetch(len - 1);
     lds_barrier();
     for (int s = len - 1; s >= 0; --s) {
         const int t = dir ? (len - 1 - s) : s;
         const int64_t row = ((int64_t)b * L + t) * D + dir;
         if (is_unit) {
-            const float dh = dh_s[tid] + d_out[((int64_t)b * L + t) * HE + tid];
-            const float *g = gates + row * 4 * HE;
-            const float ig = g[tid], fg = g[HE + tid], gg = g[2 * HE + tid], og = g[3 * HE + tid];
-            const float c = cells[row * HE + tid];
-            float c_prev = 0.f;
-            if (s > 0) {
-                const int tp = dir ? (t + 1) : (t - 1);
-                c_prev = cells[(((int64_t)b * L + tp) * D + dir) * HE + tid];
-            }
+            const float dh = dh_s[tid] + pf[6];
+            const float ig = pf[0], fg = pf[1], gg = pf[2], og = pf[3];
+            const float c = pf[4];
+            const float c_prev = pf[5];
+            if (s > 0) prefetch(s - 1);
             const float tc = tanhf_(c);
             const float dct = dc + dh * og * (1.f - tc * tc);
             const float di = dct * gg * ig * (1.f - ig);
@@ -162,7 +177,7 @@ static int launch_fwd(int B, int L, int D, const float *gx, const int32_t *lengt
     const int nt = cdiv(4 * HE, 64) * 64;
     // algorithmic work: the recurrent product h.W_hh^T per (row, step, direction); padded steps counted
     ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * HE * HE);
-    hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B), dim3(nt), 0, stream, L, D, gx, lengths, wf, bf, wr, br,
+    hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B, D), dim3(nt), 0, stream, L, D, gx, lengths, wf, bf, wr, br,
                        out, hfin, gates, cells, hprev);
     GSCAN_LAUNCHED("encoder_lstm_fwd_kernel");
     return 0;

@@ -39,8 +39,9 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(uv, B * M * 4 * H);
     SLOT(xe, B * L * E);
     SLOT(gx, B * L * D * 4 * He);
-    SLOT(enc_out, B * L * He);
-    SLOT(hN, B * He);
+    SLOT(enc_out, B * L * He);                       // enc_out | hN | dxe are zeroed together by the prologue
+    SLOT(hN, B * He);                                // (accumulation targets: direction sums, split-K tail)
+    SLOT(dxe, B * L * E);
     SLOT(enc_gates, B * L * D * 4 * He);
     SLOT(enc_cells, B * L * D * He);
     SLOT(enc_hprev, B * L * D * He);
@@ -70,7 +71,6 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(att_sum, B * M);
     SLOT(wcat5, 5 * H * 3 * H);
     SLOT(preo, B * T * H);
-    SLOT(dxe, B * L * E);
     SLOT(logits, B * T * V);
     SLOT(logp_saved, B * T * V);
     SLOT(aux_saved, B * M);
@@ -118,12 +118,13 @@ int check_dims(const gscan_dims &d) {
     return 0;
 }
 
-// Split of the long K dimension of a weight-gradient product.  Every slice ends in one float atomic per output
-// element (chip-wide atomic rate ~1.3 TB/s, MI355X_MICROARCH.md "Global float atomics"), so slices are kept
-// long (>= ~640 rows, 20 rounds of the K loop) rather than many.
+// Split of the long K dimension of a weight-gradient product.  A workgroup's K loop is a chain of dependent
+// ~1.3 us rounds when it has a CU to itself (measured: 400x100x2560 unsplit = 109 us, 8 slices = 20 us), and every
+// slice ends in one float atomic per output element (chip-wide atomic rate ~1.3 TB/s, MI355X_MICROARCH.md
+// "Global float atomics"): slices of 640 rows (20 rounds), but at least 8 of them while they stay >= 160 rows.
 static int pick_split(int M, int N, int K) {
     (void)M; (void)N;
-    return std::max(1, cdiv(K, 640));
+    return std::max(cdiv(K, 640), std::min(8, cdiv(K, 160)));
 }
 
 // weight gradient: C[M,N] += A^T . B with the long dimension (rows of the activations) as K, split over
@@ -164,7 +165,7 @@ static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, cons
 // the same sequence can be captured into a hipGraph (cross-stream capture through the events).
 // --------------------------------------------------------------------------------------
 struct SideStream {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev[16] = {};
     bool ready = false;
     int next = 0;
@@ -173,7 +174,11 @@ static SideStream g_side;
 
 static int side_init() {
     if (g_side.ready) return 0;
-    GSCAN_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+    // lowest priority: when both have work ready, the chain on the caller's stream gets the CUs first
+    int prio_least = 0, prio_greatest = 0;
+    GSCAN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, prio_least));
+    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream2, hipStreamNonBlocking, prio_least));
     for (auto &e : g_side.ev) GSCAN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     g_side.ready = true;
     return 0;
@@ -240,8 +245,8 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
         a.dwo_perm = w + ws.dwo_perm; a.xe = w + ws.xe; a.S = w + ws.S;
         a.H = H; a.He = He; a.E = E; a.D = D; a.BL = B * L; a.BT = B * T; a.Vi = d.Vi; a.V = V;
         a.wcat5 = w + ws.wcat5; a.w_ih_dec = p.dec_w_ih; a.w_q2k = p.q2k_w; a.cond = cond ? 1 : 0;
-        a.zero_extra = w + ws.dxe;                         // split-K target of the backward tail
-        a.zero_extra_count = (int64_t)B * L * E;
+        a.zero_extra = w + ws.enc_out;                     // adjacent slots enc_out | hN | dxe
+        a.zero_extra_count = (ws.dxe + (int64_t)B * L * E) - ws.enc_out;
         const int64_t n[8] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
                               (int64_t)B * L * E, (int64_t)B * T * H, (int64_t)5 * H * 3 * H, a.zero_extra_count};
         int64_t acc = 0;
@@ -291,7 +296,8 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
 }
 
 // --------------------------------------------------------------------------------------
-// backward: main stream = chain of data gradients; side stream = weight-gradient leaves
+// backward: main stream = chain of data gradients; side streams = weight-gradient leaves (the convolution's
+// gradient product + fold on its own stream: it is long and nothing but the optimiser waits for it)
 // --------------------------------------------------------------------------------------
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                   const float *dlogp, const float *daux, const float *seeds, const gscan_params &g, hipStream_t st) {
@@ -304,7 +310,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     const bool cond = d.conditional != 0;
     GSCAN_CHECK(dlogp, "backward: dlogp is NULL");
     TRY(side_init());
-    hipStream_t sd = g_side.stream;
+    hipStream_t sd = g_side.stream, sd2 = g_side.stream2;
     float *S = w + ws.S, *dS = w + ws.dS;
     const float *delta = w + ws.delta, *hprev = w + ws.hprev;
 
@@ -366,14 +372,14 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
               nullptr, w + ws.feat);
         TRY(b.launch(st));
     }
-    TRY(order_after(sd, st));
+    TRY(order_after(sd2, st));
     {   // leaf: d(Wt) = world^T . dfeat (K = B only: no split, no atomics), folded onto the conv kernels
         GemmBatch b;
         b.add(M * C, M * F, B, bt.world, 1, (int64_t)M * C, w + ws.dfeat, (int64_t)M * F, 1, w + ws.dwt, (int64_t)M * F);
-        TRY(b.launch(sd));
+        TRY(b.launch(sd2));
         float *const gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
         float *const gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
-        TRY(toeplitz_fold(gw, gb, d.G, C, Co, d.K3, B, w + ws.dwt, w + ws.dfeat, sd));
+        TRY(toeplitz_fold(gw, gb, d.G, C, Co, d.K3, B, w + ws.dwt, w + ws.dfeat, sd2));
     }
     // ---- command encoder BPTT (chain)
     TRY(encoder_lstm_backward(B, L, He, D, bt.cmd_lengths, p.enc_w_hh, p.enc_w_hh_rev, w + ws.enc_gates,
@@ -397,6 +403,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
                  nullptr, 8, st));   // K = 8He split eight ways onto the zeroed buffer
     TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));
     TRY(order_after(st, sd));          // join: every gradient is complete when the caller's stream continues
+    TRY(order_after(st, sd2));
     return 0;
 }
 

@@ -32,10 +32,10 @@ logger = logging.getLogger(__name__)
 
 class FlatAdam:
     """torch.optim.Adam(lr, betas) + LambdaLR(lr_decay ** (t / lr_decay_steps)) of train.py:67-70 over
-    the model's flat parameter buffer: one fused HIP kernel per step.  The step-dependent scalars live in a
-    two-float device buffer refreshed from the host before each step, so the launch itself is identical
-    every step (and can sit inside a captured graph); the kernel also clears the gradient buffer
-    (optimizer.zero_grad(), train.py:113)."""
+    the model's flat parameter buffer: one fused HIP kernel per step, which also clears the gradient buffer
+    (optimizer.zero_grad(), train.py:113).  Launched eagerly the step-dependent scalars are kernel arguments;
+    for a captured graph they live in a two-float device buffer refreshed from the host before each replay,
+    so the captured launch is identical every step."""
 
     def __init__(self, model: Model, learning_rate: float, adam_beta_1: float = 0.9, adam_beta_2: float = 0.999,
                  lr_decay: float = 0.9, lr_decay_steps: float = 20000.0, eps: float = 1e-8):
@@ -61,9 +61,16 @@ class FlatAdam:
                                self.steps_taken, self._host_scalars.data_ptr())
         self._dev_scalars.copy_(self._host_scalars, non_blocking=True)
 
-    def launch(self, zero_grad: bool = True) -> None:
+    def launch(self, zero_grad: bool = True, device_scalars: bool = True) -> None:
         lib = _lib.load()
         m = self.model
+        if not device_scalars:
+            fn = lib.gscan_adam_step_zero_grad if zero_grad else lib.gscan_adam_step
+            _lib.check(fn(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(), self.exp_avg.data_ptr(),
+                          self.exp_avg_sq.data_ptr(), m.flat_parameters.numel(), self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.lr_decay, self.lr_decay_steps, self.steps_taken, None,
+                          torch.cuda.current_stream().cuda_stream), "gscan_adam_step")
+            return
         _lib.check(lib.gscan_adam_step_graph(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(),
                                              self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                              m.flat_parameters.numel(), self.betas[0], self.betas[1], self.eps,
@@ -71,8 +78,8 @@ class FlatAdam:
                                              torch.cuda.current_stream().cuda_stream), "gscan_adam_step_graph")
 
     def step(self, zero_grad: bool = True) -> None:
-        self.stage_scalars()
-        self.launch(zero_grad)
+        self.steps_taken += 1
+        self.launch(zero_grad, device_scalars=False)
 
     # ---- checkpoint interop with torch.optim.Adam (model.py:246-261 stores optimizer.state_dict()) ----
     def state_dict(self) -> dict:
@@ -148,7 +155,7 @@ class TrainStep:
         self._graphs: Dict[tuple, dict] = {}
         model.flat_gradients.zero_()
         model.attach_gradients(zero=False)
-        if device.type == "cuda":
+        if device.type == "cuda" and self.graph:
             if model._mask_stream_id is None:     # one device slot per model: captured graphs keep its address
                 model._mask_stream_id = torch.zeros(1, dtype=torch.int64, device=device)
             self._host_stream_id = torch.zeros(1, dtype=torch.int64).pin_memory()
@@ -181,7 +188,11 @@ class TrainStep:
         self.model._launch_backward(fw["call"], fw["dlogp"], fw["daux"], seeds=self.seeds, attach=False)
 
     def _host_prologue(self) -> None:
-        """Per-step host work: optimizer scalars and the Philox stream id go to their device slots."""
+        """Per-step host work.  Eager: only the step counter moves (scalars travel as kernel arguments).
+        Graph replay: optimizer scalars and the Philox stream id go to their device slots."""
+        if not self.graph:
+            self.optimizer.steps_taken += 1
+            return
         self.optimizer.stage_scalars()
         self._host_stream_id[0] = self.model._dropout_calls
         self.model._mask_stream_id.copy_(self._host_stream_id, non_blocking=True)
@@ -207,7 +218,7 @@ class TrainStep:
         self.exchange.all_reduce(self.stats)
         self._section_backward(fw)
         self.exchange.all_reduce(model.flat_gradients)
-        self.optimizer.launch(zero_grad=True)
+        self.optimizer.launch(zero_grad=True, device_scalars=False)
         return self._result(fw)
 
     def _replay(self, batch) -> Dict[str, torch.Tensor]:
