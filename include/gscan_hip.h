@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 1
+#define GSCAN_ABI_VERSION 2
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
 typedef struct gscan_dims {
@@ -73,6 +73,8 @@ typedef struct gscan_batch {
     const int32_t *cmd_lengths;  /* [B]  number of real tokens per command          */
     const float   *world;        /* [B,G,G,C]                                       */
     const int64_t *targets;      /* [B,T]                                           */
+    const int64_t *target_positions; /* [B] flat grid cell of the target object (gSCAN_dataset.py:216-219),
+                                      * or NULL; only the auxiliary loss of gscan_backward_nll reads it */
 } gscan_batch;
 
 /* Scaled dropout masks (0 or 1/(1-p)), or NULL for "no dropout" (eval mode / p = 0).
@@ -157,6 +159,17 @@ int gscan_loss_seeds(const float *stats, float weight_target_loss, int auxiliary
 int gscan_backward_seeded(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
                           const gscan_masks *masks, void *workspace, const float *dlogp, const float *daux_logp,
                           const float *seeds, const gscan_params *grads, void *stream);
+
+/* loss.backward() of the reference's training loss itself (train.py:102-110), with nothing launched between
+ * gscan_forward and this call:  loss = get_loss(logp, targets) [+ weight_target_loss * get_auxiliary_loss(aux_logp,
+ * target_positions) when dims->auxiliary]  (model.py:147-164).  gscan_forward leaves per-row partial sums of both
+ * losses in the workspace; the backward kernels start from them.  stats[4] = [sum NLL, live tokens, sum aux NLL,
+ * rows] and seeds[3] = [1/tokens, w/rows, loss] are written for the caller (device, must not be NULL).
+ * Single-process form: a data-parallel step has to all-reduce `stats` before seeding (gscan_step_losses,
+ * gscan_loss_seeds, gscan_backward_seeded). */
+int gscan_backward_nll(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                       const gscan_masks *masks, void *workspace, float weight_target_loss, float *stats,
+                       float *seeds, const gscan_params *grads, void *stream);
 
 /* Adam with the step-dependent scalars [lr_t / (1 - beta1^t), 1 / sqrt(1 - beta2^t)] read from device memory
  * (gscan_adam_scalars computes them on the host); zero_grad != 0 also clears the gradient buffer

@@ -10,7 +10,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _f32p = C.POINTER(C.c_float)
 _i64p = C.POINTER(C.c_int64)
@@ -53,7 +53,7 @@ class Params(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [("commands", C.c_void_p), ("cmd_lengths", C.c_void_p), ("world", C.c_void_p),
-                ("targets", C.c_void_p)]
+                ("targets", C.c_void_p), ("target_positions", C.c_void_p)]
 
 
 class Masks(C.Structure):
@@ -79,6 +79,8 @@ PROTOTYPES = {
     "gscan_dropout_mask": (_i, [_vp, _sz, _f, _u64, _u64, _vp]),
     "gscan_step_losses": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gscan_loss_seeds": (_i, [_vp, _f, _i, _vp, _vp]),
+    "gscan_backward_nll": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _f, _vp,
+                                _vp, C.POINTER(Params), _vp]),
     "gscan_backward_seeded": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp,
                                    _vp, _vp, C.POINTER(Params), _vp]),
     "gscan_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _vp, _i, _vp]),

@@ -59,8 +59,9 @@ int gscan_backward(const gscan_dims *dims, const gscan_params *params, const gsc
                    const gscan_params *grads, void *stream) {
     ARG(dims && params && batch && workspace && grads, "backward: NULL argument");
     gscan_masks none{nullptr, nullptr, nullptr};
+    ARG(dlogp, "backward: dlogp is NULL");
     return step_backward(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, dlogp, daux_logp, nullptr,
-                         *grads, (hipStream_t)stream);
+                         nullptr, *grads, (hipStream_t)stream);
 }
 
 int gscan_backward_seeded(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
@@ -68,8 +69,20 @@ int gscan_backward_seeded(const gscan_dims *dims, const gscan_params *params, co
                           const float *seeds, const gscan_params *grads, void *stream) {
     ARG(dims && params && batch && workspace && grads, "backward: NULL argument");
     gscan_masks none{nullptr, nullptr, nullptr};
+    ARG(dlogp, "backward: dlogp is NULL");
     return step_backward(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, dlogp, daux_logp, seeds,
-                         *grads, (hipStream_t)stream);
+                         nullptr, *grads, (hipStream_t)stream);
+}
+
+int gscan_backward_nll(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                       const gscan_masks *masks, void *workspace, float weight_target_loss, float *stats,
+                       float *seeds, const gscan_params *grads, void *stream) {
+    ARG(dims && params && batch && workspace && grads && stats && seeds, "backward_nll: NULL argument");
+    ARG(!dims->auxiliary || batch->target_positions, "backward_nll: auxiliary task set but target_positions is NULL");
+    gscan_masks none{nullptr, nullptr, nullptr};
+    const NllSeed nll{weight_target_loss, stats, seeds};
+    return step_backward(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, nullptr, nullptr, nullptr,
+                         &nll, *grads, (hipStream_t)stream);
 }
 
 int gscan_step_losses(const float *logp, const int64_t *targets, const float *aux_logp, const int64_t *positions, int B,

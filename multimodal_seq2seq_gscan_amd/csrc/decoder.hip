@@ -190,7 +190,7 @@ __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bo
     o.vec = p;
     p += (backward ? 7 * HP + 15 * H : 2 * HP + 14 * H + 4 * kPartStride) + 256;
     // scratch of the fused output head, overlaid on the memories (forward: after the loop; backward: before staging)
-    const int head = backward ? kHeadChunk * (V + H + 4) + V * H : kHeadChunk * (5 * H + 4 + V) + V * H;
+    const int head = backward ? kHeadChunk * (V + H + 4) + V * H + 32 : kHeadChunk * (5 * H + 4 + V) + V * H;
     o.total = p > head ? p : head;
     return o;
 }
@@ -420,6 +420,13 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
                 a.aux_saved[(int64_t)b * M + lane] = x - lse;
                 a.aux_out[(int64_t)b * M + lane] = x - lse;
             }
+            if (a.row_stats) {                               // get_auxiliary_loss (model.py:162-164), this row's term
+                const int64_t pos = a.positions ? a.positions[b] : (int64_t)-1;
+                const float nll = wave_sum((lane < M && lane == pos) ? lse - x : 0.f);
+                if (lane == 0) a.row_stats[4 * b + 2] = nll;
+            }
+        } else if (a.row_stats && lane == 0) {
+            a.row_stats[4 * b + 2] = 0.f;
         }
     }
     if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_acc[tid];
@@ -441,6 +448,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             for (int i = 0; i < H; ++i) bw[i] = a.head_image[i * kDecThreads + tid];
         }
         for (int i = tid; i < V * H; i += kDecThreads) wh_s[i] = a.w_h2o[i];
+        float nll_acc = 0.f, cnt_acc = 0.f;                  // threads < kHeadChunk (all in wave 0): get_loss terms
         for (int t0 = 0; t0 < T; t0 += kHeadChunk) {
             const int n = min(kHeadChunk, T - t0);
             const unsigned bt0 = (unsigned)b * T + t0;
@@ -493,6 +501,22 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
                     a.logp_saved[(bt0 + tid) * V + j] = y;
                     a.logp_out[(bt0 + tid) * V + j] = y;
                 }
+                if (a.row_stats) {
+                    // the target of position t is token t+1, literal 0 after the last one (model.py:108-115);
+                    // pad targets are ignored (nn.NLLLoss(ignore_index=pad), model.py:100)
+                    const int t = t0 + tid;
+                    const int64_t tgt = (t + 1 < T) ? a.targets[(int64_t)b * T + t + 1] : (int64_t)0;
+                    if (tgt != a.pad_tgt && tgt >= 0 && tgt < V) { nll_acc += lse - row[tgt]; cnt_acc += 1.f; }
+                }
+            }
+        }
+        if (a.row_stats && wave == 0) {
+            nll_acc = wave_sum(nll_acc);
+            cnt_acc = wave_sum(cnt_acc);
+            if (lane == 0) {
+                a.row_stats[4 * b + 0] = nll_acc;
+                a.row_stats[4 * b + 1] = cnt_acc;
+                a.row_stats[4 * b + 3] = 1.f;
             }
         }
     }
@@ -605,6 +629,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
 
+    float aux_scale = (a.seeds && a.daux) ? a.seeds[1] : 1.f;
     // ---- backward of the output head for the row's T steps (log_softmax, hidden_to_output, output_to_hidden):
     //      dlogits_t = seed * (dlogp_t - exp(logp_t) sum dlogp_t), dpreo_t = W_h2o^T dlogits_t, and
     //      dS = dpreo . wo_perm ([T,H] x [H,4H]) on the matrix cores: wave w owns column tiles w, w+8, ... and keeps
@@ -622,18 +647,52 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             for (int i = 0; i < KS; ++i) bw[r][i] = (nt < NTB) ? a.wo_perm[(4 * i + fg) * 4 * H + 16 * nt + fr] : 0.f;
         }
         for (int i = tid; i < V * H; i += kDecThreads) wh_s[i] = a.w_h2o[i];
-        const float sc = a.seeds ? a.seeds[0] : 1.f;
+        float sc = a.seeds ? a.seeds[0] : 1.f;
+        if (a.nll_mode) {
+            // the loss is mean-over-live-tokens NLL (+ w * mean-over-rows auxiliary NLL): every workgroup sums the
+            // per-row partials of the forward pass in the same fixed order and seeds its row with 1/tokens, w/rows
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+            for (int r = tid; r < a.B; r += kDecThreads) {
+                const float4 x = *reinterpret_cast<const float4 *>(a.row_stats + 4 * r);
+                p0 += x.x; p1 += x.y; p2 += x.z;
+            }
+            p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+            float *red = wh_s + V * H;
+            if (lane == 0) { red[3 * wave] = p0; red[3 * wave + 1] = p1; red[3 * wave + 2] = p2; }
+            lds_barrier();
+            p0 = p1 = p2 = 0.f;
+            for (int i = 0; i < kDecThreads / 64; ++i) { p0 += red[3 * i]; p1 += red[3 * i + 1]; p2 += red[3 * i + 2]; }
+            sc = 1.f / p1;
+            aux_scale = a.aux_saved ? a.w_aux / (float)a.B : 0.f;
+            if (b == 0 && tid == 0) {
+                a.stats_out[0] = p0; a.stats_out[1] = p1; a.stats_out[2] = p2; a.stats_out[3] = (float)a.B;
+                a.seeds_out[0] = sc; a.seeds_out[1] = aux_scale;
+                a.seeds_out[2] = p0 * sc + p2 * aux_scale;
+            }
+        }
         for (int t0 = 0; t0 < T; t0 += kHeadChunk) {
             const int n = min(kHeadChunk, T - t0);
             const unsigned bt0 = (unsigned)b * T + t0;
             if (tid < n) {
-                const float *y = a.logp_saved + (bt0 + tid) * V, *dy = a.dlogp + (bt0 + tid) * V;
-                float sum = 0.f;
-                for (int j = 0; j < V; ++j) sum += dy[j];
-                for (int j = 0; j < V; ++j) {
-                    const float dl = sc * (dy[j] - expf(y[j]) * sum);
-                    dl_ch[tid * V + j] = dl;
-                    a.dlogits[(bt0 + tid) * V + j] = dl;
+                const float *y = a.logp_saved + (bt0 + tid) * V;
+                if (a.nll_mode) {                            // d(sum NLL)/d(logp) is -1 at the live target
+                    const int t = t0 + tid;
+                    const int64_t tgt = (t + 1 < T) ? a.targets[(int64_t)b * T + t + 1] : (int64_t)0;
+                    const bool live = tgt != a.pad_tgt && tgt >= 0 && tgt < V;
+                    for (int j = 0; j < V; ++j) {
+                        const float dl = live ? sc * (expf(y[j]) - (j == tgt ? 1.f : 0.f)) : 0.f;
+                        dl_ch[tid * V + j] = dl;
+                        a.dlogits[(bt0 + tid) * V + j] = dl;
+                    }
+                } else {
+                    const float *dy = a.dlogp + (bt0 + tid) * V;
+                    float sum = 0.f;
+                    for (int j = 0; j < V; ++j) sum += dy[j];
+                    for (int j = 0; j < V; ++j) {
+                        const float dl = sc * (dy[j] - expf(y[j]) * sum);
+                        dl_ch[tid * V + j] = dl;
+                        a.dlogits[(bt0 + tid) * V + j] = dl;
+                    }
                 }
             }
             lds_barrier();
@@ -686,11 +745,17 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     if (tid < H) { vt_s[tid] = a.v_t[tid]; vv_s[tid] = a.v_v[tid]; }
     if (tid < 64) {       // auxiliary head backward: d att_sum = seed1 * (daux - exp(aux_logp) sum daux)  (model.py:205)
         float da = 0.f;
-        if (a.daux) {
-            const float dy = (tid < M) ? a.daux[(int64_t)b * M + tid] : 0.f;
+        if (a.nll_mode ? (a.aux_saved != nullptr) : (a.daux != nullptr)) {
+            float dy;
+            if (a.nll_mode) {
+                const int64_t pos = a.positions ? a.positions[b] : (int64_t)-1;
+                dy = (tid < M && tid == pos) ? -1.f : 0.f;
+            } else {
+                dy = (tid < M) ? a.daux[(int64_t)b * M + tid] : 0.f;
+            }
             const float sum = wave_sum(dy);
             const float y = (tid < M) ? a.aux_saved[(int64_t)b * M + tid] : 0.f;
-            da = (tid < M) ? (a.seeds ? a.seeds[1] : 1.f) * (dy - expf(y) * sum) : 0.f;
+            da = (tid < M) ? aux_scale * (dy - expf(y) * sum) : 0.f;
         }
         datt_s[tid] = da;
     }

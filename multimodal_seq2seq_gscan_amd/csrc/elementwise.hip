@@ -439,25 +439,30 @@ struct ToeplitzArgs {
 };
 __device__ __forceinline__ int conv_kernel_size(int i, int K3) { return i == 0 ? 1 : (i == 1 ? 5 : K3); }
 
-// grid (G*G output cells, G*G*C + 1): one (row j of Wt, output cell) pair per block, so the cell / channel / tap
-// arithmetic is block-uniform and a thread only selects its feature f; the extra last row of blocks writes the
-// replicated bias
+// grid (G*G*C + 1, 4): row j of Wt per blockIdx.x (its cell / channel are block-uniform), a quarter of the output
+// cells per blockIdx.y, a thread per feature f; the extra last row writes the replicated bias.  All index
+// arithmetic that involves a division is block- or loop-uniform (scalar): the kernel is a pure store stream.
 __global__ void toeplitz_build_kernel(ToeplitzArgs a, float *__restrict__ wt, float *__restrict__ bias_rep) {
     const int G = a.G, C = a.C, Co = a.Co, F = 3 * Co, N = G * G * F, J = G * G * C;
-    const int pos = blockIdx.x, j = blockIdx.y;
-    const int r = pos / G, c = pos - r * G;
+    const int j = blockIdx.x;
     const int cell = j / C, ch = j - cell * C, r2 = cell / G, c2 = cell - r2 * G;
+    const int per = (G * G + gridDim.y - 1) / gridDim.y, pos0 = blockIdx.y * per, pos1 = min(G * G, pos0 + per);
     for (int f = threadIdx.x; f < F; f += blockDim.x) {
         const int i = (f >= Co) + (f >= 2 * Co), o = f - i * Co;
         if (j == J) {                                         // bias replicated over the G*G positions
-            bias_rep[pos * F + f] = a.b[i][o];
+            const float bv = a.b[i][o];
+            for (int pos = pos0; pos < pos1; ++pos) bias_rep[pos * F + f] = bv;
             continue;
         }
         const int k = conv_kernel_size(i, a.K3), p = k / 2;
-        const int kw = r2 - r + p, kh = c2 - c + p;
-        float v = 0.f;
-        if (kw >= 0 && kw < k && kh >= 0 && kh < k) v = a.w[i][((o * C + ch) * k + kh) * k + kw];
-        wt[(int64_t)j * N + pos * F + f] = v;
+        const float *wrow = a.w[i] + (o * C + ch) * k * k;
+        float *dst = wt + (int64_t)j * N + f;
+        int r = pos0 / G, c = pos0 - r * G;
+        for (int pos = pos0; pos < pos1; ++pos) {
+            const int kw = r2 - r + p, kh = c2 - c + p;
+            dst[pos * F] = (kw >= 0 && kw < k && kh >= 0 && kh < k) ? wrow[kh * k + kw] : 0.f;
+            if (++c == G) { c = 0; ++r; }
+        }
     }
 }
 
@@ -465,8 +470,8 @@ int toeplitz_build(const float *const (&w)[3], const float *const (&b)[3], int G
                    float *bias_rep, hipStream_t stream) {
     ToeplitzArgs a{{w[0], w[1], w[2]}, {b[0], b[1], b[2]}, G, C, Co, K3};
     const int F = 3 * Co, J = G * G * C;
-    hipLaunchKernelGGL(toeplitz_build_kernel, dim3(G * G, J + 1), dim3(std::min(256, cdiv(F, 64) * 64)), 0, stream, a,
-                       wt, bias_rep);
+    hipLaunchKernelGGL(toeplitz_build_kernel, dim3(J + 1, 4), dim3(std::min(256, cdiv(F, 64) * 64)), 0, stream, a, wt,
+                       bias_rep);
     GSCAN_LAUNCHED("toeplitz_build_kernel");
     return 0;
 }

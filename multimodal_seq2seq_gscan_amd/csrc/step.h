@@ -135,6 +135,13 @@ struct DecoderArgs {
     const float *dlogp, *daux, *seeds; // incoming gradients ([B,T,V], [B,M] or NULL) and optional device scales [2]
     float *dlogits, *dpreo;            // [B,T,V] [B,T,H] saved for the head's weight gradients
     float *ds;                         // [B,T,4H] head gradient wrt [e | ctx_text | ctx_vis | h_t] (written first)
+    // fused training loss (model.py:147-164): forward leaves per-row partial sums, backward starts from them
+    const int64_t *targets, *positions;   // [B,T]; [B] or NULL
+    int pad_tgt, B;
+    float *row_stats;                  // [B,4] = [sum NLL, live tokens, aux NLL, 1] of the row, or NULL
+    int nll_mode;                      // backward: seed from row_stats / targets instead of dlogp / daux / seeds
+    float w_aux;                       // weight of the auxiliary loss (train.py:105-107)
+    float *stats_out, *seeds_out;      // [4] batch sums, [3] = [1/tokens, w/rows, loss]; written by workgroup 0
     float *delta, *dqt, *dqv;          // [B,T,5H] = [gate deltas (4H) | dzq (H)], [B,T,H], [B,T,H]
     float *dpk_t, *dpk_v;              // [B,L,H] [B,M,H]  score-path key gradients
     float *dv_t, *dv_v;                // [H] energy-vector gradients, accumulated with atomics
@@ -162,7 +169,7 @@ int probe_read(const char *name, double *total_ms, double *flops, int64_t *launc
 struct WorkspaceSlot { const char *name; int64_t offset, count; };
 struct Workspace {
     int64_t xcol, feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
-        ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, dlogits, dpreo,
+        ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, row_stats, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
         wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, wt, dwt, bias_rep, wcat5;
     WorkspaceSlot slot[96];
@@ -173,7 +180,9 @@ int check_dims(const gscan_dims &d);
 int workspace_layout(const gscan_dims &d, Workspace *ws);
 int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                  float *logp, float *aux_logp, hipStream_t st);
+struct NllSeed { float w_aux; float *stats_out, *seeds_out; };   // backward of the training loss itself
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
-                  const float *dlogp, const float *daux, const float *seeds, const gscan_params &g, hipStream_t st);
+                  const float *dlogp, const float *daux, const float *seeds, const NllSeed *nll, const gscan_params &g,
+                  hipStream_t st);
 
 }  // namespace gscan

@@ -74,6 +74,7 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(logits, B * T * V);
     SLOT(logp_saved, B * T * V);
     SLOT(aux_saved, B * M);
+    SLOT(row_stats, B * 4);                          // per-row [sum NLL, live tokens, aux NLL, 1]
     // backward scratch
     SLOT(dlogits, B * T * V);
     SLOT(dpreo, B * T * H);
@@ -152,6 +153,8 @@ static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, cons
     a.V = d.V; a.head_image = w + ws.dec_w_head; a.wo_perm = w + ws.wo_perm; a.w_h2o = p.hid2out_w;
     a.preo = w + ws.preo; a.logits = w + ws.logits; a.logp_saved = w + ws.logp_saved;
     a.aux_saved = d.auxiliary ? w + ws.aux_saved : nullptr;
+    a.targets = bt.targets; a.positions = d.auxiliary ? bt.target_positions : nullptr;
+    a.pad_tgt = d.pad_tgt; a.B = d.B; a.row_stats = w + ws.row_stats;
     return a;
 }
 
@@ -174,11 +177,12 @@ static SideStream g_side;
 
 static int side_init() {
     if (g_side.ready) return 0;
-    // lowest priority: when both have work ready, the chain on the caller's stream gets the CUs first
+    // highest priority: the leaves these streams carry end the step (the optimiser waits for the last of them),
+    // measured 0.5% faster than lowest priority
     int prio_least = 0, prio_greatest = 0;
     GSCAN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, prio_least));
-    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream2, hipStreamNonBlocking, prio_least));
+    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, prio_greatest));
+    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream2, hipStreamNonBlocking, prio_greatest));
     for (auto &e : g_side.ev) GSCAN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     g_side.ready = true;
     return 0;
@@ -300,7 +304,8 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
 // gradient product + fold on its own stream: it is long and nothing but the optimiser waits for it)
 // --------------------------------------------------------------------------------------
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
-                  const float *dlogp, const float *daux, const float *seeds, const gscan_params &g, hipStream_t st) {
+                  const float *dlogp, const float *daux, const float *seeds, const NllSeed *nll, const gscan_params &g,
+                  hipStream_t st) {
     TRY(check_dims(d));
     Workspace ws;
     TRY(workspace_layout(d, &ws));
@@ -308,7 +313,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
               V = d.V, D = d.bidirectional ? 2 : 1;
     const int BT = B * T, BL = B * L, BM_ = B * M;
     const bool cond = d.conditional != 0;
-    GSCAN_CHECK(dlogp, "backward: dlogp is NULL");
+    GSCAN_CHECK(dlogp || nll, "backward: dlogp is NULL");
     TRY(side_init());
     hipStream_t sd = g_side.stream, sd2 = g_side.stream2;
     float *S = w + ws.S, *dS = w + ws.dS;
@@ -320,6 +325,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     const bool use_aux = d.auxiliary && daux;
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.dlogp = dlogp; a.daux = use_aux ? daux : nullptr; a.seeds = seeds;
+    if (nll) { a.nll_mode = 1; a.w_aux = nll->w_aux; a.stats_out = nll->stats_out; a.seeds_out = nll->seeds_out; }
     a.dlogits = w + ws.dlogits; a.dpreo = w + ws.dpreo; a.ds = dS;
     a.delta = w + ws.delta; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
     a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = g.txt_energy_w; a.dv_v = g.vis_energy_w;

@@ -340,7 +340,7 @@ class Model(nn.Module):
             raise RuntimeError("Model.forward runs on the HIP device only: move the model and the batch to "
                                "'cuda' (there is no CPU fallback in this package)")
 
-    def _launch_forward(self, commands, lengths, world, targets, masks):
+    def _launch_forward(self, commands, lengths, world, targets, masks, positions=None):
         lib = _lib.load()
         self._require_device(commands, world, targets)
         B, L = commands.shape
@@ -358,7 +358,10 @@ class Model(nn.Module):
         commands = commands.contiguous()
         targets = targets.contiguous()
         world = world.to(torch.float32).contiguous()
-        batch = _lib.Batch(commands.data_ptr(), lengths.data_ptr(), world.data_ptr(), targets.data_ptr())
+        if positions is not None:
+            positions = positions.view(-1).contiguous()
+        batch = _lib.Batch(commands.data_ptr(), lengths.data_ptr(), world.data_ptr(), targets.data_ptr(),
+                           _lib.ptr(positions))
         mstruct = _lib.Masks(*[_lib.ptr(m) for m in masks])
         logp = torch.empty(B, T, self._hyper["V"], dtype=torch.float32, device=commands.device)
         aux = torch.empty(B, G * G, dtype=torch.float32, device=commands.device) if self.auxiliary_task else None
@@ -367,7 +370,7 @@ class Model(nn.Module):
                                      torch.cuda.current_stream().cuda_stream), "gscan_forward")
         self._generation += 1
         call = dict(dims=dims, batch=batch, masks=mstruct, generation=self._generation,
-                    keep=(commands, lengths, world, targets, masks))
+                    keep=(commands, lengths, world, targets, masks, positions))
         if aux is None:
             if self._dummy_aux is None or self._dummy_aux.device != commands.device:
                 self._dummy_aux = torch.zeros(1, device=commands.device)
@@ -389,6 +392,19 @@ class Model(nn.Module):
                                              self._workspace.data_ptr(), dlogp.data_ptr(), _lib.ptr(daux),
                                              _lib.ptr(seeds), C.byref(self._grad_struct),
                                              torch.cuda.current_stream().cuda_stream), "gscan_backward_seeded")
+
+    def _launch_backward_nll(self, call, weight_target_loss: float, stats: torch.Tensor, seeds: torch.Tensor) -> None:
+        """loss.backward() of the training loss itself (train.py:102-110): seeded inside the backward kernels from
+        the per-row loss partials the forward pass left in the workspace; fills stats[4] and seeds[3]."""
+        lib = _lib.load()
+        if call["generation"] != self._generation:
+            raise RuntimeError("backward() after another forward(): the saved activations were overwritten "
+                               "(one in-flight step per model, as in the reference's training loop)")
+        _lib.check(lib.gscan_backward_nll(C.byref(call["dims"]), C.byref(self._param_struct), C.byref(call["batch"]),
+                                          C.byref(call["masks"]), self._workspace.data_ptr(),
+                                          float(weight_target_loss), stats.data_ptr(), seeds.data_ptr(),
+                                          C.byref(self._grad_struct), torch.cuda.current_stream().cuda_stream),
+                   "gscan_backward_nll")
 
     def workspace_view(self, call_dims: _lib.Dims, name: str) -> torch.Tensor:
         """A saved activation of the last forward/backward as a flat fp32 tensor (tests, debugging)."""

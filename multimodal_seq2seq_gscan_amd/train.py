@@ -143,12 +143,18 @@ class TrainStep:
 
     def __init__(self, model: Model, learning_rate: float = 1e-3, adam_beta_1: float = 0.9,
                  adam_beta_2: float = 0.999, lr_decay: float = 0.9, lr_decay_steps: float = 20000.0,
-                 weight_target_loss: float = 0.3, process_group=None, graph: bool = False, **_):
+                 weight_target_loss: float = 0.3, process_group=None, graph: bool = False,
+                 fused_loss: Optional[bool] = None, **_):
         self.model = model
         self.optimizer = FlatAdam(model, learning_rate, adam_beta_1, adam_beta_2, lr_decay, lr_decay_steps)
         self.weight_target_loss = float(weight_target_loss)
         self.exchange = GradientExchange(process_group)
         self.graph = bool(graph)
+        # A single process needs no statistics exchange between forward and backward: the backward kernels seed
+        # themselves from the loss partials of the forward pass (gscan_backward_nll), two launches fewer.
+        self.fused_loss = (self.exchange.world_size == 1) if fused_loss is None else bool(fused_loss)
+        if self.fused_loss and self.exchange.world_size > 1:
+            raise ValueError("fused_loss needs the global token count: not available with more than one process")
         device = model.flat_parameters.device
         self.stats = torch.zeros(4, dtype=torch.float32, device=device)
         self.seeds = torch.zeros(3, dtype=torch.float32, device=device)
@@ -169,7 +175,10 @@ class TrainStep:
         B, L = commands.shape
         T = targets.shape[1]
         masks = model._draw_masks(B, L, T, world.shape[1] ** 2, commands.device)
-        logp, aux, call = model._launch_forward(commands, batch["cmd_lengths"], world, targets, masks)
+        pos = batch["target_positions"] if model.auxiliary_task else None
+        logp, aux, call = model._launch_forward(commands, batch["cmd_lengths"], world, targets, masks, pos)
+        if self.fused_loss:
+            return {"logp": logp, "aux": aux, "call": call}
         dlogp = torch.empty_like(logp)
         daux = torch.empty_like(aux) if model.auxiliary_task else None
         pos = batch["target_positions"].view(-1).contiguous() if model.auxiliary_task else None
@@ -182,6 +191,9 @@ class TrainStep:
 
     def _section_backward(self, fw: dict) -> None:
         lib = _lib.load()
+        if self.fused_loss:
+            self.model._launch_backward_nll(fw["call"], self.weight_target_loss, self.stats, self.seeds)
+            return
         _lib.check(lib.gscan_loss_seeds(self.stats.data_ptr(), self.weight_target_loss,
                                         int(self.model.auxiliary_task), self.seeds.data_ptr(),
                                         torch.cuda.current_stream().cuda_stream), "gscan_loss_seeds")

@@ -219,3 +219,30 @@ def test_train_step_matches_reference_adam_steps():
         for n, p in model.named_parameters():
             assert torch.allclose(p.detach().cpu(), torch.from_numpy(fx["param/" + n]), atol=1e-5, rtol=0), (graph, n)
         assert model.trained_iterations == 3
+
+
+@pytest.mark.parametrize("auxiliary", [False, True])
+def test_fused_loss_backward_matches_two_phase_path(auxiliary):
+    """gscan_backward_nll (loss seeded inside the backward kernels, the single-process TrainStep) against the
+    statistics -> seeds -> gscan_backward_seeded sequence a data-parallel step uses: same loss, token count and
+    gradients (the two differ only in the order the per-row loss terms are summed)."""
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+    from multimodal_seq2seq_gscan_amd.train import TrainStep
+    cfg = model_kwargs("demo", auxiliary_task=auxiliary)
+    shape = Shape(batch=6, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=7, max_target=10,
+                  ragged=True)
+    batch = {k: v.cuda() for k, v in make_batch(shape, 321).items()}
+    results = []
+    for fused in (False, True):
+        model = build_model(cfg, fixture_params(cfg, {"seed_weights": 5}))
+        model._dropout_seed = 99
+        step = TrainStep(model, learning_rate=0.0, fused_loss=fused)      # lr 0: Adam leaves the parameters alone
+        fw = step._section_forward(dict(batch, cmd_lengths=batch["cmd_lengths"].to(torch.int32)))
+        step._section_backward(fw)
+        torch.cuda.synchronize()
+        results.append((step.seeds.cpu().clone(), step.stats.cpu().clone(), model.flat_gradients.cpu().clone()))
+    (s0, t0, g0), (s1, t1, g1) = results
+    assert torch.allclose(s0, s1, atol=1e-6, rtol=1e-5), (s0, s1)
+    assert torch.allclose(t0, t1, atol=1e-4, rtol=1e-5), (t0, t1)
+    assert t1[1].item() > 0 and g1.abs().max().item() > 0
+    assert torch.allclose(g0, g1, atol=1e-6, rtol=1e-4), (g0 - g1).abs().max().item()

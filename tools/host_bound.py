@@ -1,0 +1,29 @@
+"""Diagnostic: is the eager training step limited by the host (Python + launch calls) or by the GPU?
+Prints the host time to ISSUE K steps and the time until the GPU has finished them."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodal_seq2seq_gscan_amd.config import model_kwargs
+from multimodal_seq2seq_gscan_amd.model import Model
+from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+from multimodal_seq2seq_gscan_amd.train import TrainStep
+
+cfg = model_kwargs("compositional")
+shape = Shape(batch=256, grid=6, channels=16, input_vocab=cfg["input_vocabulary_size"],
+              target_vocab=cfg["target_vocabulary_size"], max_command=10, max_target=20, ragged=False)
+torch.manual_seed(42)
+model = Model(**cfg).cuda()
+batch = {k: v.cuda() for k, v in make_batch(shape, seed=1234).items()}
+batch["cmd_lengths"] = batch["cmd_lengths"].to(torch.int32)
+step = TrainStep(model, learning_rate=1e-3, graph="--graph" in sys.argv)
+for _ in range(10):
+    step(batch)
+torch.cuda.synchronize()
+K = 100
+t0 = time.perf_counter()
+for _ in range(K):
+    step(batch)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"issue {1e3 * (t1 - t0) / K:.4f} ms/step   complete {1e3 * (t2 - t0) / K:.4f} ms/step")
