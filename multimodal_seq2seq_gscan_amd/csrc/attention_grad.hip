@@ -1,0 +1,186 @@
+// Backward of the two attention memories once the decoder's reverse recurrence has produced the per-step
+// gradients, ONE WORKGROUP PER BATCH ROW, all products on the matrix cores:
+//   value path  dPK[m,:] += sum_t alpha[t,m] * dctx[t,:]            (context = alpha . PK, seq2seq_model.py:138-139)
+//   key layers  d enc_out = dPK_text . W_key_text                   (seq2seq_model.py:468-469)
+//               d feat    = (dPK_vis . W_key_vis) * dropout mask, zero where ReLU was inactive
+//                                                                    (seq2seq_model.py:466-467, cnn_model.py:33-35)
+//   bridge      d h_N     = d h0 . W_bridge                          (model.py:195)
+// A row's memories are small (L + G*G <= 128 keys of H floats): its dPK stays in LDS between the two stages, so the
+// chain "value path -> key layers" is one launch instead of a batched reduction plus a grouped GEMM with an HBM
+// round trip in between.  The totals dPK_text / dPK_vis are also written out: the key-layer weight gradients
+// are dense products over them (leaves of the step's schedule).
+#include "step.h"
+
+namespace gscan {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kKbThreads = 512, kKbWaves = kKbThreads / 64, kKbSteps = 32, kKbMaxTiles = 8;
+
+struct KeysLds { int dpk, al, dc, dh, total; };
+__host__ __device__ inline KeysLds keys_lds(int H, int L, int M) {
+    const int HS = (H % 8 == 4) ? H : H + 4, MT = (M + 15) / 16 + (L + 15) / 16;
+    KeysLds o;
+    int p = 0;
+    o.dpk = p; p += MT * 16 * HS;
+    o.al = p;  p += kKbSteps * MT * 16;
+    o.dc = p;  p += kKbSteps * 2 * H;
+    o.dh = p;  p += (H + 3) / 4 * 4;
+    o.total = p;
+    return o;
+}
+
+template <int H>
+__global__ __launch_bounds__(kKbThreads) void keys_backward_kernel(KeysBackwardArgs a) {
+    constexpr int HS = (H % 8 == 4) ? H : H + 4;      // dPK row stride: the 16 rows of an A fragment hit distinct banks
+    constexpr int NTH = (H + 15) / 16, KS = H / 4;
+    static_assert(NTH <= kKbMaxTiles && H % 4 == 0, "hidden size not supported");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int T = a.T, L = a.L, M = a.M;
+    const int MTV = (M + 15) / 16, MTT = (L + 15) / 16, MT = MTV + MTT, AS = MT * 16;
+    const KeysLds o = keys_lds(H, L, M);
+    float *dpk_s = sm + o.dpk, *al_s = sm + o.al, *dc_s = sm + o.dc, *dh_s = sm + o.dh;
+
+    // ---- stage 1: dPK = (score path, from the decoder kernel) + alpha^T . dctx, tiles of 16 memories x 16 features.
+    //      Memory tiles: the first MTV cover the grid cells, the rest the command tokens (both zero-padded to 16).
+    const int ntiles = MT * NTH;
+    f32x4 acc[kKbMaxTiles];
+#pragma unroll
+    for (int i = 0; i < kKbMaxTiles; ++i) {
+        const int tile = wave + kKbWaves * i;
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tile < ntiles) {
+            const int mt = tile / NTH, nt = tile - mt * NTH, k = 16 * nt + fr;
+            const bool vis = mt < MTV;
+            const int mx = vis ? M : L, m0 = 16 * (vis ? mt : mt - MTV) + 4 * fg;
+            const float *src = (vis ? a.dpk_v : a.dpk_t) + (int64_t)b * mx * H;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (m0 + r < mx && k < H) acc[i][r] = src[(m0 + r) * H + k];
+        }
+    }
+    if (tid < H) dh_s[tid] = a.dh0[(int64_t)b * H + tid];
+    for (int t0 = 0; t0 < T; t0 += kKbSteps) {
+        const int n = min(kKbSteps, T - t0);
+        const int64_t bt0 = (int64_t)b * T + t0;
+        for (int idx = tid; idx < kKbSteps * AS; idx += kKbThreads) {       // alpha, [step][padded memories]
+            const int t = idx / AS, c = idx - t * AS;
+            float v = 0.f;
+            if (t < n) {
+                if (c < MTV * 16) { if (c < M) v = a.alpha_s[(bt0 + t) * M + c]; }
+                else if (c - MTV * 16 < L) v = a.alpha_c[(bt0 + t) * L + c - MTV * 16];
+            }
+            al_s[idx] = v;
+        }
+        for (int idx = tid; idx < kKbSteps * 2 * H; idx += kKbThreads) {    // [step][dctx_text | dctx_vis]
+            const int t = idx / (2 * H), c = idx - t * 2 * H;
+            dc_s[idx] = (t < n) ? a.ds[(bt0 + t) * 4 * H + H + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kKbMaxTiles; ++i) {
+            const int tile = wave + kKbWaves * i;
+            if (tile < ntiles) {
+                const int mt = tile / NTH, nt = tile - mt * NTH;
+                const float *ap = al_s + fg * AS + 16 * mt + fr;                               // A(m, t) = alpha[t][m]
+                const float *bp = dc_s + fg * 2 * H + (mt < MTV ? H : 0) + min(16 * nt + fr, H - 1);   // B(t, k)
+#pragma unroll
+                for (int s = 0; s < kKbSteps / 4; ++s)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * AS], bp[4 * s * 2 * H], acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < kKbMaxTiles; ++i) {
+        const int tile = wave + kKbWaves * i;
+        if (tile < ntiles) {
+            const int mt = tile / NTH, nt = tile - mt * NTH, k = 16 * nt + fr;
+            const bool vis = mt < MTV;
+            const int mx = vis ? M : L, m0 = 16 * (vis ? mt : mt - MTV) + 4 * fg;
+            float *dst = (vis ? a.dpk_v : a.dpk_t) + (int64_t)b * mx * H;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k < H) {
+                    dpk_s[(16 * mt + 4 * fg + r) * HS + k] = acc[i][r];       // padded memories: exact zeros
+                    if (m0 + r < mx) dst[(m0 + r) * H + k] = acc[i][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2: through the key layers.  A job = one 16-column tile of d feat (F columns, MTV memory tiles) or
+    //      of d enc_out (He columns, MTT memory tiles); the job's B fragments (H/4 steps) are read once.
+    const int NTF = (a.F + 15) / 16, NTE = (a.He + 15) / 16;
+    for (int job = wave; job < NTF + NTE; job += kKbWaves) {
+        const bool vis = job < NTF;
+        const int nt = vis ? job : job - NTF, ncols = vis ? a.F : a.He, col = 16 * nt + fr;
+        const float *wsrc = vis ? a.w_kv : a.w_kt;
+        float bw[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bw[s] = (col < ncols) ? wsrc[(int64_t)(4 * s + fg) * ncols + col] : 0.f;
+        const int mt_lo = vis ? 0 : MTV, mt_hi = vis ? MTV : MT, mx = vis ? M : L;
+        for (int mt = mt_lo; mt < mt_hi; ++mt) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            const float *ap = dpk_s + (16 * mt + fr) * HS + fg;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], bw[s], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * (mt - mt_lo) + 4 * fg + r;
+                if (m < mx && col < ncols) {
+                    const int64_t at = ((int64_t)b * mx + m) * ncols + col;
+                    if (vis) {       // feat = relu(conv) * mask  =>  d conv = (feat != 0) ? d feat * mask : 0
+                        float v = c[r];
+                        if (a.feat[at] == 0.f) v = 0.f;
+                        else if (a.mask) v *= a.mask[at];
+                        a.dfeat[at] = v;
+                    } else {
+                        a.denc[at] = c[r];
+                    }
+                }
+            }
+        }
+    }
+    // ---- bridge: d h_N[e] = sum_k d h0[k] * W_bridge[k][e]
+    if (tid < a.He) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int k = 0; k + 1 < H; k += 2) {
+            s0 = fmaf(dh_s[k], a.w_b[(int64_t)k * a.He + tid], s0);
+            s1 = fmaf(dh_s[k + 1], a.w_b[(int64_t)(k + 1) * a.He + tid], s1);
+        }
+        a.dhN[(int64_t)b * a.He + tid] = s0 + s1;
+    }
+}
+
+template <int H>
+static int launch_keys_backward(int B, const KeysBackwardArgs &a, hipStream_t stream) {
+    const size_t bytes = (size_t)keys_lds(H, a.L, a.M).total * sizeof(float);
+    GSCAN_CHECK(bytes <= 160 * 1024, "keys backward: %zu bytes of LDS needed (L=%d cells=%d)", bytes, a.L, a.M);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GSCAN_HIP(hipFuncSetAttribute((const void *)keys_backward_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((keys_backward_kernel<H>), dim3(B), dim3(kKbThreads), bytes, stream, a);
+    GSCAN_LAUNCHED("keys_backward_kernel");
+    return 0;
+}
+
+int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream) {
+    GSCAN_CHECK(B > 0 && a.T > 0 && a.L > 0 && a.M > 0 && a.L <= 64 && a.M <= 64 && a.He > 0 && a.F > 0 && a.He <= 512,
+                "keys backward: bad dims B=%d T=%d L=%d cells=%d He=%d F=%d", B, a.T, a.L, a.M, a.He, a.F);
+    switch (H) {
+        case 20: return launch_keys_backward<20>(B, a, stream);
+        case 32: return launch_keys_backward<32>(B, a, stream);
+        case 64: return launch_keys_backward<64>(B, a, stream);
+        case 100: return launch_keys_backward<100>(B, a, stream);
+        default: break;
+    }
+    GSCAN_CHECK(false, "keys backward: decoder_hidden_size %d has no compiled kernel (20 32 64 100)", H);
+}
+
+}  // namespace gscan

@@ -170,64 +170,6 @@ int colsum_add(const float *x, int64_t ld, int rows, int N, float *out1, float *
 }
 
 // ------------------------------------------------------------------------------------------
-// Value-path gradient of additive attention (seq2seq_model.py:138, values = projected keys), both
-// attentions in one launch:   dkeys[b, m, :] += sum_t alpha[b, t, m] * dctx[b, t, :]
-// blockIdx.y = 0: textual (alpha_c [B,T,L], dctx = dS[:, H:2H]); 1: visual (alpha_s [B,T,M], dS[:, 2H:3H]).
-// One workgroup per (row, attention); alpha[b] and dctx[b] are staged in LDS in chunks of 32 steps.
-// ------------------------------------------------------------------------------------------
-constexpr int kAvgSteps = 32;
-__global__ void attn_value_grad_kernel(const float *__restrict__ alpha_c, const float *__restrict__ alpha_s,
-                                       const float *__restrict__ ds, int T, int L, int M, int H,
-                                       float *__restrict__ dpk_t, float *__restrict__ dpk_v) {
-    extern __shared__ float sm[];
-    const int b = blockIdx.x, which = blockIdx.y;
-    const int Mx = which ? M : L;
-    const float *alpha = (which ? alpha_s : alpha_c) + (int64_t)b * T * Mx;
-    const float *dctx = ds + (int64_t)b * T * 4 * H + (which ? 2 * H : H);
-    float *dkeys = (which ? dpk_v : dpk_t) + (int64_t)b * Mx * H;
-    float *al_s = sm, *dc_s = sm + kAvgSteps * Mx;
-    const int npair = Mx * H;
-    constexpr int kPerThread = 16;                   // pairs per thread (host checks Mx*H <= 16*blockDim)
-    float acc[kPerThread];
-#pragma unroll
-    for (int i = 0; i < kPerThread; ++i) acc[i] = 0.f;
-    for (int t0 = 0; t0 < T; t0 += kAvgSteps) {
-        const int nt = min(kAvgSteps, T - t0);
-        for (int i = threadIdx.x; i < nt * Mx; i += blockDim.x) al_s[i] = alpha[(int64_t)t0 * Mx + i];
-        for (int i = threadIdx.x; i < nt * H; i += blockDim.x)
-            dc_s[i] = dctx[(int64_t)(t0 + i / H) * 4 * H + i % H];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < kPerThread; ++i) {
-            const int idx = threadIdx.x + i * blockDim.x;
-            if (idx < npair) {
-                const int m = idx / H, k = idx % H;
-                float a = acc[i];
-                for (int t = 0; t < nt; ++t) a = fmaf(al_s[t * Mx + m], dc_s[t * H + k], a);
-                acc[i] = a;
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < kPerThread; ++i) {
-        const int idx = threadIdx.x + i * blockDim.x;
-        if (idx < npair) dkeys[idx] += acc[i];
-    }
-}
-
-int attn_value_grad(const float *alpha_c, const float *alpha_s, const float *ds, int B, int T, int L, int M, int H,
-                    float *dpk_t, float *dpk_v, hipStream_t stream) {
-    const int mx = std::max(L, M);
-    GSCAN_CHECK(mx * H <= 16 * 256, "attn_value_grad: %d x %d key elements per row exceed the kernel's tile", mx, H);
-    const size_t lds = (size_t)kAvgSteps * (mx + H) * sizeof(float);
-    hipLaunchKernelGGL(attn_value_grad_kernel, dim3(B, 2), dim3(256), lds, stream, alpha_c, alpha_s, ds, T, L, M, H,
-                       dpk_t, dpk_v);
-    GSCAN_LAUNCHED("attn_value_grad_kernel");
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
 // Fused Adam over the flat parameter buffer (torch.optim.Adam semantics, train.py:68,111).
 // ------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,

@@ -50,8 +50,6 @@ int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mas
 int relu_mask_backward(float *dfeat, const float *feat, const float *mask, int64_t n, hipStream_t stream);
 int vec_add(const float *a, const float *b, float *out, int n, hipStream_t stream);
 int colsum_add(const float *x, int64_t ld, int rows, int N, float *out1, float *out2, hipStream_t stream);
-int attn_value_grad(const float *alpha_c, const float *alpha_s, const float *ds, int B, int T, int L, int M, int H,
-                    float *dpk_t, float *dpk_v, hipStream_t stream);
 struct PrologueArgs {
     const float *b_ih, *b_hh, *w_o2h, *w_ih_f, *w_ih_r, *enc_emb, *dec_emb, *mask_enc, *mask_dec;
     const int64_t *commands, *targets;
@@ -151,6 +149,18 @@ struct DecoderArgs {
 bool decoder_hidden_supported(int h);
 size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward);
 int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
+
+// attention_grad.hip: value path of both attentions + key layers + bridge, one workgroup per batch row
+struct KeysBackwardArgs {
+    int T, L, M, He, F;
+    const float *alpha_c, *alpha_s, *ds;   // [B,T,L] [B,T,M] [B,T,4H] (columns H..3H = d ctx_text | d ctx_vis)
+    float *dpk_t, *dpk_v;                  // [B,L,H] [B,M,H]  in: score path, out: score + value path
+    const float *dh0;                      // [B,H]
+    const float *w_kt, *w_kv, *w_b;        // [H,He] [H,F] [H,He]
+    const float *feat, *mask;              // [B,M,F]; mask may be NULL
+    float *denc, *dhN, *dfeat;             // [B,L,He] [B,He] [B,M,F]
+};
+int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream);
 
 // probe.hip
 enum ProbeId { P_DECODER_FWD = 0, P_DECODER_BWD, P_ENCODER_FWD, P_ENCODER_BWD, P_GEMM, P_COUNT };

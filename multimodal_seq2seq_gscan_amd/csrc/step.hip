@@ -359,8 +359,17 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
                  0, nullptr, 1, st));
     TRY(order_after(sd, st));
     TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd));     // leaf
-    // value path of both attentions: dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]
-    TRY(attn_value_grad(w + ws.alpha_c, w + ws.alpha_s, dS, B, T, L, M, H, w + ws.dpk_t, w + ws.dpk_v, st));
+    {   // chain: value path of both attentions (dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]), then through the
+        // key layers and the bridge to the encoder outputs / final state / conv features — one launch, row per WG
+        KeysBackwardArgs k{};
+        k.T = T; k.L = L; k.M = M; k.He = He; k.F = F;
+        k.alpha_c = w + ws.alpha_c; k.alpha_s = w + ws.alpha_s; k.ds = dS;
+        k.dpk_t = w + ws.dpk_t; k.dpk_v = w + ws.dpk_v; k.dh0 = w + ws.dh0;
+        k.w_kt = p.txt_key_w; k.w_kv = p.vis_key_w; k.w_b = p.bridge_w;
+        k.feat = w + ws.feat; k.mask = mk.cnn;
+        k.denc = w + ws.denc; k.dhN = w + ws.dhN; k.dfeat = w + ws.dfeat;
+        TRY(keys_backward(B, H, k, st));
+    }
     TRY(order_after(sd, st));
     {   // leaves: key and bridge weights
         GemmBatch b;
@@ -368,15 +377,6 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         add_grad(b, H, He, B, w + ws.dh0, 1, H, w + ws.hN, He, 1, g.bridge_w, He, g.bridge_b);
         add_grad(b, H, F, BM_, w + ws.dpk_v, 1, H, w + ws.feat, F, 1, g.vis_key_w, F);
         TRY(b.launch(sd));
-    }
-    {   // chain: encoder outputs / final state / conv features
-        GemmBatch b;
-        b.add(BL, He, H, w + ws.dpk_t, H, 1, p.txt_key_w, He, 1, w + ws.denc, He);
-        b.add(B, He, H, w + ws.dh0, H, 1, p.bridge_w, He, 1, w + ws.dhN, He);
-        // d feat with the ReLU/dropout backward fused: feat = relu(x) * mask  =>  dx = (feat != 0) ? dfeat * mask : 0
-        b.add(BM_, F, H, w + ws.dpk_v, H, 1, p.vis_key_w, F, 1, w + ws.dfeat, F, 0.f, nullptr, 3, mk.cnn, 1, nullptr,
-              nullptr, w + ws.feat);
-        TRY(b.launch(st));
     }
     TRY(order_after(sd2, st));
     {   // leaf: d(Wt) = world^T . dfeat (K = B only: no split, no atomics), folded onto the conv kernels
