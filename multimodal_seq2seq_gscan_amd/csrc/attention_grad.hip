@@ -16,6 +16,7 @@ namespace gscan {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kKbThreads = 512, kKbWaves = kKbThreads / 64, kKbSteps = 32, kKbMaxTiles = 8;
+static_assert(kKbThreads == 16 * kKbSteps, "staging maps 16 lanes to a step");
 
 struct KeysLds { int dpk, al, dc, dh, total; };
 __host__ __device__ inline KeysLds keys_lds(int H, int L, int M) {
@@ -64,18 +65,36 @@ __global__ __launch_bounds__(kKbThreads) void keys_backward_kernel(KeysBackwardA
     for (int t0 = 0; t0 < T; t0 += kKbSteps) {
         const int n = min(kKbSteps, T - t0);
         const int64_t bt0 = (int64_t)b * T + t0;
-        for (int idx = tid; idx < kKbSteps * AS; idx += kKbThreads) {       // alpha, [step][padded memories]
-            const int t = idx / AS, c = idx - t * AS;
-            float v = 0.f;
-            if (t < n) {
-                if (c < MTV * 16) { if (c < M) v = a.alpha_s[(bt0 + t) * M + c]; }
-                else if (c - MTV * 16 < L) v = a.alpha_c[(bt0 + t) * L + c - MTV * 16];
+        {   // thread = (step t, 16 lanes across the row): no divisions, every load of a thread in flight at once
+            const int t = tid >> 4, q = tid & 15;
+            const bool live = t < n;
+            float av[kKbMaxTiles];
+#pragma unroll
+            for (int i = 0; i < kKbMaxTiles; ++i) {                         // alpha, [step][padded memories]
+                const int c = q + 16 * i;
+                av[i] = 0.f;
+                if (live && i < MT) {
+                    if (i < MTV) { if (c < M) av[i] = a.alpha_s[(bt0 + t) * M + c]; }
+                    else if (c - MTV * 16 < L) av[i] = a.alpha_c[(bt0 + t) * L + c - MTV * 16];
+                }
             }
-            al_s[idx] = v;
-        }
-        for (int idx = tid; idx < kKbSteps * 2 * H; idx += kKbThreads) {    // [step][dctx_text | dctx_vis]
-            const int t = idx / (2 * H), c = idx - t * 2 * H;
-            dc_s[idx] = (t < n) ? a.ds[(bt0 + t) * 4 * H + H + c] : 0.f;
+            constexpr int NQ = (2 * H / 4 + 15) / 16;                       // [step][dctx_text | dctx_vis], 16-byte loads
+            float4 dv[NQ];
+            const float4 *src4 = reinterpret_cast<const float4 *>(a.ds + (bt0 + (live ? t : 0)) * 4 * H + H);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int c4 = q + 16 * i;
+                dv[i] = float4{0.f, 0.f, 0.f, 0.f};
+                if (live && c4 < 2 * H / 4) dv[i] = src4[c4];
+            }
+#pragma unroll
+            for (int i = 0; i < kKbMaxTiles; ++i)
+                if (i < MT) al_s[t * AS + q + 16 * i] = av[i];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int c4 = q + 16 * i;
+                if (c4 < 2 * H / 4) *reinterpret_cast<float4 *>(dc_s + t * 2 * H + 4 * c4) = dv[i];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -146,12 +165,18 @@ __global__ __launch_bounds__(kKbThreads) void keys_backward_kernel(KeysBackwardA
     }
     // ---- bridge: d h_N[e] = sum_k d h0[k] * W_bridge[k][e]
     if (tid < a.He) {
-        float s0 = 0.f, s1 = 0.f;
-        for (int k = 0; k + 1 < H; k += 2) {
-            s0 = fmaf(dh_s[k], a.w_b[(int64_t)k * a.He + tid], s0);
-            s1 = fmaf(dh_s[k + 1], a.w_b[(int64_t)(k + 1) * a.He + tid], s1);
+        float wv[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) wv[k] = a.w_b[(int64_t)k * a.He + tid];   // all loads in flight
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+            s0 = fmaf(dh_s[k], wv[k], s0);
+            s1 = fmaf(dh_s[k + 1], wv[k + 1], s1);
+            s2 = fmaf(dh_s[k + 2], wv[k + 2], s2);
+            s3 = fmaf(dh_s[k + 3], wv[k + 3], s3);
         }
-        a.dhN[(int64_t)b * a.He + tid] = s0 + s1;
+        a.dhN[(int64_t)b * a.He + tid] = (s0 + s1) + (s2 + s3);
     }
 }
 

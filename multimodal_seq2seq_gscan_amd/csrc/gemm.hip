@@ -21,16 +21,22 @@ namespace gscan {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int TMW = 2, TNW = 2;  // MFMA tiles per wave along M / N
+constexpr int TNW = 2;           // MFMA tiles per wave along N; along M it is the kernel's template parameter TMW
 #ifndef GSCAN_GEMM_BK
 #define GSCAN_GEMM_BK 32
 #endif
-constexpr int BM = 2 * 16 * TMW, BN = 2 * 16 * TNW, BK = GSCAN_GEMM_BK;
+constexpr int BN = 2 * 16 * TNW, BK = GSCAN_GEMM_BK;
 constexpr int LDK = BK + 4;      // k-contiguous image [row][LDK]: 16-byte rows, b128 fragment reads 2-way at worst
-constexpr int LDR_A = BM + 4;    // row-contiguous image [k][LDR]: b64 reads of 2 adjacent rows, conflict-free
-constexpr int LDR_B = BN + 4;    // b64 reads of 2 adjacent columns, conflict-free
-constexpr int A_FLOATS = (BM * LDK > BK * LDR_A) ? BM * LDK : BK * LDR_A;
+constexpr int LDR_B = BN + 4;    // row-contiguous image [k][LDR]: b64 reads of 2 adjacent columns, conflict-free
 constexpr int B_FLOATS = (BN * LDK > BK * LDR_B) ? BN * LDK : BK * LDR_B;
+// Workgroup tile = (32 TMW) x 64 x 32.  TMW = 2 (64 rows) is the throughput shape; TMW = 1 (32 rows) doubles the
+// number of workgroups of a launch whose 64-row tiling would leave CUs with one or two resident workgroups and
+// nothing to hide a K round's load latency behind (most launches of the training step).
+template <int TMW> struct TileM {
+    static constexpr int BM = 2 * 16 * TMW;
+    static constexpr int LDR_A = BM + 4;   // row-contiguous image [k][LDR]
+    static constexpr int A_FLOATS = (BM * LDK > BK * LDR_A) ? BM * LDK : BK * LDR_A;
+};
 
 // Independent products are launched together as one grid ("grouped GEMM"): the step issues ~45 small
 // products, each of which alone cannot fill 256 CUs and costs a launch; workgroup -> (problem, tile, k-slice)
@@ -117,7 +123,9 @@ __device__ __forceinline__ void panel_store(float *lds, const float (&v)[ROWS * 
     }
 }
 
+template <int TMW>
 __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
+    constexpr int BM = TileM<TMW>::BM, LDR_A = TileM<TMW>::LDR_A, A_FLOATS = TileM<TMW>::A_FLOATS;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < kMaxGroup; ++i)
@@ -177,8 +185,12 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
         } else {                             // interleaved tiles: row = 2 fr + t
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const float2 x = *reinterpret_cast<const float2 *>(la + (8 * fg + s) * LDR_A + wm * 16 * TMW + 2 * fr);
-                af[0][s] = x.x; af[1][s] = x.y;
+                if constexpr (TMW == 2) {
+                    const float2 x = *reinterpret_cast<const float2 *>(la + (8 * fg + s) * LDR_A + wm * 32 + 2 * fr);
+                    af[0][s] = x.x; af[1][s] = x.y;
+                } else {
+                    af[0][s] = la[(8 * fg + s) * LDR_A + wm * 16 + fr];
+                }
             }
         }
         if (pb.kc) {                         // natural tiles: col = 16 t + fr
@@ -285,16 +297,33 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
     if (aligned16(b) && ((sbk == 1 && sbn % 4 == 0 && K % 4 == 0) || (sbn == 1 && sbk % 4 == 0 && N % 4 == 0))) flags |= 2;
     GemmProblem &p = grp_.p[grp_.count++];
     p = GemmProblem{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, gate, chunk,
-                    split_k > 1 ? 1 : 0, asum1, asum2, cdiv(N, BN), cdiv(N, BN) * cdiv(M, BM), tiles_, flags};
-    tiles_ += p.tiles_mn * split_k;
+                    split_k > 1 ? 1 : 0, asum1, asum2, 0, 0, 0, flags};      // tile bookkeeping: at launch
+    tiles_ += cdiv(N, BN) * cdiv(M, 64) * split_k;                            // in 64-row tiles
     flops_ += 2.0 * M * N * K;
 }
+
+// Launches whose 64-row tiling has fewer workgroups than this use 32-row tiles.  Measured on the training step's
+// shapes (tools/gemm_shapes.py): 32-row tiles win or tie on every product but the largest (uv 9216x400x150: 35 vs
+// 40 us; conv 256x5400x576: 36 vs 44 us; dW_ih 400x300x5120 split 8: 44 vs 48 us), 64-row tiles win once a launch
+// has thousands of workgroups (4096^3: 78 vs 72 TFLOP/s).  GSCAN_GEMM_TMW=1|2 forces a shape, for experiments.
+constexpr int kWideTileMinGroups = 2048;
 
 int GemmBatch::launch(hipStream_t stream) {
     if (bad_) return 1;
     if (grp_.count == 0) return 0;
+    static const int forced = [] { const char *e = getenv("GSCAN_GEMM_TMW"); return e ? atoi(e) : 0; }();
+    const int tmw = forced == 1 || forced == 2 ? forced : (tiles_ < kWideTileMinGroups ? 1 : 2);
+    int total = 0;
+    for (int i = 0; i < grp_.count; ++i) {
+        GemmProblem &p = grp_.p[i];
+        p.tiles_n = cdiv(p.N, BN);
+        p.tiles_mn = p.tiles_n * cdiv(p.M, 32 * tmw);
+        p.tile_begin = total;
+        total += p.tiles_mn * cdiv(p.K, p.k_chunk);
+    }
     ProbeScope probe(P_GEMM, stream, flops_);
-    hipLaunchKernelGGL(gemm_group_kernel, dim3(tiles_), dim3(256), 0, stream, grp_);
+    if (tmw == 1) hipLaunchKernelGGL(gemm_group_kernel<1>, dim3(total), dim3(256), 0, stream, grp_);
+    else hipLaunchKernelGGL(gemm_group_kernel<2>, dim3(total), dim3(256), 0, stream, grp_);
     GSCAN_LAUNCHED("gemm_group_kernel");
     return 0;
 }

@@ -169,6 +169,7 @@ static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, cons
 // --------------------------------------------------------------------------------------
 struct SideStream {
     hipStream_t stream = nullptr, stream2 = nullptr;
+    bool single = false;             // GSCAN_SINGLE_STREAM=1 (diagnostic): everything on the caller's stream
     hipEvent_t ev[16] = {};
     bool ready = false;
     int next = 0;
@@ -177,6 +178,8 @@ static SideStream g_side;
 
 static int side_init() {
     if (g_side.ready) return 0;
+    const char *single = getenv("GSCAN_SINGLE_STREAM");
+    g_side.single = single && single[0] == '1';
     // highest priority: the leaves these streams carry end the step (the optimiser waits for the last of them),
     // measured 0.5% faster than lowest priority
     int prio_least = 0, prio_greatest = 0;
@@ -189,6 +192,7 @@ static int side_init() {
 }
 // `waiter` will not run anything issued after this call until everything issued so far on `signaller` is done
 static int order_after(hipStream_t waiter, hipStream_t signaller) {
+    if (waiter == signaller) return 0;
     hipEvent_t e = g_side.ev[g_side.next];
     g_side.next = (g_side.next + 1) % 16;
     GSCAN_HIP(hipEventRecord(e, signaller));
@@ -213,7 +217,7 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     GSCAN_CHECK(logp != nullptr, "forward: logp is NULL");
     GSCAN_CHECK(!d.auxiliary || aux_logp, "forward: auxiliary task set but aux_logp is NULL");
     TRY(side_init());
-    hipStream_t sd = g_side.stream;
+    hipStream_t sd = g_side.single ? st : g_side.stream;
 
     // ================= side stream: world branch (needs only the batch, the parameters and the CNN mask) ==========
     TRY(order_after(sd, st));          // whatever produced the inputs / masks on the caller's stream
@@ -315,7 +319,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     const bool cond = d.conditional != 0;
     GSCAN_CHECK(dlogp || nll, "backward: dlogp is NULL");
     TRY(side_init());
-    hipStream_t sd = g_side.stream, sd2 = g_side.stream2;
+    hipStream_t sd = g_side.single ? st : g_side.stream, sd2 = g_side.single ? st : g_side.stream2;
     float *S = w + ws.S, *dS = w + ws.dS;
     const float *delta = w + ws.delta, *hprev = w + ws.hprev;
 

@@ -1,0 +1,58 @@
+"""Diagnostic: device time of gscan_gemm_f32 on the training step's product shapes, one launch at a time.
+
+Run under rocprofv3 --kernel-trace and feed the CSV to this script with --parse: kernel durations come from the
+trace (host launch overhead does not hide in them).
+
+    rocprofv3 --kernel-trace --output-format csv -d out -o run -- python3 tools/gemm_shapes.py
+    python tools/gemm_shapes.py --parse out/run_kernel_trace.csv
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SHAPES = [  # (label, M, N, K, layout, split)
+    ("conv", 256, 5400, 576, "nn", 1), ("uv", 9216, 400, 150, "nt", 1), ("pkv", 9216, 100, 150, "nt", 1),
+    ("ge", 5120, 400, 100, "nt", 1), ("gx", 2560, 400, 25, "nt", 1), ("ut", 2560, 400, 100, "nt", 1),
+    ("pkt", 2560, 100, 100, "nt", 1), ("dS+=", 5120, 300, 500, "nn", 1), ("dS+= s2", 5120, 300, 500, "nn", 2),
+    ("dS+= s4", 5120, 300, 500, "nn", 4),
+    ("dW_ih s8", 400, 300, 5120, "tn", 8), ("dW_ih s16", 400, 300, 5120, "tn", 16),
+    ("dW_hh s8", 400, 100, 5120, "tn", 8), ("dW_hh s16", 400, 100, 5120, "tn", 16), ("dW_hh s32", 400, 100, 5120, "tn", 32),
+    ("dW_qt s8", 100, 100, 5120, "tn", 8), ("dW_qt s32", 100, 100, 5120, "tn", 32),
+    ("dW_kv s15", 100, 150, 9216, "tn", 15), ("dW_kv s58", 100, 150, 9216, "tn", 58),
+    ("dWt", 576, 5400, 256, "tn", 1), ("dW_enc s8", 400, 100, 2560, "tn", 8), ("dW_enc s16", 400, 100, 2560, "tn", 16),
+    ("dxe s8", 2560, 25, 800, "nn", 8), ("4096^3", 4096, 4096, 4096, "nt", 1),
+]
+REPS = 3
+
+
+def run():
+    import torch
+    import gpu_ops
+    for label, M, N, K, layout, split in SHAPES:
+        A = torch.randn(M, K, device="cuda") if layout[0] == "n" else torch.randn(K, M, device="cuda").t()
+        B = torch.randn(K, N, device="cuda") if layout[1] == "n" else torch.randn(N, K, device="cuda").t()
+        Cm = torch.zeros(M, N, device="cuda")
+        args = ((A, 0, A.stride(0), A.stride(1)), (B, 0, B.stride(0), B.stride(1)), (Cm, 0, N), M, N, K)
+        kw = dict(beta=1.0, split_k=split) if split > 1 else {}
+        for _ in range(REPS):
+            gpu_ops.gemm(*args, **kw)
+        torch.cuda.synchronize()
+
+
+def parse(path):
+    import csv
+    rows = [r for r in csv.DictReader(open(path)) if "gemm_group_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    assert len(rows) == REPS * len(SHAPES), (len(rows), len(SHAPES))
+    for i, (label, M, N, K, layout, split) in enumerate(SHAPES):
+        d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[REPS * i:REPS * (i + 1)])
+        us = d[len(d) // 2] / 1e3
+        print(f"{label:10s} {M:5d}x{N:5d}x{K:5d} {layout} split={split:2d}: {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--parse":
+        parse(sys.argv[2])
+    else:
+        run()
