@@ -48,80 +48,117 @@ template <int TMW> struct TileM {
 // of a k-contiguous operand reads its 8 values with two ds_read_b128.  A row-contiguous operand interleaves its
 // MFMA tiles instead (row = 2 i + tile for A, col = 2 i + tile for B), so one ds_read_b64 per k feeds both
 // of a wave's tiles.  Either way a wave issues ~1 LDS read per 4-8 MFMAs instead of 1 per MFMA.
-// Global loads are 16-byte whenever the operand's pointer, strides and extent allow, else 4-byte.
+// Global loads are 16-byte whenever the operand's pointer, strides and extent allow, else 8- or 4-byte.
 
-struct Panel {                  // how one operand's [rows x 32] panel moves global -> registers -> LDS
-    const float *src;
-    int64_t s_row, s_k;         // element (row, k) = src[row * s_row + k * s_k]
-    int nrows, row0;
-    bool kc, vec;               // k-contiguous image?  16-byte global loads?
-};
+static_assert(BK == 32, "the panel iterator and the fragment maps below are written for 32-deep K rounds");
 
+// How one operand's [ROWS x 32] panels move global -> registers -> LDS.  A thread's loads of one K round form an
+// arithmetic progression (same k / stepping rows for a k-contiguous operand, same rows / stepping k for a
+// row-contiguous one), so everything about them is computed ONCE: the K loop pays one compare and one add per
+// load, no multiplies, no 64-bit arithmetic (measured before this: issuing a round's loads cost as many cycles
+// as its MFMAs).  vw = floats per load (4 / 2 / 1: what the operand's alignment allows).
 template <int ROWS>
-__device__ __forceinline__ void panel_load(float (&v)[ROWS * BK / 256], const Panel &p, int k0, int kend, int tid) {
-    constexpr int N = ROWS * BK / 256;      // floats per thread
-    if (p.kc) {
-        if (p.vec) {                        // BK/4 float4 per row
-#pragma unroll
-            for (int i = 0; i < N / 4; ++i) {
-                const int r = p.row0 + tid / (BK / 4) + (1024 / BK) * i, k = k0 + 4 * (tid % (BK / 4));
-                float4 x = {0.f, 0.f, 0.f, 0.f};
-                if (r < p.nrows && k < kend) x = *reinterpret_cast<const float4 *>(p.src + (int64_t)r * p.s_row + k);
-                v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
-            }
-        } else {                            // k = tid % BK, row = tid / BK + (256/BK) i
-            const int k = k0 + (tid % BK);
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const int r = p.row0 + tid / BK + (256 / BK) * i;
-                v[i] = (r < p.nrows && k < kend) ? p.src[(int64_t)r * p.s_row + (int64_t)k * p.s_k] : 0.f;
-            }
-        }
-    } else {
-        if (p.vec) {                        // 4 adjacent rows per load
-#pragma unroll
-            for (int i = 0; i < N / 4; ++i) {
-                const int r = p.row0 + 4 * (tid % (ROWS / 4)), k = k0 + tid / (ROWS / 4) + (1024 / ROWS) * i;
-                float4 x = {0.f, 0.f, 0.f, 0.f};
-                if (r < p.nrows && k < kend) x = *reinterpret_cast<const float4 *>(p.src + (int64_t)k * p.s_k + r);
-                v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
-            }
-        } else {                            // row = tid % ROWS, k = tid / ROWS + (256/ROWS) i
-            const int r = p.row0 + tid % ROWS;
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const int k = k0 + tid / ROWS + (256 / ROWS) * i;
-                v[i] = (r < p.nrows && k < kend) ? p.src[(int64_t)r * p.s_row + (int64_t)k * p.s_k] : 0.f;
-            }
-        }
-    }
-}
+struct PanelIter {
+    static constexpr int N = ROWS * BK / 256;     // floats per thread per K round
+    const float *src;
+    uint32_t off;       // element offset of load 0 of the current round
+    uint32_t istep;     // offset step between a thread's loads of one round
+    uint32_t kinc;      // offset step per K round
+    int klim;           // k-contiguous: every load reads while k0 < klim; row-contiguous: load i while k0 + kp*i < klim
+    int nlive;          // k-contiguous: loads i < nlive touch rows inside the matrix
+    int kp;             // row-contiguous: k rows between a thread's loads
+    int vw;
+    bool kc;
 
-template <int ROWS, int LDR>
-__device__ __forceinline__ void panel_store(float *lds, const float (&v)[ROWS * BK / 256], const Panel &p, int tid) {
-    constexpr int N = ROWS * BK / 256;
-    if (p.kc) {
-        if (p.vec) {
-#pragma unroll
-            for (int i = 0; i < N / 4; ++i)
-                *reinterpret_cast<float4 *>(lds + (tid / (BK / 4) + (1024 / BK) * i) * LDK + 4 * (tid % (BK / 4))) =
-                    float4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+    __device__ __forceinline__ void init(const float *base, int64_t s_row, int64_t s_k, int nrows, int row0, int vw_,
+                                         int kbeg, int kend, int tid) {
+        src = base; vw = vw_; kc = (s_k == 1);
+        const uint32_t sr = (uint32_t)s_row, sk = (uint32_t)s_k;
+        if (kc) {
+            const int ch = BK / vw, rp = 256 / ch;                 // chunks per row, rows per pass
+            const int r = row0 + tid / ch, kk = vw * (tid % ch);
+            off = (uint32_t)r * sr + (uint32_t)(kbeg + kk);
+            istep = (uint32_t)rp * sr;
+            kinc = BK;
+            klim = kend - kk;
+            nlive = r < nrows ? (nrows - r + rp - 1) / rp : 0;
+            kp = 0;
         } else {
-#pragma unroll
-            for (int i = 0; i < N; ++i) lds[(tid / BK + (256 / BK) * i) * LDK + (tid % BK)] = v[i];
-        }
-    } else {
-        if (p.vec) {
-#pragma unroll
-            for (int i = 0; i < N / 4; ++i)
-                *reinterpret_cast<float4 *>(lds + (tid / (ROWS / 4) + (1024 / ROWS) * i) * LDR + 4 * (tid % (ROWS / 4))) =
-                    float4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
-        } else {
-#pragma unroll
-            for (int i = 0; i < N; ++i) lds[(tid / ROWS + (256 / ROWS) * i) * LDR + tid % ROWS] = v[i];
+            const int rq = ROWS / vw;                              // loads per k row
+            const int r = row0 + vw * (tid % rq), kk = tid / rq;
+            kp = 256 / rq;
+            off = (uint32_t)(kbeg + kk) * sk + (uint32_t)r * sr;
+            istep = (uint32_t)kp * sk;
+            kinc = (uint32_t)BK * sk;
+            klim = r < nrows ? kend - kk : INT_MIN;
+            nlive = N;
         }
     }
-}
+
+    template <int VW>
+    __device__ __forceinline__ void load_vw(float (&v)[N], int k0) const {
+        constexpr int NL = N / VW;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const bool live = kc ? (i < nlive && k0 < klim) : (k0 + kp * i < klim);
+            const float *ptr = src + (off + (uint32_t)i * istep);
+            if constexpr (VW == 4) {
+                float4 x = {0.f, 0.f, 0.f, 0.f};
+                if (live) x = *reinterpret_cast<const float4 *>(ptr);
+                v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+            } else if constexpr (VW == 2) {
+                float2 x = {0.f, 0.f};
+                if (live) x = *reinterpret_cast<const float2 *>(ptr);
+                v[2 * i] = x.x; v[2 * i + 1] = x.y;
+            } else {
+                v[i] = live ? *ptr : 0.f;
+            }
+        }
+    }
+    // loads of the round starting at k0, then step to the next round
+    __device__ __forceinline__ void load(float (&v)[N], int k0) {
+        if (vw == 4) load_vw<4>(v, k0);
+        else if (vw == 2) load_vw<2>(v, k0);
+        else load_vw<1>(v, k0);
+        off += kinc;
+    }
+
+    // registers -> LDS image: k-contiguous [row][LDK], row-contiguous [k][LDR]
+    template <int LDR>
+    __device__ __forceinline__ void store(float *lds, const float (&v)[N], int tid) const {
+        if (kc) {
+            const int ch = BK / vw, rp = 256 / ch;
+            float *dst = lds + (tid / ch) * LDK + vw * (tid % ch);
+            if (vw == 4) {
+#pragma unroll
+                for (int i = 0; i < N / 4; ++i)
+                    *reinterpret_cast<float4 *>(dst + i * rp * LDK) = float4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+            } else if (vw == 2) {
+#pragma unroll
+                for (int i = 0; i < N / 2; ++i)
+                    *reinterpret_cast<float2 *>(dst + i * rp * LDK) = float2{v[2 * i], v[2 * i + 1]};
+            } else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) dst[i * rp * LDK] = v[i];
+            }
+        } else {
+            const int rq = ROWS / vw;
+            float *dst = lds + (tid / rq) * LDR + vw * (tid % rq);
+            if (vw == 4) {
+#pragma unroll
+                for (int i = 0; i < N / 4; ++i)
+                    *reinterpret_cast<float4 *>(dst + i * kp * LDR) = float4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+            } else if (vw == 2) {
+#pragma unroll
+                for (int i = 0; i < N / 2; ++i)
+                    *reinterpret_cast<float2 *>(dst + i * kp * LDR) = float2{v[2 * i], v[2 * i + 1]};
+            } else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) dst[i * kp * LDR] = v[i];
+            }
+        }
+    }
+};
 
 template <int TMW>
 __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
@@ -142,9 +179,12 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = bz * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
-    const Panel pa{g.a, g.sam, g.sak, g.M, m0, g.sak == 1, (g.flags & 1) != 0};
-    const Panel pb{g.b, g.sbn, g.sbk, g.N, n0, g.sbk == 1, (g.flags & 2) != 0};
     const bool do_asum = g.asum1 != nullptr && bx == 0;
+
+    PanelIter<BM> pa;
+    PanelIter<BN> pb;
+    pa.init(g.a, g.sam, g.sak, g.M, m0, 1 << (g.flags & 3), kbeg, kend, tid);
+    pb.init(g.b, g.sbn, g.sbk, g.N, n0, 1 << ((g.flags >> 2) & 3), kbeg, kend, tid);
 
     f32x4 acc[TMW][TNW];
 #pragma unroll
@@ -155,48 +195,49 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
 
     const int fr = lane & 15;   // MFMA row (A) / column (B) index
     const int fg = lane >> 4;   // lane group: k = 8*fg + step
+    // this lane's fragment bases inside an LDS image (constant over the K loop)
+    const int fa = pa.kc ? (wm * 16 * TMW + fr) * LDK + 8 * fg : (8 * fg) * LDR_A + wm * 16 * TMW + TMW * fr;
+    const int fb = pb.kc ? (wn * 16 * TNW + fr) * LDK + 8 * fg : (8 * fg) * LDR_B + wn * 16 * TNW + TNW * fr;
 
     float ra[BM * BK / 256], rb[BN * BK / 256];
-    panel_load<BM>(ra, pa, kbeg, kend, tid);
-    panel_load<BN>(rb, pb, kbeg, kend, tid);
-    panel_store<BM, LDR_A>(lds_a[0], ra, pa, tid);
-    panel_store<BN, LDR_B>(lds_b[0], rb, pb, tid);
+    pa.load(ra, kbeg);
+    pb.load(rb, kbeg);
+    pa.template store<LDR_A>(lds_a[0], ra, tid);
+    pb.template store<LDR_B>(lds_b[0], rb, tid);
     __syncthreads();
 
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
-        if (more) {   // next tile's loads fly while this tile's MFMAs run
-            panel_load<BM>(ra, pa, k0 + BK, kend, tid);
-            panel_load<BN>(rb, pb, k0 + BK, kend, tid);
+        if (more) {   // next round's loads fly while this round's MFMAs run
+            pa.load(ra, k0 + BK);
+            pb.load(rb, k0 + BK);
         }
-#pragma unroll
-        for (int kh = 0; kh < BK; kh += 32) {
-        const float *la = lds_a[buf] + (pa.kc ? kh : kh * LDR_A), *lb = lds_b[buf] + (pb.kc ? kh : kh * LDR_B);
+        const float *la = lds_a[buf] + fa, *lb = lds_b[buf] + fb;
         float af[TMW][8], bf[TNW][8];        // [tile][step]
         if (pa.kc) {                         // natural tiles: row = 16 t + fr
 #pragma unroll
             for (int t = 0; t < TMW; ++t) {
-                const float4 *q = reinterpret_cast<const float4 *>(la + (wm * 16 * TMW + 16 * t + fr) * LDK + 8 * fg);
+                const float4 *q = reinterpret_cast<const float4 *>(la + 16 * t * LDK);
                 const float4 x = q[0], y = q[1];
                 af[t][0] = x.x; af[t][1] = x.y; af[t][2] = x.z; af[t][3] = x.w;
                 af[t][4] = y.x; af[t][5] = y.y; af[t][6] = y.z; af[t][7] = y.w;
             }
-        } else {                             // interleaved tiles: row = 2 fr + t
+        } else {                             // interleaved tiles: row = TMW fr + t
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 if constexpr (TMW == 2) {
-                    const float2 x = *reinterpret_cast<const float2 *>(la + (8 * fg + s) * LDR_A + wm * 32 + 2 * fr);
+                    const float2 x = *reinterpret_cast<const float2 *>(la + s * LDR_A);
                     af[0][s] = x.x; af[1][s] = x.y;
                 } else {
-                    af[0][s] = la[(8 * fg + s) * LDR_A + wm * 16 + fr];
+                    af[0][s] = la[s * LDR_A];
                 }
             }
         }
         if (pb.kc) {                         // natural tiles: col = 16 t + fr
 #pragma unroll
             for (int t = 0; t < TNW; ++t) {
-                const float4 *q = reinterpret_cast<const float4 *>(lb + (wn * 16 * TNW + 16 * t + fr) * LDK + 8 * fg);
+                const float4 *q = reinterpret_cast<const float4 *>(lb + 16 * t * LDK);
                 const float4 x = q[0], y = q[1];
                 bf[t][0] = x.x; bf[t][1] = x.y; bf[t][2] = x.z; bf[t][3] = x.w;
                 bf[t][4] = y.x; bf[t][5] = y.y; bf[t][6] = y.z; bf[t][7] = y.w;
@@ -204,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
         } else {                             // interleaved tiles: col = 2 fr + t
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const float2 x = *reinterpret_cast<const float2 *>(lb + (8 * fg + s) * LDR_B + wn * 16 * TNW + 2 * fr);
+                const float2 x = *reinterpret_cast<const float2 *>(lb + s * LDR_B);
                 bf[0][s] = x.x; bf[1][s] = x.y;
             }
         }
@@ -216,18 +257,26 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
                 for (int j = 0; j < TNW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         if (do_asum && tid < BM) {           // column sums of A (bias gradients): sum over these 32 k
+            const float *sa = lds_a[buf];
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
             if (pa.kc) {
 #pragma unroll
-                for (int kk = 0; kk < 32; ++kk) asum += la[tid * LDK + kk];
+                for (int kk = 0; kk < 32; kk += 4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(sa + tid * LDK + kk);
+                    t0 += x.x; t1 += x.y; t2 += x.z; t3 += x.w;
+                }
             } else {
 #pragma unroll
-                for (int kk = 0; kk < 32; ++kk) asum += la[kk * LDR_A + tid];
+                for (int kk = 0; kk < 32; kk += 4) {
+                    t0 += sa[kk * LDR_A + tid]; t1 += sa[(kk + 1) * LDR_A + tid];
+                    t2 += sa[(kk + 2) * LDR_A + tid]; t3 += sa[(kk + 3) * LDR_A + tid];
+                }
             }
-        }
+            asum += (t0 + t1) + (t2 + t3);
         }
         if (more) {
-            panel_store<BM, LDR_A>(lds_a[buf ^ 1], ra, pa, tid);
-            panel_store<BN, LDR_B>(lds_b[buf ^ 1], rb, pb, tid);
+            pa.template store<LDR_A>(lds_a[buf ^ 1], ra, tid);
+            pb.template store<LDR_B>(lds_b[buf ^ 1], rb, tid);
         }
         __syncthreads();
         buf ^= 1;
@@ -238,7 +287,19 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
         if (g.asum2) atomicAdd(&g.asum2[m0 + tid], asum);
     }
 
-    // epilogue.  MFMA C/D fragment: column index = lane & 15, row index = (lane >> 4) * 4 + reg
+    // epilogue.  MFMA C/D fragment: column index = lane & 15, row index = (lane >> 4) * 4 + reg.
+    // Rows / columns of this lane and their validity first, then ONE of three store loops (split-K atomics, plain
+    // store, general epilogue): no per-element mode tests or 64-bit index arithmetic.
+    int coff[TNW];
+    bool cok[TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        const int col = n0 + wn * 16 * TNW + (pb.kc ? 16 * j + fr : TNW * fr + j);
+        coff[j] = col;
+        cok[j] = col < g.N;
+    }
+    const uint32_t ldc = (uint32_t)g.ldc;
+    const float alpha = g.alpha;
 #pragma unroll
     for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -246,28 +307,33 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
             const int ri = fg * 4 + r;                                        // MFMA row index 0..15
             const int row = m0 + wm * 16 * TMW + (pa.kc ? 16 * i + ri : TMW * ri + i);
             if (row >= g.M) continue;
+            const uint32_t roff = (uint32_t)row * ldc;
+            if (g.atomic) {
 #pragma unroll
-            for (int j = 0; j < TNW; ++j) {
-                const int col = n0 + wn * 16 * TNW + (pb.kc ? 16 * j + fr : TNW * fr + j);
-                if (col >= g.N) continue;
-                float *cp = g.c + (int64_t)row * g.ldc + col;
-                float v = g.alpha * acc[i][j][r];
-                if (g.atomic) {
-                    atomicAdd(cp, v);
-                } else {
-                    if (g.beta != 0.f) v += g.beta * (*cp);
-                    if (g.bias) v += g.bias[col];
+                for (int j = 0; j < TNW; ++j)
+                    if (cok[j]) atomicAdd(g.c + (roff + coff[j]), alpha * acc[i][j][r]);
+            } else if (g.beta == 0.f && !g.bias && g.act == 0 && !g.mask) {
+#pragma unroll
+                for (int j = 0; j < TNW; ++j)
+                    if (cok[j]) g.c[roff + coff[j]] = alpha * acc[i][j][r];
+            } else {
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) {
+                    if (!cok[j]) continue;
+                    const uint32_t at = roff + coff[j];
+                    float v = alpha * acc[i][j][r];
+                    if (g.beta != 0.f) v += g.beta * g.c[at];
+                    if (g.bias) v += g.bias[coff[j]];
                     if (g.act == 1) v = fmaxf(v, 0.f);
                     else if (g.act == 2) v = tanhf_(v);
-                    else if (g.act == 3 && g.gate[(int64_t)row * g.ldc + col] == 0.f) v = 0.f;   // ReLU backward
-                    if (g.mask) v *= g.mask[(int64_t)row * g.ldc + col];
-                    *cp = v;
+                    else if (g.act == 3 && g.gate[at] == 0.f) v = 0.f;        // ReLU backward
+                    if (g.mask) v *= g.mask[at];
+                    g.c[at] = v;
                 }
             }
         }
 }
 
-static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sak, const float *b, int64_t sbk,
                     int64_t sbn, float *c, int64_t ldc, float beta, const float *bias, int act, const float *mask,
@@ -289,12 +355,24 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
         set_error("gemm batch: split-K needs beta=1 and no epilogue (problem %d, beta=%g act=%d)", grp_.count, beta, act);
         return;
     }
-    // 16-byte global loads need: unit stride along the load direction, the other stride a multiple of 4 floats,
-    // a 16-byte aligned base, and an extent along the load direction that is a multiple of 4 (tile edges included:
-    // K slices start at multiples of 32)
-    int flags = 0;
-    if (aligned16(a) && ((sak == 1 && sam % 4 == 0 && K % 4 == 0) || (sam == 1 && sak % 4 == 0 && M % 4 == 0))) flags |= 1;
-    if (aligned16(b) && ((sbk == 1 && sbn % 4 == 0 && K % 4 == 0) || (sbn == 1 && sbk % 4 == 0 && N % 4 == 0))) flags |= 2;
+    // Width of the global loads of an operand (4 / 2 / 1 floats): unit stride along the load direction, the other
+    // stride and the extent along the load direction multiples of the width (tile edges included: K slices start at
+    // multiples of 32), and a base aligned to it.  flags = log2(width of A) | log2(width of B) << 2.
+    auto width = [](const float *ptr, int64_t s_row, int64_t s_k, int rows, int K) {
+        for (int w = 4; w > 1; w >>= 1) {
+            const bool base = (reinterpret_cast<uintptr_t>(ptr) & (4 * w - 1)) == 0;
+            if (base && ((s_k == 1 && s_row % w == 0 && K % w == 0) || (s_row == 1 && s_k % w == 0 && rows % w == 0)))
+                return w == 4 ? 2 : 1;
+        }
+        return 0;
+    };
+    const int flags = width(a, sam, sak, M, K) | (width(b, sbn, sbk, N, K) << 2);
+    if ((int64_t)M * sam + (int64_t)K * sak >= (1ll << 32) || (int64_t)N * sbn + (int64_t)K * sbk >= (1ll << 32) ||
+        (int64_t)M * ldc >= (1ll << 32)) {
+        bad_ = true;
+        set_error("gemm batch: operand of problem %d spans more than 2^32 elements", grp_.count);
+        return;
+    }
     GemmProblem &p = grp_.p[grp_.count++];
     p = GemmProblem{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, gate, chunk,
                     split_k > 1 ? 1 : 0, asum1, asum2, 0, 0, 0, flags};      // tile bookkeeping: at launch

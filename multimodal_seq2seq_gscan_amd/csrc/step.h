@@ -22,7 +22,7 @@ struct GemmProblem {
     int k_chunk, atomic;                  // K range per k-slice; split-K accumulates with atomics
     float *asum1, *asum2;                 // optional: += sum_k A(m,k) (bias gradients)
     int tiles_n, tiles_mn, tile_begin;    // grid bookkeeping
-    int flags;                            // bit 0 / 1: 16-byte global loads allowed for A / B
+    int flags;                            // log2(floats per global load) of A | of B << 2
 };
 struct GemmGroup { int count; GemmProblem p[kMaxGroup]; };
 

@@ -120,20 +120,20 @@ int check_dims(const gscan_dims &d) {
 }
 
 // Split of the long K dimension of a weight-gradient product.  A workgroup's K loop is a chain of dependent
-// ~1.3 us rounds when it has a CU to itself (measured: 400x100x2560 unsplit = 109 us, 8 slices = 20 us), and every
-// slice ends in one float atomic per output element (chip-wide atomic rate ~1.3 TB/s, MI355X_MICROARCH.md
-// "Global float atomics"): slices of 640 rows (20 rounds), but at least 8 of them while they stay >= 160 rows.
-static int pick_split(int M, int N, int K) {
-    (void)M; (void)N;
-    return std::max(cdiv(K, 640), std::min(8, cdiv(K, 160)));
-}
+// ~1.2 us rounds when it has a CU to itself, whatever the round computes (tools/gemm_shapes.py: 400x100x2560
+// unsplit = 109 us, 8 slices = 17 us), and every slice ends in one float atomic per output element; the atomics of
+// all slices of an element arrive together.  Measured on the whole step: slices of 640 rows (20 rounds), but at
+// least 8 of them while they stay >= 160 rows.  Shorter slices make single products faster in isolation
+// (100x150x9216: 32 -> 21 us from 15 to 58 slices) but the overlapped step slower (0.691 vs 0.683 ms), and the
+// eight-product decoder launch much slower (85 vs 62 us at 160/320-row slices).
+static int pick_split(int K) { return std::max(cdiv(K, 640), std::min(8, cdiv(K, 160))); }
 
 // weight gradient: C[M,N] += A^T . B with the long dimension (rows of the activations) as K, split over
 // workgroups; bias1/bias2 (optional) += column sums of the activation gradient = sum over K of A(m,k)
 static inline void add_grad(GemmBatch &g, int M, int N, int K, const float *a, int64_t sam, int64_t sak, const float *b,
                             int64_t sbk, int64_t sbn, float *c, int64_t ldc, float *bias1 = nullptr,
                             float *bias2 = nullptr) {
-    g.add(M, N, K, a, sam, sak, b, sbk, sbn, c, ldc, 1.f, nullptr, 0, nullptr, pick_split(M, N, K), bias1, bias2);
+    g.add(M, N, K, a, sam, sak, b, sbk, sbn, c, ldc, 1.f, nullptr, 0, nullptr, pick_split(K), bias1, bias2);
 }
 
 #define TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
