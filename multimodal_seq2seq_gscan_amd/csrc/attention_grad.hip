@@ -132,35 +132,63 @@ __global__ __launch_bounds__(kKbThreads) void keys_backward_kernel(KeysBackwardA
 
     // ---- stage 2: through the key layers.  A job = one 16-column tile of d feat (F columns, MTV memory tiles) or
     //      of d enc_out (He columns, MTT memory tiles); the job's B fragments (H/4 steps) are read once.
-    const int NTF = (a.F + 15) / 16, NTE = (a.He + 15) / 16;
-    for (int job = wave; job < NTF + NTE; job += kKbWaves) {
+    //      Latency, not arithmetic, bounds this stage (a wave runs two or three jobs back to back and each starts
+    //      with loads): the NEXT job's B fragments and the current job's ReLU gates / dropout masks are requested
+    //      before the current job's MFMAs, so every load has a whole job to arrive.
+    const int NTF = (a.F + 15) / 16, NTE = (a.He + 15) / 16, njobs = NTF + NTE;
+    auto load_b = [&](int job, float (&bw)[KS]) {
         const bool vis = job < NTF;
         const int nt = vis ? job : job - NTF, ncols = vis ? a.F : a.He, col = 16 * nt + fr;
         const float *wsrc = vis ? a.w_kv : a.w_kt;
-        float bw[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) bw[s] = (col < ncols) ? wsrc[(int64_t)(4 * s + fg) * ncols + col] : 0.f;
-        const int mt_lo = vis ? 0 : MTV, mt_hi = vis ? MTV : MT, mx = vis ? M : L;
-        for (int mt = mt_lo; mt < mt_hi; ++mt) {
+        for (int s = 0; s < KS; ++s) bw[s] = (job < njobs && col < ncols) ? wsrc[(int64_t)(4 * s + fg) * ncols + col] : 0.f;
+    };
+    auto run_job = [&](int job, const float (&bw)[KS]) {
+        const bool vis = job < NTF;
+        const int nt = vis ? job : job - NTF, ncols = vis ? a.F : a.He, col = 16 * nt + fr;
+        const int mt_lo = vis ? 0 : MTV, nmt = vis ? MTV : MTT, mx = vis ? M : L;
+        constexpr int kMaxMt = 4;                           // 64 memories per attention at most
+        float gate[kMaxMt][4], mk[kMaxMt][4];
+#pragma unroll
+        for (int i = 0; i < kMaxMt; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * i + 4 * fg + r;
+                gate[i][r] = 1.f; mk[i][r] = 1.f;
+                if (vis && i < nmt && m < mx && col < ncols) {
+                    const int64_t at = ((int64_t)b * mx + m) * ncols + col;
+                    gate[i][r] = a.feat[at];
+                    if (a.mask) mk[i][r] = a.mask[at];
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < kMaxMt; ++i) {
+            if (i >= nmt) continue;
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
-            const float *ap = dpk_s + (16 * mt + fr) * HS + fg;
+            const float *ap = dpk_s + (16 * (mt_lo + i) + fr) * HS + fg;
 #pragma unroll
             for (int s = 0; s < KS; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], bw[s], c, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = 16 * (mt - mt_lo) + 4 * fg + r;
+                const int m = 16 * i + 4 * fg + r;
                 if (m < mx && col < ncols) {
                     const int64_t at = ((int64_t)b * mx + m) * ncols + col;
-                    if (vis) {       // feat = relu(conv) * mask  =>  d conv = (feat != 0) ? d feat * mask : 0
-                        float v = c[r];
-                        if (a.feat[at] == 0.f) v = 0.f;
-                        else if (a.mask) v *= a.mask[at];
-                        a.dfeat[at] = v;
-                    } else {
-                        a.denc[at] = c[r];
-                    }
+                    // feat = relu(conv) * mask  =>  d conv = (feat != 0) ? d feat * mask : 0
+                    if (vis) a.dfeat[at] = (gate[i][r] == 0.f) ? 0.f : c[r] * mk[i][r];
+                    else a.denc[at] = c[r];
                 }
             }
+        }
+    };
+    {
+        float bw0[KS], bw1[KS];
+        load_b(wave, bw0);
+        for (int job = wave; job < njobs; job += 2 * kKbWaves) {
+            load_b(job + kKbWaves, bw1);
+            run_job(job, bw0);
+            if (job + kKbWaves >= njobs) break;
+            load_b(job + 2 * kKbWaves, bw0);
+            run_job(job + kKbWaves, bw1);
         }
     }
     // ---- bridge: d h_N[e] = sum_k d h0[k] * W_bridge[k][e]
