@@ -75,8 +75,8 @@ int embed_rows(const int64_t *tok, const float *table, int vocab, const float *m
 // dtable[v, :] += sum over rows with tok[row] == v, v != pad of g[row, :] * mask[row, :]
 // (the padding row of nn.Embedding(padding_idx=...) never receives gradient).
 // Vocabularies are tiny (6..21 entries), so each workgroup sums its 64 rows into a private
-// [vocab, D] table in LDS (ds_add_f32; a wave works on ONE row at a time, so its 64 lanes hit
-// 64 different columns) and flushes the table with one global atomic per touched entry.
+// [vocab, D] table in LDS (ds_add_f32; consecutive lanes take consecutive columns of a row, so a wave's
+// lanes hit different addresses) and flushes the table with one global atomic per touched entry.
 // ------------------------------------------------------------------------------------------
 constexpr int kEmbedRows = 64;
 __global__ void embed_grad_kernel(const int64_t *__restrict__ tok, const float *__restrict__ g, int64_t ldg,
@@ -87,15 +87,29 @@ __global__ void embed_grad_kernel(const int64_t *__restrict__ tok, const float *
     for (int i = threadIdx.x; i < n; i += blockDim.x) table[i] = 0.f;
     __syncthreads();
     const int r0 = blockIdx.x * kEmbedRows, r1 = min(rows, r0 + kEmbedRows);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
-    for (int r = r0 + wave; r < r1; r += nwave) {
-        const int64_t t = tok[r];
-        if (t < 0 || t >= vocab || t == pad) continue;
-        for (int d = lane; d < D; d += 64) {
-            float x = g[(int64_t)r * ldg + d];
-            if (mask) x *= mask[(int64_t)r * D + d];
-            atomicAdd(&table[t * D + d], x);
+    const int nel = (r1 - r0) * D;
+    // a thread takes (row, column) elements; four elements' loads (token -> gradient, mask) are in flight at once
+    for (int i0 = threadIdx.x; i0 < nel; i0 += 4 * blockDim.x) {
+        float x[4];
+        int at[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = i0 + u * blockDim.x;
+            at[u] = -1;
+            x[u] = 0.f;
+            if (idx < nel) {
+                const int rr = idx / D, d = idx - rr * D, r = r0 + rr;
+                const int64_t t = tok[r];
+                if (t >= 0 && t < vocab && t != pad) {
+                    at[u] = (int)t * D + d;
+                    x[u] = g[(int64_t)r * ldg + d];
+                    if (mask) x[u] *= mask[(int64_t)r * D + d];
+                }
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (at[u] >= 0) atomicAdd(&table[at[u]], x[u]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {

@@ -191,12 +191,14 @@ static int side_init() {
     return 0;
 }
 // `waiter` will not run anything issued after this call until everything issued so far on `signaller` is done
-static int order_after(hipStream_t waiter, hipStream_t signaller) {
+// (a record costs the signalling stream a ~6 us bubble on MI355X, so fork points are few and an event is shared)
+static int order_after(hipStream_t waiter, hipStream_t signaller, hipStream_t waiter2 = nullptr) {
     if (waiter == signaller) return 0;
     hipEvent_t e = g_side.ev[g_side.next];
     g_side.next = (g_side.next + 1) % 16;
     GSCAN_HIP(hipEventRecord(e, signaller));
     GSCAN_HIP(hipStreamWaitEvent(waiter, e, 0));
+    if (waiter2 && waiter2 != signaller) GSCAN_HIP(hipStreamWaitEvent(waiter2, e, 0));
     return 0;
 }
 
@@ -354,15 +356,17 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         } else {
             add_grad(b, H, H, BT, w + ws.dqv, 1, H, hprev, H, 1, g.vis_query_w, H);
         }
+        // gradient wrt the embedded target token (the e columns of dS): only the embedding table consumes it, so
+        // this third of the LSTM-input back-propagation is a leaf too
+        b.add(BT, H, 4 * H, delta, 5 * H, 1, w + ws.wcat5, 3 * H, 1, dS, 4 * H, 1.f);
         TRY(b.launch(sd));
         TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, sd));
+        TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd));
     }
-    // chain: gradient wrt [e | ctx_text | ctx_vis] through the LSTM input and the conditional query
-    // (one product: [delta | dzq] . [W_ih ; (0 | W_q2k[:, ctx] | 0)], K = 5H when conditional)
-    TRY(gemm_f32(BT, 3 * H, cond ? 5 * H : 4 * H, 1.f, delta, 5 * H, 1, w + ws.wcat5, 3 * H, 1, 1.f, dS, 4 * H, nullptr,
-                 0, nullptr, 1, st));
-    TRY(order_after(sd, st));
-    TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd));     // leaf
+    // chain: gradient wrt [ctx_text | ctx_vis] through the LSTM input and the conditional query
+    // (one product: [delta | dzq] . [W_ih[:, ctx] ; (W_q2k[:, ctx_text] | 0)], K = 5H when conditional)
+    TRY(gemm_f32(BT, 2 * H, cond ? 5 * H : 4 * H, 1.f, delta, 5 * H, 1, w + ws.wcat5 + H, 3 * H, 1, 1.f, dS + H, 4 * H,
+                 nullptr, 0, nullptr, 1, st));
     {   // chain: value path of both attentions (dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]), then through the
         // key layers and the bridge to the encoder outputs / final state / conv features — one launch, row per WG
         KeysBackwardArgs k{};
@@ -374,7 +378,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         k.denc = w + ws.denc; k.dhN = w + ws.dhN; k.dfeat = w + ws.dfeat;
         TRY(keys_backward(B, H, k, st));
     }
-    TRY(order_after(sd, st));
+    TRY(order_after(sd, st, sd2));     // one event releases both leaf streams
     {   // leaves: key and bridge weights
         GemmBatch b;
         add_grad(b, H, He, BL, w + ws.dpk_t, 1, H, w + ws.enc_out, He, 1, g.txt_key_w, He);
@@ -382,7 +386,6 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         add_grad(b, H, F, BM_, w + ws.dpk_v, 1, H, w + ws.feat, F, 1, g.vis_key_w, F);
         TRY(b.launch(sd));
     }
-    TRY(order_after(sd2, st));
     {   // leaf: d(Wt) = world^T . dfeat (K = B only: no split, no atomics), folded onto the conv kernels
         GemmBatch b;
         b.add(M * C, M * F, B, bt.world, 1, (int64_t)M * C, w + ws.dfeat, (int64_t)M * F, 1, w + ws.dwt, (int64_t)M * F);
