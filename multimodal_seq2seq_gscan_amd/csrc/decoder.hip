@@ -28,7 +28,7 @@
 //             or W_query_vis[k,:];            [6H,7H) W_query_vis[k,:] applied to the conditional query
 //   backward  the transposes: task (seg,k) holds column k of block seg of [W_hh (4 blocks) | W_query_text |
 //             W_q2k[:, :H] or W_query_vis] and of W_query_vis; dh_{t-1}[k] = sum over the six blocks.
-// decoder_weight_images() writes both register images once per step ([slot][i][thread], coalesced).
+// The step prologue kernel writes both register images once per step ([slot][i][thread], coalesced; step.h).
 #include "step.h"
 
 namespace gscan {
@@ -934,59 +934,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_acc[tid];
 }
 
-// ------------------------------------------------------------------------------------------
-// Register images of the decoder weights, written once per step (both directions of use):
-//   image[(slot*K0 + i)*512 + tid] = element i of the half-row that thread tid keeps in slot `slot`.
-// forward image: task r -> row of the stacked matrix; backward image: task (seg,k) -> column k of block seg.
-// ------------------------------------------------------------------------------------------
-__global__ void decoder_weight_image_kernel(const float *__restrict__ w_hh, const float *__restrict__ w_qt,
-                                            const float *__restrict__ w_qv, const float *__restrict__ w_q2k,
-                                            const float *__restrict__ wo_perm, int H, int cond, int slots, int k0,
-                                            float *__restrict__ fwd_image, float *__restrict__ bwd_image,
-                                            float *__restrict__ head_image) {
-    const int total = slots * k0 * kDecThreads;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * total + H * kDecThreads;
-         idx += gridDim.x * blockDim.x) {
-        if (idx >= 2 * total) {      // head image: MFMA B fragments, lane (fg, fr) of wave w at step i holds
-            const int e = idx - 2 * total, tid = e % kDecThreads, i = e / kDecThreads;   // wo_perm[16w + fr][4i + fg]
-            const int n = 16 * (tid >> 6) + (tid & 15), k = 4 * i + ((tid >> 4) & 3);
-            head_image[e] = (n < H) ? wo_perm[(int64_t)n * 4 * H + k] : 0.f;
-            continue;
-        }
-        const bool bwd = idx >= total;
-        const int e = bwd ? idx - total : idx;
-        const int tid = e % kDecThreads, i = (e / kDecThreads) % k0, s = e / (kDecThreads * k0);
-        const int r = s * kDecPairs + (tid >> 1), kk = (tid & 1) * k0 + i;       // kk: position along the dot
-        float v = 0.f;
-        const int rows = (cond ? 7 : 6) * H;
-        if (r < rows && kk < H) {
-            const int sg = r / H, q = r % H;                                      // block, index inside it
-            if (!bwd) {          // row q of block sg, element kk
-                if (sg < 4) v = w_hh[(int64_t)r * H + kk];
-                else if (sg == 4) v = w_qt[(int64_t)q * H + kk];
-                else if (sg == 5) v = cond ? w_q2k[(int64_t)q * 2 * H + kk] : w_qv[(int64_t)q * H + kk];
-                else v = w_qv[(int64_t)q * H + kk];
-            } else {             // column q of block sg, element (row) kk
-                if (sg < 4) v = w_hh[(int64_t)(sg * H + kk) * H + q];
-                else if (sg == 4) v = w_qt[(int64_t)kk * H + q];
-                else if (sg == 5) v = cond ? w_q2k[(int64_t)kk * 2 * H + q] : w_qv[(int64_t)kk * H + q];
-                else v = w_qv[(int64_t)kk * H + q];
-            }
-        }
-        (bwd ? bwd_image : fwd_image)[e] = v;
-    }
-}
-
-int decoder_weight_images(const float *w_hh, const float *w_qt, const float *w_qv, const float *w_q2k,
-                          const float *wo_perm, int H, bool cond, float *fwd_image, float *bwd_image,
-                          float *head_image, hipStream_t stream) {
-    const DecoderGeometry g = decoder_geometry(H, cond);
-    const int total = 2 * (int)g.image_floats + H * kDecThreads;
-    hipLaunchKernelGGL(decoder_weight_image_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, stream, w_hh,
-                       w_qt, w_qv, w_q2k, wo_perm, H, cond ? 1 : 0, g.slots, g.k0, fwd_image, bwd_image, head_image);
-    GSCAN_LAUNCHED("decoder_weight_image_kernel");
-    return 0;
-}
+// Register images of the decoder weights are written once per step by the step prologue kernel
+// (decoder_image_element in step.h; layout described there).
 
 // ------------------------------------------------------------------------------------------
 // host side

@@ -306,10 +306,11 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 //   seg 6  wcat5[5H,3H]        = [W_ih_dec ; (0 | W_q2k[:, H:2H] | 0)]: one product then carries delta AND dzq back to
 //                                [e | ctx_text | ctx_vis]
 //   seg 7  zero_extra          = 0   (accumulation targets: encoder direction sums enc_out / hN, split-K dxe)
+//   seg 8  register images of the decoder's recurrent weights and of the output head (step.h)
 // ------------------------------------------------------------------------------------------
 
 __global__ void prologue_kernel(PrologueArgs a) {
-    const int64_t total = a.end[7];
+    const int64_t total = a.end[8];
     const int H = a.H;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -350,14 +351,16 @@ __global__ void prologue_kernel(PrologueArgs a) {
             if (row < 4 * H) v = a.w_ih_dec[i];
             else if (a.cond && col >= H && col < 2 * H) v = a.w_q2k[(int64_t)(row - 4 * H) * 2 * H + col];
             a.wcat5[i] = v;
-        } else {
+        } else if (idx < a.end[7]) {
             a.zero_extra[idx - a.end[6]] = 0.f;
+        } else {
+            decoder_image_element(a.img, (int)(idx - a.end[7]));
         }
     }
 }
 
 int step_prologue(const PrologueArgs &args, hipStream_t stream) {
-    const int64_t total = args.end[7];
+    const int64_t total = args.end[8];
     hipLaunchKernelGGL(prologue_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, stream,
                        args);
     GSCAN_LAUNCHED("prologue_kernel");

@@ -41,6 +41,61 @@ private:
     bool bad_ = false;
 };
 
+// decoder.hip
+constexpr int kDecThreads = 512;   // 8 waves: 2 per SIMD, 256-VGPR budget
+constexpr int kDecPairs = 256;     // lane pairs; a weight row lives in one pair
+struct DecoderGeometry { int rows, slots, k0; int64_t image_floats; };
+DecoderGeometry decoder_geometry(int H, bool cond);
+// Register images of the decoder weights (written once per step, by the prologue kernel):
+//   fwd/bwd image[(slot*K0 + i)*512 + tid] = element i of the half-row that thread tid keeps in slot `slot`
+//     (task r = slot*256 + tid/2, position kk = (tid&1)*K0 + i along the dot); forward: row q of block sg of
+//     [W_hh (4 blocks) | W_query_text | W_q2k[:, :H] or W_query_vis | W_query_vis]; backward: column q of block sg;
+//   head image[i*512 + tid] = MFMA B fragment of the permuted output_to_hidden: wo_perm[16 w + fr][4 i + fg].
+struct DecoderImageArgs {
+    const float *w_hh, *w_qt, *w_qv, *w_q2k, *w_o2h;
+    float *fwd_image, *bwd_image, *head_image;
+    int H, cond, slots, k0;
+};
+#ifdef __HIPCC__
+// element e of the concatenation [fwd image | bwd image | head image]
+__device__ __forceinline__ void decoder_image_element(const DecoderImageArgs &a, int e) {
+    const int H = a.H, total = a.slots * a.k0 * kDecThreads;
+    if (e >= 2 * total) {
+        const int x = e - 2 * total, tid = x % kDecThreads, i = x / kDecThreads;
+        const int n = 16 * (tid >> 6) + (tid & 15), k = 4 * i + ((tid >> 4) & 3);     // wo_perm[n][k], k in S order
+        float v = 0.f;
+        if (n < H) {
+            const int seg = k / H, kk = k - seg * H;                                   // [e | ctx_t | ctx_v | h]
+            const int src = (seg == 0 ? 0 : seg == 1 ? 2 * H : seg == 2 ? 3 * H : H) + kk;   // W_o2h: [e | h | ctx_t | ctx_v]
+            v = a.w_o2h[(int64_t)n * 4 * H + src];
+        }
+        a.head_image[x] = v;
+        return;
+    }
+    const bool bwd = e >= total;
+    const int x = bwd ? e - total : e;
+    const int tid = x % kDecThreads, i = (x / kDecThreads) % a.k0, s = x / (kDecThreads * a.k0);
+    const int r = s * kDecPairs + (tid >> 1), kk = (tid & 1) * a.k0 + i;               // kk: position along the dot
+    float v = 0.f;
+    const int rows = (a.cond ? 7 : 6) * H;
+    if (r < rows && kk < H) {
+        const int sg = r / H, q = r % H;                                               // block, index inside it
+        if (!bwd) {          // row q of block sg, element kk
+            if (sg < 4) v = a.w_hh[(int64_t)r * H + kk];
+            else if (sg == 4) v = a.w_qt[(int64_t)q * H + kk];
+            else if (sg == 5) v = a.cond ? a.w_q2k[(int64_t)q * 2 * H + kk] : a.w_qv[(int64_t)q * H + kk];
+            else v = a.w_qv[(int64_t)q * H + kk];
+        } else {             // column q of block sg, element (row) kk
+            if (sg < 4) v = a.w_hh[(int64_t)(sg * H + kk) * H + q];
+            else if (sg == 4) v = a.w_qt[(int64_t)kk * H + q];
+            else if (sg == 5) v = a.cond ? a.w_q2k[(int64_t)kk * 2 * H + q] : a.w_qv[(int64_t)kk * H + q];
+            else v = a.w_qv[(int64_t)kk * H + q];
+        }
+    }
+    (bwd ? a.bwd_image : a.fwd_image)[x] = v;
+}
+#endif
+
 // elementwise.hip
 int world_im2col(const float *world, int B, int G, int C, int K3, float *xcol, hipStream_t stream);
 int embed_rows(const int64_t *tok, const float *table, int vocab, const float *mask, int rows, int D, float *out,
@@ -58,7 +113,8 @@ struct PrologueArgs {
     int cond;
     int64_t zero_extra_count;
     int H, He, E, D, BL, BT, Vi, V;
-    int64_t end[8];
+    int64_t end[9];
+    DecoderImageArgs img;
 };
 int step_prologue(const PrologueArgs &args, hipStream_t stream);
 int toeplitz_build(const float *const (&w)[3], const float *const (&b)[3], int G, int C, int Co, int K3, float *wt,
@@ -98,14 +154,7 @@ int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, c
                           const float *w_hh_r, const float *gates, const float *cells, const float *d_out,
                           const float *d_h_final, float *delta, hipStream_t stream);
 
-// decoder.hip
-constexpr int kDecThreads = 512;   // 8 waves: 2 per SIMD, 256-VGPR budget
-constexpr int kDecPairs = 256;     // lane pairs; a weight row lives in one pair
-struct DecoderGeometry { int rows, slots, k0; int64_t image_floats; };
-DecoderGeometry decoder_geometry(int H, bool cond);
-int decoder_weight_images(const float *w_hh, const float *w_qt, const float *w_qv, const float *w_q2k,
-                          const float *wo_perm, int H, bool cond, float *fwd_image, float *bwd_image,
-                          float *head_image, hipStream_t stream);
+// decoder.hip (geometry and weight images: declared above, next to the prologue that writes the images)
 constexpr int kHeadChunk = 32;     // target steps per pass of the fused output head (two 16-row MFMA tiles)
 
 struct DecoderArgs {
@@ -114,7 +163,7 @@ struct DecoderArgs {
     const float *pk_t, *u_t, *u2_t;    // [B,L,H] [B,L,4H] [B,L,H]
     const float *pk_v, *u_v;           // [B,M,H] [B,M,4H]
     const float *ge;                   // [B,T,4H] embedding part of the gates + both biases
-    const float *w_image;              // register image of the recurrent weights (decoder_weight_images)
+    const float *w_image;              // register image of the recurrent weights (decoder_image_element)
     const float *b_q2k, *v_t, *v_v;
     float *hprev;                      // [B,T,H]  hprev[b,0] = h0 = c0 on entry; kernel fills t+1
     float *s;                          // [B,T,4H] = [e | ctx_text | ctx_vis | h_t]; kernel fills 3 parts

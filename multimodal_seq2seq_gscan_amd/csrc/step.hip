@@ -257,14 +257,16 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
         a.wcat5 = w + ws.wcat5; a.w_ih_dec = p.dec_w_ih; a.w_q2k = p.q2k_w; a.cond = cond ? 1 : 0;
         a.zero_extra = w + ws.enc_out;                     // adjacent slots enc_out | hN | dxe
         a.zero_extra_count = (ws.dxe + (int64_t)B * L * E) - ws.enc_out;
-        const int64_t n[8] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
-                              (int64_t)B * L * E, (int64_t)B * T * H, (int64_t)5 * H * 3 * H, a.zero_extra_count};
+        const DecoderGeometry geo = decoder_geometry(H, cond);
+        a.img = DecoderImageArgs{p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, p.out2hid_w, w + ws.dec_w_fwd,
+                                 w + ws.dec_w_bwd, w + ws.dec_w_head, H, cond ? 1 : 0, geo.slots, geo.k0};
+        const int64_t n[9] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
+                              (int64_t)B * L * E, (int64_t)B * T * H, (int64_t)5 * H * 3 * H, a.zero_extra_count,
+                              2 * geo.image_floats + (int64_t)H * kDecThreads};
         int64_t acc = 0;
-        for (int i = 0; i < 8; ++i) { acc += n[i]; a.end[i] = acc; }
+        for (int i = 0; i < 9; ++i) { acc += n[i]; a.end[i] = acc; }
         TRY(step_prologue(a, st));
     }
-    TRY(decoder_weight_images(p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, w + ws.wo_perm, H, cond,
-                              w + ws.dec_w_fwd, w + ws.dec_w_bwd, w + ws.dec_w_head, st));
     {
         GemmBatch g;
         // encoder input projections W_ih x + b_ih, both directions (seq2seq_model.py:70)
