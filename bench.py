@@ -30,6 +30,19 @@ import torch.distributed as dist  # noqa: E402
 # fp32 matrix peak of MI355X (v_mfma_f32_*_f32 = the fp32 vector rate), MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP32_TFLOPS = 157.3
 PROBES = ("decoder_forward", "decoder_backward", "encoder_forward", "encoder_backward", "gemm")
+# HBM-side bytes per launch of the GEMM family come from separate rocprofv3 PMC passes over this same workload
+# (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process): tools/pmc_traffic.py writes the file
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+
+
+def pmc_traffic(kernel_family: str):
+    if kernel_family != "gemm" or not os.path.exists(PMC_TRAFFIC):
+        return None
+    try:
+        with open(PMC_TRAFFIC) as f:
+            return round(float(json.load(f)["traffic_bytes_per_launch"]))
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def algorithmic_mflop_per_example(cfg: dict, G: int, L: int, T: int) -> float:
@@ -191,8 +204,9 @@ def main():
                        "launch": "hipGraph replay (3 graphs per step)" if args.graph else "eager, 24 launches per step on 3 streams"},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(d["tflops"], 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_FP32_TFLOPS, 4),
-                         "traffic": None, "avg_launch_us": round(d["avg_us"], 2),
-                         "note": "fp32 matrix peak = fp32 vector peak on gfx950; algorithmic flops per launch in DESIGN.md"},
+                         "traffic": pmc_traffic(dominant), "avg_launch_us": round(d["avg_us"], 2),
+                         "note": "fp32 matrix peak = fp32 vector peak on gfx950; algorithmic flops per launch in "
+                                 "DESIGN.md; traffic = HBM-side bytes per launch from the PMC passes in profiles/"},
             "kernel_families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in families.items()},
             "step_algorithmic_tflops": round(ex_per_s * mflop / 1e6, 3),
             "final_loss": round(loss, 4),
