@@ -111,6 +111,24 @@ int gscan_backward(const gscan_dims *dims, const gscan_params *params, const gsc
                    const gscan_masks *masks, void *workspace, const float *dlogp, const float *daux_logp,
                    const gscan_params *grads, void *stream);
 
+/* ---- greedy decoding (seq2seq/predict.py:82-115): encode once, then one decoder step per call ---- */
+
+/* Model.encode_input (model.py:172-180) plus what predict.py computes once per example before its decoding loop
+ * (:87-96): both encoders, the projected keys of both attentions and the bridge tanh(W h_N + b).  dims->T must be
+ * 1; `workspace` (gscan_workspace_bytes of the same dims) then holds, under the names gscan_workspace_find knows,
+ * "feat" [B,G*G,3Co], "enc_out" [B,L,He], "hN" [B,He], "pkv" [B,G*G,H], "pkt" [B,L,H] and "hprev" [B,H] = the
+ * initial decoder state (h0 = c0).  batch->targets / target_positions are not read; masks is normally NULL. */
+int gscan_encode(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                 const gscan_masks *masks, void *workspace, void *stream);
+
+/* Model.decode_input = BahdanauAttentionDecoderRNN.forward_step (seq2seq_model.py:359-431) for all B rows, eval
+ * mode, on the memories the last gscan_encode left in `workspace`:  tokens [B] -> logits [B,V] (un-normalised, as
+ * the reference returns them), the new state (h_out, c_out [B,H]; may alias h_in / c_in) and the two attention
+ * distributions alpha_text [B,L], alpha_vis [B,G*G].  Only batch->cmd_lengths is read from `batch`. */
+int gscan_decode_step(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                      const int64_t *tokens, const float *h_in, const float *c_in, void *workspace, float *logits,
+                      float *h_out, float *c_out, float *alpha_text, float *alpha_vis, void *stream);
+
 /* Model.get_loss (seq2seq/model.py:147-160): NLL of targets shifted left by one with a PAD
  * appended, over positions whose shifted target != pad.  Writes loss_sum[0] = sum of -logp
  * and count[0] = number of such positions (as float); the reference's loss is

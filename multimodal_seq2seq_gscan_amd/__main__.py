@@ -121,8 +121,53 @@ def main(flags):
             model.save_checkpoint("checkpoint.pth.tar", is_best=False, optimizer_state_dict=step.optimizer.state_dict())
         logger.info("Finished training.")
     elif flags["mode"] == "test":
-        raise NotImplementedError("greedy decoding (predict.py) is outside the training hot path built so far "
-                                  "(SURVEY.md §8 f2)")
+        # seq2seq/__main__.py:124-163 + predict.py:17-54: greedy-decode every example of each split and write
+        # <split>_<output_file_name> with the reference's record schema.  Synthetic data has no vocabulary, so the
+        # "input" / "prediction" / "target" fields hold token ids instead of words.
+        import json
+        from .config import model_kwargs
+        from .model import Model
+        from .predict import predict, sequence_accuracy
+        from .synthetic import Shape, make_batch
+        if not torch.cuda.is_available():
+            raise RuntimeError("greedy decoding runs on the HIP device only (no CPU fallback in this package)")
+        if not flags["synthetic_data"]:
+            raise NotImplementedError(
+                "reading data/<split>/dataset.txt is the next row of the scope table (SURVEY.md §8 f1/f3); "
+                "pass --synthetic_data to decode synthetic examples")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        assert os.path.isfile(flags["resume_from_file"]), "No checkpoint found at {}".format(flags["resume_from_file"])
+        cfg = model_kwargs("compositional")
+        cfg.update({k: flags[k] for k in cfg if k in flags})
+        model = Model(**cfg).cuda()
+        logger.info("Loading checkpoint from file at '{}'".format(flags["resume_from_file"]))
+        model.load_model(flags["resume_from_file"])
+        logger.info("Loaded checkpoint '{}' (iter {})".format(flags["resume_from_file"], model.trained_iterations))
+        n_examples = flags["max_testing_examples"] or 64
+        for split_index, split in enumerate(flags["splits"].split(",")):
+            def iterator():
+                done = 0
+                while done < n_examples:
+                    n = min(256, n_examples - done)
+                    b = make_batch(Shape(batch=n, ragged=True), seed=flags["seed"] * 7919 + 31 * split_index + done)
+                    yield (b["commands"].cuda(), b["cmd_lengths"].tolist(), [None] * n, b["world"].cuda(), [None] * n,
+                           b["targets"].cuda(), b["tgt_lengths"].tolist(), None, b["target_positions"].cuda())
+                    done += n
+            output = []
+            for (inp, derivation, situation, out_seq, tgt, aw_c, aw_s, pos_acc) in predict(
+                    iterator(), model=model, max_decoding_steps=flags["max_decoding_steps"],
+                    pad_idx=cfg["target_pad_idx"], sos_idx=1, eos_idx=cfg["target_eos_idx"]):
+                accuracy = sequence_accuracy(out_seq, tgt[0].tolist()[1:-1])
+                output.append({"input": inp[0].tolist()[1:-1], "prediction": out_seq, "derivation": derivation,
+                               "target": tgt[0].tolist()[1:-1], "situation": situation,
+                               "attention_weights_input": aw_c, "attention_weights_situation": aw_s,
+                               "accuracy": accuracy, "exact_match": True if accuracy == 100 else False,
+                               "position_accuracy": pos_acc})
+            output_file_path = os.path.join(flags["output_directory"], "_".join([split, flags["output_file_name"]]))
+            with open(output_file_path, mode="w") as outfile:
+                json.dump(output, outfile, indent=4)
+            logger.info("Wrote predictions for {} examples.".format(len(output)))
+            logger.info("Saved predictions to {}".format(output_file_path))
     elif flags["mode"] == "predict":
         raise NotImplementedError()
     else:

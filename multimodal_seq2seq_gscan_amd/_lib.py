@@ -79,6 +79,9 @@ PROTOTYPES = {
     "gscan_dropout_mask": (_i, [_vp, _sz, _f, _u64, _u64, _vp]),
     "gscan_step_losses": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gscan_loss_seeds": (_i, [_vp, _f, _i, _vp, _vp]),
+    "gscan_encode": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp]),
+    "gscan_decode_step": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _vp]),
     "gscan_backward_nll": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _f, _vp,
                                 _vp, C.POINTER(Params), _vp]),
     "gscan_backward_seeded": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp,

@@ -85,6 +85,23 @@ int gscan_backward_nll(const gscan_dims *dims, const gscan_params *params, const
                          &nll, *grads, (hipStream_t)stream);
 }
 
+int gscan_encode(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                 const gscan_masks *masks, void *workspace, void *stream) {
+    ARG(dims && params && batch && workspace, "encode: NULL argument");
+    gscan_masks none{nullptr, nullptr, nullptr};
+    return step_encode(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, (hipStream_t)stream);
+}
+
+int gscan_decode_step(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                      const int64_t *tokens, const float *h_in, const float *c_in, void *workspace, float *logits,
+                      float *h_out, float *c_out, float *alpha_text, float *alpha_vis, void *stream) {
+    ARG(dims && params && batch && batch->cmd_lengths && tokens && h_in && c_in && workspace && logits && h_out &&
+            c_out && alpha_text && alpha_vis,
+        "decode_step: NULL argument");
+    return step_decode_one(*dims, *params, *batch, tokens, h_in, c_in, (float *)workspace, logits, h_out, c_out,
+                           alpha_text, alpha_vis, (hipStream_t)stream);
+}
+
 int gscan_step_losses(const float *logp, const int64_t *targets, const float *aux_logp, const int64_t *positions, int B,
                       int T, int V, int M, int pad, float *stats, float *dlogp, float *daux, void *stream) {
     ARG(logp && targets && stats && dlogp && B > 0 && T > 0 && V > 0, "step_losses: bad argument");

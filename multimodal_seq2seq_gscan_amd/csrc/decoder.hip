@@ -257,8 +257,9 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     lds_barrier();
     float c = 0.f;
     if (tid < H) {
-        c = a.hprev[(int64_t)b * T * H + tid];              // c0 = h0 (seq2seq_model.py:494-504)
-        h_s[tid] = c;
+        const float h0 = a.hprev[(int64_t)b * T * H + tid];
+        c = a.c0 ? a.c0[(int64_t)b * H + tid] : h0;         // c0 = h0 unless given (seq2seq_model.py:494-504)
+        h_s[tid] = h0;
         vt_s[tid] = a.v_t[tid];
         vv_s[tid] = a.v_v[tid];
     }
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             a.cells[bt * H + tid] = c;
             a.s[bt * 4 * H + 3 * H + tid] = h;
             if (t + 1 < T) a.hprev[(bt + 1) * H + tid] = h;
+            else if (a.h_last) a.h_last[(int64_t)b * H + tid] = h;
         } else if (tid >= 128 && tid < 128 + H) {
             const int r = 4 * H + (tid - 128);
             a.s[bt * 4 * H + 2 * H + (tid - 128)] = (part_s[r] + part_s[kPartStride + r]) +

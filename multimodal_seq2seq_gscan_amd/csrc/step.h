@@ -165,7 +165,9 @@ struct DecoderArgs {
     const float *ge;                   // [B,T,4H] embedding part of the gates + both biases
     const float *w_image;              // register image of the recurrent weights (decoder_image_element)
     const float *b_q2k, *v_t, *v_v;
-    float *hprev;                      // [B,T,H]  hprev[b,0] = h0 = c0 on entry; kernel fills t+1
+    float *hprev;                      // [B,T,H]  hprev[b,0] = h0 (= c0 unless c0 is given) on entry; kernel fills t+1
+    const float *c0;                   // [B,H] initial cell state, or NULL for c0 = h0 (seq2seq_model.py:494-504)
+    float *h_last;                     // [B,H] h after the last step, or NULL
     float *s;                          // [B,T,4H] = [e | ctx_text | ctx_vis | h_t]; kernel fills 3 parts
     float *cells, *gates;              // [B,T,H] [B,T,4H]
     float *alpha_c, *alpha_s;          // [B,T,L] [B,T,M]
@@ -240,6 +242,11 @@ int workspace_layout(const gscan_dims &d, Workspace *ws);
 int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                  float *logp, float *aux_logp, hipStream_t st);
 struct NllSeed { float w_aux; float *stats_out, *seeds_out; };   // backward of the training loss itself
+int step_encode(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
+                hipStream_t st);
+int step_decode_one(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const int64_t *tokens,
+                    const float *h_in, const float *c_in, float *w, float *logits, float *h_out, float *c_out,
+                    float *alpha_text, float *alpha_vis, hipStream_t st);
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                   const float *dlogp, const float *daux, const float *seeds, const NllSeed *nll, const gscan_params &g,
                   hipStream_t st);

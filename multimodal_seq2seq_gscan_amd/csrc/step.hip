@@ -205,19 +205,19 @@ static int order_after(hipStream_t waiter, hipStream_t signaller, hipStream_t wa
 // --------------------------------------------------------------------------------------
 // forward
 // --------------------------------------------------------------------------------------
-int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk,
-                 float *w, float *logp, float *aux_logp, hipStream_t st) {
-    TRY(check_dims(d));
-    Workspace ws;
-    TRY(workspace_layout(d, &ws));
+// Everything before the decoder: both encoders, the projected keys and their gate images, the bridge, and the
+// per-step weight images.  teacher_forced = the target tokens of all T steps are known (training / scoring):
+// their embeddings and the embedding part of the gate pre-activations are computed here too.
+static int encode_branches(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk,
+                           float *w, const Workspace &ws, bool teacher_forced, hipStream_t st) {
     const int B = d.B, L = d.L, T = d.T, M = d.G * d.G, C = d.C, Co = d.Co, F = 3 * Co, E = d.E, He = d.He, H = d.H,
               V = d.V, D = d.bidirectional ? 2 : 1;
     const bool cond = d.conditional != 0;
     GSCAN_CHECK(!cond || (p.q2k_w && p.q2k_b), "forward: conditional attention needs queries_to_keys parameters");
     GSCAN_CHECK(D == 1 || (p.enc_w_ih_rev && p.enc_w_hh_rev && p.enc_b_ih_rev && p.enc_b_hh_rev),
                 "forward: bidirectional encoder needs the *_reverse parameters");
-    GSCAN_CHECK(logp != nullptr, "forward: logp is NULL");
-    GSCAN_CHECK(!d.auxiliary || aux_logp, "forward: auxiliary task set but aux_logp is NULL");
+    GSCAN_CHECK(bt.commands && bt.cmd_lengths && bt.world && (!teacher_forced || bt.targets),
+                "forward: NULL array in the batch");
     TRY(side_init());
     hipStream_t sd = g_side.single ? st : g_side.stream;
 
@@ -250,7 +250,8 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
         PrologueArgs a{};
         a.b_ih = p.dec_b_ih; a.b_hh = p.dec_b_hh; a.w_o2h = p.out2hid_w;
         a.w_ih_f = p.enc_w_ih; a.w_ih_r = p.enc_w_ih_rev; a.enc_emb = p.enc_emb; a.dec_emb = p.dec_emb;
-        a.mask_enc = mk.enc; a.mask_dec = mk.dec; a.commands = bt.commands; a.targets = bt.targets;
+        a.mask_enc = mk.enc; a.mask_dec = mk.dec; a.commands = bt.commands;
+        a.targets = teacher_forced ? bt.targets : nullptr;
         a.bsum = w + ws.bsum; a.wo_perm = w + ws.wo_perm; a.wih_stack = w + ws.wih_stack;
         a.dwo_perm = w + ws.dwo_perm; a.xe = w + ws.xe; a.S = w + ws.S;
         a.H = H; a.He = He; a.E = E; a.D = D; a.BL = B * L; a.BT = B * T; a.Vi = d.Vi; a.V = V;
@@ -261,7 +262,8 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
         a.img = DecoderImageArgs{p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, p.out2hid_w, w + ws.dec_w_fwd,
                                  w + ws.dec_w_bwd, w + ws.dec_w_head, H, cond ? 1 : 0, geo.slots, geo.k0};
         const int64_t n[9] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
-                              (int64_t)B * L * E, (int64_t)B * T * H, (int64_t)5 * H * 3 * H, a.zero_extra_count,
+                              (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
+                              a.zero_extra_count,
                               2 * geo.image_floats + (int64_t)H * kDecThreads};
         int64_t acc = 0;
         for (int i = 0; i < 9; ++i) { acc += n[i]; a.end[i] = acc; }
@@ -275,7 +277,8 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
             g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih_rev, 1, E, w + ws.gx + 4 * He, (int64_t)D * 4 * He, 0.f,
                   p.enc_b_ih_rev);
         // decoder: embedding part of the gate pre-activations for all t (teacher forcing)
-        g.add(B * T, 4 * H, H, w + ws.S, 4 * H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge, 4 * H, 0.f, w + ws.bsum);
+        if (teacher_forced)
+            g.add(B * T, 4 * H, H, w + ws.S, 4 * H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge, 4 * H, 0.f, w + ws.bsum);
         // composite weights for the textual memories
         g.add(4 * H, He, H, p.dec_w_ih + H, 3 * H, 1, p.txt_key_w, He, 1, w + ws.w_ck, He);
         if (cond) g.add(H, He, H, p.q2k_w + H, 2 * H, 1, p.txt_key_w, He, 1, w + ws.w_2kk, He);
@@ -294,6 +297,19 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
         TRY(g.launch(st));
     }
     TRY(order_after(st, sd));          // join: the decoder needs both branches
+    return 0;
+}
+
+int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk,
+                 float *w, float *logp, float *aux_logp, hipStream_t st) {
+    TRY(check_dims(d));
+    Workspace ws;
+    TRY(workspace_layout(d, &ws));
+    const int B = d.B, H = d.H;
+    const bool cond = d.conditional != 0;
+    GSCAN_CHECK(logp != nullptr, "forward: logp is NULL");
+    GSCAN_CHECK(!d.auxiliary || aux_logp, "forward: auxiliary task set but aux_logp is NULL");
+    TRY(encode_branches(d, p, bt, mk, w, ws, true, st));
 
     // ---- the T-step recurrence; its epilogue is the output head, which does not feed back
     // (seq2seq_model.py:421-424: S . wo_perm^T, then W_h2o) and log_softmax (model.py:203, :166-170) of the row's
@@ -305,6 +321,47 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     a.stamps = probe_stamps_enabled() ? w + ws.stamps : nullptr;
     TRY(decoder_run(false, B, H, cond, a, st));
     return 0;
+}
+
+// --------------------------------------------------------------------------------------
+// greedy decoding (predict.py:82-115): encode once, then one decoder step per call with the caller's token
+// --------------------------------------------------------------------------------------
+int step_encode(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
+                hipStream_t st) {
+    TRY(check_dims(d));
+    GSCAN_CHECK(d.T == 1, "encode: dims.T must be 1 (the workspace is laid out for single decoder steps), got %d", d.T);
+    Workspace ws;
+    TRY(workspace_layout(d, &ws));
+    return encode_branches(d, p, bt, mk, w, ws, false, st);
+}
+
+int step_decode_one(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const int64_t *tokens,
+                    const float *h_in, const float *c_in, float *w, float *logits, float *h_out, float *c_out,
+                    float *alpha_text, float *alpha_vis, hipStream_t st) {
+    TRY(check_dims(d));
+    GSCAN_CHECK(d.T == 1, "decode_step: dims.T must be 1, got %d", d.T);
+    Workspace ws;
+    TRY(workspace_layout(d, &ws));
+    const int B = d.B, H = d.H, V = d.V;
+    // e = Emb_dec[token] (eval mode: no dropout), then its part of the gate pre-activations
+    TRY(embed_rows(tokens, p.dec_emb, V, nullptr, B, H, w + ws.S, 4 * H, st));
+    TRY(gemm_f32(B, 4 * H, H, 1.f, w + ws.S, 4 * H, 1, p.dec_w_ih, 1, 3 * H, 0.f, w + ws.ge, 4 * H, w + ws.bsum, 0,
+                 nullptr, 1, st));
+    gscan_batch step_batch = bt;
+    step_batch.targets = tokens;
+    DecoderArgs a = decoder_args(d, p, step_batch, w, ws);
+    a.w_image = w + ws.dec_w_fwd;
+    a.hprev = const_cast<float *>(h_in);       // T = 1: row 0 is read, nothing is written
+    a.c0 = c_in;
+    a.h_last = h_out;
+    a.cells = c_out;
+    a.logits = logits;
+    a.alpha_c = alpha_text;
+    a.alpha_s = alpha_vis;
+    a.logp_out = w + ws.logp_saved;
+    a.aux_saved = nullptr; a.aux_out = nullptr; a.row_stats = nullptr;
+    a.stamps = nullptr;
+    return decoder_run(false, B, H, d.conditional != 0, a, st);
 }
 
 // --------------------------------------------------------------------------------------

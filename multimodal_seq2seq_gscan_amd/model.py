@@ -37,6 +37,27 @@ class _Holder(nn.Module):
         raise RuntimeError("parameter holder: the forward pass is Model.forward (HIP)")
 
 
+class _HipLinear(nn.Linear):
+    """An nn.Linear (same parameters, same initialisation, same state_dict keys) whose forward is the library's
+    fp32 MFMA GEMM.  predict.py:87-96 calls `visual_attention.key_layer`, `textual_attention.key_layer` and
+    `enc_hidden_to_dec_hidden` directly, so these three layers must compute; inference only (no autograd)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("this layer runs on the HIP device only (there is no CPU fallback in this package)")
+        lib = _lib.load()
+        xin = x.detach().to(torch.float32).contiguous()
+        K, N = self.in_features, self.out_features
+        if xin.shape[-1] != K:
+            raise ValueError(f"expected {K} input features, got {xin.shape[-1]}")
+        M = xin.numel() // K
+        out = torch.empty(*xin.shape[:-1], N, dtype=torch.float32, device=x.device)
+        _lib.check(lib.gscan_gemm_f32(M, N, K, 1.0, xin.data_ptr(), K, 1, self.weight.data_ptr(), 1, K, 0.0,
+                                      out.data_ptr(), N, _lib.ptr(self.bias), 0, None, 1,
+                                      torch.cuda.current_stream().cuda_stream), "gscan_gemm_f32")
+        return out
+
+
 class _WorldEncoderParams(_Holder):
     """cnn_model.py:7-20 — three same-padded convolutions with kernels 1, 5 and cnn_kernel_size."""
 
@@ -53,7 +74,7 @@ class _AttentionParams(_Holder):
 
     def __init__(self, key_size: int, query_size: int, hidden_size: int):
         super().__init__()
-        self.key_layer = nn.Linear(key_size, hidden_size, bias=False)
+        self.key_layer = _HipLinear(key_size, hidden_size, bias=False)
         self.query_layer = nn.Linear(query_size, hidden_size, bias=False)
         self.energy_layer = nn.Linear(hidden_size, 1, bias=False)
 
@@ -83,6 +104,12 @@ class _DecoderParams(_Holder):
         self.visual_attention = visual_attention
         self.output_to_hidden = nn.Linear(hidden_size * 4, hidden_size, bias=False)
         self.hidden_to_output = nn.Linear(hidden_size, output_size, bias=False)
+        self.num_layers = num_layers
+
+    def initialize_hidden(self, encoder_message: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """seq2seq_model.py:494-504: hidden and cell state of every layer start from the same message."""
+        message = encoder_message.unsqueeze(0).expand(self.num_layers, -1, -1).contiguous()
+        return message.clone(), message.clone()
 
 
 def _as_int32_lengths(lengths, device) -> torch.Tensor:
@@ -186,7 +213,8 @@ class Model(nn.Module):
                                                  decoder_hidden_size)
         self.encoder = _CommandEncoderParams(input_vocabulary_size, embedding_dimension, encoder_hidden_size,
                                              num_encoder_layers, encoder_bidirectional, input_padding_idx)
-        self.enc_hidden_to_dec_hidden = nn.Linear(encoder_hidden_size, decoder_hidden_size)
+        self.enc_hidden_to_dec_hidden = _HipLinear(encoder_hidden_size, decoder_hidden_size)
+        self.tanh = nn.Tanh()
         self.textual_attention = _AttentionParams(encoder_hidden_size, decoder_hidden_size, decoder_hidden_size)
         self.attention_decoder = _DecoderParams(decoder_hidden_size, target_vocabulary_size, num_decoder_layers,
                                                 target_pad_idx, self.textual_attention, self.visual_attention,
@@ -223,6 +251,7 @@ class Model(nn.Module):
         self._mask_key = None
         self._mask_stream_id = None      # device uint64 holding the Philox stream id (graph replay), or None
         self._anchor = None
+        self._decode_state = None        # dims / batch of the last encode_input (greedy decoding)
         self._flatten()
 
     # ---- flat parameter / gradient buffers ------------------------------------------------
@@ -475,11 +504,78 @@ class Model(nn.Module):
             self.best_exact_match, self.best_accuracy = exact_match, accuracy
             self.best_iteration = self.trained_iterations
 
-    # encode_input / decode_input belong to the greedy-decode path (predict.py), SURVEY.md §8 f2: next
-    def encode_input(self, *args, **kwargs):
-        raise NotImplementedError("greedy decoding (predict.py) is outside the training hot path built so far")
+    # ---- greedy decoding surface (model.py:172-188, used by predict.py:82-106) ---------------------
+    def encode_input(self, commands_input: torch.LongTensor, commands_lengths: List[int],
+                     situations_input: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """model.py:172-180.  Runs both encoders — and, for the decode_input calls that follow, the key projections
+        and the bridge — in one library call; returns the reference's dictionary."""
+        lib = _lib.load()
+        self._require_device(commands_input, situations_input)
+        device = commands_input.device
+        lengths = _as_int32_lengths(commands_lengths, device)
+        B, L = commands_input.shape
+        G = situations_input.shape[1]
+        if situations_input.shape != (B, G, G, self._hyper["C"]):
+            raise ValueError(f"situations_input must be [B,G,G,{self._hyper['C']}], got {tuple(situations_input.shape)}")
+        assert lengths.numel() == B, "Wrong amount of lengths passed to .forward()"   # seq2seq_model.py:57
+        dims = self._dims(B, L, 1, G)
+        need = lib.gscan_workspace_bytes(C.byref(dims))
+        if need == 0:
+            raise _lib.GscanError("unsupported dimensions: " + lib.gscan_last_error().decode())
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        commands = commands_input.contiguous()
+        world = situations_input.to(torch.float32).contiguous()
+        batch = _lib.Batch(commands.data_ptr(), lengths.data_ptr(), world.data_ptr(), None, None)
+        masks = _lib.Masks(None, None, None)      # eval semantics: predict() calls model.eval() first (predict.py:70)
+        _lib.check(lib.gscan_encode(C.byref(dims), C.byref(self._param_struct), C.byref(batch), C.byref(masks),
+                                    self._workspace.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "gscan_encode")
+        self._generation += 1
+        M, F, He = G * G, 3 * self._hyper["Co"], self._hyper["He"]
+        self._decode_state = dict(dims=dims, batch=batch, generation=self._generation, B=B, L=L, M=M,
+                                  keep=(commands, lengths, world))
+        feat = self.workspace_view(dims, "feat").view(B, M, F).clone()
+        enc_out = self.workspace_view(dims, "enc_out").view(B, L, He).transpose(0, 1).contiguous()
+        hidden = self.workspace_view(dims, "hN").view(B, He).clone()
+        return {"encoded_situations": feat,
+                "encoded_commands": {"encoder_outputs": enc_out, "sequence_lengths": commands_lengths},
+                "hidden_states": hidden}
 
-    decode_input = encode_input
+    def decode_input(self, target_token: torch.LongTensor, hidden: Tuple[torch.Tensor, torch.Tensor],
+                     encoder_outputs: torch.Tensor, input_lengths: List[int],
+                     encoded_situations: torch.Tensor):
+        """model.py:182-188 = one decoder step (seq2seq_model.py:359-431) for all rows.  As in predict.py:87-106,
+        `encoder_outputs` / `encoded_situations` are the PROJECTED keys of the latest encode_input; the step runs on
+        the copies that call left on the device (the arguments are checked for shape only).  Returns the
+        reference's tuple (logits, (h, c), alpha_vis, alpha_text, alpha_vis)."""
+        lib = _lib.load()
+        st = self._decode_state
+        if st is None or st["generation"] != self._generation:
+            raise RuntimeError("decode_input() needs the encode_input() of the same examples first "
+                               "(the encoded memories live in the model's device workspace)")
+        B, L, M, H = st["B"], st["L"], st["M"], self._hyper["H"]
+        h, c = hidden
+        if tuple(encoder_outputs.shape) != (L, B, H) or tuple(encoded_situations.shape) != (B, M, H):
+            raise ValueError(f"projected keys must be [{L},{B},{H}] and [{B},{M},{H}], got "
+                             f"{tuple(encoder_outputs.shape)} and {tuple(encoded_situations.shape)}")
+        assert len(input_lengths) == B                                   # seq2seq_model.py:120
+        device = h.device
+        self._require_device(h, c, target_token)
+        tokens = target_token.reshape(B).to(torch.int64).contiguous()
+        h_in = h.reshape(B, H).to(torch.float32).contiguous()
+        c_in = c.reshape(B, H).to(torch.float32).contiguous()
+        V = self._hyper["V"]
+        logits = torch.empty(B, V, dtype=torch.float32, device=device)
+        h_out, c_out = torch.empty_like(h_in), torch.empty_like(c_in)
+        alpha_text = torch.empty(B, L, dtype=torch.float32, device=device)
+        alpha_vis = torch.empty(B, M, dtype=torch.float32, device=device)
+        _lib.check(lib.gscan_decode_step(C.byref(st["dims"]), C.byref(self._param_struct), C.byref(st["batch"]),
+                                         tokens.data_ptr(), h_in.data_ptr(), c_in.data_ptr(),
+                                         self._workspace.data_ptr(), logits.data_ptr(), h_out.data_ptr(),
+                                         c_out.data_ptr(), alpha_text.data_ptr(), alpha_vis.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "gscan_decode_step")
+        return logits, (h_out.unsqueeze(0), c_out.unsqueeze(0)), alpha_vis, alpha_text, alpha_vis
 
     # ---- checkpoints (model.py:228-261): same dictionary keys, same file names ----------------
     def get_current_state(self) -> dict:

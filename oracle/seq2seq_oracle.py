@@ -196,6 +196,50 @@ def decoder(p: Params, hN: torch.Tensor, enc_out: torch.Tensor, cmd_lengths, fea
     return torch.stack(logits, dim=1), att_sum
 
 
+def greedy_decode(p: Params, commands: torch.Tensor, cmd_lengths, world: torch.Tensor, sos_idx: int, eos_idx: int,
+                  max_decoding_steps: int, conditional: bool, bidirectional: bool = True) -> List[dict]:
+    """seq2seq/predict.py:57-128 restated: for every row on its own, encode, then feed back the argmax token until
+    EOS or until `decoding_iteration <= max_decoding_steps` fails (so at most max_decoding_steps + 1 steps).
+    Returns per row: tokens (with the final EOS if one was produced), per-step logits and both attention rows."""
+    feats = world_encoder(p, world)
+    hN, enc_out = command_encoder(p, commands, cmd_lengths, bidirectional=bidirectional)
+    lens = _lengths(cmd_lengths, commands.device)
+    pk_vis_all = feats @ p["visual_attention.key_layer.weight"].t()            # predict.py:87-88
+    pk_txt_all = enc_out @ p["textual_attention.key_layer.weight"].t()         # :89-90
+    w_ih = p["attention_decoder.lstm.weight_ih_l0"]
+    w_hh = p["attention_decoder.lstm.weight_hh_l0"]
+    bias = p["attention_decoder.lstm.bias_ih_l0"] + p["attention_decoder.lstm.bias_hh_l0"]
+    w_o2h = p["attention_decoder.output_to_hidden.weight"]
+    w_h2o = p["attention_decoder.hidden_to_output.weight"]
+    rows = []
+    for r in range(commands.shape[0]):
+        pk_vis, pk_txt, n = pk_vis_all[r:r + 1], pk_txt_all[r:r + 1], lens[r:r + 1]
+        full = torch.full((1,), pk_vis.shape[1], dtype=torch.long)
+        h = torch.tanh(hN[r:r + 1] @ p["enc_hidden_to_dec_hidden.weight"].t() + p["enc_hidden_to_dec_hidden.bias"])
+        c = h.clone()                                                          # :95-96
+        token, it = sos_idx, 0
+        out = {"tokens": [], "logits": [], "alpha_text": [], "alpha_vis": []}
+        while token != eos_idx and it <= max_decoding_steps:                   # :101
+            e = p["attention_decoder.embedding.weight"][torch.tensor([token])]
+            ctx_c, a_c = additive_attention("textual_attention", p, h, pk_txt, n)
+            if conditional:
+                q = torch.tanh(torch.cat([h, ctx_c], dim=1) @ p["attention_decoder.queries_to_keys.weight"].t()
+                               + p["attention_decoder.queries_to_keys.bias"])
+            else:
+                q = h
+            ctx_s, a_s = additive_attention("visual_attention", p, q, pk_vis, full)
+            h, c, _ = lstm_cell(torch.cat([e, ctx_c, ctx_s], dim=1) @ w_ih.t() + bias, h, c, w_hh)
+            logit = (torch.cat([e, h, ctx_c, ctx_s], dim=1) @ w_o2h.t()) @ w_h2o.t()
+            token = int(torch.log_softmax(logit, dim=-1).max(dim=-1)[1].item())   # :106-107
+            out["tokens"].append(token)
+            out["logits"].append(logit[0])
+            out["alpha_text"].append(a_c[0])
+            out["alpha_vis"].append(a_s[0])
+            it += 1
+        rows.append(out)
+    return rows
+
+
 # ----------------------------------------------------------------------------------
 # a7  Model.forward                       seq2seq/model.py:206-219
 # ----------------------------------------------------------------------------------

@@ -104,3 +104,21 @@ def test_known_parameter_totals():
         assert list(init[workload]["params"].keys()) == list(shapes.keys())
         for k, s in shapes.items():
             assert tuple(init[workload]["params"][k]["shape"]) == tuple(s)
+
+
+def test_oracle_greedy_decode_matches_reference_predict_loop():
+    """oracle.greedy_decode against the reference's own encode_input / decode_input loop (predict.py:82-115, one
+    example at a time): same tokens, same stopping step, logits and attention rows within tolerance."""
+    fx = load_fixture("demo_greedy.npz")
+    cfg = model_kwargs("demo", conditional_attention=True, auxiliary_task=True)
+    params = fixture_params(cfg, fx)
+    batch = fixture_batch(fx)
+    rows = oracle.greedy_decode(params, batch["commands"], batch["cmd_lengths"], batch["world"], int(fx["sos"]),
+                                int(fx["eos"]), int(fx["max_steps"]), conditional=True)
+    for r, row in enumerate(rows):
+        n = int(fx["nsteps"][r])
+        assert row["tokens"] == fx["tokens"][r, :n].tolist(), r
+        L = int(batch["cmd_lengths"][r])
+        assert torch.allclose(torch.stack(row["logits"]), torch.from_numpy(fx["logits"][r, :n]), atol=2e-5)
+        assert torch.allclose(torch.stack(row["alpha_text"])[:, :L], torch.from_numpy(fx["alpha_text"][r, :n, :L]), atol=2e-5)
+        assert torch.allclose(torch.stack(row["alpha_vis"]), torch.from_numpy(fx["alpha_vis"][r, :n]), atol=2e-5)

@@ -246,3 +246,105 @@ def test_fused_loss_backward_matches_two_phase_path(auxiliary):
     assert torch.allclose(t0, t1, atol=1e-4, rtol=1e-5), (t0, t1)
     assert t1[1].item() > 0 and g1.abs().max().item() > 0
     assert torch.allclose(g0, g1, atol=1e-6, rtol=1e-4), (g0 - g1).abs().max().item()
+
+
+def test_decode_input_steps_match_teacher_forced_forward():
+    """encode_input + one decode_input per target token (the greedy-decoding surface, predict.py:82-106) reproduces
+    the teacher-forced forward pass: same logits step by step, same attention, same final state."""
+    cfg = model_kwargs("demo", conditional_attention=True, auxiliary_task=True)
+    fx = load_fixture("demo_cond1_aux1.npz")
+    model = build_model(cfg, fixture_params(cfg, fx)).eval()
+    batch = fixture_batch(fx)
+    d = {k: v.cuda() for k, v in batch.items()}
+    with torch.no_grad():
+        logp, _ = model(commands_input=d["commands"], commands_lengths=batch["cmd_lengths"].tolist(),
+                        situations_input=d["world"], target_batch=d["targets"],
+                        target_lengths=batch["tgt_lengths"].tolist())
+        enc = model.encode_input(commands_input=d["commands"], commands_lengths=batch["cmd_lengths"].tolist(),
+                                 situations_input=d["world"])
+        keys_vis = model.visual_attention.key_layer(enc["encoded_situations"])
+        keys_txt = model.textual_attention.key_layer(enc["encoded_commands"]["encoder_outputs"])
+        hidden = model.attention_decoder.initialize_hidden(
+            model.tanh(model.enc_hidden_to_dec_hidden(enc["hidden_states"])))
+        B, T = d["targets"].shape
+        att = torch.zeros(B, keys_vis.shape[1], device="cuda")
+        for t in range(T):
+            out, hidden, ctx, a_txt, a_vis = model.decode_input(
+                target_token=d["targets"][:, t], hidden=hidden, encoder_outputs=keys_txt,
+                input_lengths=batch["cmd_lengths"].tolist(), encoded_situations=keys_vis)
+            assert torch.allclose(torch.log_softmax(out, -1), logp[:, t], atol=TOL), t
+            assert torch.allclose(a_vis.sum(1), torch.ones(B, device="cuda"), atol=1e-5)
+            att += a_vis
+        aux = model.auxiliary_task_forward(att)
+    assert torch.allclose(logp.cpu(), torch.from_numpy(fx["logp"]), atol=TOL)
+    assert torch.allclose(aux.cpu(), torch.from_numpy(fx["aux_logp"]), atol=TOL)
+    # the encoder side of the dictionary against the oracle
+    from oracle import seq2seq_oracle as oracle
+    params = fixture_params(cfg, fx)
+    feats = oracle.world_encoder(params, batch["world"])
+    hN, enc_out = oracle.command_encoder(params, batch["commands"], batch["cmd_lengths"])
+    assert torch.allclose(enc["encoded_situations"].cpu(), feats, atol=5e-5)
+    assert torch.allclose(enc["encoded_commands"]["encoder_outputs"].cpu(), enc_out.transpose(0, 1), atol=5e-5)
+    assert torch.allclose(enc["hidden_states"].cpu(), hN, atol=5e-5)
+
+
+def test_greedy_predict_matches_reference_loop():
+    """predict() (batched greedy decoding on the HIP path) against the reference's own per-example
+    encode_input / decode_input loop (tests/golden/demo_greedy.npz): same tokens, stopping steps, attention."""
+    from multimodal_seq2seq_gscan_amd.predict import evaluate, predict
+    fx = load_fixture("demo_greedy.npz")
+    cfg = model_kwargs("demo", conditional_attention=True, auxiliary_task=True)
+    model = build_model(cfg, fixture_params(cfg, fx))
+    batch = fixture_batch(fx)
+    d = {k: v.cuda() for k, v in batch.items()}
+    B = d["commands"].shape[0]
+
+    def iterator(batch_size):
+        for lo in range(0, B, batch_size):
+            hi = min(B, lo + batch_size)
+            yield (d["commands"][lo:hi], batch["cmd_lengths"][lo:hi].tolist(), [f"d{i}" for i in range(lo, hi)],
+                   d["world"][lo:hi], [{"id": i} for i in range(lo, hi)], d["targets"][lo:hi],
+                   batch["tgt_lengths"][lo:hi].tolist(), None, d["target_positions"][lo:hi])
+
+    sos, eos, steps = int(fx["sos"]), int(fx["eos"]), int(fx["max_steps"])
+    for batch_size in (B, 1, 4):
+        outs = list(predict(iterator(batch_size), model, steps, 0, sos, eos))
+        assert len(outs) == B
+        for r, (inp, deriv, spec, out_seq, tgt, a_txt, a_vis, aux_acc) in enumerate(outs):
+            n = int(fx["nsteps"][r])
+            ref_tokens = fx["tokens"][r, :n].tolist()
+            if ref_tokens[-1] == eos:
+                ref_tokens, n = ref_tokens[:-1], n - 1
+            assert out_seq == ref_tokens, (batch_size, r)
+            assert deriv == f"d{r}" and spec == {"id": r}
+            L = int(batch["cmd_lengths"][r])
+            assert inp.shape == (1, L) and len(a_txt) == n and len(a_vis) == n
+            if n:
+                assert torch.allclose(torch.tensor(a_txt), torch.from_numpy(fx["alpha_text"][r, :n, :L]), atol=1e-4)
+                assert torch.allclose(torch.tensor(a_vis), torch.from_numpy(fx["alpha_vis"][r, :n]), atol=1e-4)
+    acc, exact, aux = evaluate(iterator(3), model, steps, 0, sos, eos)
+    assert 0.0 <= acc <= 100.0 and 0.0 <= exact <= 100.0 and 0.0 <= aux <= 100.0
+
+
+def test_command_line_train_then_test_modes(tmp_path):
+    """`python -m seq2seq --mode=train ... --synthetic_data` then `--mode=test` (seq2seq/__main__.py:21-167): the
+    training loop runs, writes the reference's checkpoint dictionary, and the test mode decodes greedily from it
+    and writes <split>_predict.json with the reference's record schema (predict.py:44-51)."""
+    import json
+    from multimodal_seq2seq_gscan_amd.__main__ import main, parser
+    out = str(tmp_path)
+    common = ["--output_directory", out, "--synthetic_data", "--training_batch_size", "8", "--seed", "3"]
+    main(vars(parser.parse_args(["--mode", "train", "--max_training_iterations", "3", "--synthetic_batches", "3",
+                                 "--print_every", "2"] + common)))
+    ckpt = torch.load(f"{out}/checkpoint.pth.tar", map_location="cpu", weights_only=False)
+    assert ckpt["iteration"] == 3 and "state_dict" in ckpt and "optimizer_state_dict" in ckpt
+    main(vars(parser.parse_args(["--mode", "test", "--resume_from_file", f"{out}/checkpoint.pth.tar",
+                                 "--max_testing_examples", "5", "--max_decoding_steps", "6", "--splits", "test,dev"]
+                                + common)))
+    for split in ("test", "dev"):
+        records = json.load(open(f"{out}/{split}_predict.json"))
+        assert len(records) == 5
+        for rec in records:
+            assert set(rec) == {"input", "prediction", "derivation", "target", "situation", "attention_weights_input",
+                                "attention_weights_situation", "accuracy", "exact_match", "position_accuracy"}
+            assert len(rec["prediction"]) <= 7 and len(rec["attention_weights_situation"]) == len(rec["prediction"])
