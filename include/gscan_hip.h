@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 2
+#define GSCAN_ABI_VERSION 3
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
 typedef struct gscan_dims {
@@ -161,6 +161,12 @@ int gscan_adam_step_zero_grad(float *param, float *grad, float *exp_avg, float *
                               float beta1, float beta2, float eps, float lr_decay, float lr_decay_steps,
                               int64_t step, const float *grad_scale, void *stream);
 
+/* gscan_adam_step_zero_grad on gradients of a SUM loss: every gradient is divided by count[0] (device scalar: the
+ * all-reduced number of live target tokens) before the update. */
+int gscan_adam_step_mean(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr,
+                         float beta1, float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step,
+                         const float *count, void *stream);
+
 /* ---- the same loop body for a captured (hipGraph) step: everything that changes from step to step is read from
  * device memory, so one captured sequence can be replayed unchanged ---- */
 
@@ -182,12 +188,16 @@ int gscan_backward_seeded(const gscan_dims *dims, const gscan_params *params, co
  * gscan_forward and this call:  loss = get_loss(logp, targets) [+ weight_target_loss * get_auxiliary_loss(aux_logp,
  * target_positions) when dims->auxiliary]  (model.py:147-164).  gscan_forward leaves per-row partial sums of both
  * losses in the workspace; the backward kernels start from them.  stats[4] = [sum NLL, live tokens, sum aux NLL,
- * rows] and seeds[3] = [1/tokens, w/rows, loss] are written for the caller (device, must not be NULL).
- * Single-process form: a data-parallel step has to all-reduce `stats` before seeding (gscan_step_losses,
- * gscan_loss_seeds, gscan_backward_seeded). */
+ * rows] and seeds[3] = [seed of the sequence loss, seed of the auxiliary loss, loss] are written for the caller
+ * (device, must not be NULL).
+ * sum_reduction = 0: the reference's loss as is (mean over live tokens + w * mean over rows; seeds 1/tokens, w/rows).
+ * sum_reduction = 1: gradients of  sum NLL + w * sum aux NLL  (seeds 1, w) — the data-parallel form: every rank adds
+ * its sums, ONE all-reduce carries gradients and `stats` together, and the optimiser divides by the global token
+ * count (gscan_adam_step_mean).  With the auxiliary loss the two terms need different divisors; a data-parallel
+ * step then all-reduces `stats` first (gscan_step_losses, gscan_loss_seeds, gscan_backward_seeded). */
 int gscan_backward_nll(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
-                       const gscan_masks *masks, void *workspace, float weight_target_loss, float *stats,
-                       float *seeds, const gscan_params *grads, void *stream);
+                       const gscan_masks *masks, void *workspace, float weight_target_loss, int sum_reduction,
+                       float *stats, float *seeds, const gscan_params *grads, void *stream);
 
 /* Adam with the step-dependent scalars [lr_t / (1 - beta1^t), 1 / sqrt(1 - beta2^t)] read from device memory
  * (gscan_adam_scalars computes them on the host); zero_grad != 0 also clears the gradient buffer

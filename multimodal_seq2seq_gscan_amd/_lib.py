@@ -10,7 +10,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _f32p = C.POINTER(C.c_float)
 _i64p = C.POINTER(C.c_int64)
@@ -82,8 +82,9 @@ PROTOTYPES = {
     "gscan_encode": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp]),
     "gscan_decode_step": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp]),
-    "gscan_backward_nll": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _f, _vp,
-                                _vp, C.POINTER(Params), _vp]),
+    "gscan_backward_nll": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _f, _i,
+                                _vp, _vp, C.POINTER(Params), _vp]),
+    "gscan_adam_step_mean": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i64, _vp, _vp]),
     "gscan_backward_seeded": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp,
                                    _vp, _vp, C.POINTER(Params), _vp]),
     "gscan_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _vp, _i, _vp]),

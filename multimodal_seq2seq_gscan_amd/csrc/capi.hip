@@ -75,12 +75,12 @@ int gscan_backward_seeded(const gscan_dims *dims, const gscan_params *params, co
 }
 
 int gscan_backward_nll(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
-                       const gscan_masks *masks, void *workspace, float weight_target_loss, float *stats,
-                       float *seeds, const gscan_params *grads, void *stream) {
+                       const gscan_masks *masks, void *workspace, float weight_target_loss, int sum_reduction,
+                       float *stats, float *seeds, const gscan_params *grads, void *stream) {
     ARG(dims && params && batch && workspace && grads && stats && seeds, "backward_nll: NULL argument");
     ARG(!dims->auxiliary || batch->target_positions, "backward_nll: auxiliary task set but target_positions is NULL");
     gscan_masks none{nullptr, nullptr, nullptr};
-    const NllSeed nll{weight_target_loss, stats, seeds};
+    const NllSeed nll{weight_target_loss, sum_reduction != 0, stats, seeds};
     return step_backward(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, nullptr, nullptr, nullptr,
                          &nll, *grads, (hipStream_t)stream);
 }
@@ -166,6 +166,14 @@ int gscan_adam_step_zero_grad(float *param, float *grad, float *exp_avg, float *
     ARG(param && grad && exp_avg && exp_avg_sq && n > 0, "adam_step_zero_grad: bad argument");
     return adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, lr_decay, lr_decay_steps, step,
                      grad_scale, nullptr, 1, (hipStream_t)stream);
+}
+
+int gscan_adam_step_mean(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr,
+                         float beta1, float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step,
+                         const float *count, void *stream) {
+    ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && count, "adam_step_mean: bad argument");
+    return adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, lr_decay, lr_decay_steps, step,
+                     count, nullptr, 1 | 2, (hipStream_t)stream);
 }
 
 int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, void *stream) {

@@ -664,8 +664,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             lds_barrier();
             p0 = p1 = p2 = 0.f;
             for (int i = 0; i < kDecThreads / 64; ++i) { p0 += red[3 * i]; p1 += red[3 * i + 1]; p2 += red[3 * i + 2]; }
-            sc = 1.f / p1;
-            aux_scale = a.aux_saved ? a.w_aux / (float)a.B : 0.f;
+            sc = (a.nll_mode == 2) ? 1.f : 1.f / p1;
+            aux_scale = a.aux_saved ? ((a.nll_mode == 2) ? a.w_aux : a.w_aux / (float)a.B) : 0.f;
             if (b == 0 && tid == 0) {
                 a.stats_out[0] = p0; a.stats_out[1] = p1; a.stats_out[2] = p2; a.stats_out[3] = (float)a.B;
                 a.seeds_out[0] = sc; a.seeds_out[1] = aux_scale;

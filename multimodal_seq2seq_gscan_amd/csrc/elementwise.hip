@@ -190,11 +190,11 @@ __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float 
                             float *__restrict__ v, size_t n, float step_size, float beta1, float beta2, float eps,
                             float inv_sqrt_bc2, const float *__restrict__ grad_scale,
                             const float *__restrict__ dev_scalars, int zero_grad) {
-    const float gs = grad_scale ? grad_scale[0] : 1.f;
+    const float gs = grad_scale ? ((zero_grad & 2) ? 1.f / grad_scale[0] : grad_scale[0]) : 1.f;
     if (dev_scalars) { step_size = dev_scalars[0]; inv_sqrt_bc2 = dev_scalars[1]; }   // graph replay: per-step values
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gs;
-        if (zero_grad) g[i] = 0.f;                 // optimizer.zero_grad() of train.py:113 folded in
+        if (zero_grad & 1) g[i] = 0.f;             // optimizer.zero_grad() of train.py:113 folded in
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         m[i] = mi;

@@ -124,7 +124,7 @@ int toeplitz_fold(float *const (&gw)[3], float *const (&gb)[3], int G, int C, in
 int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream);
 int adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
               float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
-              const float *dev_scalars, int zero_grad, hipStream_t stream);
+              const float *dev_scalars, int zero_grad, hipStream_t stream);   // zero_grad bit 1: grad_scale divides
 void adam_scalars(float lr, float beta1, float beta2, float lr_decay, float lr_decay_steps, int64_t step,
                   float *step_size, float *inv_sqrt_bc2);
 int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream);
@@ -189,6 +189,7 @@ struct DecoderArgs {
     int pad_tgt, B;
     float *row_stats;                  // [B,4] = [sum NLL, live tokens, aux NLL, 1] of the row, or NULL
     int nll_mode;                      // backward: seed from row_stats / targets instead of dlogp / daux / seeds
+                                       // (1: mean loss as the reference's, 2: sum loss for the data-parallel step)
     float w_aux;                       // weight of the auxiliary loss (train.py:105-107)
     float *stats_out, *seeds_out;      // [4] batch sums, [3] = [1/tokens, w/rows, loss]; written by workgroup 0
     float *delta, *dqt, *dqv;          // [B,T,5H] = [gate deltas (4H) | dzq (H)], [B,T,H], [B,T,H]
@@ -241,7 +242,7 @@ int check_dims(const gscan_dims &d);
 int workspace_layout(const gscan_dims &d, Workspace *ws);
 int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                  float *logp, float *aux_logp, hipStream_t st);
-struct NllSeed { float w_aux; float *stats_out, *seeds_out; };   // backward of the training loss itself
+struct NllSeed { float w_aux; bool sum; float *stats_out, *seeds_out; };   // backward of the training loss itself
 int step_encode(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                 hipStream_t st);
 int step_decode_one(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const int64_t *tokens,

@@ -390,7 +390,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     const bool use_aux = d.auxiliary && daux;
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.dlogp = dlogp; a.daux = use_aux ? daux : nullptr; a.seeds = seeds;
-    if (nll) { a.nll_mode = 1; a.w_aux = nll->w_aux; a.stats_out = nll->stats_out; a.seeds_out = nll->seeds_out; }
+    if (nll) { a.nll_mode = nll->sum ? 2 : 1; a.w_aux = nll->w_aux; a.stats_out = nll->stats_out; a.seeds_out = nll->seeds_out; }
     a.dlogits = w + ws.dlogits; a.dpreo = w + ws.dpreo; a.ds = dS;
     a.delta = w + ws.delta; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
     a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = g.txt_energy_w; a.dv_v = g.vis_energy_w;

@@ -265,7 +265,10 @@ class Model(nn.Module):
         device = some.device
         total = sum(p.numel() for p in params.values())
         flat = torch.empty(total, dtype=torch.float32, device=device)
-        grad = torch.zeros(total, dtype=torch.float32, device=device)
+        # four extra floats behind the gradients: the loss statistics of a data-parallel step travel in the same
+        # all-reduce as the gradients (train.TrainStep)
+        self._grad_store = torch.zeros(total + 4, dtype=torch.float32, device=device)
+        grad = self._grad_store[:total]
         self._offsets: Dict[str, Tuple[int, int]] = {}
         off = 0
         for name, p in params.items():
@@ -422,7 +425,8 @@ class Model(nn.Module):
                                              _lib.ptr(seeds), C.byref(self._grad_struct),
                                              torch.cuda.current_stream().cuda_stream), "gscan_backward_seeded")
 
-    def _launch_backward_nll(self, call, weight_target_loss: float, stats: torch.Tensor, seeds: torch.Tensor) -> None:
+    def _launch_backward_nll(self, call, weight_target_loss: float, stats: torch.Tensor, seeds: torch.Tensor,
+                             sum_reduction: bool = False) -> None:
         """loss.backward() of the training loss itself (train.py:102-110): seeded inside the backward kernels from
         the per-row loss partials the forward pass left in the workspace; fills stats[4] and seeds[3]."""
         lib = _lib.load()
@@ -431,7 +435,8 @@ class Model(nn.Module):
                                "(one in-flight step per model, as in the reference's training loop)")
         _lib.check(lib.gscan_backward_nll(C.byref(call["dims"]), C.byref(self._param_struct), C.byref(call["batch"]),
                                           C.byref(call["masks"]), self._workspace.data_ptr(),
-                                          float(weight_target_loss), stats.data_ptr(), seeds.data_ptr(),
+                                          float(weight_target_loss), int(sum_reduction), stats.data_ptr(),
+                                          seeds.data_ptr(),
                                           C.byref(self._grad_struct), torch.cuda.current_stream().cuda_stream),
                    "gscan_backward_nll")
 

@@ -61,6 +61,16 @@ class FlatAdam:
                                self.steps_taken, self._host_scalars.data_ptr())
         self._dev_scalars.copy_(self._host_scalars, non_blocking=True)
 
+    def launch_mean(self, count: torch.Tensor) -> None:
+        """Adam + zero_grad on gradients of a SUM loss: divided by the device scalar `count` (global token count)."""
+        lib = _lib.load()
+        m = self.model
+        _lib.check(lib.gscan_adam_step_mean(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(),
+                                            self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                            m.flat_parameters.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                            self.lr_decay, self.lr_decay_steps, self.steps_taken, count.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "gscan_adam_step_mean")
+
     def launch(self, zero_grad: bool = True, device_scalars: bool = True) -> None:
         lib = _lib.load()
         m = self.model
@@ -104,8 +114,10 @@ class FlatAdam:
 
 
 class GradientExchange:
-    """The data-parallel exchange of one step: a 4-float statistics all-reduce before backward, one flat
-    gradient all-reduce after it.  With a single process both are no-ops."""
+    """The data-parallel exchange of one step.  Without the auxiliary loss: ONE all-reduce of
+    [gradients of the local SUM loss | sum NLL, tokens, ., rows] (`mean_from_sums`).  With it (two different
+    divisors): a 4-float statistics all-reduce before backward (`seeds`), one flat gradient all-reduce after it.
+    With a single process all of them are no-ops."""
 
     def __init__(self, process_group=None):
         self.group = process_group
@@ -117,6 +129,15 @@ class GradientExchange:
         if self.world_size > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def mean_from_sums(self, grads_and_stats: torch.Tensor):
+        """grads_and_stats = [d(sum NLL of this rank's rows)/d(params) | sum NLL, tokens, sum aux NLL, rows]: after
+        the all-reduce the reference's global-batch loss is stats[0]/stats[1] and its gradient is the reduced
+        gradient divided by stats[1] (model.py:147-160: mean over the live tokens of the WHOLE minibatch).  Returns
+        (reduced buffer, global token count as a 1-element view, loss)."""
+        self.all_reduce(grads_and_stats)
+        stats = grads_and_stats[-4:]
+        return grads_and_stats, stats[1:2], stats[0] / stats[1]
 
     def seeds(self, stats: torch.Tensor, weight_target_loss: float, auxiliary: bool):
         """stats = [sum NLL, tokens, sum aux NLL, rows] of THIS rank.  Returns (global stats, seed for
@@ -155,6 +176,9 @@ class TrainStep:
         self.fused_loss = (self.exchange.world_size == 1) if fused_loss is None else bool(fused_loss)
         if self.fused_loss and self.exchange.world_size > 1:
             raise ValueError("fused_loss needs the global token count: not available with more than one process")
+        # Several processes, no auxiliary loss: every rank back-propagates its SUM loss, the statistics ride behind
+        # the gradients in one all-reduce and Adam divides by the global token count.
+        self.single_exchange = self.exchange.world_size > 1 and not model.auxiliary_task and not self.graph
         device = model.flat_parameters.device
         self.stats = torch.zeros(4, dtype=torch.float32, device=device)
         self.seeds = torch.zeros(3, dtype=torch.float32, device=device)
@@ -177,7 +201,7 @@ class TrainStep:
         masks = model._draw_masks(B, L, T, world.shape[1] ** 2, commands.device)
         pos = batch["target_positions"] if model.auxiliary_task else None
         logp, aux, call = model._launch_forward(commands, batch["cmd_lengths"], world, targets, masks, pos)
-        if self.fused_loss:
+        if self.fused_loss or self.single_exchange:
             return {"logp": logp, "aux": aux, "call": call}
         dlogp = torch.empty_like(logp)
         daux = torch.empty_like(aux) if model.auxiliary_task else None
@@ -227,6 +251,13 @@ class TrainStep:
             return self._replay(batch)
         self._host_prologue()
         fw = self._section_forward(batch)
+        if self.single_exchange:
+            store = model._grad_store
+            model._launch_backward_nll(fw["call"], self.weight_target_loss, store[-4:], self.seeds, sum_reduction=True)
+            _, count, loss = self.exchange.mean_from_sums(store)
+            self.optimizer.launch_mean(count)
+            model.update_state(is_best=False)
+            return {"loss": loss, "tokens": count[0], "logp": fw["logp"], "aux": fw["aux"]}
         self.exchange.all_reduce(self.stats)
         self._section_backward(fw)
         self.exchange.all_reduce(model.flat_gradients)

@@ -348,3 +348,44 @@ def test_command_line_train_then_test_modes(tmp_path):
             assert set(rec) == {"input", "prediction", "derivation", "target", "situation", "attention_weights_input",
                                 "attention_weights_situation", "accuracy", "exact_match", "position_accuracy"}
             assert len(rec["prediction"]) <= 7 and len(rec["attention_weights_situation"]) == len(rec["prediction"])
+
+
+def test_sum_reduction_backward_plus_mean_adam_equals_the_fused_step():
+    """The data-parallel building blocks on one GPU: gscan_backward_nll(sum_reduction=1) writes sum-loss gradients
+    and the statistics behind them; gscan_adam_step_mean divides by the token count.  Gradients / count must equal
+    the mean-loss gradients of the single-process fused step, and the update must be Adam's on those."""
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+    from multimodal_seq2seq_gscan_amd.train import TrainStep
+    from oracle import seq2seq_oracle as oracle
+    cfg = model_kwargs("demo", cnn_dropout_p=0.0, encoder_dropout_p=0.0, decoder_dropout_p=0.0)
+    shape = Shape(batch=6, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=7, max_target=10,
+                  ragged=True)
+    batch = {k: v.cuda() for k, v in make_batch(shape, 55).items()}
+    batch["cmd_lengths"] = batch["cmd_lengths"].to(torch.int32)
+    a = build_model(cfg, fixture_params(cfg, {"seed_weights": 8}))
+    b = build_model(cfg, fixture_params(cfg, {"seed_weights": 8}))
+    a.train(), b.train()
+    sa, sb = TrainStep(a, learning_rate=1e-2), TrainStep(b, learning_rate=1e-2)
+    sa._host_prologue(), sb._host_prologue()
+    sa._section_backward(sa._section_forward(batch))            # mean loss (gscan_backward_nll, sum_reduction=0)
+    fw = sb._section_forward(batch)
+    store = b._grad_store
+    b._launch_backward_nll(fw["call"], sb.weight_target_loss, store[-4:], sb.seeds, sum_reduction=True)
+    _, count, loss = sb.exchange.mean_from_sums(store)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - sa.seeds[2].item()) < 1e-6 and count.item() == sa.stats[1].item()
+    g_mean = (b.flat_gradients / count).cpu()
+    assert torch.allclose(g_mean, a.flat_gradients.cpu(), atol=1e-7, rtol=1e-4)
+    # the optimiser launch: Adam on grad / count, gradients cleared
+    p0 = b.flat_parameters.cpu().clone()
+    sb.optimizer.launch_mean(count)
+    torch.cuda.synchronize()
+    ref = [p0.clone()]
+    oracle.adam_step(ref, [g_mean], [torch.zeros_like(p0)], [torch.zeros_like(p0)], 1, 1e-2, lr_decay=0.9,
+                     lr_decay_steps=20000.0)
+    solid = g_mean.abs() > 1e-5            # Adam's first step is lr * g / (|g| + eps): rounding noise in |g| ~ eps
+    got = b.flat_parameters.cpu()          # is amplified to the size of the step, so compare where g is solid
+    assert solid.sum().item() > 0.5 * solid.numel()
+    assert torch.allclose(got[solid], ref[0][solid], atol=2e-6, rtol=0)
+    assert (got - p0).abs().max().item() <= 1e-2 * 1.001
+    assert b.flat_gradients.abs().max().item() == 0.0          # zero_grad folded into the optimiser launch
