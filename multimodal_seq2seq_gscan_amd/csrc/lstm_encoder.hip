@@ -1,9 +1,9 @@
 // Command encoder recurrence (seq2seq/seq2seq_model.py:62-88), forward and backward.
 //
 // The reference sorts rows by length, packs them and calls nn.LSTM.  Rows are independent,
-// so here one workgroup owns one command for its whole length: the recurrent matrix W_hh
-// (4He x He floats) lives in the VGPRs of the workgroup for all time steps (thread j holds
-// row j), h is broadcast from LDS, and there is no global traffic inside the loop except the
+// so here one workgroup owns one command (and direction) for its whole length: the recurrent
+// matrix W_hh (4He x He floats) lives in the VGPRs of the workgroup for all time steps (a thread
+// holds two rows), h is broadcast from LDS, and there is no global traffic inside the loop except the
 // precomputed input projection gx[t] coming in and the saved activations going out.  Length
 // masking replaces packing: a row simply stops after its own length (the reverse direction
 // starts at its last real token), outputs at padded positions stay zero.
@@ -16,39 +16,56 @@
 
 namespace gscan {
 
-template <int HE>
-__device__ __forceinline__ float dot_lds(const float (&w)[HE], const float *v) {
+// R rows of weights against one LDS vector: the vector is read once (same address in every lane: LDS broadcast,
+// 8 cycles of LDS bandwidth per 16-byte wave read whatever the lanes hold) and feeds R dot products.  The
+// recurrences are bound by exactly these reads, so a thread keeps TWO weight rows (R = 2) when the register file
+// allows (He <= 100): half as many waves read the same vector.
+template <int HE, int R>
+__device__ __forceinline__ void dots_lds(const float (&w)[R][HE], const float *v, float (&out)[R]) {
     static_assert(HE % 4 == 0, "hidden size must be a multiple of 4");
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float a0[R], a1[R], a2[R], a3[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a0[r] = a1[r] = a2[r] = a3[r] = 0.f;
     const float4 *v4 = reinterpret_cast<const float4 *>(v);
 #pragma unroll
     for (int i = 0; i < HE / 4; ++i) {
-        const float4 x = v4[i];          // same address in every lane: LDS broadcast
-        a0 = fmaf(w[4 * i + 0], x.x, a0);
-        a1 = fmaf(w[4 * i + 1], x.y, a1);
-        a2 = fmaf(w[4 * i + 2], x.z, a2);
-        a3 = fmaf(w[4 * i + 3], x.w, a3);
+        const float4 x = v4[i];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            a0[r] = fmaf(w[r][4 * i + 0], x.x, a0[r]);
+            a1[r] = fmaf(w[r][4 * i + 1], x.y, a1[r]);
+            a2[r] = fmaf(w[r][4 * i + 2], x.z, a2[r]);
+            a3[r] = fmaf(w[r][4 * i + 3], x.w, a3[r]);
+        }
     }
-    return (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r] = (a0[r] + a1[r]) + (a2[r] + a3[r]);
 }
+
+template <int HE> struct EncShape {
+    static constexpr int R = HE <= 100 ? 2 : 1;                       // weight rows (forward) / columns (backward) per thread
+    static constexpr int kThreads = ((4 * HE / R + 63) / 64) * 64;
+};
 
 // grid (B, D): the two directions of a row run as two workgroups (they only meet in the sums below).
 // `out` and `h_final` must be zero on entry: each direction ADDS its h (0 + h_f + h_r in either order is the same
 // float: two-operand addition commutes), which is how the directions are summed (seq2seq_model.py:77-81).
+// Thread j < 4He/R owns gate rows j + r*(4He/R), r < R  (R = 2: [i | f] rows and the matching [g | o] rows).
 template <int HE>
-__global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_fwd_kernel(int L, int D, const float *__restrict__ gx,
+__global__ __launch_bounds__(EncShape<HE>::kThreads) void encoder_lstm_fwd_kernel(int L, int D, const float *__restrict__ gx,
                                         const int32_t *__restrict__ lengths, const float *__restrict__ w_hh_f,
                                         const float *__restrict__ b_hh_f, const float *__restrict__ w_hh_r,
                                         const float *__restrict__ b_hh_r, float *__restrict__ out,
                                         float *__restrict__ h_final, float *__restrict__ gates,
                                         float *__restrict__ cells, float *__restrict__ hprev) {
+    constexpr int R = EncShape<HE>::R, NT = 4 * HE / R;              // owning threads
     __shared__ __attribute__((aligned(16))) float h_s[HE];
     __shared__ float gate_s[4 * HE];
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
     int len = lengths[b];
     len = max(0, min(len, L));
-    const bool is_gate = j < 4 * HE, is_unit = j < HE;
-    float w[HE];
+    const bool is_gate = j < NT, is_unit = j < HE;
+    float w[R][HE];
 
     // padded positions: zero saved h_prev (it multiplies delta = 0 in a GEMM later); out stays zero
     for (int idx = j; idx < (L - len) * HE; idx += blockDim.x) {
@@ -58,31 +75,49 @@ __global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_fwd_ke
 
     const float *w_hh = dir ? w_hh_r : w_hh_f;
     const float *b_hh = dir ? b_hh_r : b_hh_f;
-    float bias = 0.f;
-    if (is_gate) {
+    float bias[R];
 #pragma unroll
-        for (int k = 0; k < HE; ++k) w[k] = w_hh[(int64_t)j * HE + k];
-        bias = b_hh[j];
+    for (int r = 0; r < R; ++r) {
+        bias[r] = 0.f;
+        if (is_gate) {
+            const int row = j + r * NT;
+#pragma unroll
+            for (int k = 0; k < HE; ++k) w[r][k] = w_hh[(int64_t)row * HE + k];
+            bias[r] = b_hh[row];
+        }
     }
     float c = 0.f;
     if (is_unit) h_s[j] = 0.f;
     // the input projection of step s+1 is fetched while step s computes
-    auto gx_at = [&](int s) {
+    float gx_next[R];
+    auto fetch = [&](int s) {
         const int t = dir ? (len - 1 - s) : s;
-        return gx[(((int64_t)b * L + t) * D + dir) * 4 * HE + j];
+        const float *g = gx + (((int64_t)b * L + t) * D + dir) * 4 * HE;
+#pragma unroll
+        for (int r = 0; r < R; ++r) gx_next[r] = g[j + r * NT] + bias[r];
     };
-    float gx_next = (is_gate && len > 0) ? gx_at(0) + bias : 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) gx_next[r] = 0.f;
+    if (is_gate && len > 0) fetch(0);
     lds_barrier();
     for (int s = 0; s < len; ++s) {
         const int t = dir ? (len - 1 - s) : s;
         const int64_t row = ((int64_t)b * L + t) * D + dir;
-        const float gx_cur = gx_next;
-        if (is_gate && s + 1 < len) gx_next = gx_at(s + 1) + bias;
+        float gx_cur[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) gx_cur[r] = gx_next[r];
+        if (is_gate && s + 1 < len) fetch(s + 1);
         if (is_gate) {
-            const float pre = gx_cur + dot_lds<HE>(w, h_s);
-            const float a = (j >= 2 * HE && j < 3 * HE) ? tanhf_(pre) : sigmoidf_(pre);
-            gate_s[j] = a;
-            gates[row * 4 * HE + j] = a;
+            float dot[R];
+            dots_lds<HE, R>(w, h_s, dot);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int gr = j + r * NT;                            // gate row: [i | f | g | o] blocks of He
+                const float pre = gx_cur[r] + dot[r];
+                const float a = (gr >= 2 * HE && gr < 3 * HE) ? tanhf_(pre) : sigmoidf_(pre);
+                gate_s[gr] = a;
+                gates[row * 4 * HE + gr] = a;
+            }
         }
         if (is_unit) hprev[row * HE + j] = h_s[j];
         lds_barrier();
@@ -99,25 +134,31 @@ __global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_fwd_ke
     if (is_unit) atomicAdd(h_final + (int64_t)b * HE + j, h_s[j]);
 }
 
+// Backward: thread (seg, q) owns columns q + r*(He/R), r < R, of block seg of W_hh (its R dot products share the
+// delta segment they read); dh_{t-1}[k] = sum of the four blocks' partial products.
 template <int HE>
-__global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_bwd_kernel(int L, int D, const int32_t *__restrict__ lengths,
+__global__ __launch_bounds__(EncShape<HE>::kThreads) void encoder_lstm_bwd_kernel(int L, int D, const int32_t *__restrict__ lengths,
                                         const float *__restrict__ w_hh_f, const float *__restrict__ w_hh_r,
                                         const float *__restrict__ gates, const float *__restrict__ cells,
                                         const float *__restrict__ d_out, const float *__restrict__ d_h_final,
                                         float *__restrict__ delta) {
+    constexpr int R = EncShape<HE>::R, KQ = HE / R, NT = 4 * KQ;
+    static_assert(HE % R == 0, "hidden size must divide by the columns per thread");
     __shared__ __attribute__((aligned(16))) float delta_s[4 * HE];
     __shared__ float part_s[4 * HE];
     __shared__ float dh_s[HE];
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
     int len = lengths[b];
     len = max(0, min(len, L));
-    const bool active = tid < 4 * HE, is_unit = tid < HE;
-    const int seg = tid / HE, k = tid % HE;
+    const bool active = tid < NT, is_unit = tid < HE;
+    const int seg = tid / KQ, q = tid % KQ;
     const float *w_hh = dir ? w_hh_r : w_hh_f;
-    float wt[HE];
+    float wt[R][HE];
     if (active) {
 #pragma unroll
-        for (int jj = 0; jj < HE; ++jj) wt[jj] = w_hh[(int64_t)(seg * HE + jj) * HE + k];
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int jj = 0; jj < HE; ++jj) wt[r][jj] = w_hh[(int64_t)(seg * HE + jj) * HE + q + r * KQ];
     }
     for (int idx = tid; idx < (L - len) * 4 * HE; idx += blockDim.x) {
         const int t = len + idx / (4 * HE), jj = idx % (4 * HE);
@@ -163,7 +204,12 @@ __global__ __launch_bounds__(((4 * HE + 63) / 64) * 64) void encoder_lstm_bwd_ke
             dg_out[tid] = di; dg_out[HE + tid] = df; dg_out[2 * HE + tid] = dg; dg_out[3 * HE + tid] = d_o;
         }
         lds_barrier();
-        if (active) part_s[tid] = dot_lds<HE>(wt, delta_s + seg * HE);
+        if (active) {
+            float part[R];
+            dots_lds<HE, R>(wt, delta_s + seg * HE, part);
+#pragma unroll
+            for (int r = 0; r < R; ++r) part_s[seg * HE + q + r * KQ] = part[r];
+        }
         lds_barrier();
         if (is_unit) dh_s[tid] = (part_s[tid] + part_s[HE + tid]) + (part_s[2 * HE + tid] + part_s[3 * HE + tid]);
         lds_barrier();
@@ -174,7 +220,7 @@ template <int HE>
 static int launch_fwd(int B, int L, int D, const float *gx, const int32_t *lengths, const float *wf, const float *bf,
                       const float *wr, const float *br, float *out, float *hfin, float *gates, float *cells,
                       float *hprev, hipStream_t stream) {
-    const int nt = cdiv(4 * HE, 64) * 64;
+    const int nt = EncShape<HE>::kThreads;
     // algorithmic work: the recurrent product h.W_hh^T per (row, step, direction); padded steps counted
     ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * HE * HE);
     hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B, D), dim3(nt), 0, stream, L, D, gx, lengths, wf, bf, wr, br,
@@ -186,7 +232,7 @@ template <int HE>
 static int launch_bwd(int B, int L, int D, const int32_t *lengths, const float *wf, const float *wr,
                       const float *gates, const float *cells, const float *d_out, const float *d_hfin, float *delta,
                       hipStream_t stream) {
-    const int nt = cdiv(4 * HE, 64) * 64;
+    const int nt = EncShape<HE>::kThreads;
     ProbeScope probe(P_ENCODER_BWD, stream, 2.0 * B * L * D * 4 * HE * HE);
     hipLaunchKernelGGL(encoder_lstm_bwd_kernel<HE>, dim3(B, D), dim3(nt), 0, stream, L, D, lengths, wf, wr, gates,
                        cells, d_out, d_hfin, delta);
