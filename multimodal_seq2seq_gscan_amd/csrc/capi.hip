@@ -211,7 +211,7 @@ int gscan_encoder_lstm_forward(int B, int L, int He, int D, const float *gx, con
     GSCAN_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * L * He, (hipStream_t)stream));
     GSCAN_HIP(hipMemsetAsync(h_final, 0, sizeof(float) * (size_t)B * He, (hipStream_t)stream));
     return encoder_lstm_forward(B, L, He, D, gx, lengths, w_hh_fwd, b_hh_fwd, w_hh_rev, b_hh_rev, out, h_final, gates,
-                                cells, hprev, (hipStream_t)stream);
+                                cells, hprev, nullptr, (hipStream_t)stream);
 }
 
 int gscan_encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_fwd,

@@ -307,10 +307,11 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 //                                [e | ctx_text | ctx_vis]
 //   seg 7  zero_extra          = 0   (accumulation targets: encoder direction sums enc_out / hN, split-K dxe)
 //   seg 8  register images of the decoder's recurrent weights and of the output head (step.h)
+//   seg 9  register image of the encoder's recurrent weights: [dir][r][k][thread] = W_hh_dir[thread + r*NT][k]
 // ------------------------------------------------------------------------------------------
 
 __global__ void prologue_kernel(PrologueArgs a) {
-    const int64_t total = a.end[8];
+    const int64_t total = a.end[9];
     const int H = a.H;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -353,14 +354,18 @@ __global__ void prologue_kernel(PrologueArgs a) {
             a.wcat5[i] = v;
         } else if (idx < a.end[7]) {
             a.zero_extra[idx - a.end[6]] = 0.f;
-        } else {
+        } else if (idx < a.end[8]) {
             decoder_image_element(a.img, (int)(idx - a.end[7]));
+        } else {
+            const int i = (int)(idx - a.end[8]), He = a.He, nt = 4 * He / a.enc_rows;
+            const int j = i % nt, k = (i / nt) % He, r = (i / (nt * He)) % a.enc_rows, dir = i / (4 * He * He);
+            a.enc_image[i] = (dir ? a.enc_w_hh_r : a.enc_w_hh_f)[(int64_t)(j + r * nt) * He + k];
         }
     }
 }
 
 int step_prologue(const PrologueArgs &args, hipStream_t stream) {
-    const int64_t total = args.end[8];
+    const int64_t total = args.end[9];
     hipLaunchKernelGGL(prologue_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, stream,
                        args);
     GSCAN_LAUNCHED("prologue_kernel");

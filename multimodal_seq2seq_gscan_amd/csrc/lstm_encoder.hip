@@ -57,7 +57,8 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads) void encoder_lstm_fwd_kerne
                                         const float *__restrict__ b_hh_f, const float *__restrict__ w_hh_r,
                                         const float *__restrict__ b_hh_r, float *__restrict__ out,
                                         float *__restrict__ h_final, float *__restrict__ gates,
-                                        float *__restrict__ cells, float *__restrict__ hprev) {
+                                        float *__restrict__ cells, float *__restrict__ hprev,
+                                        const float *__restrict__ w_image) {
     constexpr int R = EncShape<HE>::R, NT = 4 * HE / R;              // owning threads
     __shared__ __attribute__((aligned(16))) float h_s[HE];
     __shared__ float gate_s[4 * HE];
@@ -81,8 +82,14 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads) void encoder_lstm_fwd_kerne
         bias[r] = 0.f;
         if (is_gate) {
             const int row = j + r * NT;
+            if (w_image) {         // [dir][r][k][thread]: consecutive lanes read consecutive floats
+                const float *img = w_image + ((int64_t)(dir * R + r) * HE) * NT + j;
 #pragma unroll
-            for (int k = 0; k < HE; ++k) w[r][k] = w_hh[(int64_t)row * HE + k];
+                for (int k = 0; k < HE; ++k) w[r][k] = img[k * NT];
+            } else {               // a row per lane straight from W_hh: 64 cache lines per load (tests, one-off calls)
+#pragma unroll
+                for (int k = 0; k < HE; ++k) w[r][k] = w_hh[(int64_t)row * HE + k];
+            }
             bias[r] = b_hh[row];
         }
     }
@@ -219,12 +226,12 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads) void encoder_lstm_bwd_kerne
 template <int HE>
 static int launch_fwd(int B, int L, int D, const float *gx, const int32_t *lengths, const float *wf, const float *bf,
                       const float *wr, const float *br, float *out, float *hfin, float *gates, float *cells,
-                      float *hprev, hipStream_t stream) {
+                      float *hprev, const float *w_image, hipStream_t stream) {
     const int nt = EncShape<HE>::kThreads;
     // algorithmic work: the recurrent product h.W_hh^T per (row, step, direction); padded steps counted
     ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * HE * HE);
     hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B, D), dim3(nt), 0, stream, L, D, gx, lengths, wf, bf, wr, br,
-                       out, hfin, gates, cells, hprev);
+                       out, hfin, gates, cells, hprev, w_image);
     GSCAN_LAUNCHED("encoder_lstm_fwd_kernel");
     return 0;
 }
@@ -249,13 +256,22 @@ bool hidden_size_supported(int h) {
     return false;
 }
 
+int encoder_rows_per_thread(int He) {
+    switch (He) {
+#define X(n) case n: return EncShape<n>::R;
+        GSCAN_HIDDEN_SIZES(X)
+#undef X
+        default: return 1;
+    }
+}
+
 int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths, const float *w_hh_f,
                          const float *b_hh_f, const float *w_hh_r, const float *b_hh_r, float *out, float *h_final,
-                         float *gates, float *cells, float *hprev, hipStream_t stream) {
+                         float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream) {
     GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm: bad dims B=%d L=%d D=%d", B, L, D);
     GSCAN_CHECK(D == 1 || (w_hh_r && b_hh_r), "encoder lstm: reverse weights missing");
     switch (He) {
-#define X(n) case n: return launch_fwd<n>(B, L, D, gx, lengths, w_hh_f, b_hh_f, w_hh_r, b_hh_r, out, h_final, gates, cells, hprev, stream);
+#define X(n) case n: return launch_fwd<n>(B, L, D, gx, lengths, w_hh_f, b_hh_f, w_hh_r, b_hh_r, out, h_final, gates, cells, hprev, w_image, stream);
         GSCAN_HIDDEN_SIZES(X)
 #undef X
         default: break;

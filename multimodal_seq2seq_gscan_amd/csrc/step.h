@@ -113,8 +113,12 @@ struct PrologueArgs {
     int cond;
     int64_t zero_extra_count;
     int H, He, E, D, BL, BT, Vi, V;
-    int64_t end[9];
+    int64_t end[10];
     DecoderImageArgs img;
+    // seg 9: register image of the encoder's recurrent weights, [dir][r][k][thread] (lstm_encoder.hip)
+    const float *enc_w_hh_f, *enc_w_hh_r;
+    float *enc_image;
+    int enc_rows;                          // weight rows per thread
 };
 int step_prologue(const PrologueArgs &args, hipStream_t stream);
 int toeplitz_build(const float *const (&w)[3], const float *const (&b)[3], int G, int C, int Co, int K3, float *wt,
@@ -149,7 +153,8 @@ int sequence_metrics(const float *logp, const int64_t *targets, int B, int T, in
 bool hidden_size_supported(int h);
 int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths, const float *w_hh_f,
                          const float *b_hh_f, const float *w_hh_r, const float *b_hh_r, float *out, float *h_final,
-                         float *gates, float *cells, float *hprev, hipStream_t stream);
+                         float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream);
+int encoder_rows_per_thread(int He);   // rows of W_hh a thread of the forward kernel keeps (layout of its image)
 int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_f,
                           const float *w_hh_r, const float *gates, const float *cells, const float *d_out,
                           const float *d_h_final, float *delta, hipStream_t stream);
@@ -233,7 +238,7 @@ struct Workspace {
     int64_t xcol, feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, row_stats, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
-        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, wt, dwt, bias_rep, wcat5;
+        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, wt, dwt, bias_rep, wcat5;
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;

@@ -58,6 +58,7 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(dec_w_fwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
     SLOT(dec_w_bwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
     SLOT(dec_w_head, H * kDecThreads);
+    SLOT(enc_w_image, D * 4 * He * He);
     SLOT(hprev, B * T * H);
     SLOT(S, B * T * 4 * H);
     SLOT(ge, B * T * 4 * H);
@@ -261,12 +262,14 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         const DecoderGeometry geo = decoder_geometry(H, cond);
         a.img = DecoderImageArgs{p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, p.out2hid_w, w + ws.dec_w_fwd,
                                  w + ws.dec_w_bwd, w + ws.dec_w_head, H, cond ? 1 : 0, geo.slots, geo.k0};
-        const int64_t n[9] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
-                              (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
-                              a.zero_extra_count,
-                              2 * geo.image_floats + (int64_t)H * kDecThreads};
+        a.enc_w_hh_f = p.enc_w_hh; a.enc_w_hh_r = p.enc_w_hh_rev; a.enc_image = w + ws.enc_w_image;
+        a.enc_rows = encoder_rows_per_thread(He);
+        const int64_t n[10] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
+                               (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
+                               a.zero_extra_count, 2 * geo.image_floats + (int64_t)H * kDecThreads,
+                               (int64_t)D * 4 * He * He};
         int64_t acc = 0;
-        for (int i = 0; i < 9; ++i) { acc += n[i]; a.end[i] = acc; }
+        for (int i = 0; i < 10; ++i) { acc += n[i]; a.end[i] = acc; }
         TRY(step_prologue(a, st));
     }
     {
@@ -287,7 +290,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     // command encoder recurrence (seq2seq_model.py:62-88)
     TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, p.enc_w_hh, p.enc_b_hh, p.enc_w_hh_rev,
                              p.enc_b_hh_rev, w + ws.enc_out, w + ws.hN, w + ws.enc_gates, w + ws.enc_cells,
-                             w + ws.enc_hprev, st));
+                             w + ws.enc_hprev, w + ws.enc_w_image, st));
     {   // projected textual keys (:468-469), their images, and the bridge (model.py:195)
         GemmBatch g;
         g.add(B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H);
