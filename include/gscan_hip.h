@@ -240,11 +240,12 @@ int gscan_world_im2col(const float *world, int B, int G, int C, int K3, float *x
 
 /* Masked per-row LSTM over the command (seq2seq/seq2seq_model.py:62-88).
  * gx [B,L,D,4He] = W_ih x + b_ih (D directions); out [B,L,He] = sum of directions,
- * zero at t >= len; h_final [B,He].  gates/cells/hprev [B,L,D,*] are saved for backward. */
+ * zero at t >= len; h_final [B,He].  gates/cells/hprev [B,L,D,*] are saved for backward.
+ * w_image_scratch: D*4He*He floats of device scratch (the kernel reads W_hh through a register image). */
 int gscan_encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths,
                                const float *w_hh_fwd, const float *b_hh_fwd, const float *w_hh_rev,
                                const float *b_hh_rev, float *out, float *h_final, float *gates,
-                               float *cells, float *hprev, void *stream);
+                               float *cells, float *hprev, float *w_image_scratch, void *stream);
 int gscan_encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_fwd,
                                 const float *w_hh_rev, const float *gates, const float *cells,
                                 const float *d_out, const float *d_h_final, float *delta, void *stream);

@@ -95,7 +95,8 @@ PROTOTYPES = {
     "gscan_probe_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "gscan_gemm_f32": (_i, [_i, _i, _i, _f, _vp, _i64, _i64, _vp, _i64, _i64, _f, _vp, _i64, _vp, _i, _vp, _i, _vp]),
     "gscan_world_im2col": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "gscan_encoder_lstm_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gscan_encoder_lstm_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _vp]),
     "gscan_encoder_lstm_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -203,15 +203,17 @@ int gscan_world_im2col(const float *world, int B, int G, int C, int K3, float *x
 int gscan_encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths,
                                const float *w_hh_fwd, const float *b_hh_fwd, const float *w_hh_rev,
                                const float *b_hh_rev, float *out, float *h_final, float *gates, float *cells,
-                               float *hprev, void *stream) {
-    ARG(gx && lengths && w_hh_fwd && b_hh_fwd && out && h_final && gates && cells && hprev,
+                               float *hprev, float *w_image_scratch, void *stream) {
+    ARG(gx && lengths && w_hh_fwd && b_hh_fwd && out && h_final && gates && cells && hprev && w_image_scratch,
         "encoder_lstm_forward: NULL argument");
-    ARG(B > 0 && L > 0 && He > 0, "encoder_lstm_forward: bad dims");
-    // the kernel accumulates the direction sums into out / h_final
+    ARG(B > 0 && L > 0 && He > 0 && (D == 1 || D == 2), "encoder_lstm_forward: bad dims");
+    ARG(hidden_size_supported(He), "encoder_lstm_forward: hidden size has no compiled kernel");
+    // the kernel accumulates the direction sums into out / h_final and reads its weights from a register image
     GSCAN_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * L * He, (hipStream_t)stream));
     GSCAN_HIP(hipMemsetAsync(h_final, 0, sizeof(float) * (size_t)B * He, (hipStream_t)stream));
+    if (int rc = encoder_weight_image(w_hh_fwd, w_hh_rev, He, D, w_image_scratch, (hipStream_t)stream)) return rc;
     return encoder_lstm_forward(B, L, He, D, gx, lengths, w_hh_fwd, b_hh_fwd, w_hh_rev, b_hh_rev, out, h_final, gates,
-                                cells, hprev, nullptr, (hipStream_t)stream);
+                                cells, hprev, w_image_scratch, (hipStream_t)stream);
 }
 
 int gscan_encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_fwd,

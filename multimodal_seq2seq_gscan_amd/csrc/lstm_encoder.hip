@@ -23,23 +23,23 @@ namespace gscan {
 template <int HE, int R>
 __device__ __forceinline__ void dots_lds(const float (&w)[R][HE], const float *v, float (&out)[R]) {
     static_assert(HE % 4 == 0, "hidden size must be a multiple of 4");
-    float a0[R], a1[R], a2[R], a3[R];
+    float a0[R], a1[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) a0[r] = a1[r] = a2[r] = a3[r] = 0.f;
+    for (int r = 0; r < R; ++r) a0[r] = a1[r] = 0.f;
     const float4 *v4 = reinterpret_cast<const float4 *>(v);
 #pragma unroll
     for (int i = 0; i < HE / 4; ++i) {
         const float4 x = v4[i];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < R; ++r) {              // R * 2 independent chains: enough to cover the FMA latency
             a0[r] = fmaf(w[r][4 * i + 0], x.x, a0[r]);
             a1[r] = fmaf(w[r][4 * i + 1], x.y, a1[r]);
-            a2[r] = fmaf(w[r][4 * i + 2], x.z, a2[r]);
-            a3[r] = fmaf(w[r][4 * i + 3], x.w, a3[r]);
+            a0[r] = fmaf(w[r][4 * i + 2], x.z, a0[r]);
+            a1[r] = fmaf(w[r][4 * i + 3], x.w, a1[r]);
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) out[r] = (a0[r] + a1[r]) + (a2[r] + a3[r]);
+    for (int r = 0; r < R; ++r) out[r] = a0[r] + a1[r];
 }
 
 template <int HE> struct EncShape {
@@ -52,7 +52,7 @@ template <int HE> struct EncShape {
 // float: two-operand addition commutes), which is how the directions are summed (seq2seq_model.py:77-81).
 // Thread j < 4He/R owns gate rows j + r*(4He/R), r < R  (R = 2: [i | f] rows and the matching [g | o] rows).
 template <int HE>
-__global__ __launch_bounds__(EncShape<HE>::kThreads) void encoder_lstm_fwd_kernel(int L, int D, const float *__restrict__ gx,
+__global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_kernel(int L, int D, const float *__restrict__ gx,
                                         const int32_t *__restrict__ lengths, const float *__restrict__ w_hh_f,
                                         const float *__restrict__ b_hh_f, const float *__restrict__ w_hh_r,
                                         const float *__restrict__ b_hh_r, float *__restrict__ out,
@@ -82,38 +82,40 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads) void encoder_lstm_fwd_kerne
         bias[r] = 0.f;
         if (is_gate) {
             const int row = j + r * NT;
-            if (w_image) {         // [dir][r][k][thread]: consecutive lanes read consecutive floats
-                const float *img = w_image + ((int64_t)(dir * R + r) * HE) * NT + j;
+            // register image [dir][r][k][thread]: consecutive lanes read consecutive floats (a row per lane straight
+            // from W_hh would touch 64 cache lines per load; keeping both paths in one kernel cost 96 spilled VGPRs)
+            const float *img = w_image + ((int64_t)(dir * R + r) * HE) * NT + j;
 #pragma unroll
-                for (int k = 0; k < HE; ++k) w[r][k] = img[k * NT];
-            } else {               // a row per lane straight from W_hh: 64 cache lines per load (tests, one-off calls)
-#pragma unroll
-                for (int k = 0; k < HE; ++k) w[r][k] = w_hh[(int64_t)row * HE + k];
-            }
+            for (int k = 0; k < HE; ++k) w[r][k] = img[k * NT];
             bias[r] = b_hh[row];
         }
     }
     float c = 0.f;
     if (is_unit) h_s[j] = 0.f;
-    // the input projection of step s+1 is fetched while step s computes
-    float gx_next[R];
-    auto fetch = [&](int s) {
+    // The input projections are fetched TWO steps ahead: memory operations retire in order on this hardware, so a
+    // wait for a load also waits for every store issued before it — with a one-step distance each step would wait
+    // for the previous step's stores to be acknowledged.  For the same reason the direction sum (atomics) is not
+    // issued inside the loop: h_t is kept in LDS and added to `out` once, after the last step.
+    extern __shared__ float hist_s[];                        // [L][HE]
+    float gx_a[R], gx_b[R];                                  // projections of steps s and s+1 (bias included)
+    auto fetch = [&](int s, float (&dst)[R]) {
         const int t = dir ? (len - 1 - s) : s;
         const float *g = gx + (((int64_t)b * L + t) * D + dir) * 4 * HE;
 #pragma unroll
-        for (int r = 0; r < R; ++r) gx_next[r] = g[j + r * NT] + bias[r];
+        for (int r = 0; r < R; ++r) dst[r] = g[j + r * NT] + bias[r];
     };
 #pragma unroll
-    for (int r = 0; r < R; ++r) gx_next[r] = 0.f;
-    if (is_gate && len > 0) fetch(0);
+    for (int r = 0; r < R; ++r) gx_a[r] = gx_b[r] = 0.f;
+    if (is_gate && len > 0) fetch(0, gx_a);
+    if (is_gate && len > 1) fetch(1, gx_b);
     lds_barrier();
     for (int s = 0; s < len; ++s) {
         const int t = dir ? (len - 1 - s) : s;
         const int64_t row = ((int64_t)b * L + t) * D + dir;
         float gx_cur[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) gx_cur[r] = gx_next[r];
-        if (is_gate && s + 1 < len) fetch(s + 1);
+        for (int r = 0; r < R; ++r) { gx_cur[r] = gx_a[r]; gx_a[r] = gx_b[r]; }
+        if (is_gate && s + 2 < len) fetch(s + 2, gx_b);
         if (is_gate) {
             float dot[R];
             dots_lds<HE, R>(w, h_s, dot);
@@ -134,17 +136,20 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads) void encoder_lstm_fwd_kerne
             const float h = og * tanhf_(c);
             cells[row * HE + j] = c;
             h_s[j] = h;
-            atomicAdd(out + ((int64_t)b * L + t) * HE + j, h);
+            hist_s[t * HE + j] = h;
         }
         lds_barrier();
     }
-    if (is_unit) atomicAdd(h_final + (int64_t)b * HE + j, h_s[j]);
+    if (is_unit) {
+        atomicAdd(h_final + (int64_t)b * HE + j, h_s[j]);
+        for (int t = 0; t < len; ++t) atomicAdd(out + ((int64_t)b * L + t) * HE + j, hist_s[t * HE + j]);
+    }
 }
 
 // Backward: thread (seg, q) owns columns q + r*(He/R), r < R, of block seg of W_hh (its R dot products share the
 // delta segment they read); dh_{t-1}[k] = sum of the four blocks' partial products.
 template <int HE>
-__global__ __launch_bounds__(EncShape<HE>::kThreads) void encoder_lstm_bwd_kernel(int L, int D, const int32_t *__restrict__ lengths,
+__global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_kernel(int L, int D, const int32_t *__restrict__ lengths,
                                         const float *__restrict__ w_hh_f, const float *__restrict__ w_hh_r,
                                         const float *__restrict__ gates, const float *__restrict__ cells,
                                         const float *__restrict__ d_out, const float *__restrict__ d_h_final,
@@ -230,7 +235,7 @@ static int launch_fwd(int B, int L, int D, const float *gx, const int32_t *lengt
     const int nt = EncShape<HE>::kThreads;
     // algorithmic work: the recurrent product h.W_hh^T per (row, step, direction); padded steps counted
     ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * HE * HE);
-    hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B, D), dim3(nt), 0, stream, L, D, gx, lengths, wf, bf, wr, br,
+    hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B, D), dim3(nt), (size_t)L * HE * sizeof(float), stream, L, D, gx, lengths, wf, bf, wr, br,
                        out, hfin, gates, cells, hprev, w_image);
     GSCAN_LAUNCHED("encoder_lstm_fwd_kernel");
     return 0;
@@ -256,6 +261,24 @@ bool hidden_size_supported(int h) {
     return false;
 }
 
+// image[dir][r][k][j] = W_hh_dir[j + r*NT][k], NT = 4He / rows-per-thread (the step prologue writes the same image)
+__global__ void encoder_weight_image_kernel(const float *__restrict__ w_f, const float *__restrict__ w_r, int He,
+                                            int D, int rows, float *__restrict__ image) {
+    const int nt = 4 * He / rows, total = D * 4 * He * He;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i % nt, k = (i / nt) % He, r = (i / (nt * He)) % rows, dir = i / (4 * He * He);
+        image[i] = (dir ? w_r : w_f)[(int64_t)(j + r * nt) * He + k];
+    }
+}
+
+int encoder_weight_image(const float *w_hh_f, const float *w_hh_r, int He, int D, float *image, hipStream_t stream) {
+    const int total = D * 4 * He * He;
+    hipLaunchKernelGGL(encoder_weight_image_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, stream, w_hh_f,
+                       w_hh_r, He, D, encoder_rows_per_thread(He), image);
+    GSCAN_LAUNCHED("encoder_weight_image_kernel");
+    return 0;
+}
+
 int encoder_rows_per_thread(int He) {
     switch (He) {
 #define X(n) case n: return EncShape<n>::R;
@@ -270,6 +293,7 @@ int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int
                          float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream) {
     GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm: bad dims B=%d L=%d D=%d", B, L, D);
     GSCAN_CHECK(D == 1 || (w_hh_r && b_hh_r), "encoder lstm: reverse weights missing");
+    GSCAN_CHECK(w_image, "encoder lstm: weight image missing");
     switch (He) {
 #define X(n) case n: return launch_fwd<n>(B, L, D, gx, lengths, w_hh_f, b_hh_f, w_hh_r, b_hh_r, out, h_final, gates, cells, hprev, w_image, stream);
         GSCAN_HIDDEN_SIZES(X)

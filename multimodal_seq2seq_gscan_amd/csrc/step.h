@@ -155,6 +155,7 @@ int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int
                          const float *b_hh_f, const float *w_hh_r, const float *b_hh_r, float *out, float *h_final,
                          float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream);
 int encoder_rows_per_thread(int He);   // rows of W_hh a thread of the forward kernel keeps (layout of its image)
+int encoder_weight_image(const float *w_hh_f, const float *w_hh_r, int He, int D, float *image, hipStream_t stream);
 int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_f,
                           const float *w_hh_r, const float *gates, const float *cells, const float *d_out,
                           const float *d_h_final, float *delta, hipStream_t stream);

@@ -133,10 +133,12 @@ def test_encoder_lstm_forward_backward(lib, He, bidir):
     wd = [dev(w) for w in w_hh] + [None]
     bd = [dev(b) for b in b_hh] + [None]
     gx_d, d_out_d, d_h_d = dev(gx), dev(d_out * live), dev(d_h)
+    scratch = torch.empty(D * 4 * He * He, device="cuda")         # register image of W_hh, written by the call
     _lib.check(lib.gscan_encoder_lstm_forward(B, L, He, D, gx_d.data_ptr(), len_d.data_ptr(), wd[0].data_ptr(),
                                               bd[0].data_ptr(), _lib.ptr(wd[1]), _lib.ptr(bd[1]),
                                               c["out"].data_ptr(), c["hf"].data_ptr(), c["gates"].data_ptr(),
-                                              c["cells"].data_ptr(), c["hprev"].data_ptr(), gpu_ops.stream()), "fwd")
+                                              c["cells"].data_ptr(), c["hprev"].data_ptr(), scratch.data_ptr(),
+                                              gpu_ops.stream()), "fwd")
     assert (c["out"].cpu() - out_ref.detach()).abs().max().item() < 2e-5
     assert (c["hf"].cpu() - h_ref.detach()).abs().max().item() < 2e-5
     _lib.check(lib.gscan_encoder_lstm_backward(B, L, He, D, len_d.data_ptr(), wd[0].data_ptr(), _lib.ptr(wd[1]),
