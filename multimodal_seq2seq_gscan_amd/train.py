@@ -165,7 +165,7 @@ class TrainStep:
     def __init__(self, model: Model, learning_rate: float = 1e-3, adam_beta_1: float = 0.9,
                  adam_beta_2: float = 0.999, lr_decay: float = 0.9, lr_decay_steps: float = 20000.0,
                  weight_target_loss: float = 0.3, process_group=None, graph: bool = False,
-                 fused_loss: Optional[bool] = None, **_):
+                 fused_loss: Optional[bool] = None, single_exchange: Optional[bool] = None, **_):
         self.model = model
         self.optimizer = FlatAdam(model, learning_rate, adam_beta_1, adam_beta_2, lr_decay, lr_decay_steps)
         self.weight_target_loss = float(weight_target_loss)
@@ -178,7 +178,13 @@ class TrainStep:
             raise ValueError("fused_loss needs the global token count: not available with more than one process")
         # Several processes, no auxiliary loss: every rank back-propagates its SUM loss, the statistics ride behind
         # the gradients in one all-reduce and Adam divides by the global token count.
-        self.single_exchange = self.exchange.world_size > 1 and not model.auxiliary_task and not self.graph
+        if single_exchange is None:
+            single_exchange = self.exchange.world_size > 1 and not model.auxiliary_task and not self.graph
+        elif single_exchange and (model.auxiliary_task or self.graph):
+            raise ValueError("the one-collective step needs a single loss term and eager launches")
+        self.single_exchange = bool(single_exchange)
+        if self.single_exchange:
+            self.fused_loss = False
         device = model.flat_parameters.device
         self.stats = torch.zeros(4, dtype=torch.float32, device=device)
         self.seeds = torch.zeros(3, dtype=torch.float32, device=device)

@@ -389,3 +389,29 @@ def test_sum_reduction_backward_plus_mean_adam_equals_the_fused_step():
     assert torch.allclose(got[solid], ref[0][solid], atol=2e-6, rtol=0)
     assert (got - p0).abs().max().item() <= 1e-2 * 1.001
     assert b.flat_gradients.abs().max().item() == 0.0          # zero_grad folded into the optimiser launch
+
+
+def test_one_collective_train_step_tracks_the_fused_step():
+    """TrainStep's data-parallel form (sum-loss backward, statistics behind the gradients, mean Adam), run with a
+    single process where the all-reduce is the identity: three steps give the losses of the single-process fused
+    step and parameters within the optimiser's step size of it (Adam amplifies rounding noise in ~1e-9 gradients
+    to the size of one step, so the comparison cannot be tighter than that)."""
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+    from multimodal_seq2seq_gscan_amd.train import TrainStep
+    cfg = model_kwargs("demo", cnn_dropout_p=0.0, encoder_dropout_p=0.0, decoder_dropout_p=0.0)
+    shape = Shape(batch=6, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=7, max_target=10,
+                  ragged=True)
+    a = build_model(cfg, fixture_params(cfg, {"seed_weights": 9}))
+    b = build_model(cfg, fixture_params(cfg, {"seed_weights": 9}))
+    sa = TrainStep(a, learning_rate=1e-3)
+    sb = TrainStep(b, learning_rate=1e-3, single_exchange=True)
+    assert sa.fused_loss and sb.single_exchange and not sb.fused_loss
+    for i in range(3):
+        batch = {k: v.cuda() for k, v in make_batch(shape, 300 + i).items()}
+        la, lb = sa(batch)["loss"].item(), sb(batch)["loss"].item()
+        assert abs(la - lb) < 1e-4, (i, la, lb)
+    torch.cuda.synchronize()
+    assert (a.flat_parameters - b.flat_parameters).abs().max().item() < 3.5e-3
+    differing = ((a.flat_parameters - b.flat_parameters).abs() > 1e-5).float().mean().item()
+    assert differing < 0.05, differing
+    assert a.trained_iterations == b.trained_iterations == 3
