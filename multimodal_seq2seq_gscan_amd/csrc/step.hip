@@ -459,9 +459,10 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     // ---- command encoder BPTT (chain)
     TRY(encoder_lstm_backward(B, L, He, D, bt.cmd_lengths, p.enc_w_hh, p.enc_w_hh_rev, w + ws.enc_gates,
                               w + ws.enc_cells, w + ws.denc, w + ws.dhN, w + ws.enc_delta, st));
-    TRY(order_after(sd, st));
     const int64_t ldd = (int64_t)D * 4 * He;
-    {   // leaves: encoder LSTM weights
+    {   // tail, on the caller's stream (the leaf streams are still busy with the key / conv gradients and would
+        // finish last otherwise): the encoder LSTM weight gradients and d(embedded command) for both directions
+        // (K = 8He split eight ways onto the zeroed buffer) in one launch, then the embedding table
         GemmBatch b;
         for (int dir = 0; dir < D; ++dir) {
             const float *dl = w + ws.enc_delta + dir * 4 * He;
@@ -471,11 +472,10 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
                      gb_hh);
             add_grad(b, 4 * He, E, BL, dl, 1, ldd, w + ws.xe, E, 1, gw_ih, E);
         }
-        TRY(b.launch(sd));
+        b.add(BL, E, D * 4 * He, w + ws.enc_delta, ldd, 1, w + ws.wih_stack, E, 1, w + ws.dxe, E, 1.f, nullptr, 0, nullptr,
+              8);
+        TRY(b.launch(st));
     }
-    // chain tail: d(embedded command) for both directions at once, then the embedding table
-    TRY(gemm_f32(BL, E, D * 4 * He, 1.f, w + ws.enc_delta, ldd, 1, w + ws.wih_stack, E, 1, 1.f, w + ws.dxe, E, nullptr, 0,
-                 nullptr, 8, st));   // K = 8He split eight ways onto the zeroed buffer
     TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));
     TRY(order_after(st, sd));          // join: every gradient is complete when the caller's stream continues
     TRY(order_after(st, sd2));
