@@ -201,7 +201,7 @@ def main():
                                    f"dropout {cfg['encoder_dropout_p']}/{cfg['decoder_dropout_p']}/{cfg['cnn_dropout_p']}, "
                                    f"conditional attention, Adam+LR step included",
                        "global_batch": world * B, "parallelism": f"dp{world}", "parameters": model.flat_parameters.numel(),
-                       "launch": "hipGraph replay (3 graphs per step)" if args.graph else "eager, 24 launches per step on 3 streams"},
+                       "launch": "hipGraph replay (3 graphs per step)" if args.graph else "eager, 22 launches per step on 3 streams"},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(d["tflops"], 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_FP32_TFLOPS, 4),
                          "traffic": pmc_traffic(dominant), "avg_launch_us": round(d["avg_us"], 2),
