@@ -168,7 +168,15 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
     for (int i = 1; i < kMaxGroup; ++i)
         if (i < grp.count && (int)blockIdx.x >= grp.p[i].tile_begin) pi = i;
     const GemmProblem &g = grp.p[pi];
-    const int local = blockIdx.x - g.tile_begin;
+    // XCD-aware order (GSCAN_GEMM_XCD=0 disables): workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.
+    // Workgroup l of a problem takes tile (l % 8) * per + l / 8, so an XCD works on one contiguous eighth of the
+    // tile space and its L2 sees each operand panel of that eighth once.
+    int local = blockIdx.x - g.tile_begin;
+    if (grp.xcd_per[pi] > 0) {
+        const int per = grp.xcd_per[pi], x = local & 7, j = local >> 3;
+        local = x * per + j;
+        if (j >= per || local >= g.tiles_mn * g.nsplit) return;
+    }
     const int bz = local / g.tiles_mn, rem = local % g.tiles_mn;
     const int by = rem / g.tiles_n, bx = rem % g.tiles_n;
     __shared__ __attribute__((aligned(16))) float lds_a[2][A_FLOATS];
@@ -375,7 +383,7 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
     }
     GemmProblem &p = grp_.p[grp_.count++];
     p = GemmProblem{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, gate, chunk,
-                    split_k > 1 ? 1 : 0, asum1, asum2, 0, 0, 0, flags};      // tile bookkeeping: at launch
+                    split_k > 1 ? 1 : 0, asum1, asum2, 0, 0, 0, 0, flags};   // tile bookkeeping: at launch
     tiles_ += cdiv(N, BN) * cdiv(M, 64) * split_k;                            // in 64-row tiles
     flops_ += 2.0 * M * N * K;
 }
@@ -391,13 +399,17 @@ int GemmBatch::launch(hipStream_t stream) {
     if (grp_.count == 0) return 0;
     static const int forced = [] { const char *e = getenv("GSCAN_GEMM_TMW"); return e ? atoi(e) : 0; }();
     const int tmw = forced == 1 || forced == 2 ? forced : (tiles_ < kWideTileMinGroups ? 1 : 2);
+    static const int xcd = [] { const char *e = getenv("GSCAN_GEMM_XCD"); return e ? atoi(e) : 1; }();   // on by default
     int total = 0;
     for (int i = 0; i < grp_.count; ++i) {
         GemmProblem &p = grp_.p[i];
         p.tiles_n = cdiv(p.N, BN);
         p.tiles_mn = p.tiles_n * cdiv(p.M, 32 * tmw);
+        p.nsplit = cdiv(p.K, p.k_chunk);
         p.tile_begin = total;
-        total += p.tiles_mn * cdiv(p.K, p.k_chunk);
+        const int n = p.tiles_mn * p.nsplit;
+        grp_.xcd_per[i] = (xcd && n >= 16) ? cdiv(n, 8) : 0;
+        total += grp_.xcd_per[i] ? 8 * grp_.xcd_per[i] : n;
     }
     ProbeScope probe(P_GEMM, stream, flops_);
     if (tmw == 1) hipLaunchKernelGGL(gemm_group_kernel<1>, dim3(total), dim3(256), 0, stream, grp_);

@@ -21,10 +21,10 @@ struct GemmProblem {
     const float *mask, *gate;             // elementwise, same indexing as C
     int k_chunk, atomic;                  // K range per k-slice; split-K accumulates with atomics
     float *asum1, *asum2;                 // optional: += sum_k A(m,k) (bias gradients)
-    int tiles_n, tiles_mn, tile_begin;    // grid bookkeeping
+    int tiles_n, tiles_mn, tile_begin, nsplit;   // grid bookkeeping
     int flags;                            // log2(floats per global load) of A | of B << 2
 };
-struct GemmGroup { int count; GemmProblem p[kMaxGroup]; };
+struct GemmGroup { int count; int xcd_per[kMaxGroup]; GemmProblem p[kMaxGroup]; };
 
 // Builder for one grouped launch of independent products.
 class GemmBatch {
