@@ -415,3 +415,56 @@ def test_one_collective_train_step_tracks_the_fused_step():
     differing = ((a.flat_parameters - b.flat_parameters).abs() > 1e-5).float().mean().item()
     assert differing < 0.05, differing
     assert a.trained_iterations == b.trained_iterations == 3
+
+
+EDGE_CASES = [
+    # name, model overrides, Shape overrides, post-processing of the batch
+    ("single_row", {}, dict(batch=1), None),
+    ("odd_batch_min_lengths", {}, dict(batch=3, max_command=3, max_target=2), None),
+    ("one_step_targets", {}, dict(batch=2, max_target=1), "sos_only"),
+    ("t33_crosses_head_chunk", {}, dict(batch=2, max_target=33), None),
+    ("t65_three_chunks", {"conditional_attention": False}, dict(batch=2, max_target=65), None),
+    ("grid3", {}, dict(batch=2, grid=3), None),
+    ("grid8_max_cells_aux", {"auxiliary_task": True}, dict(batch=2, grid=8), None),
+    ("hidden32_unidirectional", {"encoder_hidden_size": 32, "decoder_hidden_size": 32, "encoder_bidirectional": False,
+                                 "embedding_dimension": 6}, dict(batch=3), None),
+    ("hidden64_k3_nocond", {"encoder_hidden_size": 64, "decoder_hidden_size": 64, "cnn_kernel_size": 3,
+                            "conditional_attention": False, "embedding_dimension": 8}, dict(batch=2), None),
+    ("length_one_commands", {}, dict(batch=4), "short_commands"),
+    ("all_pad_targets_row", {}, dict(batch=3), "pad_row"),
+]
+
+
+@pytest.mark.parametrize("name,overrides,shape_kw,post", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
+def test_edge_shapes_against_oracle(name, overrides, shape_kw, post):
+    """Ragged / minimal / maximal shapes and the other compiled hidden sizes: log-probabilities, loss and every
+    gradient of the HIP step against the CPU oracle (itself pinned to the reference) on the same seeded inputs."""
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+    from oracle import seq2seq_oracle as oracle
+    from weights import golden_weights
+    cfg = model_kwargs("demo", cnn_dropout_p=0.0, encoder_dropout_p=0.0, decoder_dropout_p=0.0, **overrides)
+    kw = dict(batch=4, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=7, max_target=10, ragged=True)
+    kw.update(shape_kw)
+    batch = make_batch(Shape(**kw), seed=len(name))
+    if post == "sos_only":                 # T = 1: only the SOS column (every shifted target is the literal 0 = pad)
+        batch["targets"] = batch["targets"][:, :1].contiguous()
+        batch["tgt_lengths"] = torch.ones_like(batch["tgt_lengths"])
+    elif post == "short_commands":         # rows with a single real token
+        batch["cmd_lengths"] = torch.tensor([batch["commands"].shape[1], 1, 1, 2])
+        for r, n in enumerate(batch["cmd_lengths"].tolist()):
+            batch["commands"][r, n:] = 0
+    elif post == "pad_row":                # a row whose targets are all padding contributes nothing to the loss
+        batch["targets"][1, 1:] = 0
+        batch["tgt_lengths"][1] = 1
+    params = {k: torch.from_numpy(v) for k, v in golden_weights(cfg, 17).items()}
+    model = build_model(cfg, params)
+    logp, aux, loss, grads = run_step(model, batch, cfg)
+    ref_loss, ref_grads, ref_logp = oracle.loss_and_grads(params, batch, conditional=cfg["conditional_attention"],
+                                                          auxiliary=cfg["auxiliary_task"],
+                                                          bidirectional=cfg["encoder_bidirectional"])
+    assert torch.isfinite(logp).all()
+    assert (logp - ref_logp).abs().max().item() < TOL, name
+    if torch.isfinite(ref_loss):
+        assert abs(loss - ref_loss.item()) < TOL, (loss, ref_loss.item())
+        for k, g in grads.items():
+            assert torch.allclose(g, ref_grads[k], atol=TOL, rtol=1e-3), (name, k, (g - ref_grads[k]).abs().max().item())
