@@ -94,3 +94,40 @@ def test_cpu_tensors_fail_loudly():
     with pytest.raises(RuntimeError, match="HIP device only"):
         model(commands_input=b["commands"], commands_lengths=b["cmd_lengths"].tolist(),
               situations_input=b["world"], target_batch=b["targets"], target_lengths=b["tgt_lengths"].tolist())
+
+
+def test_reference_checkpoint_loads_and_round_trips(tmp_path):
+    """tests/golden/demo_reference_checkpoint.pth.tar was written by the REFERENCE's Model.save_checkpoint after two
+    Adam steps (model.py:246-261).  It must load here — weights, counters, and the torch.optim.Adam state into the
+    flat fused optimiser — and a checkpoint saved from here must carry the same dictionary (the generating script
+    also checks that the reference loads ours)."""
+    from multimodal_seq2seq_gscan_amd.train import FlatAdam
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo_reference_checkpoint.pth.tar")
+    ref = torch.load(path, map_location="cpu", weights_only=False)
+    cfg = model_kwargs("demo", output_directory=str(tmp_path), cnn_hidden_num_channels=4, cnn_kernel_size=3)
+    model = Model(**cfg)
+    opt_state = model.load_model(path)
+    assert model.trained_iterations == ref["iteration"] == 2 and model.best_iteration == ref["best_iteration"] == 2
+    assert model.best_exact_match == 2.5 and model.best_accuracy == 12.5
+    sd = model.state_dict()
+    assert list(sd) == list(ref["state_dict"])
+    for k, v in ref["state_dict"].items():
+        assert torch.equal(sd[k].cpu(), v), k
+    opt = FlatAdam(model, 1e-3)
+    opt.load_state_dict(opt_state)
+    assert opt.steps_taken == 2
+    names = [n for n, _ in model.named_parameters()]
+    for i, n in enumerate(names):
+        off, cnt = model._offsets[n]
+        assert torch.equal(opt.exp_avg[off:off + cnt].cpu(), ref["optimizer_state_dict"]["state"][i]["exp_avg"].reshape(-1))
+        assert torch.equal(opt.exp_avg_sq[off:off + cnt].cpu(),
+                           ref["optimizer_state_dict"]["state"][i]["exp_avg_sq"].reshape(-1))
+    out = model.save_checkpoint("again.pth.tar", is_best=False, optimizer_state_dict=opt.state_dict())
+    again = torch.load(out, map_location="cpu", weights_only=False)
+    assert set(again) == set(ref)
+    assert set(again["optimizer_state_dict"]) == set(ref["optimizer_state_dict"])
+    g0, r0 = again["optimizer_state_dict"]["param_groups"][0], ref["optimizer_state_dict"]["param_groups"][0]
+    assert g0["params"] == r0["params"] and g0["betas"] == tuple(r0["betas"]) and g0["eps"] == r0["eps"]
+    for i in ref["optimizer_state_dict"]["state"]:
+        a, b = again["optimizer_state_dict"]["state"][i], ref["optimizer_state_dict"]["state"][i]
+        assert torch.equal(a["exp_avg"], b["exp_avg"]) and float(a["step"]) == float(b["step"])
