@@ -80,6 +80,58 @@ def _synthetic_batches(flags, rank: int, world: int):
         yield {k: v.cuda(non_blocking=True) for k, v in shard_batch(cpu, rank, world).items()}
 
 
+def _test_on_dataset(flags) -> None:
+    """seq2seq/__main__.py:124-163 + predict.py:17-54: greedy-decode every example of each split of a gSCAN dataset
+    file and write <split>_<output_file_name> with the reference's records (words, not ids)."""
+    import json
+    from .config import model_kwargs
+    from .dataset import GroundedScanDataset
+    from .model import Model
+    from .predict import predict, sequence_accuracy
+    data_path = os.path.join(flags["data_directory"], "dataset.txt")
+    assert os.path.exists(os.path.join(flags["data_directory"], flags["input_vocab_path"])) and os.path.exists(
+        os.path.join(flags["data_directory"], flags["target_vocab_path"])), \
+        "No vocabs found at {} and {}".format(flags["input_vocab_path"], flags["target_vocab_path"])
+    for split in flags["splits"].split(","):
+        logger.info("Loading {} dataset split...".format(split))
+        test_set = GroundedScanDataset(data_path, flags["data_directory"], split=split,
+                                       input_vocabulary_file=flags["input_vocab_path"],
+                                       target_vocabulary_file=flags["target_vocab_path"], generate_vocabulary=False,
+                                       k=flags["k"])
+        test_set.read_dataset(max_examples=None)
+        logger.info("Done Loading {} dataset split.".format(flags["split"]))
+        logger.info("  Loaded {} examples.".format(test_set.num_examples))
+        logger.info("  Input vocabulary size: {}".format(test_set.input_vocabulary_size))
+        logger.info("  Output vocabulary size: {}".format(test_set.target_vocabulary_size))
+        cfg = model_kwargs("compositional")
+        cfg.update({k: flags[k] for k in cfg if k in flags})
+        cfg.update(input_vocabulary_size=test_set.input_vocabulary_size,
+                   target_vocabulary_size=test_set.target_vocabulary_size, num_cnn_channels=test_set.image_channels,
+                   input_padding_idx=test_set.input_vocabulary.pad_idx, target_pad_idx=test_set.target_vocabulary.pad_idx,
+                   target_eos_idx=test_set.target_vocabulary.eos_idx)
+        model = Model(**cfg).cuda()
+        assert os.path.isfile(flags["resume_from_file"]), "No checkpoint found at {}".format(flags["resume_from_file"])
+        logger.info("Loading checkpoint from file at '{}'".format(flags["resume_from_file"]))
+        model.load_model(flags["resume_from_file"])
+        logger.info("Loaded checkpoint '{}' (iter {})".format(flags["resume_from_file"], model.trained_iterations))
+        vocab, output = test_set.target_vocabulary, []
+        for (inp, derivation, situation, out_seq, tgt, aw_c, aw_s, pos_acc) in predict(
+                test_set.get_data_iterator(batch_size=256), model=model, max_decoding_steps=flags["max_decoding_steps"],
+                pad_idx=vocab.pad_idx, sos_idx=vocab.sos_idx, eos_idx=vocab.eos_idx,
+                max_examples_to_evaluate=flags["max_testing_examples"]):
+            accuracy = sequence_accuracy(out_seq, tgt[0].tolist()[1:-1])
+            output.append({"input": test_set.array_to_sentence(inp[0].tolist(), "input")[1:-1],
+                           "prediction": test_set.array_to_sentence(out_seq, "target"), "derivation": derivation,
+                           "target": test_set.array_to_sentence(tgt[0].tolist(), "target")[1:-1], "situation": situation,
+                           "attention_weights_input": aw_c, "attention_weights_situation": aw_s, "accuracy": accuracy,
+                           "exact_match": True if accuracy == 100 else False, "position_accuracy": pos_acc})
+        output_file_path = os.path.join(flags["output_directory"], "_".join([split, flags["output_file_name"]]))
+        with open(output_file_path, mode="w") as outfile:
+            json.dump(output, outfile, indent=4)
+        logger.info("Wrote predictions for {} examples.".format(len(output)))
+        logger.info("Saved predictions to {}".format(output_file_path))
+
+
 def main(flags):
     logging.basicConfig(format="%(asctime)-15s %(message)s", level=logging.DEBUG, datefmt="%Y-%m-%d %H:%M")
     for argument, value in flags.items():
@@ -103,9 +155,10 @@ def main(flags):
         rank, world = _init_distributed()
         torch.manual_seed(flags["seed"])                      # train.py:27 (identical init on every rank)
         if not flags["synthetic_data"]:
-            raise NotImplementedError(
-                "reading data/<split>/dataset.txt is the next row of the scope table (SURVEY.md §8 f1/f3); "
-                "pass --synthetic_data to run the training hot path on synthetic batches")
+            from .train import train_on_dataset
+            train_on_dataset(data_path=os.path.join(flags["data_directory"], "dataset.txt"), rank=rank,
+                             world_size=world, **flags)
+            return
         cfg = model_kwargs("compositional")
         cfg.update({k: flags[k] for k in cfg if k in flags})
         model = Model(**cfg).cuda()
@@ -131,11 +184,10 @@ def main(flags):
         from .synthetic import Shape, make_batch
         if not torch.cuda.is_available():
             raise RuntimeError("greedy decoding runs on the HIP device only (no CPU fallback in this package)")
-        if not flags["synthetic_data"]:
-            raise NotImplementedError(
-                "reading data/<split>/dataset.txt is the next row of the scope table (SURVEY.md §8 f1/f3); "
-                "pass --synthetic_data to decode synthetic examples")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if not flags["synthetic_data"]:
+            _test_on_dataset(flags)
+            return
         assert os.path.isfile(flags["resume_from_file"]), "No checkpoint found at {}".format(flags["resume_from_file"])
         cfg = model_kwargs("compositional")
         cfg.update({k: flags[k] for k in cfg if k in flags})

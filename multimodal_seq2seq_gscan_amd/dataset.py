@@ -1,0 +1,249 @@
+"""gSCAN dataset reader and batcher without the simulator.
+
+The reference reads `data/<split>/dataset.txt` through `GroundedScan.load_dataset_from_file`
+(GroundedScan/dataset.py:487-514), re-plays every situation in its grid-world simulator to obtain the grid tensor
+(`get_examples_with_image`, dataset.py:137-163 -> `Grid.encode`, gym_minigrid/minigrid.py:380-399), keeps every
+example as separate device tensors and concatenates them per batch (seq2seq/gSCAN_dataset.py:184-278).
+
+Here the JSON is read directly.  What the simulator would draw is already in the file: each placed object carries
+its attribute vector (`"vector": "0001010100"` = sizes | shapes + colours one-hot, world.py:415-434) and its cell,
+and the agent cell / direction are plain numbers, so the `[G, G, C]` tensor of `Grid.encode` — object vector, then
+one agent bit, then a one-hot of the four directions, indexed `[row, column, :]` — is filled without `gym`.
+Examples are packed ONCE into contiguous host arrays (tokens int64 padded to the split's longest sequence, grids
+uint8: 240 bytes per 4x4x15 example), a batch is a slice of them: one pinned staging buffer, asynchronous copies,
+the grid expanded to fp32 on the device.  The yielded tuple is the reference's 9-tuple (gSCAN_dataset.py:229-231).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import random
+from collections import Counter, defaultdict
+from typing import Dict, Iterator, List, Optional
+
+import numpy as np
+import torch
+
+logger = logging.getLogger(__name__)
+
+
+class Vocabulary:
+    """seq2seq/gSCAN_dataset.py:17-102: <PAD>=0, <SOS>=1, <EOS>=2, then words in order of first appearance; unknown
+    words map to <PAD>.  Same JSON on disk (`to_dict`)."""
+
+    def __init__(self, sos_token="<SOS>", eos_token="<EOS>", pad_token="<PAD>"):
+        self.sos_token, self.eos_token, self.pad_token = sos_token, eos_token, pad_token
+        self._idx_to_word = [pad_token, sos_token, eos_token]
+        self._word_to_idx = defaultdict(int)
+        self._word_to_idx[pad_token] = 0
+        self._word_to_idx[sos_token] = 1
+        self._word_to_idx[eos_token] = 2
+        self._word_frequencies = Counter()
+
+    def word_to_idx(self, word: str) -> int:
+        return self._word_to_idx.get(word, 0)
+
+    def idx_to_word(self, idx: int) -> str:
+        return self._idx_to_word[idx]
+
+    def contains_word(self, word: str) -> bool:
+        return self.word_to_idx(word) != 0
+
+    def add_sentence(self, sentence: List[str]) -> None:
+        for word in sentence:
+            if word not in self._word_to_idx:
+                self._word_to_idx[word] = self.size
+                self._idx_to_word.append(word)
+            self._word_frequencies[word] += 1
+
+    def most_common(self, n=10):
+        return self._word_frequencies.most_common(n=n)
+
+    pad_idx = property(lambda self: self.word_to_idx(self.pad_token))
+    sos_idx = property(lambda self: self.word_to_idx(self.sos_token))
+    eos_idx = property(lambda self: self.word_to_idx(self.eos_token))
+    size = property(lambda self: len(self._idx_to_word))
+
+    @classmethod
+    def load(cls, path: str) -> "Vocabulary":
+        assert os.path.exists(path), "Trying to load a vocabulary from a non-existing file {}".format(path)
+        with open(path, "r") as infile:
+            data = json.load(infile)
+        vocab = cls(sos_token=data["sos_token"], eos_token=data["eos_token"], pad_token=data["pad_token"])
+        vocab._idx_to_word = list(data["idx_to_word"])
+        vocab._word_to_idx = defaultdict(int)
+        for word, idx in data["word_to_idx"].items():
+            vocab._word_to_idx[word] = idx
+        vocab._word_frequencies = Counter(data["word_frequencies"])
+        return vocab
+
+    def to_dict(self) -> dict:
+        return {"sos_token": self.sos_token, "eos_token": self.eos_token, "pad_token": self.pad_token,
+                "idx_to_word": self._idx_to_word, "word_to_idx": dict(self._word_to_idx),
+                "word_frequencies": dict(self._word_frequencies)}
+
+    def save(self, path: str) -> str:
+        with open(path, "w") as outfile:
+            json.dump(self.to_dict(), outfile, indent=4)
+        return path
+
+
+def parse_command_repr(command_repr: str) -> List[str]:
+    """GroundedScan/dataset.py `parse_command_repr`: commands are comma-joined words."""
+    return command_repr.split(",")
+
+
+def encode_situation(situation: dict) -> np.ndarray:
+    """`Grid.encode` (gym_minigrid/minigrid.py:380-399) from the situation dictionary of the data file:
+    uint8 [G, G, C], C = len(object vector) + 1 + 4, indexed [row, column, :]."""
+    G = int(situation["grid_size"])
+    objects = situation["placed_objects"]
+    n_attr = len(next(iter(objects.values()))["vector"]) if objects else len(situation["target_object"]["vector"])
+    grid = np.zeros((G, G, n_attr + 5), dtype=np.uint8)
+    for obj in objects.values():
+        row, col = int(obj["position"]["row"]), int(obj["position"]["column"])
+        grid[row, col, :n_attr] = np.frombuffer(obj["vector"].encode("ascii"), dtype=np.uint8) - ord("0")
+    row, col = int(situation["agent_position"]["row"]), int(situation["agent_position"]["column"])
+    grid[row, col, n_attr] = 1
+    grid[row, col, n_attr + 1 + int(situation["agent_direction"])] = 1
+    return grid
+
+
+def load_examples(path_to_data: str, k: int = 0) -> Dict[str, List[dict]]:
+    """The `examples` of a dataset file by split, with `k` random examples of the `adverb_1` split moved into
+    train AND dev (GroundedScan/dataset.py:499-510; `random.sample`, unseeded there as well)."""
+    with open(path_to_data, "r") as infile:
+        all_data = json.load(infile)
+    splits: Dict[str, List[dict]] = defaultdict(list)
+    for split, examples in all_data["examples"].items():
+        moved = set(random.sample(range(len(examples)), k=k)) if split == "adverb_1" and k else set()
+        for i, example in enumerate(examples):
+            if i in moved:
+                splits["train"].append(example)
+                splits["dev"].append(example)
+            else:
+                splits[split].append(example)
+    return splits
+
+
+class GroundedScanDataset:
+    """seq2seq/gSCAN_dataset.py:105-310 with the same constructor, attributes and iterator tuple."""
+
+    def __init__(self, path_to_data: str, save_directory: str, k: int, split="train", input_vocabulary_file="",
+                 target_vocabulary_file="", generate_vocabulary=False, vocabularies=None):
+        """`vocabularies` (additive): an (input, target) pair of Vocabulary objects to share with another split
+        instead of reading them back from the files the training split has just written."""
+        assert os.path.exists(path_to_data), "Trying to read a gSCAN dataset from a non-existing file {}.".format(
+            path_to_data)
+        if not generate_vocabulary and vocabularies is None:
+            assert os.path.exists(os.path.join(save_directory, input_vocabulary_file)) and os.path.exists(
+                os.path.join(save_directory, target_vocabulary_file)), \
+                "Trying to load vocabularies from non-existing files."
+        if split == "test" and generate_vocabulary:
+            logger.warning("WARNING: generating a vocabulary from the test set.")
+        self._raw = load_examples(path_to_data, k=k)[split]
+        self.image_dimensions = None
+        self.image_channels = 3
+        self.split = split
+        self.directory = save_directory
+        self._order = np.zeros(0, dtype=np.int64)
+        self._input_lengths = np.zeros(0, dtype=np.int64)
+        self._target_lengths = np.zeros(0, dtype=np.int64)
+        if vocabularies is not None:
+            self.input_vocabulary, self.target_vocabulary = vocabularies
+        elif generate_vocabulary:
+            logger.info("Generating vocabularies...")
+            self.input_vocabulary, self.target_vocabulary = Vocabulary(), Vocabulary()
+            for example in self._raw:                                        # read_vocabularies, :153-160
+                self.input_vocabulary.add_sentence(parse_command_repr(example["command"]))
+                self.target_vocabulary.add_sentence(parse_command_repr(example["target_commands"]))
+            logger.info("Done generating vocabularies.")
+        else:
+            logger.info("Loading vocabularies...")
+            self.input_vocabulary = Vocabulary.load(os.path.join(save_directory, input_vocabulary_file))
+            self.target_vocabulary = Vocabulary.load(os.path.join(save_directory, target_vocabulary_file))
+            logger.info("Done loading vocabularies.")
+
+    # ---- vocabulary plumbing (:162-176, :280-310) ------------------------------------------------
+    def save_vocabularies(self, input_vocabulary_file: str, target_vocabulary_file: str):
+        self.input_vocabulary.save(os.path.join(self.directory, input_vocabulary_file))
+        self.target_vocabulary.save(os.path.join(self.directory, target_vocabulary_file))
+
+    def get_vocabulary(self, vocabulary: str) -> Vocabulary:
+        if vocabulary == "input":
+            return self.input_vocabulary
+        if vocabulary == "target":
+            return self.target_vocabulary
+        raise ValueError("Specified unknown vocabulary in sentence_to_array: {}".format(vocabulary))
+
+    def sentence_to_array(self, sentence: List[str], vocabulary: str) -> List[int]:
+        vocab = self.get_vocabulary(vocabulary)
+        return [vocab.sos_idx] + [vocab.word_to_idx(word) for word in sentence] + [vocab.eos_idx]
+
+    def array_to_sentence(self, sentence_array: List[int], vocabulary: str) -> List[str]:
+        vocab = self.get_vocabulary(vocabulary)
+        return [vocab.idx_to_word(int(idx)) for idx in sentence_array]
+
+    num_examples = property(lambda self: len(self._order))
+    input_vocabulary_size = property(lambda self: self.input_vocabulary.size)
+    target_vocabulary_size = property(lambda self: self.target_vocabulary.size)
+
+    # ---- packing (:233-278) ---------------------------------------------------------------------
+    def read_dataset(self, max_examples=None, simple_situation_representation=True) -> None:
+        """Convert the split to packed host arrays.  `max_examples` keeps the reference's off-by-one: reading stops
+        once MORE than max_examples examples are held (gSCAN_dataset.py:243-245)."""
+        if not simple_situation_representation:
+            raise NotImplementedError("Full RGB input image not implemented (the reference CLI rejects it too).")
+        logger.info("Converting dataset to tensors...")
+        raw = self._raw if not max_examples else self._raw[:max_examples + 1]
+        inputs = [self.sentence_to_array(parse_command_repr(e["command"]), "input") for e in raw]
+        targets = [self.sentence_to_array(parse_command_repr(e["target_commands"]), "target") for e in raw]
+        n = len(raw)
+        self._input_lengths = np.array([len(x) for x in inputs], dtype=np.int64)
+        self._target_lengths = np.array([len(x) for x in targets], dtype=np.int64)
+        self._commands = np.zeros((n, int(self._input_lengths.max(initial=0))), dtype=np.int64)
+        self._targets = np.zeros((n, int(self._target_lengths.max(initial=0))), dtype=np.int64)
+        for i, (x, y) in enumerate(zip(inputs, targets)):
+            self._commands[i, :len(x)] = x
+            self._targets[i, :len(y)] = y
+        grids = [encode_situation(e["situation"]) for e in raw]
+        self._grids = np.stack(grids) if grids else np.zeros((0, 0, 0, 0), dtype=np.uint8)
+        if n:
+            self.image_dimensions, self.image_channels = int(self._grids.shape[1]), int(self._grids.shape[-1])
+        sit = [e["situation"] for e in raw]
+        self._agent_positions = np.array(
+            [int(s["agent_position"]["row"]) * int(s["grid_size"]) + int(s["agent_position"]["column"]) for s in sit],
+            dtype=np.int64)
+        self._target_positions = np.array(
+            [int(s["target_object"]["position"]["row"]) * int(s["grid_size"]) +
+             int(s["target_object"]["position"]["column"]) for s in sit], dtype=np.int64)
+        self._situations = sit
+        self._derivations = [e.get("derivation") for e in raw]
+        self._order = np.arange(n, dtype=np.int64)
+
+    def shuffle_data(self) -> None:
+        """:177-183 (np.random.permutation, unseeded there as well)."""
+        self._order = self._order[np.random.permutation(len(self._order))]
+
+    # ---- batches (:184-231) ---------------------------------------------------------------------
+    def get_data_iterator(self, batch_size=10, device: Optional[torch.device] = None) -> Iterator[tuple]:
+        """Yields (input_batch [B,L] i64, input_lengths, derivations, situation_batch [B,G,G,C] f32, situations,
+        target_batch [B,T] i64, target_lengths, agent_positions [B] i64, target_positions [B] i64), every batch
+        padded to ITS longest sequences, the last one short (as the reference)."""
+        if device is None:
+            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        pin = device.type == "cuda"
+        for lo in range(0, len(self._order), batch_size):
+            idx = self._order[lo:lo + batch_size]
+            in_len, tgt_len = self._input_lengths[idx], self._target_lengths[idx]
+            L, T = int(in_len.max()), int(tgt_len.max())
+
+            def ship(array: np.ndarray) -> torch.Tensor:
+                t = torch.from_numpy(np.ascontiguousarray(array))
+                return (t.pin_memory() if pin else t).to(device, non_blocking=True)
+
+            yield (ship(self._commands[idx, :L]), in_len, [self._derivations[i] for i in idx],
+                   ship(self._grids[idx]).to(torch.float32), [self._situations[i] for i in idx],
+                   ship(self._targets[idx, :T]), tgt_len, ship(self._agent_positions[idx]),
+                   ship(self._target_positions[idx]))

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
+import os
 import math
 from typing import Dict, Iterable, Optional
 
@@ -350,3 +351,99 @@ def train(batches: Iterable[Dict[str, torch.Tensor]], model: Model, max_training
                                                              step.optimizer.current_lr(), aux_acc))
         it += 1
     return step
+
+
+def train_on_dataset(data_path: str, data_directory: str, generate_vocabularies: bool, input_vocab_path: str,
+                     target_vocab_path: str, training_batch_size: int, max_training_iterations: int,
+                     print_every: int, evaluate_every: int, max_decoding_steps: int, output_directory: str,
+                     resume_from_file: str = "", k: int = 0, max_training_examples=None, max_testing_examples=None,
+                     weight_target_loss: float = 0.3, seed: int = 42, rank: int = 0, world_size: int = 1,
+                     evaluation_batch_size: int = 256, **flags) -> Model:
+    """seq2seq/train.py:17-154 on a gSCAN dataset file: the reference's loop — shuffle, iterate batches, step,
+    log every `print_every`, greedy-decode the dev split every `evaluate_every` and checkpoint on a new best exact
+    match — with the HIP step, the packed batcher (dataset.py) and batched evaluation.  Under torch.distributed
+    every rank reads the same file, shuffles with the same seed and trains on its rows of each batch."""
+    import numpy as np
+    from .config import model_kwargs
+    from .dataset import GroundedScanDataset
+    from .predict import evaluate
+
+    torch.manual_seed(seed)                                     # train.py:27
+    np.random.seed(seed)                                        # the same shuffle on every rank
+    logger.info("Loading Training set...")
+    training_set = GroundedScanDataset(data_path, data_directory, split="train", input_vocabulary_file=input_vocab_path,
+                                       target_vocabulary_file=target_vocab_path,
+                                       generate_vocabulary=generate_vocabularies, k=k)
+    training_set.read_dataset(max_examples=max_training_examples)
+    logger.info("Done Loading Training set.")
+    logger.info("  Loaded {} training examples.".format(training_set.num_examples))
+    logger.info("  Input vocabulary size training set: {}".format(training_set.input_vocabulary_size))
+    logger.info("  Most common input words: {}".format(training_set.input_vocabulary.most_common(5)))
+    logger.info("  Output vocabulary size training set: {}".format(training_set.target_vocabulary_size))
+    logger.info("  Most common target words: {}".format(training_set.target_vocabulary.most_common(5)))
+    if generate_vocabularies and rank == 0:
+        training_set.save_vocabularies(input_vocab_path, target_vocab_path)
+        logger.info("Saved vocabularies to {} for input and {} for target.".format(input_vocab_path, target_vocab_path))
+    logger.info("Loading Dev. set...")
+    dev_set = GroundedScanDataset(data_path, data_directory, split="dev", k=0,
+                                  vocabularies=(training_set.input_vocabulary, training_set.target_vocabulary))
+    dev_set.read_dataset(max_examples=None)
+    dev_set.shuffle_data()                                       # train.py:52-53
+    logger.info("Done Loading Dev. set.")
+
+    cfg = model_kwargs("compositional")
+    cfg.update({key: flags[key] for key in cfg if key in flags})
+    cfg.update(input_vocabulary_size=training_set.input_vocabulary_size,
+               target_vocabulary_size=training_set.target_vocabulary_size,
+               num_cnn_channels=training_set.image_channels,
+               input_padding_idx=training_set.input_vocabulary.pad_idx,
+               target_pad_idx=training_set.target_vocabulary.pad_idx,
+               target_eos_idx=training_set.target_vocabulary.eos_idx, output_directory=output_directory)
+    model = Model(**cfg).cuda()
+    optim = {key: flags[key] for key in ("learning_rate", "adam_beta_1", "adam_beta_2", "lr_decay", "lr_decay_steps")
+             if key in flags}
+    step = TrainStep(model, weight_target_loss=weight_target_loss, **optim)
+    best_exact_match = 0
+    if resume_from_file:
+        assert os.path.isfile(resume_from_file), "No checkpoint found at {}".format(resume_from_file)
+        logger.info("Loading checkpoint from file at '{}'".format(resume_from_file))
+        step.optimizer.load_state_dict(model.load_model(resume_from_file))
+        logger.info("Loaded checkpoint '{}' (iter {})".format(resume_from_file, model.trained_iterations))
+    logger.info("Training starts..")
+    training_iteration = model.trained_iterations if resume_from_file else 1
+    vocab = dev_set.target_vocabulary
+    while training_iteration < max_training_iterations:          # train.py:88
+        training_set.shuffle_data()
+        for (commands, cmd_lengths, _, world, _, targets, tgt_lengths, _, positions) in training_set.get_data_iterator(
+                batch_size=training_batch_size):
+            batch = {"commands": commands, "cmd_lengths": torch.as_tensor(cmd_lengths), "world": world,
+                     "targets": targets, "tgt_lengths": torch.as_tensor(tgt_lengths), "target_positions": positions}
+            if world_size > 1:
+                batch = {key: value.cuda() if key.endswith("lengths") else value
+                         for key, value in shard_batch(batch, rank, world_size).items()}
+            out = step(batch)
+            if training_iteration % print_every == 0 and rank == 0:
+                accuracy, exact_match = model.get_metrics(out["logp"], batch["targets"])
+                aux_acc = (model.get_auxiliary_accuracy(out["aux"], batch["target_positions"])
+                           if model.auxiliary_task else 0.0)
+                logger.info("Iteration %08d, loss %8.4f, accuracy %5.2f, exact match %5.2f, learning_rate %.5f,"
+                            " aux. accuracy target pos %5.2f" % (training_iteration, out["loss"].item(), accuracy,
+                                                                 exact_match, step.optimizer.current_lr(), aux_acc))
+            if training_iteration % evaluate_every == 0 and rank == 0:      # train.py:129-149
+                logger.info("Evaluating..")
+                accuracy, exact_match, target_accuracy = evaluate(
+                    dev_set.get_data_iterator(batch_size=evaluation_batch_size), model=model,
+                    max_decoding_steps=max_decoding_steps, pad_idx=vocab.pad_idx, sos_idx=vocab.sos_idx,
+                    eos_idx=vocab.eos_idx, max_examples_to_evaluate=max_testing_examples)
+                logger.info("  Evaluation Accuracy: %5.2f Exact Match: %5.2f "
+                            " Target Accuracy: %5.2f" % (accuracy, exact_match, target_accuracy))
+                if exact_match > best_exact_match:
+                    best_exact_match = exact_match
+                    model.update_state(accuracy=accuracy, exact_match=exact_match, is_best=True)
+                    model.save_checkpoint(file_name="checkpoint.pth.tar", is_best=True,
+                                          optimizer_state_dict=step.optimizer.state_dict())
+            training_iteration += 1
+            if training_iteration > max_training_iterations:
+                break
+    logger.info("Finished training.")
+    return model

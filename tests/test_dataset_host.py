@@ -1,0 +1,85 @@
+"""The simulator-free dataset reader and batcher on CPU.
+
+tests/golden/readme_demo_dataset.txt holds the one data example the reference publishes (README.md:78-166, the
+first example of the split "situational_1") plus variations of it; the README also states what the grid tensor
+of that example must contain (README.md:181-185), which is the known answer checked here."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from multimodal_seq2seq_gscan_amd.dataset import GroundedScanDataset, Vocabulary, encode_situation, load_examples
+
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readme_demo_dataset.txt")
+
+
+def test_grid_encoding_matches_the_readme_known_answer():
+    example = json.load(open(DATA))["examples"]["situational_1"][0]
+    grid = encode_situation(example["situation"])
+    assert grid.shape == (4, 4, 15) and grid.dtype == np.uint8
+    # README.md:181-185: channels = [size 1..4, circle, square, red, green, yellow, blue, agent, east, south, west,
+    # north]; "the green square of size 4 in row 1 and column 1 ... [0,0,0,1,0,1,0,1,0,0,0,0,0,0,0]"
+    assert grid[1, 1].tolist() == [0, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0]
+    assert grid[3, 2].tolist() == [1, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0]        # red circle of size 1
+    assert grid[2, 3].tolist() == [0] * 10 + [1, 1, 0, 0, 0]                            # agent, direction 0
+    assert int(grid.sum()) == 4 * 3 + 2 and grid[0].sum() == 0
+
+
+def test_vocabulary_indices_and_json_round_trip(tmp_path):
+    v = Vocabulary()
+    v.add_sentence(["walk", "to", "a", "red", "circle"])
+    v.add_sentence(["walk", "to", "a", "circle"])
+    assert (v.pad_idx, v.sos_idx, v.eos_idx, v.size) == (0, 1, 2, 8)
+    assert [v.word_to_idx(w) for w in ("walk", "to", "a", "red", "circle", "unseen")] == [3, 4, 5, 6, 7, 0]
+    assert v.idx_to_word(6) == "red" and v.contains_word("red") and not v.contains_word("unseen")
+    assert v.most_common(1) == [("walk", 2)]
+    path = v.save(str(tmp_path / "vocab.txt"))
+    assert set(json.load(open(path))) == {"sos_token", "eos_token", "pad_token", "idx_to_word", "word_to_idx",
+                                          "word_frequencies"}                     # gSCAN_dataset.py:89-97
+    w = Vocabulary.load(path)
+    assert w.to_dict() == v.to_dict()
+
+
+def test_reader_and_batcher_follow_the_reference_contract(tmp_path):
+    work = str(tmp_path)
+    with pytest.raises(AssertionError):
+        GroundedScanDataset(DATA, work, k=0, split="train", input_vocabulary_file="in.txt",
+                            target_vocabulary_file="out.txt", generate_vocabulary=False)   # no vocabulary files yet
+    train = GroundedScanDataset(DATA, work, k=0, split="train", generate_vocabulary=True)
+    train.read_dataset()
+    assert train.num_examples == 8 and train.image_dimensions == 4 and train.image_channels == 15
+    assert train.input_vocabulary_size == 3 + 7 and train.target_vocabulary_size == 3 + 3
+    train.save_vocabularies("in.txt", "out.txt")
+    dev = GroundedScanDataset(DATA, work, k=0, split="dev", input_vocabulary_file="in.txt",
+                              target_vocabulary_file="out.txt")
+    dev.read_dataset()
+    assert dev.input_vocabulary.to_dict() == train.input_vocabulary.to_dict()
+    batches = list(train.get_data_iterator(batch_size=3, device=torch.device("cpu")))
+    assert [b[0].shape[0] for b in batches] == [3, 3, 2]                         # the last batch is short
+    inp, in_len, deriv, world, sit, tgt, tgt_len, agent_pos, tgt_pos = batches[0]
+    assert inp.dtype == torch.int64 and world.dtype == torch.float32 and world.shape == (3, 4, 4, 15)
+    assert in_len.tolist() == [7, 6, 7] and inp.shape == (3, 7)                 # padded to the batch's longest row
+    assert inp[0].tolist() == [1, 3, 4, 5, 6, 7, 2] and inp[1].tolist() == [1, 3, 4, 5, 7, 2, 0]
+    assert tgt_len.tolist() == [7, 4, 6] and tgt[1].tolist() == [1, 3, 4, 2, 0, 0, 0]
+    assert agent_pos.tolist() == [2 * 4 + 3, 0, 2 * 4 + 3] and tgt_pos.tolist() == [3 * 4 + 2, 3 * 4 + 2, 1 * 4 + 1]
+    assert deriv[0].startswith("NP -> NN") and sit[1]["agent_direction"] == 3
+    assert world[1, 0, 0].tolist() == [0] * 10 + [1, 0, 0, 0, 1]
+    assert train.array_to_sentence(tgt[1].tolist()[:4], "target") == ["<SOS>", "turn left", "walk", "<EOS>"]
+    np.random.seed(0)
+    train.shuffle_data()
+    again = torch.cat([b[0][:, :6] for b in train.get_data_iterator(batch_size=8, device=torch.device("cpu"))])
+    assert again.shape[0] == 8
+    # max_examples keeps the reference's off-by-one (reading stops once MORE than max_examples are held)
+    few = GroundedScanDataset(DATA, work, k=0, split="train", generate_vocabulary=True)
+    few.read_dataset(max_examples=2)
+    assert few.num_examples == 3
+
+
+def test_k_shot_moves_adverb_examples_into_train_and_dev():
+    base = load_examples(DATA, k=0)
+    assert len(base["adverb_1"]) == 3 and len(base["train"]) == 8 and len(base["dev"]) == 3
+    moved = load_examples(DATA, k=2)
+    assert len(moved["adverb_1"]) == 1 and len(moved["train"]) == 10 and len(moved["dev"]) == 5

@@ -1,6 +1,8 @@
 """Parity of the HIP training step with the reference: golden fixtures (outputs of the reference itself)
 and the CPU oracle on the same seeded inputs.  Tolerance 1e-4 absolute on log-probabilities and loss
 (BASELINE.json north star, fp32); gradients 1e-4 absolute + 1e-3 relative.  Run: pytest -m gpu."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -468,3 +470,32 @@ def test_edge_shapes_against_oracle(name, overrides, shape_kw, post):
         assert abs(loss - ref_loss.item()) < TOL, (loss, ref_loss.item())
         for k, g in grads.items():
             assert torch.allclose(g, ref_grads[k], atol=TOL, rtol=1e-3), (name, k, (g - ref_grads[k]).abs().max().item())
+
+
+def test_command_line_on_a_dataset_file(tmp_path):
+    """`python -m seq2seq --mode=train --data_directory=... --generate_vocabularies` on a gSCAN dataset file (the
+    README's demo command, README.md:177, on the README's published example and variations of it), with evaluation
+    and best-checkpointing (train.py:129-149), then `--mode=test` writing <split>_predict.json with words."""
+    import json
+    import shutil
+    from multimodal_seq2seq_gscan_amd.__main__ import main, parser
+    data_dir = tmp_path / "data"
+    data_dir.mkdir()
+    shutil.copyfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readme_demo_dataset.txt"),
+                    data_dir / "dataset.txt")
+    out = str(tmp_path / "out")
+    common = ["--data_directory", str(data_dir), "--output_directory", out, "--embedding_dimension", "5",
+              "--encoder_hidden_size", "20", "--decoder_hidden_size", "20", "--seed", "1"]
+    main(vars(parser.parse_args(["--mode", "train", "--max_training_iterations", "60", "--training_batch_size", "5",
+                                 "--print_every", "20", "--evaluate_every", "30", "--generate_vocabularies",
+                                 "--max_decoding_steps", "8", "--learning_rate", "0.01"] + common)))
+    assert os.path.exists(data_dir / "training_input_vocab.txt") and os.path.exists(data_dir / "training_target_vocab.txt")
+    ckpt = torch.load(f"{out}/model_best.pth.tar", map_location="cpu", weights_only=False)
+    assert ckpt["best_exact_match"] > 0 and ckpt["state_dict"]["encoder.embedding.weight"].shape == (10, 5)
+    main(vars(parser.parse_args(["--mode", "test", "--resume_from_file", f"{out}/model_best.pth.tar",
+                                 "--splits", "test,situational_1", "--max_decoding_steps", "8"] + common)))
+    records = json.load(open(f"{out}/situational_1_predict.json"))
+    assert len(records) == 1 and records[0]["input"] == ["walk", "to", "a", "red", "circle"]
+    assert records[0]["target"] == ["turn left", "turn left", "walk", "turn left", "walk"]
+    assert all(w in ("turn left", "turn right", "walk", "<EOS>", "<SOS>", "<PAD>") for w in records[0]["prediction"])
+    assert len(json.load(open(f"{out}/test_predict.json"))) == 2
