@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 3
+#define GSCAN_ABI_VERSION 4
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
 typedef struct gscan_dims {
@@ -234,9 +234,19 @@ int gscan_gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam
                    const float *b, int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc,
                    const float *bias, int act, const float *mask, int split_k, void *stream);
 
-/* im2col of the world tensor for the three convolutions (seq2seq/cnn_model.py:28-31):
- * xcol [B*G*G, C*(1+25+K3*K3)], column (conv, ch, kh, kw) holds world[b, r+kw-p, c+kh-p, ch]. */
-int gscan_world_im2col(const float *world, int B, int G, int C, int K3, float *xcol, void *stream);
+/* ConvolutionalNet.forward (seq2seq/cnn_model.py:22-36) on its own: the three same-padded convolutions (kernels
+ * 1, 5, K3; kh walks grid columns and kw grid rows because the reference convolves the transposed image), bias,
+ * ReLU and dropout mask, as ONE product world[B, G*G*C] . Wt[G*G*C, G*G*3Co] with the Toeplitz image Wt of the
+ * kernels.  conv_w[i] [Co,C,k_i,k_i], conv_b[i] [Co]; mask [B,G*G,3Co] or NULL; feat [B,G*G,3Co].
+ * wt_scratch: (G*G*C + 1) * G*G*3Co floats. */
+int gscan_world_encoder_forward(const float *world, const float *const conv_w[3], const float *const conv_b[3], int B,
+                                int G, int C, int Co, int K3, const float *mask, float *wt_scratch, float *feat,
+                                void *stream);
+/* Its weight gradients: given d(loss)/d(conv output before ReLU/dropout) `dfeat` [B,G*G,3Co], ADDS the kernel and
+ * bias gradients into grad_w[i] / grad_b[i] (d Wt = world^T . dfeat folded back onto the kernels).
+ * dwt_scratch: G*G*C * G*G*3Co floats. */
+int gscan_world_encoder_backward(const float *world, const float *dfeat, int B, int G, int C, int Co, int K3,
+                                 float *dwt_scratch, float *const grad_w[3], float *const grad_b[3], void *stream);
 
 /* Masked per-row LSTM over the command (seq2seq/seq2seq_model.py:62-88).
  * gx [B,L,D,4He] = W_ih x + b_ih (D directions); out [B,L,He] = sum of directions,

@@ -10,7 +10,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _f32p = C.POINTER(C.c_float)
 _i64p = C.POINTER(C.c_int64)
@@ -94,7 +94,8 @@ PROTOTYPES = {
     "gscan_probe_reset": (_i, []),
     "gscan_probe_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "gscan_gemm_f32": (_i, [_i, _i, _i, _f, _vp, _i64, _i64, _vp, _i64, _i64, _f, _vp, _i64, _vp, _i, _vp, _i, _vp]),
-    "gscan_world_im2col": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "gscan_world_encoder_forward": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gscan_world_encoder_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "gscan_encoder_lstm_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _vp]),
     "gscan_encoder_lstm_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -195,9 +195,32 @@ int gscan_gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam
                     (hipStream_t)stream);
 }
 
-int gscan_world_im2col(const float *world, int B, int G, int C, int K3, float *xcol, void *stream) {
-    ARG(world && xcol, "im2col: NULL argument");
-    return world_im2col(world, B, G, C, K3, xcol, (hipStream_t)stream);
+int gscan_world_encoder_forward(const float *world, const float *const conv_w[3], const float *const conv_b[3], int B,
+                                int G, int C, int Co, int K3, const float *mask, float *wt_scratch, float *feat,
+                                void *stream) {
+    ARG(world && conv_w && conv_b && wt_scratch && feat, "world_encoder_forward: NULL argument");
+    ARG(B > 0 && G > 0 && C > 0 && Co > 0 && K3 > 0 && (K3 & 1), "world_encoder_forward: bad dims");
+    const int M = G * G, F = 3 * Co;
+    float *wt = wt_scratch, *bias_rep = wt_scratch + (size_t)M * C * M * F;
+    const float *const cw[3] = {conv_w[0], conv_w[1], conv_w[2]};
+    const float *const cb[3] = {conv_b[0], conv_b[1], conv_b[2]};
+    if (int rc = toeplitz_build(cw, cb, G, C, Co, K3, wt, bias_rep, (hipStream_t)stream)) return rc;
+    GemmBatch g;
+    g.add(B, M * F, M * C, world, (int64_t)M * C, 1, wt, (int64_t)M * F, 1, feat, (int64_t)M * F, 0.f, bias_rep, 1, mask);
+    return g.launch((hipStream_t)stream);
+}
+
+int gscan_world_encoder_backward(const float *world, const float *dfeat, int B, int G, int C, int Co, int K3,
+                                 float *dwt_scratch, float *const grad_w[3], float *const grad_b[3], void *stream) {
+    ARG(world && dfeat && dwt_scratch && grad_w && grad_b, "world_encoder_backward: NULL argument");
+    ARG(B > 0 && G > 0 && C > 0 && Co > 0 && K3 > 0 && (K3 & 1), "world_encoder_backward: bad dims");
+    const int M = G * G, F = 3 * Co;
+    GemmBatch g;
+    g.add(M * C, M * F, B, world, 1, (int64_t)M * C, dfeat, (int64_t)M * F, 1, dwt_scratch, (int64_t)M * F);
+    if (int rc = g.launch((hipStream_t)stream)) return rc;
+    float *const gw[3] = {grad_w[0], grad_w[1], grad_w[2]};
+    float *const gb[3] = {grad_b[0], grad_b[1], grad_b[2]};
+    return toeplitz_fold(gw, gb, G, C, Co, K3, B, dwt_scratch, dfeat, (hipStream_t)stream);
 }
 
 int gscan_encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths,

@@ -1,48 +1,10 @@
-// Small memory-bound kernels of the training step: im2col of the world tensor, embedding
-// gather / gradient scatter, ReLU+dropout backward, column sums (bias gradients), the
-// attention value-path gradient, fused Adam and the Philox dropout-mask generator.
+// Small memory-bound kernels of the training step: embedding gather / gradient scatter, the step
+// prologue (weight images, embeddings, zeroing), the Toeplitz image of the convolutions and its
+// gradient fold, fused Adam and the Philox dropout-mask generator.
 // All are one-pass, coalesced along the innermost (feature) dimension.
 #include "step.h"
 
 namespace gscan {
-
-// ------------------------------------------------------------------------------------------
-// im2col for conv_1 (k=1), conv_2 (k=5), conv_3 (k=K3) — seq2seq/cnn_model.py:28-31.
-// Column (conv, ch, kh, kw) of row (b, r, c) = world[b, r + kw - p, c + kh - p, ch]: the
-// reference convolves the transposed image, so kh walks grid columns and kw grid rows.
-// ------------------------------------------------------------------------------------------
-__global__ void im2col_kernel(const float *__restrict__ world, int B, int G, int C, int K3, int Ktot,
-                              float *__restrict__ xcol) {
-    const int64_t total = (int64_t)B * G * G * Ktot;
-    const int k2 = 25 * C, k1 = C;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(idx % Ktot);
-        const int64_t row = idx / Ktot;
-        const int c = (int)(row % G), r = (int)((row / G) % G);
-        const int64_t b = row / ((int64_t)G * G);
-        int kk, local;
-        if (col < k1) { kk = 1; local = col; }
-        else if (col < k1 + k2) { kk = 5; local = col - k1; }
-        else { kk = K3; local = col - k1 - k2; }
-        const int p = kk / 2;
-        const int kw = local % kk, kh = (local / kk) % kk, ch = local / (kk * kk);
-        const int rr = r + kw - p, cc = c + kh - p;
-        float v = 0.f;
-        if (rr >= 0 && rr < G && cc >= 0 && cc < G) v = world[((b * G + rr) * G + cc) * C + ch];
-        xcol[idx] = v;
-    }
-}
-
-int world_im2col(const float *world, int B, int G, int C, int K3, float *xcol, hipStream_t stream) {
-    GSCAN_CHECK(B > 0 && G > 0 && C > 0 && K3 > 0 && (K3 & 1), "im2col: bad dims B=%d G=%d C=%d K3=%d", B, G, C, K3);
-    const int Ktot = C * (1 + 25 + K3 * K3);
-    const int64_t total = (int64_t)B * G * G * Ktot;
-    const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 256 * 16);
-    hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, stream, world, B, G, C, K3, Ktot, xcol);
-    GSCAN_LAUNCHED("im2col_kernel");
-    return 0;
-}
 
 // ------------------------------------------------------------------------------------------
 // out[row, 0:D] (row stride ldo) = table[tok[row], :] * mask[row, :]
@@ -125,61 +87,6 @@ int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mas
     hipLaunchKernelGGL(embed_grad_kernel, dim3(cdiv(rows, kEmbedRows)), dim3(256), lds, stream, tok, g, ldg, mask,
                        rows, D, vocab, pad, dtable);
     GSCAN_LAUNCHED("embed_grad_kernel");
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// ReLU + dropout backward for the conv features (cnn_model.py:32-35):
-// feat = relu(x) * mask  =>  dx = (feat != 0) ? dfeat * mask : 0.   In place on dfeat.
-// ------------------------------------------------------------------------------------------
-__global__ void relu_mask_bwd_kernel(float *__restrict__ dfeat, const float *__restrict__ feat,
-                                     const float *__restrict__ mask, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float d = dfeat[i];
-        d = (feat[i] != 0.f) ? (mask ? d * mask[i] : d) : 0.f;
-        dfeat[i] = d;
-    }
-}
-
-int relu_mask_backward(float *dfeat, const float *feat, const float *mask, int64_t n, hipStream_t stream) {
-    hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3((int)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0, stream,
-                       dfeat, feat, mask, n);
-    GSCAN_LAUNCHED("relu_mask_bwd_kernel");
-    return 0;
-}
-
-// out[i] = a[i] + b[i]  (sum of the two LSTM bias vectors)
-__global__ void vec_add_kernel(const float *a, const float *b, float *out, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] + b[i];
-}
-int vec_add(const float *a, const float *b, float *out, int n, hipStream_t stream) {
-    hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, a, b, out, n);
-    GSCAN_LAUNCHED("vec_add_kernel");
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// Column sums: out1[n] += sum_r x[r*ld + n]  (and out2[n] += the same, for the twin LSTM
-// biases b_ih / b_hh which always receive identical gradients).  Rows are split over
-// blockIdx.y, columns over lanes; one atomic per (block, column).
-// ------------------------------------------------------------------------------------------
-__global__ void colsum_kernel(const float *__restrict__ x, int64_t ld, int rows, int N, float *out1, float *out2,
-                              int rows_per_block) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    float acc = 0.f;
-    for (int r = r0; r < r1; ++r) acc += x[(int64_t)r * ld + n];
-    atomicAdd(&out1[n], acc);
-    if (out2) atomicAdd(&out2[n], acc);
-}
-
-int colsum_add(const float *x, int64_t ld, int rows, int N, float *out1, float *out2, hipStream_t stream) {
-    const int rpb = 128;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), cdiv(rows, rpb)), dim3(64), 0, stream, x, ld, rows, N, out1,
-                       out2, rpb);
-    GSCAN_LAUNCHED("colsum_kernel");
     return 0;
 }
 

@@ -1,58 +1,10 @@
-// log_softmax (forward/backward) over short rows, and the masked NLL reductions of
-// Model.get_loss / get_auxiliary_loss / get_metrics (seq2seq/model.py:117-164).
-// Rows are short (V = 6..9 target words, G*G = 16..36 cells): one lane per row keeps the
-// row in registers; consecutive lanes read consecutive rows (row-major, so a wave reads a
-// contiguous V*64-float span).
+// The masked NLL reductions of Model.get_loss / get_auxiliary_loss / get_metrics (seq2seq/model.py:117-164) as
+// stand-alone kernels (autograd and data-parallel paths; the single-process training step computes its loss inside
+// the decoder kernels).  log_softmax itself lives in the decoder kernels' epilogue / prologue.
 #include "step.h"
 
 namespace gscan {
 
-
-__global__ void log_softmax_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ y2,
-                                   int rows, int n) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const float *xr = x + (int64_t)r * n;
-    float mx = -INFINITY;
-    for (int j = 0; j < n; ++j) mx = fmaxf(mx, xr[j]);
-    float s = 0.f;
-    for (int j = 0; j < n; ++j) s += expf(xr[j] - mx);
-    const float lse = mx + logf(s);
-    float *yr = y + (int64_t)r * n;
-    for (int j = 0; j < n; ++j) yr[j] = xr[j] - lse;
-    if (y2) {                                    // second copy (the caller's output next to the saved one)
-        float *y2r = y2 + (int64_t)r * n;
-        for (int j = 0; j < n; ++j) y2r[j] = xr[j] - lse;
-    }
-}
-
-// dx = dy - exp(y) * sum(dy)
-// dx = scale * (dy - exp(y) * sum(dy));  scale (device scalar, optional) seeds the backward pass with
-// 1/tokens_global or w/rows_global without a host round trip
-__global__ void log_softmax_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy,
-                                       float *__restrict__ dx, int rows, int n, const float *__restrict__ scale) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const float sc = scale ? scale[0] : 1.f;
-    const float *yr = y + (int64_t)r * n, *dr = dy + (int64_t)r * n;
-    float s = 0.f;
-    for (int j = 0; j < n; ++j) s += dr[j];
-    float *xr = dx + (int64_t)r * n;
-    for (int j = 0; j < n; ++j) xr[j] = sc * (dr[j] - expf(yr[j]) * s);
-}
-
-int log_softmax_rows(const float *x, float *y, float *y2, int rows, int n, hipStream_t stream) {
-    GSCAN_CHECK(n >= 1 && n <= 4096, "log_softmax: row length %d unsupported", n);
-    hipLaunchKernelGGL(log_softmax_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, x, y, y2, rows, n);
-    GSCAN_LAUNCHED("log_softmax_kernel");
-    return 0;
-}
-int log_softmax_rows_backward(const float *y, const float *dy, float *dx, int rows, int n, const float *scale,
-                              hipStream_t stream) {
-    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, y, dy, dx, rows, n, scale);
-    GSCAN_LAUNCHED("log_softmax_bwd_kernel");
-    return 0;
-}
 
 // ------------------------------------------------------------------------------------------
 // Model.get_loss: target of position (b,t) is targets[b,t+1] (PAD for t = T-1); positions whose

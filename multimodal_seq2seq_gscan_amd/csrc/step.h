@@ -97,14 +97,10 @@ __device__ __forceinline__ void decoder_image_element(const DecoderImageArgs &a,
 #endif
 
 // elementwise.hip
-int world_im2col(const float *world, int B, int G, int C, int K3, float *xcol, hipStream_t stream);
 int embed_rows(const int64_t *tok, const float *table, int vocab, const float *mask, int rows, int D, float *out,
                int64_t ldo, hipStream_t stream);
 int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mask, int rows, int D, int vocab,
                int pad, float *dtable, hipStream_t stream);
-int relu_mask_backward(float *dfeat, const float *feat, const float *mask, int64_t n, hipStream_t stream);
-int vec_add(const float *a, const float *b, float *out, int n, hipStream_t stream);
-int colsum_add(const float *x, int64_t ld, int rows, int N, float *out1, float *out2, hipStream_t stream);
 struct PrologueArgs {
     const float *b_ih, *b_hh, *w_o2h, *w_ih_f, *w_ih_r, *enc_emb, *dec_emb, *mask_enc, *mask_dec;
     const int64_t *commands, *targets;
@@ -136,9 +132,6 @@ int dropout_masks(float *out, const size_t (&n)[3], const float (&p)[3], uint64_
                   const uint64_t *dev_stream_id, hipStream_t stream);
 
 // loss.hip
-int log_softmax_rows(const float *x, float *y, float *y2, int rows, int n, hipStream_t stream);
-int log_softmax_rows_backward(const float *y, const float *dy, float *dx, int rows, int n, const float *scale,
-                              hipStream_t stream);
 int step_losses(const float *logp, const int64_t *targets, const float *aux, const int64_t *pos, int B, int T, int V,
                 int M, int pad, float *stats, float *dlogp, float *daux, hipStream_t stream);
 int loss_seeds(const float *stats, float w, int auxiliary, float *seeds, hipStream_t stream);
@@ -236,7 +229,7 @@ int probe_read(const char *name, double *total_ms, double *flops, int64_t *launc
 // step.hip
 struct WorkspaceSlot { const char *name; int64_t offset, count; };
 struct Workspace {
-    int64_t xcol, feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
+    int64_t feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, row_stats, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
         wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, wt, dwt, bias_rep, wcat5;

@@ -18,7 +18,6 @@ namespace gscan {
 int workspace_layout(const gscan_dims &d, Workspace *ws) {
     const int64_t B = d.B, L = d.L, T = d.T, M = (int64_t)d.G * d.G, Co = d.Co, F = 3 * Co, E = d.E, He = d.He,
                   H = d.H, V = d.V, D = d.bidirectional ? 2 : 1;
-    const int64_t Ktot = (int64_t)d.C * (1 + 25 + (int64_t)d.K3 * d.K3);
     int64_t p = 0;
     int n = 0;
     auto take = [&](const char *name, int64_t count) {
@@ -30,7 +29,6 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
         return ws->slot[n - 1].offset;
     };
 #define SLOT(field, count) ws->field = take(#field, (count))
-    SLOT(xcol, 64);                                  // (im2col buffer of the first design; unused)
     SLOT(wt, M * d.C * M * F);
     SLOT(dwt, M * d.C * M * F);
     SLOT(bias_rep, M * F);

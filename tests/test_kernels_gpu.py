@@ -69,28 +69,43 @@ def test_gemm_epilogues_and_split_k(lib):
     assert got[:, :5].abs().max().item() == 0 and got[:, 5 + N:].abs().max().item() == 0
 
 
-def test_world_im2col_and_conv(lib):
-    """im2col + GEMM equals the reference's conv2d on the transposed image (cnn_model.py:28-34)."""
+def test_world_encoder_forward_and_weight_gradients(lib):
+    """The Toeplitz product equals the reference's three conv2d on the transposed image + ReLU + dropout mask
+    (cnn_model.py:28-35), and its gradient product folded back equals autograd's kernel / bias gradients."""
+    import ctypes as C
     import gpu_ops
     from multimodal_seq2seq_gscan_amd import _lib
     g = torch.Generator().manual_seed(3)
-    B, G, Cc, K3, Co = 3, 6, 16, 7, 50
+    B, G, Cc, K3, Co = 5, 6, 16, 7, 50
+    M, F = G * G, 3 * Co
     world = (torch.rand(B, G, G, Cc, generator=g) > 0.8).float()
-    Ktot = Cc * (1 + 25 + K3 * K3)
-    xcol = torch.empty(B * G * G, Ktot, device="cuda")
-    world_d = dev(world)                       # keep device tensors referenced while kernels use their pointers
-    _lib.check(lib.gscan_world_im2col(world_d.data_ptr(), B, G, Cc, K3, xcol.data_ptr(), gpu_ops.stream()), "im2col")
-    off = 0
-    for k in (1, 5, K3):
-        W = torch.randn(Co, Cc, k, k, generator=g) * 0.1
-        bias = torch.randn(Co, generator=g) * 0.1
-        kk = Cc * k * k
-        out = torch.zeros(B * G * G, Co, device="cuda")
-        W_d, bias_d = dev(W), dev(bias)
-        gpu_ops.gemm((xcol, off, Ktot, 1), (W_d, 0, 1, kk), (out, 0, Co), B * G * G, Co, kk, bias=bias_d)
-        ref = torch.nn.functional.conv2d(world.transpose(1, 3), W, bias, padding=k // 2).transpose(1, 3)
-        assert (out.cpu().view(B, G, G, Co) - ref).abs().max().item() < 1e-4, f"kernel {k}"
-        off += kk
+    Ws = [(torch.randn(Co, Cc, k, k, generator=g) * 0.1).requires_grad_(True) for k in (1, 5, K3)]
+    bs = [(torch.randn(Co, generator=g) * 0.1).requires_grad_(True) for _ in range(3)]
+    mask = (torch.rand(B, M, F, generator=g) > 0.1).float() / 0.9
+    ref = torch.cat([torch.nn.functional.conv2d(world.transpose(1, 3), W, b, padding=W.shape[-1] // 2).transpose(1, 3)
+                     for W, b in zip(Ws, bs)], dim=3).reshape(B, M, F)
+    feat_ref = torch.relu(ref) * mask
+    d_out = torch.randn(B, M, F, generator=g)
+    feat_ref.backward(d_out)
+    world_d, mask_d = dev(world), dev(mask)
+    W_d, b_d = [dev(W.detach()) for W in Ws], [dev(b.detach()) for b in bs]
+    ptrs = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    scratch = torch.empty((M * Cc + 1) * M * F, device="cuda")
+    feat = torch.empty(B, M, F, device="cuda")
+    _lib.check(lib.gscan_world_encoder_forward(world_d.data_ptr(), ptrs(W_d), ptrs(b_d), B, G, Cc, Co, K3,
+                                               mask_d.data_ptr(), scratch.data_ptr(), feat.data_ptr(),
+                                               gpu_ops.stream()), "world_encoder_forward")
+    assert (feat.cpu() - feat_ref.detach()).abs().max().item() < 1e-4
+    # d(pre-activation) = d_out * mask where ReLU was active (what the step's key-layer kernel hands over)
+    dpre = dev(d_out * mask * (ref > 0).float())
+    gW = [torch.zeros_like(W) for W in W_d]
+    gb = [torch.zeros_like(b) for b in b_d]
+    dwt = torch.empty(M * Cc * M * F, device="cuda")
+    _lib.check(lib.gscan_world_encoder_backward(world_d.data_ptr(), dpre.data_ptr(), B, G, Cc, Co, K3, dwt.data_ptr(),
+                                                ptrs(gW), ptrs(gb), gpu_ops.stream()), "world_encoder_backward")
+    for W, b, gw_, gb_ in zip(Ws, bs, gW, gb):
+        assert torch.allclose(gw_.cpu(), W.grad, atol=1e-4, rtol=1e-4), W.shape
+        assert torch.allclose(gb_.cpu(), b.grad, atol=1e-4, rtol=1e-4)
 
 
 def _lstm_reference(x, lengths, lstm):
