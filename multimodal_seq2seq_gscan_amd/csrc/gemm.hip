@@ -3,9 +3,9 @@
 //
 //   C[M,N] = act(alpha * A.B + beta * C + bias[n]) * mask[m,n]           (+ optional  asum[m] += sum_k A(m,k))
 //
-// Every dense contraction of the training step that is not inside a time loop goes through
-// this kernel: the im2col convolutions, key/value projections, LSTM input projections, the
-// output head, and all weight-gradient products (K = B*T rows, split over workgroups).
+// Every dense contraction of the training step that is not inside a per-row kernel goes through
+// this kernel: the Toeplitz-expanded convolutions, key/value projections, LSTM input projections,
+// and all weight-gradient products (K = B*T rows, split over workgroups).
 // Operands are addressed with (row, col) strides so the reference's [out,in] parameter
 // layout and its transposes are consumed in place; nothing is re-packed in HBM.
 //
@@ -13,7 +13,7 @@
 // K/BK dependent "load tile -> MFMA" rounds, not FLOPs.  Hence: BK = 32 (few rounds), the next
 // tile's global loads are issued into registers BEFORE the current tile's MFMAs and written to
 // the other LDS buffer after them (one barrier per round), and the long-K weight-gradient
-// products are split over blockIdx.z with float-atomic accumulation into the zeroed gradient.
+// products are split into K slices with float-atomic accumulation into the zeroed gradient.
 // Tile geometry and LDS images are described next to the kernel below.
 #include "step.h"
 
@@ -42,8 +42,8 @@ template <int TMW> struct TileM {
 // products, each of which alone cannot fill 256 CUs and costs a launch; workgroup -> (problem, tile, k-slice)
 // is a scan over at most kMaxGroup prefix sums held in kernel arguments.
 //
-// Tile geometry.  Workgroup 64 x 64 x 32, 4 waves as 2 x 2, each wave 32 x 32 = 2 x 2 MFMA tiles of 16 x 16
-// (many small tiles: these products are latency-bound, occupancy hides more than a bigger tile saves).
+// Tile geometry.  Workgroup (32 TMW) x 64 x 32, 4 waves as 2 x 2, each wave (16 TMW) x 32 = TMW x 2 MFMA tiles
+// of 16 x 16 (many small tiles: these products are latency-bound, occupancy hides more than a bigger tile saves).
 // Within a 32-deep tile the MFMA k index of lane group g (= lane >> 4) at step s (0..7) is k = 8 g + s, so a lane
 // of a k-contiguous operand reads its 8 values with two ds_read_b128.  A row-contiguous operand interleaves its
 // MFMA tiles instead (row = 2 i + tile for A, col = 2 i + tile for B), so one ds_read_b64 per k feeds both
