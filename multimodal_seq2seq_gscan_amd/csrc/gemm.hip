@@ -22,20 +22,18 @@ namespace gscan {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int TNW = 2;           // MFMA tiles per wave along N; along M it is the kernel's template parameter TMW
-#ifndef GSCAN_GEMM_BK
-#define GSCAN_GEMM_BK 32
-#endif
-constexpr int BN = 2 * 16 * TNW, BK = GSCAN_GEMM_BK;
-constexpr int LDK = BK + 4;      // k-contiguous image [row][LDK]: 16-byte rows, b128 fragment reads 2-way at worst
+constexpr int BN = 2 * 16 * TNW;
+// Depth of a K round (template parameter BK of the kernel): 32; 64 is compiled for experiments (see launch()).
+template <int BK> struct TileK { static constexpr int LDK = BK + 4; };      // k-contiguous image [row][LDK]: 16-byte rows, b128 fragment reads 2-way at worst
 constexpr int LDR_B = BN + 4;    // row-contiguous image [k][LDR]: b64 reads of 2 adjacent columns, conflict-free
-constexpr int B_FLOATS = (BN * LDK > BK * LDR_B) ? BN * LDK : BK * LDR_B;
+template <int BK> constexpr int b_floats() { return (BN * (BK + 4) > BK * LDR_B) ? BN * (BK + 4) : BK * LDR_B; }
 // Workgroup tile = (32 TMW) x 64 x 32.  TMW = 2 (64 rows) is the throughput shape; TMW = 1 (32 rows) doubles the
 // number of workgroups of a launch whose 64-row tiling would leave CUs with one or two resident workgroups and
 // nothing to hide a K round's load latency behind (most launches of the training step).
-template <int TMW> struct TileM {
+template <int TMW, int BK = 32> struct TileM {
     static constexpr int BM = 2 * 16 * TMW;
     static constexpr int LDR_A = BM + 4;   // row-contiguous image [k][LDR]
-    static constexpr int A_FLOATS = (BM * LDK > BK * LDR_A) ? BM * LDK : BK * LDR_A;
+    static constexpr int A_FLOATS = (BM * (BK + 4) > BK * LDR_A) ? BM * (BK + 4) : BK * LDR_A;
 };
 
 // Independent products are launched together as one grid ("grouped GEMM"): the step issues ~45 small
@@ -50,15 +48,16 @@ template <int TMW> struct TileM {
 // of a wave's tiles.  Either way a wave issues ~1 LDS read per 4-8 MFMAs instead of 1 per MFMA.
 // Global loads are 16-byte whenever the operand's pointer, strides and extent allow, else 8- or 4-byte.
 
-static_assert(BK == 32, "the panel iterator and the fragment maps below are written for 32-deep K rounds");
 
 // How one operand's [ROWS x 32] panels move global -> registers -> LDS.  A thread's loads of one K round form an
 // arithmetic progression (same k / stepping rows for a k-contiguous operand, same rows / stepping k for a
 // row-contiguous one), so everything about them is computed ONCE: the K loop pays one compare and one add per
 // load, no multiplies, no 64-bit arithmetic (measured before this: issuing a round's loads cost as many cycles
 // as its MFMAs).  vw = floats per load (4 / 2 / 1: what the operand's alignment allows).
-template <int ROWS>
+template <int ROWS, int BK>
 struct PanelIter {
+    static_assert(BK % 32 == 0, "a K round is one or more 32-deep halves (fragment maps of the kernel)");
+    static constexpr int LDK = BK + 4;
     static constexpr int N = ROWS * BK / 256;     // floats per thread per K round
     const float *src;
     uint32_t off;       // element offset of load 0 of the current round
@@ -160,9 +159,10 @@ struct PanelIter {
     }
 };
 
-template <int TMW>
+template <int TMW, int BK>
 __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
-    constexpr int BM = TileM<TMW>::BM, LDR_A = TileM<TMW>::LDR_A, A_FLOATS = TileM<TMW>::A_FLOATS;
+    constexpr int BM = TileM<TMW, BK>::BM, LDR_A = TileM<TMW, BK>::LDR_A, A_FLOATS = TileM<TMW, BK>::A_FLOATS;
+    constexpr int LDK = BK + 4, B_FLOATS = b_floats<BK>();
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < kMaxGroup; ++i)
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
     const int kend = min(g.K, kbeg + g.k_chunk);
     const bool do_asum = g.asum1 != nullptr && bx == 0;
 
-    PanelIter<BM> pa;
-    PanelIter<BN> pb;
+    PanelIter<BM, BK> pa;
+    PanelIter<BN, BK> pb;
     pa.init(g.a, g.sam, g.sak, g.M, m0, 1 << (g.flags & 3), kbeg, kend, tid);
     pb.init(g.b, g.sbn, g.sbk, g.N, n0, 1 << ((g.flags >> 2) & 3), kbeg, kend, tid);
 
@@ -221,7 +221,9 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
             pa.load(ra, k0 + BK);
             pb.load(rb, k0 + BK);
         }
-        const float *la = lds_a[buf] + fa, *lb = lds_b[buf] + fb;
+#pragma unroll
+        for (int kh = 0; kh < BK; kh += 32) {
+        const float *la = lds_a[buf] + fa + (pa.kc ? kh : kh * LDR_A), *lb = lds_b[buf] + fb + (pb.kc ? kh : kh * LDR_B);
         float af[TMW][8], bf[TNW][8];        // [tile][step]
         if (pa.kc) {                         // natural tiles: row = 16 t + fr
 #pragma unroll
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
                 for (int j = 0; j < TNW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         if (do_asum && tid < BM) {           // column sums of A (bias gradients): sum over these 32 k
-            const float *sa = lds_a[buf];
+            const float *sa = lds_a[buf] + (pa.kc ? kh : kh * LDR_A);
             float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
             if (pa.kc) {
 #pragma unroll
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
                 }
             }
             asum += (t0 + t1) + (t2 + t3);
+        }
         }
         if (more) {
             pa.template store<LDR_A>(lds_a[buf ^ 1], ra, tid);
@@ -356,7 +359,7 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
     }
     if (split_k < 1) split_k = 1;
     int chunk = cdiv(K, split_k);
-    chunk = cdiv(chunk, BK) * BK;
+    chunk = cdiv(chunk, 64) * 64;          // K slices start at multiples of the deepest K round
     split_k = cdiv(K, chunk);
     if (split_k > 1 && !(beta == 1.f && act == 0 && !bias && !mask)) {
         bad_ = true;
@@ -412,8 +415,15 @@ int GemmBatch::launch(hipStream_t stream) {
         total += grp_.xcd_per[i] ? 8 * grp_.xcd_per[i] : n;
     }
     ProbeScope probe(P_GEMM, stream, flops_);
-    if (tmw == 1) hipLaunchKernelGGL(gemm_group_kernel<1>, dim3(total), dim3(256), 0, stream, grp_);
-    else hipLaunchKernelGGL(gemm_group_kernel<2>, dim3(total), dim3(256), 0, stream, grp_);
+    // 64-deep K rounds (GSCAN_GEMM_BK=64, experiments): isolated long-K split products gain 10-20 % (a round's
+    // load latency is paid half as often), but the overlapped training step loses 3 % to the larger workgroups
+    // (52 KB of LDS, +40 VGPRs), so 32 is what every launch uses.
+    static const int forced_bk = [] { const char *e = getenv("GSCAN_GEMM_BK"); return e ? atoi(e) : 0; }();
+    const bool deep = forced_bk == 64;
+    if (tmw == 1 && deep) hipLaunchKernelGGL((gemm_group_kernel<1, 64>), dim3(total), dim3(256), 0, stream, grp_);
+    else if (tmw == 1) hipLaunchKernelGGL((gemm_group_kernel<1, 32>), dim3(total), dim3(256), 0, stream, grp_);
+    else if (deep) hipLaunchKernelGGL((gemm_group_kernel<2, 64>), dim3(total), dim3(256), 0, stream, grp_);
+    else hipLaunchKernelGGL((gemm_group_kernel<2, 32>), dim3(total), dim3(256), 0, stream, grp_);
     GSCAN_LAUNCHED("gemm_group_kernel");
     return 0;
 }
