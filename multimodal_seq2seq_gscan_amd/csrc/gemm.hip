@@ -54,7 +54,11 @@ template <int TMW, int BK = 32> struct TileM {
 // row-contiguous one), so everything about them is computed ONCE: the K loop pays one compare and one add per
 // load, no multiplies, no 64-bit arithmetic (measured before this: issuing a round's loads cost as many cycles
 // as its MFMAs).  vw = floats per load (4 / 2 / 1: what the operand's alignment allows).
-template <int ROWS, int BK>
+// KCT / VWT: layout known at compile time (1 / 0 = k-contiguous or not, 4 / 2 / 1 floats per load) or -1 / 0 = read
+// from the problem at run time.  With compile-time layouts the K loop is straight-line code and the compiler's
+// s_waitcnt insertion counts outstanding loads exactly; with run-time branches around the loads it falls back to
+// vmcnt(0) at the joins, which serialises a round's A and B loads.
+template <int ROWS, int BK, int KCT = -1, int VWT = 0>
 struct PanelIter {
     static_assert(BK % 32 == 0, "a K round is one or more 32-deep halves (fragment maps of the kernel)");
     static constexpr int LDK = BK + 4;
@@ -66,14 +70,17 @@ struct PanelIter {
     int klim;           // k-contiguous: every load reads while k0 < klim; row-contiguous: load i while k0 + kp*i < klim
     int nlive;          // k-contiguous: loads i < nlive touch rows inside the matrix
     int kp;             // row-contiguous: k rows between a thread's loads
-    int vw;
-    bool kc;
+    int vw_rt;
+    bool kc_rt;
+    __device__ __forceinline__ bool is_kc() const { return KCT >= 0 ? (KCT != 0) : kc_rt; }
+    __device__ __forceinline__ int width() const { return VWT > 0 ? VWT : vw_rt; }
 
     __device__ __forceinline__ void init(const float *base, int64_t s_row, int64_t s_k, int nrows, int row0, int vw_,
                                          int kbeg, int kend, int tid) {
-        src = base; vw = vw_; kc = (s_k == 1);
+        src = base; vw_rt = vw_; kc_rt = (s_k == 1);
+        const int vw = width();
         const uint32_t sr = (uint32_t)s_row, sk = (uint32_t)s_k;
-        if (kc) {
+        if (is_kc()) {
             const int ch = BK / vw, rp = 256 / ch;                 // chunks per row, rows per pass
             const int r = row0 + tid / ch, kk = vw * (tid % ch);
             off = (uint32_t)r * sr + (uint32_t)(kbeg + kk);
@@ -94,51 +101,63 @@ struct PanelIter {
         }
     }
 
+    // Loads are UNCONDITIONAL (a dead load reads element 0 of the operand instead) and their registers are not
+    // written before them; dead values are zeroed when they are consumed (store()).  The obvious form — zero the
+    // registers, then load under a lane mask — makes the compiler put s_waitcnt vmcnt(0) in front of every load
+    // (write-after-write on the registers of the previous round's load, counted conservatively across the
+    // branches), which serialised the A and B panel loads of a round and exposed a full load latency per round.
     template <int VW>
-    __device__ __forceinline__ void load_vw(float (&v)[N], int k0) const {
+    __device__ __forceinline__ uint32_t load_vw(float (&v)[N], int k0) const {
         constexpr int NL = N / VW;
+        uint32_t mask = 0;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const bool live = kc ? (i < nlive && k0 < klim) : (k0 + kp * i < klim);
-            const float *ptr = src + (off + (uint32_t)i * istep);
+            const bool live = is_kc() ? (i < nlive && k0 < klim) : (k0 + kp * i < klim);
+            mask |= (live ? 1u : 0u) << i;
+            const float *ptr = src + (live ? off + (uint32_t)i * istep : 0u);
             if constexpr (VW == 4) {
-                float4 x = {0.f, 0.f, 0.f, 0.f};
-                if (live) x = *reinterpret_cast<const float4 *>(ptr);
+                const float4 x = *reinterpret_cast<const float4 *>(ptr);
                 v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
             } else if constexpr (VW == 2) {
-                float2 x = {0.f, 0.f};
-                if (live) x = *reinterpret_cast<const float2 *>(ptr);
+                const float2 x = *reinterpret_cast<const float2 *>(ptr);
                 v[2 * i] = x.x; v[2 * i + 1] = x.y;
             } else {
-                v[i] = live ? *ptr : 0.f;
+                v[i] = *ptr;
             }
         }
+        return mask;
     }
-    // loads of the round starting at k0, then step to the next round
-    __device__ __forceinline__ void load(float (&v)[N], int k0) {
-        if (vw == 4) load_vw<4>(v, k0);
-        else if (vw == 2) load_vw<2>(v, k0);
-        else load_vw<1>(v, k0);
+    // loads of the round starting at k0 (returns the mask of live loads), then step to the next round
+    __device__ __forceinline__ uint32_t load(float (&v)[N], int k0) {
+        uint32_t mask;
+        const int vw = width();
+        if (vw == 4) mask = load_vw<4>(v, k0);
+        else if (vw == 2) mask = load_vw<2>(v, k0);
+        else mask = load_vw<1>(v, k0);
         off += kinc;
+        return mask;
     }
 
     // registers -> LDS image: k-contiguous [row][LDK], row-contiguous [k][LDR]
     template <int LDR>
-    __device__ __forceinline__ void store(float *lds, const float (&v)[N], int tid) const {
-        if (kc) {
+    __device__ __forceinline__ void store(float *lds, const float (&v)[N], uint32_t mask, int tid) const {
+        auto val = [&](int load, int e) { return ((mask >> load) & 1u) ? v[e] : 0.f; };
+        const int vw = width();
+        if (is_kc()) {
             const int ch = BK / vw, rp = 256 / ch;
             float *dst = lds + (tid / ch) * LDK + vw * (tid % ch);
             if (vw == 4) {
 #pragma unroll
                 for (int i = 0; i < N / 4; ++i)
-                    *reinterpret_cast<float4 *>(dst + i * rp * LDK) = float4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+                    *reinterpret_cast<float4 *>(dst + i * rp * LDK) =
+                        float4{val(i, 4 * i), val(i, 4 * i + 1), val(i, 4 * i + 2), val(i, 4 * i + 3)};
             } else if (vw == 2) {
 #pragma unroll
                 for (int i = 0; i < N / 2; ++i)
-                    *reinterpret_cast<float2 *>(dst + i * rp * LDK) = float2{v[2 * i], v[2 * i + 1]};
+                    *reinterpret_cast<float2 *>(dst + i * rp * LDK) = float2{val(i, 2 * i), val(i, 2 * i + 1)};
             } else {
 #pragma unroll
-                for (int i = 0; i < N; ++i) dst[i * rp * LDK] = v[i];
+                for (int i = 0; i < N; ++i) dst[i * rp * LDK] = val(i, i);
             }
         } else {
             const int rq = ROWS / vw;
@@ -146,41 +165,27 @@ struct PanelIter {
             if (vw == 4) {
 #pragma unroll
                 for (int i = 0; i < N / 4; ++i)
-                    *reinterpret_cast<float4 *>(dst + i * kp * LDR) = float4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+                    *reinterpret_cast<float4 *>(dst + i * kp * LDR) =
+                        float4{val(i, 4 * i), val(i, 4 * i + 1), val(i, 4 * i + 2), val(i, 4 * i + 3)};
             } else if (vw == 2) {
 #pragma unroll
                 for (int i = 0; i < N / 2; ++i)
-                    *reinterpret_cast<float2 *>(dst + i * kp * LDR) = float2{v[2 * i], v[2 * i + 1]};
+                    *reinterpret_cast<float2 *>(dst + i * kp * LDR) = float2{val(i, 2 * i), val(i, 2 * i + 1)};
             } else {
 #pragma unroll
-                for (int i = 0; i < N; ++i) dst[i * kp * LDR] = v[i];
+                for (int i = 0; i < N; ++i) dst[i * kp * LDR] = val(i, i);
             }
         }
     }
 };
 
-template <int TMW, int BK>
-__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
-    constexpr int BM = TileM<TMW, BK>::BM, LDR_A = TileM<TMW, BK>::LDR_A, A_FLOATS = TileM<TMW, BK>::A_FLOATS;
-    constexpr int LDK = BK + 4, B_FLOATS = b_floats<BK>();
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < kMaxGroup; ++i)
-        if (i < grp.count && (int)blockIdx.x >= grp.p[i].tile_begin) pi = i;
-    const GemmProblem &g = grp.p[pi];
-    // XCD-aware order (GSCAN_GEMM_XCD=0 disables): workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.
-    // Workgroup l of a problem takes tile (l % 8) * per + l / 8, so an XCD works on one contiguous eighth of the
-    // tile space and its L2 sees each operand panel of that eighth once.
-    int local = blockIdx.x - g.tile_begin;
-    if (grp.xcd_per[pi] > 0) {
-        const int per = grp.xcd_per[pi], x = local & 7, j = local >> 3;
-        local = x * per + j;
-        if (j >= per || local >= g.tiles_mn * g.nsplit) return;
-    }
+template <int TMW, int BK, int KCA, int KCB, int VWT>
+__device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float (&lds_a)[2][TileM<TMW, BK>::A_FLOATS],
+                                          float (&lds_b)[2][b_floats<BK>()]) {
+    constexpr int BM = TileM<TMW, BK>::BM, LDR_A = TileM<TMW, BK>::LDR_A;
+    constexpr int LDK = BK + 4;
     const int bz = local / g.tiles_mn, rem = local % g.tiles_mn;
     const int by = rem / g.tiles_n, bx = rem % g.tiles_n;
-    __shared__ __attribute__((aligned(16))) float lds_a[2][A_FLOATS];
-    __shared__ __attribute__((aligned(16))) float lds_b[2][B_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -189,8 +194,8 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
     const int kend = min(g.K, kbeg + g.k_chunk);
     const bool do_asum = g.asum1 != nullptr && bx == 0;
 
-    PanelIter<BM, BK> pa;
-    PanelIter<BN, BK> pb;
+    PanelIter<BM, BK, KCA, VWT> pa;
+    PanelIter<BN, BK, KCB, VWT> pb;
     pa.init(g.a, g.sam, g.sak, g.M, m0, 1 << (g.flags & 3), kbeg, kend, tid);
     pb.init(g.b, g.sbn, g.sbk, g.N, n0, 1 << ((g.flags >> 2) & 3), kbeg, kend, tid);
 
@@ -204,28 +209,28 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
     const int fr = lane & 15;   // MFMA row (A) / column (B) index
     const int fg = lane >> 4;   // lane group: k = 8*fg + step
     // this lane's fragment bases inside an LDS image (constant over the K loop)
-    const int fa = pa.kc ? (wm * 16 * TMW + fr) * LDK + 8 * fg : (8 * fg) * LDR_A + wm * 16 * TMW + TMW * fr;
-    const int fb = pb.kc ? (wn * 16 * TNW + fr) * LDK + 8 * fg : (8 * fg) * LDR_B + wn * 16 * TNW + TNW * fr;
+    const int fa = pa.is_kc() ? (wm * 16 * TMW + fr) * LDK + 8 * fg : (8 * fg) * LDR_A + wm * 16 * TMW + TMW * fr;
+    const int fb = pb.is_kc() ? (wn * 16 * TNW + fr) * LDK + 8 * fg : (8 * fg) * LDR_B + wn * 16 * TNW + TNW * fr;
 
     float ra[BM * BK / 256], rb[BN * BK / 256];
-    pa.load(ra, kbeg);
-    pb.load(rb, kbeg);
-    pa.template store<LDR_A>(lds_a[0], ra, tid);
-    pb.template store<LDR_B>(lds_b[0], rb, tid);
+    uint32_t ma = pa.load(ra, kbeg);
+    uint32_t mb = pb.load(rb, kbeg);
+    pa.template store<LDR_A>(lds_a[0], ra, ma, tid);
+    pb.template store<LDR_B>(lds_b[0], rb, mb, tid);
     __syncthreads();
 
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) {   // next round's loads fly while this round's MFMAs run
-            pa.load(ra, k0 + BK);
-            pb.load(rb, k0 + BK);
+            ma = pa.load(ra, k0 + BK);
+            mb = pb.load(rb, k0 + BK);
         }
 #pragma unroll
         for (int kh = 0; kh < BK; kh += 32) {
-        const float *la = lds_a[buf] + fa + (pa.kc ? kh : kh * LDR_A), *lb = lds_b[buf] + fb + (pb.kc ? kh : kh * LDR_B);
+        const float *la = lds_a[buf] + fa + (pa.is_kc() ? kh : kh * LDR_A), *lb = lds_b[buf] + fb + (pb.is_kc() ? kh : kh * LDR_B);
         float af[TMW][8], bf[TNW][8];        // [tile][step]
-        if (pa.kc) {                         // natural tiles: row = 16 t + fr
+        if (pa.is_kc()) {                         // natural tiles: row = 16 t + fr
 #pragma unroll
             for (int t = 0; t < TMW; ++t) {
                 const float4 *q = reinterpret_cast<const float4 *>(la + 16 * t * LDK);
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
                 }
             }
         }
-        if (pb.kc) {                         // natural tiles: col = 16 t + fr
+        if (pb.is_kc()) {                         // natural tiles: col = 16 t + fr
 #pragma unroll
             for (int t = 0; t < TNW; ++t) {
                 const float4 *q = reinterpret_cast<const float4 *>(lb + 16 * t * LDK);
@@ -267,9 +272,9 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
                 for (int j = 0; j < TNW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         if (do_asum && tid < BM) {           // column sums of A (bias gradients): sum over these 32 k
-            const float *sa = lds_a[buf] + (pa.kc ? kh : kh * LDR_A);
+            const float *sa = lds_a[buf] + (pa.is_kc() ? kh : kh * LDR_A);
             float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-            if (pa.kc) {
+            if (pa.is_kc()) {
 #pragma unroll
                 for (int kk = 0; kk < 32; kk += 4) {
                     const float4 x = *reinterpret_cast<const float4 *>(sa + tid * LDK + kk);
@@ -286,8 +291,8 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
         }
         }
         if (more) {
-            pa.template store<LDR_A>(lds_a[buf ^ 1], ra, tid);
-            pb.template store<LDR_B>(lds_b[buf ^ 1], rb, tid);
+            pa.template store<LDR_A>(lds_a[buf ^ 1], ra, ma, tid);
+            pb.template store<LDR_B>(lds_b[buf ^ 1], rb, mb, tid);
         }
         __syncthreads();
         buf ^= 1;
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
     bool cok[TNW];
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
-        const int col = n0 + wn * 16 * TNW + (pb.kc ? 16 * j + fr : TNW * fr + j);
+        const int col = n0 + wn * 16 * TNW + (pb.is_kc() ? 16 * j + fr : TNW * fr + j);
         coff[j] = col;
         cok[j] = col < g.N;
     }
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ri = fg * 4 + r;                                        // MFMA row index 0..15
-            const int row = m0 + wm * 16 * TMW + (pa.kc ? 16 * i + ri : TMW * ri + i);
+            const int row = m0 + wm * 16 * TMW + (pa.is_kc() ? 16 * i + ri : TMW * ri + i);
             if (row >= g.M) continue;
             const uint32_t roff = (uint32_t)row * ldc;
             if (g.atomic) {
@@ -344,6 +349,39 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
             }
         }
 }
+
+template <int TMW, int BK>
+__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
+    constexpr int A_FLOATS = TileM<TMW, BK>::A_FLOATS, B_FLOATS = b_floats<BK>();
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxGroup; ++i)
+        if (i < grp.count && (int)blockIdx.x >= grp.p[i].tile_begin) pi = i;
+    const GemmProblem &g = grp.p[pi];
+    // XCD-aware order (GSCAN_GEMM_XCD=0 disables): workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.
+    // Workgroup l of a problem takes tile (l % 8) * per + l / 8, so an XCD works on one contiguous eighth of the
+    // tile space and its L2 sees each operand panel of that eighth once.
+    int local = blockIdx.x - g.tile_begin;
+    if (grp.xcd_per[pi] > 0) {
+        const int per = grp.xcd_per[pi], x = local & 7, j = local >> 3;
+        local = x * per + j;
+        if (j >= per || local >= g.tiles_mn * g.nsplit) return;
+    }
+    __shared__ __attribute__((aligned(16))) float lds_a[2][A_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds_b[2][B_FLOATS];
+    // one workgroup-uniform dispatch to a copy of the tile code specialised for the problem's operand layouts
+    // (16-byte loads on both operands: every large product of the step); anything else takes the generic copy
+    const bool kca = g.sak == 1, kcb = g.sbk == 1;
+    if ((g.flags & 15) == (2 | (2 << 2))) {
+        if (kca && kcb) gemm_tile<TMW, BK, 1, 1, 4>(g, local, lds_a, lds_b);
+        else if (kca) gemm_tile<TMW, BK, 1, 0, 4>(g, local, lds_a, lds_b);
+        else if (!kcb) gemm_tile<TMW, BK, 0, 0, 4>(g, local, lds_a, lds_b);
+        else gemm_tile<TMW, BK, 0, 1, 4>(g, local, lds_a, lds_b);
+    } else {
+        gemm_tile<TMW, BK, -1, -1, 0>(g, local, lds_a, lds_b);
+    }
+}
+
 
 
 void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sak, const float *b, int64_t sbk,
