@@ -179,7 +179,7 @@ struct PanelIter {
     }
 };
 
-template <int TMW, int BK, int KCA, int KCB, int VWT>
+template <int TMW, int BK, int KCA, int KCB, int VWA, int VWB>
 __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float (&lds_a)[2][TileM<TMW, BK>::A_FLOATS],
                                           float (&lds_b)[2][b_floats<BK>()]) {
     constexpr int BM = TileM<TMW, BK>::BM, LDR_A = TileM<TMW, BK>::LDR_A;
@@ -194,8 +194,8 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
     const int kend = min(g.K, kbeg + g.k_chunk);
     const bool do_asum = g.asum1 != nullptr && bx == 0;
 
-    PanelIter<BM, BK, KCA, VWT> pa;
-    PanelIter<BN, BK, KCB, VWT> pb;
+    PanelIter<BM, BK, KCA, VWA> pa;
+    PanelIter<BN, BK, KCB, VWB> pb;
     pa.init(g.a, g.sam, g.sak, g.M, m0, 1 << (g.flags & 3), kbeg, kend, tid);
     pb.init(g.b, g.sbn, g.sbk, g.N, n0, 1 << ((g.flags >> 2) & 3), kbeg, kend, tid);
 
@@ -372,13 +372,18 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
     // one workgroup-uniform dispatch to a copy of the tile code specialised for the problem's operand layouts
     // (16-byte loads on both operands: every large product of the step); anything else takes the generic copy
     const bool kca = g.sak == 1, kcb = g.sbk == 1;
-    if ((g.flags & 15) == (2 | (2 << 2))) {
-        if (kca && kcb) gemm_tile<TMW, BK, 1, 1, 4>(g, local, lds_a, lds_b);
-        else if (kca) gemm_tile<TMW, BK, 1, 0, 4>(g, local, lds_a, lds_b);
-        else if (!kcb) gemm_tile<TMW, BK, 0, 0, 4>(g, local, lds_a, lds_b);
-        else gemm_tile<TMW, BK, 0, 1, 4>(g, local, lds_a, lds_b);
+    const int wa = g.flags & 3, wb = (g.flags >> 2) & 3;             // log2 of the load widths
+    if (wa == 2 && wb == 2) {
+        if (kca && kcb) gemm_tile<TMW, BK, 1, 1, 4, 4>(g, local, lds_a, lds_b);
+        else if (kca) gemm_tile<TMW, BK, 1, 0, 4, 4>(g, local, lds_a, lds_b);
+        else if (!kcb) gemm_tile<TMW, BK, 0, 0, 4, 4>(g, local, lds_a, lds_b);
+        else gemm_tile<TMW, BK, 0, 1, 4, 4>(g, local, lds_a, lds_b);
+    } else if (wa == 1 && wb == 1 && kca && kcb) {                 // rows of 150 features: 8-byte loads
+        gemm_tile<TMW, BK, 1, 1, 2, 2>(g, local, lds_a, lds_b);
+    } else if (wa == 2 && wb == 1 && !kca && !kcb) {               // weight gradient against 150-wide rows
+        gemm_tile<TMW, BK, 0, 0, 4, 2>(g, local, lds_a, lds_b);
     } else {
-        gemm_tile<TMW, BK, -1, -1, 0>(g, local, lds_a, lds_b);
+        gemm_tile<TMW, BK, -1, -1, 0, 0>(g, local, lds_a, lds_b);
     }
 }
 
