@@ -9,7 +9,8 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgscan_hip.so")
+# GSCAN_HIP_LIB: development override, used by tools/variants.py to time experimental builds side by side
+LIB_PATH = os.environ.get("GSCAN_HIP_LIB") or os.path.join(HERE, "libgscan_hip.so")
 ABI_VERSION = 4
 
 _f32p = C.POINTER(C.c_float)

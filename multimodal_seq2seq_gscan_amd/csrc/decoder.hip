@@ -45,6 +45,14 @@ namespace gscan {
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// Returns x behind a compiler barrier.  Inside the time loops it keeps per-thread addresses that are cheap to
+// recompute from being hoisted out of the loop, where they would be spilled to scratch and reloaded (with a full
+// vmcnt drain) in every phase.
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // lane <-> lane^1 exchange on the DPP datapath (quad_perm [1,0,3,2]); both lanes of a pair must be active
 __device__ __forceinline__ float pair_sum(float v) { return v + dpp_move<0xb1, 0xf>(v); }
 
@@ -52,32 +60,36 @@ __device__ __forceinline__ float pair_sum(float v) { return v + dpp_move<0xb1, 0
 // (v_pk_fma_f32).  The vector is read in chunks of four float4; the next chunk's reads are issued before the
 // current chunk's FMAs, so the LDS latency is paid about once per dot instead of once per read.
 constexpr int kDotChunk = 4;
+#ifndef GSCAN_DEC_BWD_CHUNK
+#define GSCAN_DEC_BWD_CHUNK 4
+#endif
+constexpr int kBwdDotChunk = GSCAN_DEC_BWD_CHUNK;   // the backward dots are single-row: fewer reads in flight, fewer registers
 
-template <int K0>
-__device__ __forceinline__ void load_chunk(float4 (&x)[kDotChunk], const float4 *v4, int c) {
+template <int K0, int CH>
+__device__ __forceinline__ void load_chunk(float4 (&x)[CH], const float4 *v4, int c) {
 #pragma unroll
-    for (int j = 0; j < kDotChunk; ++j)
-        if (c * kDotChunk + j < K0 / 4) x[j] = v4[c * kDotChunk + j];
+    for (int j = 0; j < CH; ++j)
+        if (c * CH + j < K0 / 4) x[j] = v4[c * CH + j];
 }
 
 // NS dots that share the same vector: out[s] = sum_i w[s][i] * v[i]
-template <int NS, int K0>
+template <int NS, int K0, int CH = kDotChunk>
 __device__ __forceinline__ void shared_dots(const float (&w)[NS][K0], const float *v, float (&out)[NS]) {
-    constexpr int NQ = K0 / 4, NC = (NQ + kDotChunk - 1) / kDotChunk;
+    constexpr int NQ = K0 / 4, NC = (NQ + CH - 1) / CH;
     const float4 *v4 = reinterpret_cast<const float4 *>(v);
     f32x2 a01[NS], a23[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) { a01[s] = f32x2{0.f, 0.f}; a23[s] = f32x2{0.f, 0.f}; }
-    float4 xa[kDotChunk], xb[kDotChunk];
-    load_chunk<K0>(xa, v4, 0);
+    float4 xa[CH], xb[CH];
+    load_chunk<K0, CH>(xa, v4, 0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        float4 (&cur)[kDotChunk] = (c & 1) ? xb : xa;
-        float4 (&nxt)[kDotChunk] = (c & 1) ? xa : xb;
-        if (c + 1 < NC) load_chunk<K0>(nxt, v4, c + 1);
+        float4 (&cur)[CH] = (c & 1) ? xb : xa;
+        float4 (&nxt)[CH] = (c & 1) ? xa : xb;
+        if (c + 1 < NC) load_chunk<K0, CH>(nxt, v4, c + 1);
 #pragma unroll
-        for (int j = 0; j < kDotChunk; ++j) {
-            const int q = c * kDotChunk + j;
+        for (int j = 0; j < CH; ++j) {
+            const int q = c * CH + j;
             if (q < NQ) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -91,11 +103,11 @@ __device__ __forceinline__ void shared_dots(const float (&w)[NS][K0], const floa
     for (int s = 0; s < NS; ++s) out[s] = (a01[s].x + a01[s].y) + (a23[s].x + a23[s].y);
 }
 
-template <int K0>
+template <int K0, int CH = kDotChunk>
 __device__ __forceinline__ float half_dot(const float (&w)[K0], const float *v) {
     const float(&w1)[1][K0] = reinterpret_cast<const float(&)[1][K0]>(w);
     float out[1];
-    shared_dots<1, K0>(w1, v, out);
+    shared_dots<1, K0, CH>(w1, v, out);
     return out[0];
 }
 
@@ -227,12 +239,15 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     const DecoderLds o = decoder_lds(H, L, M, a.V, COND, false);
     float *Uv = smem + o.uv, *PKv = smem + o.pkv, *Ut = smem + o.ut, *PKt = smem + o.pkt, *U2t = smem + o.u2t;
     float *vec = smem + o.vec;
-    float *h_s = vec, *q2_s = vec + HP;                     // dot inputs, zero-padded to HP
-    float *qt_s = vec + 2 * HP, *qv_s = qt_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H;
+    float *h_s = vec;                                       // dot input, zero-padded to HP
+    float *qt_s = vec + HP, *qv_s = qt_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H;
     float *gsum_s = vv_s + H;                               // [4H] ge + gh + uc per gate row
     float *col_s = gsum_s + 4 * H;                          // [6H] textual column sums
-    float *part_s = col_s + 6 * H;                          // [4][kPartStride] visual partial column sums
-    float *sc_s = part_s + 4 * kPartStride, *al_s = sc_s + 64, *stamp_acc = sc_s + 192;
+    float *q2_s = col_s + 6 * H;                            // dot input, zero-padded to HP; above col_s so that
+                                                            // q2_s[r - 5H] is a positive offset from &col_s[r]
+    float *part_s = q2_s + HP;                              // [4][kPartStride] visual partial column sums
+    float *sc_s = part_s + 4 * kPartStride, *bq_s = sc_s + 64, *stamp_acc = sc_s + 192;
+    static_assert(H <= 128, "bq_s holds one bias per hidden unit in 128 floats");
     long long stamp_prev = a.stamps ? clock64() : 0;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     stage(Ut, a.u_t + (int64_t)b * L * 4 * H, L * 4 * H, tid, kDecThreads);
     stage(PKt, a.pk_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
     if (COND) stage(U2t, a.u2_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
-    if (tid < 2 * HP) vec[tid] = 0.f;                       // zero the padding of h_s / q2_s
+    if (tid < HP) { h_s[tid] = 0.f; q2_s[tid] = 0.f; }      // zero the padding of the dot inputs
     if (tid < 16) stamp_acc[tid] = 0.f;
     lds_barrier();
     float c = 0.f;
@@ -263,12 +278,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         vt_s[tid] = a.v_t[tid];
         vv_s[tid] = a.v_v[tid];
     }
-    float bq[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int r = s * kDecPairs + pair;
-        bq[s] = (COND && r >= 5 * H && r < 6 * H) ? a.b_q2k[r - 5 * H] : 0.f;
-    }
+    if (COND && tid < H) bq_s[tid] = a.b_q2k[tid];
     float att_acc = 0.f;                                    // wave 0, lane m
     lds_barrier();
 
@@ -279,7 +289,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {                      // embedding part of the gates: issued early, used in C2
             const int r = s * kDecPairs + pair;
-            ge[s] = (r < 4 * H) ? a.ge[bt * 4 * H + r] : 0.f;
+            // unconditional in the slots that hold gate rows: a guarded load makes the compiler drain vmcnt first
+            ge[s] = (s * kDecPairs < 4 * H) ? a.ge[bt * 4 * H + min(r, 4 * H - 1)] : 0.f;
         }
 
         // ---- A: everything that multiplies h_{t-1} -------------------------------------------
@@ -290,8 +301,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             const float acc = pair_sum(gh[s]);
             gh[s] = acc;                                    // gate rows and q2k rows keep it for phase C2
             if (r >= 4 * H && r < 6 * H && half == 0) {
-                if (r < 5 * H) { qt_s[r - 4 * H] = acc; a.qt[bt * H + r - 4 * H] = acc; }
-                else if (!COND) { qv_s[r - 5 * H] = acc; a.qv[bt * H + r - 5 * H] = acc; }
+                if (r < 5 * H) qt_s[r - 4 * H] = acc;           // saved to global in C2 (see there)
+                else if (!COND) qv_s[r - 5 * H] = acc;
             }
         }
         lds_barrier();
@@ -309,7 +320,6 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             const float mx = wave_max(x);
             const float e = (lane < len) ? __expf(x - mx) : 0.f;
             alpha = e * __builtin_amdgcn_rcpf(wave_sum(e));
-            if (wave == 0 && lane < L) a.alpha_c[bt * L + lane] = alpha;
         }
         // ---- C1: textual column sums sum_m alpha_m [U_t | PK_t | U2_t][m, :], one column quad per thread --
         if (wave < (NQT + 63) / 64) {
@@ -325,6 +335,9 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         lds_barrier();
         GSCAN_STAMP(3)
         // ---- C2: hand the sums to their owners: gate rows, textual context, conditional query ------
+        // This is the one place where a wave waits for a global load (ge).  vmcnt counts stores too and the wait
+        // is a full drain here, so every store of phases A-C1 is issued after it instead of before: a store then
+        // has most of a step to be acknowledged before the next drain.
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int r = s * kDecPairs + pair;
@@ -333,13 +346,19 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
                     gsum_s[r] = ge[s] + gh[s] + col_s[r];
                 } else if (r < 5 * H) {
                     a.s[bt * 4 * H + H + (r - 4 * H)] = col_s[r];
-                } else if (COND && r < 6 * H) {
-                    const float q = tanhf_(gh[s] + col_s[r] + bq[s]);   // seq2seq_model.py:394-396
-                    q2_s[r - 5 * H] = q;
-                    a.q2[bt * H + r - 5 * H] = q;
+                    a.qt[bt * H + r - 4 * H] = gh[s];
+                } else if (r < 6 * H) {
+                    if (COND) {
+                        const float q = tanhf_(gh[s] + col_s[r] + bq_s[r - 5 * H]);   // seq2seq_model.py:394-396
+                        q2_s[r - 5 * H] = q;
+                        a.q2[bt * H + r - 5 * H] = q;
+                    } else {
+                        a.qv[bt * H + r - 5 * H] = gh[s];
+                    }
                 }
             }
         }
+        if (wave == 0 && lane < L) a.alpha_c[bt * L + lane] = alpha;
         if (COND) {
             lds_barrier();
             GSCAN_STAMP(4)
@@ -403,7 +422,6 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             a.cells[bt * H + tid] = c;
             a.s[bt * 4 * H + 3 * H + tid] = h;
             if (t + 1 < T) a.hprev[(bt + 1) * H + tid] = h;
-            else if (a.h_last) a.h_last[(int64_t)b * H + tid] = h;
         } else if (tid >= 128 && tid < 128 + H) {
             const int r = 4 * H + (tid - 128);
             a.s[bt * 4 * H + 2 * H + (tid - 128)] = (part_s[r] + part_s[kPartStride + r]) +
@@ -412,6 +430,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         lds_barrier();
         GSCAN_STAMP(8)
     }
+    if (a.h_last && tid < H) a.h_last[(int64_t)b * H + tid] = h_s[tid];   // h_T (own LDS write, no barrier needed)
     if (wave == 0) {
         if (lane < M) a.att_sum[(int64_t)b * M + lane] = att_acc;
         if (a.aux_saved) {                                   // auxiliary head: log_softmax over the cells (model.py:205)
@@ -562,6 +581,7 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
                                             int pk_off, int u2_off, int n, const float *add, float *sc_s, int wave,
                                             int nwave, int lane) {
     constexpr int Q = H / 4, NQ = (WITH_U2 ? 6 : 5) * Q, NI = (NQ + 63) / 64;
+    lane = opaque(lane);
     float4 x[NI];
     int yoff[NI], ystr[NI];
 #pragma unroll
@@ -767,23 +787,28 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     // saved activations of step t are fetched one iteration ahead (their HBM/L2 latency hides behind step t+1)
     float pf[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float alpha_v_pf = 0.f, alpha_c_pf = 0.f, alpha_v_nx = 0.f, alpha_c_nx = 0.f;   // lane m of every wave
+    // every saved-activation access is base (SGPR pair) + one unsigned 32-bit offset, so that no per-thread
+    // 64-bit pointer has to stay live (or spill) across the loop
+    const unsigned utid = (unsigned)tid, uH = (unsigned)H, row0 = (unsigned)b * T;
     auto prefetch = [&](int t) {
-        const unsigned bt = (unsigned)b * T + t;
-        alpha_v_nx = (lane < M) ? a.alpha_s[bt * M + lane] : 0.f;
-        alpha_c_nx = (lane < L) ? a.alpha_c[bt * L + lane] : 0.f;
+        const unsigned bt = row0 + t;
+        const int ln = opaque(lane);
+        alpha_v_nx = a.alpha_s[bt * M + min(ln, M - 1)];    // lanes >= M / L hold a copy; masked where it is used
+        alpha_c_nx = a.alpha_c[bt * L + min(ln, L - 1)];
         if (tid < H) {
-            const float *g = a.gates + bt * 4 * H;
-            pf[0] = g[tid]; pf[1] = g[H + tid]; pf[2] = g[2 * H + tid]; pf[3] = g[3 * H + tid];
-            pf[4] = a.cells[bt * H + tid];
-            pf[5] = (t > 0) ? a.cells[(bt - 1) * H + tid] : a.hprev[(int64_t)b * T * H + tid];
-            pf[6] = a.ds[bt * 4 * H + 3 * H + tid];
+            const unsigned g = bt * 4 * uH + utid;
+            pf[0] = a.gates[g]; pf[1] = a.gates[g + uH]; pf[2] = a.gates[g + 2 * uH]; pf[3] = a.gates[g + 3 * uH];
+            pf[4] = a.cells[bt * uH + utid];
+            const float *prev = (t > 0) ? a.cells : a.hprev;          // c_{t-1}, or c_0 = h_0 (model.py:195)
+            pf[5] = prev[(t > 0 ? bt - 1 : row0) * uH + utid];
+            pf[6] = a.ds[g + 3 * uH];
         } else if (tid >= 128 && tid < 128 + H) {
-            const int kk = tid - 128;
-            pf[0] = a.ds[bt * 4 * H + H + kk];
-            pf[1] = a.ds[bt * 4 * H + 2 * H + kk];
-            pf[2] = a.qt[bt * H + kk];
-            pf[3] = a.qv[bt * H + kk];
-            if (COND) pf[4] = a.q2[bt * H + kk];
+            const unsigned kk = utid - 128;
+            pf[0] = a.ds[bt * 4 * uH + uH + kk];
+            pf[1] = a.ds[bt * 4 * uH + 2 * uH + kk];
+            pf[2] = a.qt[bt * uH + kk];
+            pf[3] = a.qv[bt * uH + kk];
+            if (COND) pf[4] = a.q2[bt * uH + kk];
         }
     };
     prefetch(T - 1);
@@ -810,8 +835,11 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             const float d_o = dh * tc * og * (1.f - og);
             dc = dct * fg;
             d_s[tid] = di; d_s[HP + tid] = df; d_s[2 * HP + tid] = dg; d_s[3 * HP + tid] = d_o;
-            float *dp = a.delta + bt * 5 * H;            // rows of [delta (4H) | dzq (H)]
-            dp[tid] = di; dp[H + tid] = df; dp[2 * H + tid] = dg; dp[3 * H + tid] = d_o;
+            const unsigned dp = bt * 5 * uH + utid;      // rows of [delta (4H) | dzq (H)]
+            a.delta[dp] = di; a.delta[dp + uH] = df; a.delta[dp + 2 * uH] = dg; a.delta[dp + 3 * uH] = d_o;
+            // dqt of step t+1, kept in LDS by this thread since phase 7 of that step: stores go out right after
+            // the wait for the prefetched activations above (vmcnt counts them: the next wait is a full step away)
+            if (t + 1 < T) a.dqt[(bt + 1) * uH + utid] = d_s[4 * HP + tid];
         } else if (tid >= 128 && tid < 128 + H) {
             // external gradients wrt the two contexts (output head) and the saved queries
             const int kk = tid - 128;
@@ -856,7 +884,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             for (int s = 0; s < NS; ++s) {
                 const int r = s * kDecPairs + pair;
                 if (r >= 6 * H && r < 7 * H) {
-                    const float dq2 = pair_sum(half_dot<K0>(wt[s], dqv_s + half * K0));
+                    const float dq2 = pair_sum(half_dot<K0, kBwdDotChunk>(wt[s], dqv_s + half * K0));
                     const float q = q2_s[r - 6 * H];
                     const float dz = dq2 * (1.f - q * q);
                     if (half == 0) { d_s[5 * HP + r - 6 * H] = dz; a.delta[bt * 5 * H + 4 * H + r - 6 * H] = dz; }
@@ -884,7 +912,6 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
 #pragma unroll
             for (int cch = 0; cch < kDecThreads / 64; ++cch) dq += part_s[cch * H + tid];
             d_s[4 * HP + tid] = dq;
-            a.dqt[bt * H + tid] = dq;
         }
         lds_barrier();
         GSCAN_STAMP(8)
@@ -896,7 +923,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             const int r = s * kDecPairs + pair;
             if (r < 6 * H) {
                 const int sg = r / H;
-                const float part = pair_sum(half_dot<K0>(wt[s], d_s + sg * HP + half * K0));
+                const float part = pair_sum(half_dot<K0, kBwdDotChunk>(wt[s], d_s + sg * HP + half * K0));
                 if (half == 0) part_s[r] = part;             // r = sg*H + k
             }
         }
@@ -906,6 +933,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
 
     // ---- epilogue: initial-state gradient through the bridge tanh, key and energy gradients ----
     if (tid < H) {
+        a.dqt[row0 * uH + utid] = d_s[4 * HP + tid];     // step 0's dqt (deferred like the others)
         float dh = 0.f;
 #pragma unroll
         for (int sgi = 0; sgi < 6; ++sgi) dh += part_s[sgi * H + tid];

@@ -3,8 +3,8 @@
 // The reference sorts rows by length, packs them and calls nn.LSTM.  Rows are independent,
 // so here one workgroup owns one command (and direction) for its whole length: the recurrent
 // matrix W_hh (4He x He floats) lives in the VGPRs of the workgroup for all time steps (a thread
-// holds two rows), h is broadcast from LDS, and there is no global traffic inside the loop except the
-// precomputed input projection gx[t] coming in and the saved activations going out.  Length
+// holds two rows), h is broadcast from LDS, and the command's projections and saved activations stay in LDS for
+// the whole loop (see "LDS residency" below).  Length
 // masking replaces packing: a row simply stops after its own length (the reverse direction
 // starts at its last real token), outputs at padded positions stay zero.
 //
@@ -47,107 +47,113 @@ template <int HE> struct EncShape {
     static constexpr int kThreads = ((4 * HE / R + 63) / 64) * 64;
 };
 
+// LDS residency.  A wait for a prefetched load (s_waitcnt vmcnt) also waits for every store the wave issued
+// before it, and under divergent control flow the compiler can only emit the full drain vmcnt(0) — with global
+// loads and stores inside the time loop each step paid a store acknowledgement.  A command is short (its whole
+// history is 6 He floats per step), so both recurrences keep it in LDS: everything a (row, direction) reads is
+// staged before the loop with 16-byte coalesced loads, results are written in place, and one coalesced write-back
+// follows the loop.  There is no global memory operation inside either time loop.
+//   forward   g_s [len][4He] input projections + b_hh  ->  gate activations (in place)
+//             c_s [len][He] cells, h_s [len][He] outputs, z_s [He] the zero initial state
+//   backward  d_s [len][4He] gate activations  ->  gate pre-activation gradients (in place)
+//             c_s [len][He] cells, o_s [len][He] gradient wrt the summed outputs, part_s [4He] partial dh
+constexpr size_t kEncLdsLimit = 160 * 1024;
+inline size_t encoder_fwd_lds(int L, int HE) { return ((size_t)L * 6 * HE + HE) * sizeof(float); }
+inline size_t encoder_bwd_lds(int L, int HE) { return ((size_t)L * 6 * HE + 4 * HE) * sizeof(float); }
+
 // grid (B, D): the two directions of a row run as two workgroups (they only meet in the sums below).
 // `out` and `h_final` must be zero on entry: each direction ADDS its h (0 + h_f + h_r in either order is the same
 // float: two-operand addition commutes), which is how the directions are summed (seq2seq_model.py:77-81).
 // Thread j < 4He/R owns gate rows j + r*(4He/R), r < R  (R = 2: [i | f] rows and the matching [g | o] rows).
 template <int HE>
 __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_kernel(int L, int D, const float *__restrict__ gx,
-                                        const int32_t *__restrict__ lengths, const float *__restrict__ w_hh_f,
-                                        const float *__restrict__ b_hh_f, const float *__restrict__ w_hh_r,
+                                        const int32_t *__restrict__ lengths, const float *__restrict__ b_hh_f,
                                         const float *__restrict__ b_hh_r, float *__restrict__ out,
                                         float *__restrict__ h_final, float *__restrict__ gates,
                                         float *__restrict__ cells, float *__restrict__ hprev,
                                         const float *__restrict__ w_image) {
     constexpr int R = EncShape<HE>::R, NT = 4 * HE / R;              // owning threads
-    __shared__ __attribute__((aligned(16))) float h_s[HE];
-    __shared__ float gate_s[4 * HE];
-    const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x, nthr = blockDim.x;
     int len = lengths[b];
     len = max(0, min(len, L));
+    float *g_s = lds, *c_s = g_s + len * 4 * HE, *h_s = c_s + len * HE, *z_s = h_s + len * HE;
     const bool is_gate = j < NT, is_unit = j < HE;
-    float w[R][HE];
+    const int64_t row0 = (int64_t)b * L;                             // row of (b, t, dir) = (row0 + t) * D + dir
 
-    // padded positions: zero saved h_prev (it multiplies delta = 0 in a GEMM later); out stays zero
-    for (int idx = j; idx < (L - len) * HE; idx += blockDim.x) {
-        const int t = len + idx / HE, k = idx % HE;
-        hprev[(((int64_t)b * L + t) * D + dir) * HE + k] = 0.f;
+    // stage the input projections of the whole command, recurrent bias added (seq2seq_model.py:74)
+    {
+        const float *bias = dir ? b_hh_r : b_hh_f;                   // a parameter: no 16-byte alignment promised
+        for (int idx = j; idx < len * HE; idx += nthr) {
+            const int t = idx / HE, q = idx - t * HE;
+            const float4 x = *reinterpret_cast<const float4 *>(gx + ((row0 + t) * D + dir) * 4 * HE + 4 * q);
+            const float4 bb = {bias[4 * q], bias[4 * q + 1], bias[4 * q + 2], bias[4 * q + 3]};
+            *reinterpret_cast<float4 *>(g_s + t * 4 * HE + 4 * q) = float4{x.x + bb.x, x.y + bb.y, x.z + bb.z, x.w + bb.w};
+        }
     }
-
-    const float *w_hh = dir ? w_hh_r : w_hh_f;
-    const float *b_hh = dir ? b_hh_r : b_hh_f;
-    float bias[R];
+    // padded positions: zero saved h_prev (it multiplies delta = 0 in a GEMM later); out stays zero
+    for (int idx = j; idx < (L - len) * HE; idx += nthr) {
+        const int t = len + idx / HE, k = idx % HE;
+        hprev[((row0 + t) * D + dir) * HE + k] = 0.f;
+    }
+    // register image [dir][r][k][thread]: consecutive lanes read consecutive floats (a row per lane straight from
+    // W_hh would touch 64 cache lines per load)
+    float w[R][HE];
+    if (is_gate) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        bias[r] = 0.f;
-        if (is_gate) {
-            const int row = j + r * NT;
-            // register image [dir][r][k][thread]: consecutive lanes read consecutive floats (a row per lane straight
-            // from W_hh would touch 64 cache lines per load; keeping both paths in one kernel cost 96 spilled VGPRs)
+        for (int r = 0; r < R; ++r) {
             const float *img = w_image + ((int64_t)(dir * R + r) * HE) * NT + j;
 #pragma unroll
             for (int k = 0; k < HE; ++k) w[r][k] = img[k * NT];
-            bias[r] = b_hh[row];
         }
     }
+    if (is_unit) z_s[j] = 0.f;
     float c = 0.f;
-    if (is_unit) h_s[j] = 0.f;
-    // The input projections are fetched TWO steps ahead: memory operations retire in order on this hardware, so a
-    // wait for a load also waits for every store issued before it — with a one-step distance each step would wait
-    // for the previous step's stores to be acknowledged.  For the same reason the direction sum (atomics) is not
-    // issued inside the loop: h_t is kept in LDS and added to `out` once, after the last step.
-    extern __shared__ float hist_s[];                        // [L][HE]
-    float gx_a[R], gx_b[R];                                  // projections of steps s and s+1 (bias included)
-    auto fetch = [&](int s, float (&dst)[R]) {
-        const int t = dir ? (len - 1 - s) : s;
-        const float *g = gx + (((int64_t)b * L + t) * D + dir) * 4 * HE;
-#pragma unroll
-        for (int r = 0; r < R; ++r) dst[r] = g[j + r * NT] + bias[r];
-    };
-#pragma unroll
-    for (int r = 0; r < R; ++r) gx_a[r] = gx_b[r] = 0.f;
-    if (is_gate && len > 0) fetch(0, gx_a);
-    if (is_gate && len > 1) fetch(1, gx_b);
+    const float *h_prev = z_s;
     lds_barrier();
     for (int s = 0; s < len; ++s) {
         const int t = dir ? (len - 1 - s) : s;
-        const int64_t row = ((int64_t)b * L + t) * D + dir;
-        float gx_cur[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { gx_cur[r] = gx_a[r]; gx_a[r] = gx_b[r]; }
-        if (is_gate && s + 2 < len) fetch(s + 2, gx_b);
+        float *g = g_s + t * 4 * HE;
         if (is_gate) {
             float dot[R];
-            dots_lds<HE, R>(w, h_s, dot);
+            dots_lds<HE, R>(w, h_prev, dot);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int gr = j + r * NT;                            // gate row: [i | f | g | o] blocks of He
-                const float pre = gx_cur[r] + dot[r];
-                const float a = (gr >= 2 * HE && gr < 3 * HE) ? tanhf_(pre) : sigmoidf_(pre);
-                gate_s[gr] = a;
-                gates[row * 4 * HE + gr] = a;
+                const float pre = g[gr] + dot[r];
+                g[gr] = (gr >= 2 * HE && gr < 3 * HE) ? tanhf_(pre) : sigmoidf_(pre);
             }
         }
-        if (is_unit) hprev[row * HE + j] = h_s[j];
         lds_barrier();
         if (is_unit) {
-            const float ig = gate_s[j], fg = gate_s[HE + j], gg = gate_s[2 * HE + j], og = gate_s[3 * HE + j];
+            const float ig = g[j], fg = g[HE + j], gg = g[2 * HE + j], og = g[3 * HE + j];
             c = fg * c + ig * gg;
-            const float h = og * tanhf_(c);
-            cells[row * HE + j] = c;
-            h_s[j] = h;
-            hist_s[t * HE + j] = h;
+            c_s[t * HE + j] = c;
+            h_s[t * HE + j] = og * tanhf_(c);
         }
+        h_prev = h_s + t * HE;
         lds_barrier();
     }
-    if (is_unit) {
-        atomicAdd(h_final + (int64_t)b * HE + j, h_s[j]);
-        for (int t = 0; t < len; ++t) atomicAdd(out + ((int64_t)b * L + t) * HE + j, hist_s[t * HE + j]);
+    // write-back: saved activations for the backward pass, the direction sums (atomics: two addends commute)
+    for (int idx = j; idx < len * HE; idx += nthr) {
+        const int t = idx / HE, q = idx - t * HE;
+        *reinterpret_cast<float4 *>(gates + ((row0 + t) * D + dir) * 4 * HE + 4 * q) =
+            *reinterpret_cast<const float4 *>(g_s + t * 4 * HE + 4 * q);
     }
+    for (int idx = j; idx < len * HE; idx += nthr) {
+        const int t = idx / HE, k = idx - t * HE;
+        const int64_t row = (row0 + t) * D + dir;
+        const bool first = dir ? (t == len - 1) : (t == 0);
+        cells[row * HE + k] = c_s[idx];
+        hprev[row * HE + k] = first ? 0.f : h_s[(dir ? t + 1 : t - 1) * HE + k];
+        atomicAdd(out + (row0 + t) * HE + k, h_s[idx]);
+    }
+    if (is_unit && len > 0) atomicAdd(h_final + (int64_t)b * HE + j, h_s[(dir ? 0 : len - 1) * HE + j]);
 }
 
 // Backward: thread (seg, q) owns columns q + r*(He/R), r < R, of block seg of W_hh (its R dot products share the
-// delta segment they read); dh_{t-1}[k] = sum of the four blocks' partial products.
+// delta segment they read); dh_{t-1}[k] = sum of the four blocks' partial products, taken by unit k at the top of
+// the next step.
 template <int HE>
 __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_kernel(int L, int D, const int32_t *__restrict__ lengths,
                                         const float *__restrict__ w_hh_f, const float *__restrict__ w_hh_r,
@@ -156,14 +162,31 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_ke
                                         float *__restrict__ delta) {
     constexpr int R = EncShape<HE>::R, KQ = HE / R, NT = 4 * KQ;
     static_assert(HE % R == 0, "hidden size must divide by the columns per thread");
-    __shared__ __attribute__((aligned(16))) float delta_s[4 * HE];
-    __shared__ float part_s[4 * HE];
-    __shared__ float dh_s[HE];
-    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
     int len = lengths[b];
     len = max(0, min(len, L));
+    float *d_s = lds, *c_s = d_s + len * 4 * HE, *o_s = c_s + len * HE, *part_s = o_s + len * HE;
     const bool active = tid < NT, is_unit = tid < HE;
     const int seg = tid / KQ, q = tid % KQ;
+    const int64_t row0 = (int64_t)b * L;
+    for (int idx = tid; idx < len * HE; idx += nthr) {                // saved activations of the whole command
+        const int t = idx / HE, k4 = idx - t * HE;
+        *reinterpret_cast<float4 *>(d_s + t * 4 * HE + 4 * k4) =
+            *reinterpret_cast<const float4 *>(gates + ((row0 + t) * D + dir) * 4 * HE + 4 * k4);
+    }
+    for (int idx = tid; idx < len * HE / 4; idx += nthr) {
+        const int t = idx / (HE / 4), k4 = idx - t * (HE / 4);
+        *reinterpret_cast<float4 *>(c_s + t * HE + 4 * k4) =
+            *reinterpret_cast<const float4 *>(cells + ((row0 + t) * D + dir) * HE + 4 * k4);
+        *reinterpret_cast<float4 *>(o_s + t * HE + 4 * k4) =
+            *reinterpret_cast<const float4 *>(d_out + (row0 + t) * HE + 4 * k4);
+    }
+    for (int i = tid; i < 4 * HE; i += nthr) part_s[i] = (i < HE) ? d_h_final[(int64_t)b * HE + i] : 0.f;
+    for (int idx = tid; idx < (L - len) * HE; idx += nthr) {          // padded positions get delta = 0
+        const int t = len + idx / HE, k4 = idx % HE;
+        *reinterpret_cast<float4 *>(delta + ((row0 + t) * D + dir) * 4 * HE + 4 * k4) = float4{0.f, 0.f, 0.f, 0.f};
+    }
     const float *w_hh = dir ? w_hh_r : w_hh_f;
     float wt[R][HE];
     if (active) {
@@ -172,71 +195,63 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_ke
 #pragma unroll
             for (int jj = 0; jj < HE; ++jj) wt[r][jj] = w_hh[(int64_t)(seg * HE + jj) * HE + q + r * KQ];
     }
-    for (int idx = tid; idx < (L - len) * 4 * HE; idx += blockDim.x) {
-        const int t = len + idx / (4 * HE), jj = idx % (4 * HE);
-        delta[(((int64_t)b * L + t) * D + dir) * 4 * HE + jj] = 0.f;
-    }
     float dc = 0.f;
-    if (is_unit) dh_s[tid] = d_h_final[(int64_t)b * HE + tid];
-    // saved activations of the next step to process are fetched while the current one computes
-    float pf[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto prefetch = [&](int s) {
-        const int t = dir ? (len - 1 - s) : s;
-        const int64_t row = ((int64_t)b * L + t) * D + dir;
-        const float *g = gates + row * 4 * HE;
-        pf[0] = g[tid]; pf[1] = g[HE + tid]; pf[2] = g[2 * HE + tid]; pf[3] = g[3 * HE + tid];
-        pf[4] = cells[row * HE + tid];
-        pf[5] = 0.f;
-        if (s > 0) {
-            const int tp = dir ? (t + 1) : (t - 1);
-            pf[5] = cells[(((int64_t)b * L + tp) * D + dir) * HE + tid];
-        }
-        pf[6] = d_out[((int64_t)b * L + t) * HE + tid];
-    };
-    if (is_unit && len > 0) prefetch(len - 1);
     lds_barrier();
     for (int s = len - 1; s >= 0; --s) {
         const int t = dir ? (len - 1 - s) : s;
-        const int64_t row = ((int64_t)b * L + t) * D + dir;
+        float *g = d_s + t * 4 * HE;
         if (is_unit) {
-            const float dh = dh_s[tid] + pf[6];
-            const float ig = pf[0], fg = pf[1], gg = pf[2], og = pf[3];
-            const float c = pf[4];
-            const float c_prev = pf[5];
-            if (s > 0) prefetch(s - 1);
+            const float dh = ((part_s[tid] + part_s[HE + tid]) + (part_s[2 * HE + tid] + part_s[3 * HE + tid])) +
+                             o_s[t * HE + tid];
+            const float ig = g[tid], fg = g[HE + tid], gg = g[2 * HE + tid], og = g[3 * HE + tid];
+            const float c = c_s[t * HE + tid];
+            const float c_prev = (s > 0) ? c_s[(dir ? t + 1 : t - 1) * HE + tid] : 0.f;
             const float tc = tanhf_(c);
             const float dct = dc + dh * og * (1.f - tc * tc);
-            const float di = dct * gg * ig * (1.f - ig);
-            const float df = dct * c_prev * fg * (1.f - fg);
-            const float dg = dct * ig * (1.f - gg * gg);
-            const float d_o = dh * tc * og * (1.f - og);
             dc = dct * fg;
-            delta_s[tid] = di; delta_s[HE + tid] = df; delta_s[2 * HE + tid] = dg; delta_s[3 * HE + tid] = d_o;
-            float *dg_out = delta + row * 4 * HE;
-            dg_out[tid] = di; dg_out[HE + tid] = df; dg_out[2 * HE + tid] = dg; dg_out[3 * HE + tid] = d_o;
+            g[tid] = dct * gg * ig * (1.f - ig);
+            g[HE + tid] = dct * c_prev * fg * (1.f - fg);
+            g[2 * HE + tid] = dct * ig * (1.f - gg * gg);
+            g[3 * HE + tid] = dh * tc * og * (1.f - og);
         }
         lds_barrier();
         if (active) {
             float part[R];
-            dots_lds<HE, R>(wt, delta_s + seg * HE, part);
+            dots_lds<HE, R>(wt, g + seg * HE, part);
 #pragma unroll
             for (int r = 0; r < R; ++r) part_s[seg * HE + q + r * KQ] = part[r];
         }
         lds_barrier();
-        if (is_unit) dh_s[tid] = (part_s[tid] + part_s[HE + tid]) + (part_s[2 * HE + tid] + part_s[3 * HE + tid]);
-        lds_barrier();
+    }
+    for (int idx = tid; idx < len * HE; idx += nthr) {
+        const int t = idx / HE, k4 = idx - t * HE;
+        *reinterpret_cast<float4 *>(delta + ((row0 + t) * D + dir) * 4 * HE + 4 * k4) =
+            *reinterpret_cast<const float4 *>(d_s + t * 4 * HE + 4 * k4);
     }
 }
 
+template <typename K>
+static int encoder_lds_attr(K kernel, size_t bytes, bool &attr_set) {
+    GSCAN_CHECK(bytes <= kEncLdsLimit, "encoder lstm: a command of this length needs %zu bytes of LDS (limit %zu)", bytes,
+                kEncLdsLimit);
+    if (!attr_set) {
+        GSCAN_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLdsLimit));
+        attr_set = true;
+    }
+    return 0;
+}
+
 template <int HE>
-static int launch_fwd(int B, int L, int D, const float *gx, const int32_t *lengths, const float *wf, const float *bf,
-                      const float *wr, const float *br, float *out, float *hfin, float *gates, float *cells,
-                      float *hprev, const float *w_image, hipStream_t stream) {
+static int launch_fwd(int B, int L, int D, const float *gx, const int32_t *lengths, const float *bf, const float *br,
+                      float *out, float *hfin, float *gates, float *cells, float *hprev, const float *w_image,
+                      hipStream_t stream) {
     const int nt = EncShape<HE>::kThreads;
+    static bool attr_set = false;
+    if (int rc = encoder_lds_attr(encoder_lstm_fwd_kernel<HE>, encoder_fwd_lds(L, HE), attr_set)) return rc;
     // algorithmic work: the recurrent product h.W_hh^T per (row, step, direction); padded steps counted
     ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * HE * HE);
-    hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B, D), dim3(nt), (size_t)L * HE * sizeof(float), stream, L, D, gx, lengths, wf, bf, wr, br,
-                       out, hfin, gates, cells, hprev, w_image);
+    hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B, D), dim3(nt), encoder_fwd_lds(L, HE), stream, L, D, gx, lengths,
+                       bf, br, out, hfin, gates, cells, hprev, w_image);
     GSCAN_LAUNCHED("encoder_lstm_fwd_kernel");
     return 0;
 }
@@ -245,9 +260,11 @@ static int launch_bwd(int B, int L, int D, const int32_t *lengths, const float *
                       const float *gates, const float *cells, const float *d_out, const float *d_hfin, float *delta,
                       hipStream_t stream) {
     const int nt = EncShape<HE>::kThreads;
+    static bool attr_set = false;
+    if (int rc = encoder_lds_attr(encoder_lstm_bwd_kernel<HE>, encoder_bwd_lds(L, HE), attr_set)) return rc;
     ProbeScope probe(P_ENCODER_BWD, stream, 2.0 * B * L * D * 4 * HE * HE);
-    hipLaunchKernelGGL(encoder_lstm_bwd_kernel<HE>, dim3(B, D), dim3(nt), 0, stream, L, D, lengths, wf, wr, gates,
-                       cells, d_out, d_hfin, delta);
+    hipLaunchKernelGGL(encoder_lstm_bwd_kernel<HE>, dim3(B, D), dim3(nt), encoder_bwd_lds(L, HE), stream, L, D, lengths, wf,
+                       wr, gates, cells, d_out, d_hfin, delta);
     GSCAN_LAUNCHED("encoder_lstm_bwd_kernel");
     return 0;
 }
@@ -294,8 +311,9 @@ int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int
     GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm: bad dims B=%d L=%d D=%d", B, L, D);
     GSCAN_CHECK(D == 1 || (w_hh_r && b_hh_r), "encoder lstm: reverse weights missing");
     GSCAN_CHECK(w_image, "encoder lstm: weight image missing");
+    GSCAN_CHECK(((uintptr_t)gx | (uintptr_t)gates) % 16 == 0, "encoder lstm: gx and gates must be 16-byte aligned");
     switch (He) {
-#define X(n) case n: return launch_fwd<n>(B, L, D, gx, lengths, w_hh_f, b_hh_f, w_hh_r, b_hh_r, out, h_final, gates, cells, hprev, w_image, stream);
+#define X(n) case n: return launch_fwd<n>(B, L, D, gx, lengths, b_hh_f, b_hh_r, out, h_final, gates, cells, hprev, w_image, stream);
         GSCAN_HIDDEN_SIZES(X)
 #undef X
         default: break;
@@ -307,6 +325,8 @@ int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, c
                           const float *w_hh_r, const float *gates, const float *cells, const float *d_out,
                           const float *d_h_final, float *delta, hipStream_t stream) {
     GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm bwd: bad dims B=%d L=%d D=%d", B, L, D);
+    GSCAN_CHECK(((uintptr_t)gates | (uintptr_t)cells | (uintptr_t)d_out | (uintptr_t)delta) % 16 == 0,
+                "encoder lstm bwd: gates, cells, d_out and delta must be 16-byte aligned");
     switch (He) {
 #define X(n) case n: return launch_bwd<n>(B, L, D, lengths, w_hh_f, w_hh_r, gates, cells, d_out, d_h_final, delta, stream);
         GSCAN_HIDDEN_SIZES(X)
