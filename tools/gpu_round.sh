@@ -1,0 +1,21 @@
+#!/bin/bash
+# One GPU call's worth of evidence: parity tests, bench line, rocprofv3 kernel stats, PMC traffic passes.
+# usage (on the GPU box, from the repo root): bash tools/gpu_round.sh <tag>   -> files under gpurun_out/<tag>/
+set -eo pipefail
+tag=${1:-run}
+out=gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1 || { tail -30 "$out/pytest_gpu.log"; exit 1; }
+tail -3 "$out/pytest_gpu.log"
+timeout -k 10 300 python bench.py > "$out/bench_line.json" 2> "$out/bench.err" || { tail -30 "$out/bench.err"; exit 1; }
+cat "$out/bench_line.json"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -o run -- python3 bench.py --cpu-seconds 0 > "$out/prof_bench.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_f" -o run -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$out/pmc_f.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_w" -o run -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$out/pmc_w.log" 2>&1
+python tools/pmc_traffic.py "$(find $out/pmc_f -name '*counter_collection.csv' | head -1)" "$(find $out/pmc_w -name '*counter_collection.csv' | head -1)" gemm_group_kernel > "$out/pmc_traffic.json"
+cat "$out/pmc_traffic.json"
+cp "$(find $out/prof -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
+head -12 "$out/kernel_stats.csv"
+# raw traces are large: keep only the summaries
+rm -rf "$out/prof" "$out/pmc_f" "$out/pmc_w"
