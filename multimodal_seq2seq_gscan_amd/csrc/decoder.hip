@@ -42,6 +42,14 @@ namespace gscan {
         stamp_prev = now_;                                                     \
     }
 
+// Once-per-launch stamps (prologue / epilogue pieces) go straight to slots 10..15 of the stamp buffer.
+#define GSCAN_STAMP_ONCE(i)                                                    \
+    if (a.stamps && blockIdx.x == 0 && tid == 0) {                             \
+        const long long now_ = clock64();                                      \
+        a.stamps[i] = (float)(now_ - stamp_prev);                              \
+        stamp_prev = now_;                                                     \
+    }
+
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -59,6 +67,7 @@ __device__ __forceinline__ float pair_sum(float v) { return v + dpp_move<0xb1, 0
 // Dot products of register-resident half rows with an LDS vector (K0 % 4 == 0), as packed FMAs
 // (v_pk_fma_f32).  The vector is read in chunks of four float4; the next chunk's reads are issued before the
 // current chunk's FMAs, so the LDS latency is paid about once per dot instead of once per read.
+constexpr int kWaitVmcnt0 = 0x0F70;   // s_waitcnt vmcnt(0) only (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
 constexpr int kDotChunk = 4;
 #ifndef GSCAN_DEC_BWD_CHUNK
 #define GSCAN_DEC_BWD_CHUNK 4
@@ -281,6 +290,11 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     if (COND && tid < H) bq_s[tid] = a.b_q2k[tid];
     float att_acc = 0.f;                                    // wave 0, lane m
     lds_barrier();
+    // The weight registers are complete from here on, and the compiler's wait-count bookkeeping is told so: without
+    // this explicit wait it re-checks "the first weight load may still be in flight" at the top of EVERY iteration
+    // with s_waitcnt vmcnt(2), which in steady state drains the previous step's stores (vmcnt counts in order).
+    __builtin_amdgcn_s_waitcnt(kWaitVmcnt0);
+    GSCAN_STAMP_ONCE(10)
 
     for (int t = 0; t < T; ++t) {
         GSCAN_STAMP(0)
@@ -338,12 +352,19 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         // This is the one place where a wave waits for a global load (ge).  vmcnt counts stores too and the wait
         // is a full drain here, so every store of phases A-C1 is issued after it instead of before: a store then
         // has most of a step to be acknowledged before the next drain.
+        // all of them are consumed here, BEFORE this phase's stores: a wait behind a store would wait for its
+        // acknowledgement too
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            ge[s] += gh[s];
+            asm volatile("" : "+v"(ge[s]));                  // keeps the additions (and their wait) up here
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int r = s * kDecPairs + pair;
             if (half == 0) {
                 if (r < 4 * H) {
-                    gsum_s[r] = ge[s] + gh[s] + col_s[r];
+                    gsum_s[r] = ge[s] + col_s[r];
                 } else if (r < 5 * H) {
                     a.s[bt * 4 * H + H + (r - 4 * H)] = col_s[r];
                     a.qt[bt * H + r - 4 * H] = gh[s];
@@ -450,7 +471,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             a.row_stats[4 * b + 2] = 0.f;
         }
     }
-    if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_acc[tid];
+    if (a.stamps && blockIdx.x == 0 && tid < 10) a.stamps[tid] = stamp_acc[tid];
 
     // ---- output head of the row's T steps (it does not feed back, seq2seq_model.py:421-424):
     //      preo = S . wo_perm^T  ([T,4H] x [4H,H]) on the matrix cores, logits_t = W_h2o . preo_t,
@@ -541,6 +562,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             }
         }
     }
+    GSCAN_STAMP_ONCE(11)
 }
 
 // Backward of s_m = v . tanh(q + PK_m) for one attention.  Lane m of `dsm` holds d s_m.  Wave w owns the memories
@@ -748,6 +770,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         }
         __syncthreads();                                     // the row's dS is visible to the workgroup
     }
+    GSCAN_STAMP_ONCE(10)
 
     float wt[NS][K0];
 #pragma unroll
@@ -811,14 +834,19 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             if (COND) pf[4] = a.q2[bt * uH + kk];
         }
     };
-    prefetch(T - 1);
     lds_barrier();
+    __builtin_amdgcn_s_waitcnt(kWaitVmcnt0);                // weights and staging complete (see the forward kernel)
+    prefetch(T - 1);
+    GSCAN_STAMP_ONCE(11)
 
     for (int t = T - 1; t >= 0; --t) {
         GSCAN_STAMP(0)
         const unsigned bt = (unsigned)b * T + t;
         alpha_v_pf = alpha_v_nx;
         alpha_c_pf = alpha_c_nx;
+        // consumed HERE (a step after their loads were issued), not at their first use in phases 3 / 6, where the
+        // in-order vmcnt wait would also cover this iteration's prefetch and stores
+        asm volatile("" : "+v"(alpha_v_pf), "+v"(alpha_c_pf));
         // ---- 1: dh_t = sum of the six partial products of step t+1; LSTM cell backward ------------
         if (tid < H) {
             float dh = pf[6];
@@ -961,7 +989,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         for (int cch = 0; cch < kDecThreads / 64; ++cch) x += part_s[cch * H + tid];
         atomicAdd(&a.dv_t[tid], x);
     }
-    if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_acc[tid];
+    if (a.stamps && blockIdx.x == 0 && tid < 10) a.stamps[tid] = stamp_acc[tid];
+    GSCAN_STAMP_ONCE(12)
 }
 
 // Register images of the decoder weights are written once per step by the step prologue kernel

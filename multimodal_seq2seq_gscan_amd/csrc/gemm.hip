@@ -185,7 +185,11 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
     constexpr int BM = TileM<TMW, BK>::BM, LDR_A = TileM<TMW, BK>::LDR_A;
     constexpr int LDK = BK + 4;
     const int bz = local / g.tiles_mn, rem = local % g.tiles_mn;
-    const int by = rem / g.tiles_n, bx = rem % g.tiles_n;
+    // Tile order inside a problem: M tiles slowest by default; N tiles slowest (flag 16) when B is the larger operand,
+    // so that an XCD's contiguous share of the tiles reads a slice of the LARGE operand and all of the small one.
+    const int tiles_m = g.tiles_mn / g.tiles_n;
+    const bool n_major = (g.flags & 16) != 0;
+    const int by = n_major ? rem % tiles_m : rem / g.tiles_n, bx = n_major ? rem / tiles_m : rem % g.tiles_n;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -446,12 +450,14 @@ int GemmBatch::launch(hipStream_t stream) {
     static const int forced = [] { const char *e = getenv("GSCAN_GEMM_TMW"); return e ? atoi(e) : 0; }();
     const int tmw = forced == 1 || forced == 2 ? forced : (tiles_ < kWideTileMinGroups ? 1 : 2);
     static const int xcd = [] { const char *e = getenv("GSCAN_GEMM_XCD"); return e ? atoi(e) : 1; }();   // on by default
+    static const int order = [] { const char *e = getenv("GSCAN_GEMM_ORDER"); return e ? atoi(e) : 1; }();
     int total = 0;
     for (int i = 0; i < grp_.count; ++i) {
         GemmProblem &p = grp_.p[i];
         p.tiles_n = cdiv(p.N, BN);
         p.tiles_mn = p.tiles_n * cdiv(p.M, 32 * tmw);
         p.nsplit = cdiv(p.K, p.k_chunk);
+        if (order && p.nsplit == 1 && p.N > p.M) p.flags |= 16;
         p.tile_begin = total;
         const int n = p.tiles_mn * p.nsplit;
         grp_.xcd_per[i] = (xcd && n >= 16) ? cdiv(n, 8) : 0;
