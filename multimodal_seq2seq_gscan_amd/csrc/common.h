@@ -39,14 +39,18 @@ void set_error(const char *fmt, ...);
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 #if defined(__HIPCC__)
-// sigmoid / tanh through v_exp_f32 and v_rcp_f32 (1 ulp each): absolute error ~1e-7, two transcendental
-// issues per call instead of an IEEE division sequence; both saturate cleanly for large |x|.
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// sigmoid / tanh through v_exp_f32 (2^x) and v_rcp_f32 (1 ulp each): absolute error ~1e-7, two transcendental
+// issues and two (sigmoid) / three (tanh) plain VALU operations per call; both saturate cleanly for large |x|
+// (2^(+big) = inf, rcp(inf) = 0).  tanh x = 2 sigmoid(2x) - 1: the recurrent kernels are bound by VALU issue, and
+// the (1 - e) / (1 + e) form with |x| and copysign costs three more instructions per call for a relative accuracy
+// near 0 that nothing downstream needs.
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 __device__ __forceinline__ float tanhf_(float x) {
-    const float e = __expf(-2.0f * fabsf(x));                       // in (0, 1]
-    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-    return copysignf(t, x);
+    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x));
+    return fmaf(2.0f, r, -1.0f);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
@@ -73,6 +77,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_move<0x142, 0xa>(v);
     v += dpp_move<0x143, 0xc>(v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// G independent sums, step by step: the DPP chain of one sum is ~10 dependent instructions with wait states
+// between them, G chains issued round-robin fill each other's gaps.
+template <int G>
+__device__ __forceinline__ void wave_sum_n(float (&v)[G]) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) v[i] += dpp_move<0xb1, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < G; ++i) v[i] += dpp_move<0x4e, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < G; ++i) v[i] += dpp_move<0x124, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < G; ++i) v[i] += dpp_move<0x128, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < G; ++i) v[i] += dpp_move<0x142, 0xa>(v[i]);
+#pragma unroll
+    for (int i = 0; i < G; ++i) v[i] += dpp_move<0x143, 0xc>(v[i]);
+#pragma unroll
+    for (int i = 0; i < G; ++i) v[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_move<0xb1, 0xf>(v));

@@ -133,37 +133,50 @@ __device__ __forceinline__ float split_weighted_sum(const float *al, const float
     return a0 + (a1 + a2);
 }
 
-// Additive-attention scores s_m = v . tanh(q + PK_m) for m < n: each wave takes m = wave, wave+nwave, ...
-// four at a time (all key reads first, then the tanh's, then four independent DPP reductions).  A lane owns the
-// feature indices lane and lane+64; v and q for them are read once.
+// Additive-attention scores s_m = v . tanh(q + PK_m) for m < n.  Wave w takes m = w, w+nwave, ... in balanced rounds
+// of G <= 5 memories; a round is ONE straight-line block (G is a template parameter, reads of memories past the end
+// are clamped to the last one and only the final write is guarded), so the scheduler interleaves the G tanh chains
+// and the G DPP reductions instead of running them one after the other between branches — a lone reduction is a
+// ~140-cycle dependent chain, and the 36 cells of a 6x6 grid are one round of five.  A lane owns the feature
+// indices lane and lane+64; v and q for them are read once.
+constexpr int kScoreGroup = 5;
+template <int H, int G>
+__device__ __forceinline__ void score_round(float v1, float v2, float q1, float q2, int k1, int k2, const float *pk,
+                                            int n, float *sc_s, int m0, int nwave, int lane) {
+    float x1[G], x2[G], p[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int m = min(m0 + i * nwave, n - 1);                  // scalar arithmetic (m0 is an SGPR)
+        x1[i] = pk[m * H + k1];
+        x2[i] = pk[m * H + k2];
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) p[i] = fmaf(v1, tanhf_(q1 + x1[i]), v2 * tanhf_(q2 + x2[i]));
+    wave_sum_n<G>(p);
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+        if (lane == 0 && m0 + i * nwave < n) sc_s[m0 + i * nwave] = p[i];
+}
+
 template <int H>
 __device__ __forceinline__ void attention_scores(const float *v_s, const float *q_s, const float *pk, int n,
-                                                 float *sc_s, int wave, int nwave, int lane) {
+                                                 float *sc_s, int wave_v, int nwave, int lane) {
     static_assert(H <= 128, "two feature indices per lane");
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v);
     const bool has2 = lane + 64 < H, has1 = lane < H;
     const int k1 = has1 ? lane : 0, k2 = has2 ? lane + 64 : 0;
     const float v1 = has1 ? v_s[k1] : 0.f, v2 = has2 ? v_s[k2] : 0.f;
     const float q1 = q_s[k1], q2 = q_s[k2];
-    for (int m0 = wave; m0 < n; m0 += 4 * nwave) {
-        float x1[4], x2[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = min(m0 + i * nwave, n - 1);
-            x1[i] = pk[m * H + k1];
-            x2[i] = pk[m * H + k2];
-        }
-        float p[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (m0 + i * nwave < n)           // wave-uniform: a short last round costs only its own tanh's
-                p[i] = fmaf(v1, tanhf_(q1 + x1[i]), v2 * tanhf_(q2 + x2[i]));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + i * nwave;
-            if (m < n) {
-                const float t = wave_sum(p[i]);
-                if (lane == 0) sc_s[m] = t;
-            }
+    const int per = (n + nwave - 1) / nwave;                        // memories of the busiest wave
+    const int rounds = (per + kScoreGroup - 1) / kScoreGroup;
+    const int grp = (per + rounds - 1) / rounds;                    // memories per wave per round
+    for (int m0 = wave; m0 < n; m0 += grp * nwave) {
+        switch (grp) {
+            case 1: score_round<H, 1>(v1, v2, q1, q2, k1, k2, pk, n, sc_s, m0, nwave, lane); break;
+            case 2: score_round<H, 2>(v1, v2, q1, q2, k1, k2, pk, n, sc_s, m0, nwave, lane); break;
+            case 3: score_round<H, 3>(v1, v2, q1, q2, k1, k2, pk, n, sc_s, m0, nwave, lane); break;
+            case 4: score_round<H, 4>(v1, v2, q1, q2, k1, k2, pk, n, sc_s, m0, nwave, lane); break;
+            default: score_round<H, 5>(v1, v2, q1, q2, k1, k2, pk, n, sc_s, m0, nwave, lane); break;
         }
     }
 }
