@@ -120,19 +120,6 @@ __device__ __forceinline__ float half_dot(const float (&w)[K0], const float *v) 
     return out[0];
 }
 
-// this lane's share of sum_{m<n} al[m] * mat[m*stride]: m = half, half+2, ... (the pair adds the two shares)
-__device__ __forceinline__ float split_weighted_sum(const float *al, const float *mat, int stride, int n, int half) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    int m = half;
-    for (; m + 4 < n; m += 6) {
-        a0 = fmaf(al[m + 0], mat[(m + 0) * stride], a0);
-        a1 = fmaf(al[m + 2], mat[(m + 2) * stride], a1);
-        a2 = fmaf(al[m + 4], mat[(m + 4) * stride], a2);
-    }
-    for (; m < n; m += 2) a0 = fmaf(al[m], mat[m * stride], a0);
-    return a0 + (a1 + a2);
-}
-
 // Additive-attention scores s_m = v . tanh(q + PK_m) for m < n.  Wave w takes m = w, w+nwave, ... in balanced rounds
 // of G <= 5 memories; a round is ONE straight-line block (G is a template parameter, reads of memories past the end
 // are clamped to the last one and only the final write is guarded), so the scheduler interleaves the G tanh chains

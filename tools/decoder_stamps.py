@@ -15,11 +15,17 @@ from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
 ap = argparse.ArgumentParser()
 ap.add_argument("--target-length", type=int, default=20)
 ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--config", default="compositional", choices=["compositional", "demo"])
 args = ap.parse_args()
 lib = _lib.load()
-cfg = model_kwargs("compositional")
+cfg = model_kwargs(args.config)
 model = Model(**cfg).cuda().eval()
-batch = {k: v.cuda() for k, v in make_batch(Shape(batch=args.batch, max_target=args.target_length), 1).items()}
+shape = Shape(batch=args.batch, max_target=args.target_length)
+if args.config == "demo":
+    from multimodal_seq2seq_gscan_amd.synthetic import S0_DEMO
+    import dataclasses
+    shape = dataclasses.replace(S0_DEMO, batch=args.batch, max_target=args.target_length)
+batch = {k: v.cuda() for k, v in make_batch(shape, 1).items()}
 lib.gscan_probe_enable(2)
 for _ in range(3):
     model.zero_grad()
@@ -29,7 +35,7 @@ for _ in range(3):
     model.get_loss(logp, batch["targets"]).backward()
 torch.cuda.synchronize()
 B, L = batch["commands"].shape
-dims = model._dims(B, L, args.target_length, 6)
+dims = model._dims(B, L, args.target_length, batch["world"].shape[1])
 st = model.workspace_view(dims, "stamps").cpu()
 for name, row in (("forward", st[:16]), ("backward", st[16:32])):
     tot = row.sum().item()   # slot 0 of the first step includes nothing else: once-per-launch pieces are in slots 10..
