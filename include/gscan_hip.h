@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 4
+#define GSCAN_ABI_VERSION 5
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
 typedef struct gscan_dims {
@@ -221,6 +221,16 @@ int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t st
  * and returns the summed duration, the summed ALGORITHMIC flops (DESIGN.md states the per-launch
  * formulas) and the launch count since the last reset.  Do not enable during graph capture. */
 int gscan_probe_enable(int on);
+/* In-kernel timeline (diagnostic): with a device buffer of GSCAN_TRACE_WORDS uint64 set (zeroed by the caller), the
+ * first workgroup of every kernel launch appends (kernel id, grid size, 100 MHz device clock) to the start list and
+ * the last workgroup appends the same to the end list on exit: words [0],[1] = list lengths, then two lists of
+ * GSCAN_TRACE_RECORDS records of 3 words.  No profiler is involved, so the timeline of an undisturbed step can be
+ * read (tools/device_timeline.py).  NULL switches tracing off.  Synchronises the device.  The stamps are compiled in
+ * only with -DGSCAN_TRACE (they cost 1.4 % of a step when merely present); the shipped build returns an error for a
+ * non-NULL buffer. */
+#define GSCAN_TRACE_RECORDS 256
+#define GSCAN_TRACE_WORDS (2 + 2 * 3 * GSCAN_TRACE_RECORDS)
+int gscan_trace_set(unsigned long long *device_buffer);
 int gscan_probe_reset(void);
 int gscan_probe_read(const char *name, double *total_ms, double *flops, int64_t *launches);
 

@@ -11,7 +11,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # GSCAN_HIP_LIB: development override, used by tools/variants.py to time experimental builds side by side
 LIB_PATH = os.environ.get("GSCAN_HIP_LIB") or os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _f32p = C.POINTER(C.c_float)
 _i64p = C.POINTER(C.c_int64)
@@ -90,6 +90,7 @@ PROTOTYPES = {
                                    _vp, _vp, C.POINTER(Params), _vp]),
     "gscan_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _vp, _i, _vp]),
     "gscan_adam_scalars": (None, [_f, _f, _f, _f, _f, _i64, _vp]),
+    "gscan_trace_set": (_i, [_vp]),
     "gscan_dropout_masks": (_i, [_vp, _sz, _sz, _sz, _f, _f, _f, _u64, _u64, _vp, _vp]),
     "gscan_probe_enable": (_i, [_i]),
     "gscan_probe_reset": (_i, []),

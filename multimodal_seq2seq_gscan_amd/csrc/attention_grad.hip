@@ -33,6 +33,7 @@ __host__ __device__ inline KeysLds keys_lds(int H, int L, int M) {
 
 template <int H>
 __global__ __launch_bounds__(kKbThreads) void keys_backward_kernel(KeysBackwardArgs a) {
+    TraceScope trace_scope(TK_KEYS_BWD);
     constexpr int HS = (H % 8 == 4) ? H : H + 4;      // dPK row stride: the 16 rows of an A fragment hit distinct banks
     constexpr int NTH = (H + 15) / 16, KS = H / 4;
     static_assert(NTH <= kKbMaxTiles && H % 4 == 0, "hidden size not supported");
@@ -235,5 +236,7 @@ int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream) {
     }
     GSCAN_CHECK(false, "keys backward: decoder_hidden_size %d has no compiled kernel (20 32 64 100)", H);
 }
+
+GSCAN_TRACE_TU(attention_grad)
 
 }  // namespace gscan

@@ -134,6 +134,21 @@ int gscan_dropout_masks(float *out, size_t n_cnn, size_t n_enc, size_t n_dec, fl
     return dropout_masks(out, n, p, seed, stream_id, dev_stream_id, (hipStream_t)stream);
 }
 
+int gscan_trace_set(unsigned long long *device_buffer) {
+    static_assert(GSCAN_TRACE_RECORDS == kTraceRecords, "header and kernels disagree on the trace buffer layout");
+#ifndef GSCAN_TRACE
+    GSCAN_CHECK(device_buffer == nullptr, "trace_set: this build has no in-kernel stamps (compile every source with "
+                                          "-DGSCAN_TRACE: tools/device_timeline.py does)");
+#endif
+    GSCAN_HIP(hipDeviceSynchronize());
+    int rc = trace_set_gemm(device_buffer) | trace_set_elementwise(device_buffer) | trace_set_loss(device_buffer) |
+             trace_set_lstm_encoder(device_buffer) | trace_set_decoder(device_buffer) |
+             trace_set_attention_grad(device_buffer);
+    GSCAN_CHECK(rc == 0, "trace_set: hipMemcpyToSymbol failed");
+    GSCAN_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
 int gscan_sequence_nll(const float *logp, const int64_t *targets, int B, int T, int V, int pad, float *loss_sum,
                        float *count, float *dlogp, void *stream) {
     ARG(logp && targets && loss_sum && count && B > 0 && T > 0 && V > 0, "sequence_nll: bad argument");

@@ -38,7 +38,47 @@ void set_error(const char *fmt, ...);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Kernel ids of the in-kernel timeline (diagnostic, tools/device_timeline.py).
+enum TraceKernel { TK_DROPOUT = 1, TK_TOEPLITZ_BUILD, TK_PROLOGUE, TK_GEMM, TK_ENCODER_FWD, TK_DECODER_FWD, TK_DECODER_BWD,
+                   TK_KEYS_BWD, TK_UNPERMUTE, TK_EMBED_GRAD, TK_ENCODER_BWD, TK_TOEPLITZ_FOLD, TK_ADAM, TK_LOSS, TK_OTHER };
+constexpr int kTraceRecords = 256;     // per list; buffer = 2 counters + 2 lists of kTraceRecords x (kid, grid, ticks)
+
 #if defined(__HIPCC__)
+// In-kernel timeline without a profiler in the way, compiled in with -DGSCAN_TRACE only (tools/device_timeline.py
+// builds that variant): when a trace buffer is set (gscan_trace_set), the first workgroup
+// of every launch appends (kernel id, grid size, s_memrealtime) to the start list and the LAST workgroup (highest block
+// index: dispatched last) appends the same to the end list when its thread 0 leaves the kernel.  The 100 MHz
+// constant clock is shared by the whole device, so the records of kernels on different streams line up.  The pointer is a per-translation-unit device variable (no
+// relocatable device code): every .hip file with kernels defines its setter with GSCAN_TRACE_TU.
+static __device__ unsigned long long *g_trace_buf;
+struct TraceScope {
+    int kid;
+    __device__ __forceinline__ void put(int list) const {
+        unsigned long long *t = g_trace_buf;
+        const unsigned long long i = atomicAdd(&t[list], 1ull);
+        if (i < (unsigned long long)kTraceRecords) {
+            unsigned long long *r = t + 2 + (size_t)list * 3 * kTraceRecords + 3 * i;
+            r[0] = (unsigned long long)kid;
+            r[1] = (unsigned long long)gridDim.x * gridDim.y;
+            r[2] = wall_clock64();
+        }
+    }
+#ifndef GSCAN_TRACE         // the shipped build: no code (the two tests per workgroup cost the step 1.4 %)
+    __device__ __forceinline__ explicit TraceScope(int k) : kid(k) {}
+#else
+    __device__ __forceinline__ explicit TraceScope(int k) : kid(k) {
+        if (g_trace_buf && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) put(0);
+    }
+    __device__ __forceinline__ ~TraceScope() {
+        if (g_trace_buf && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0) put(1);
+    }
+#endif
+};
+#define GSCAN_TRACE_TU(name)                                                                        \
+    int trace_set_##name(unsigned long long *buf) {                                                 \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; \
+    }
+
 // sigmoid / tanh through v_exp_f32 (2^x) and v_rcp_f32 (1 ulp each): absolute error ~1e-7, two transcendental
 // issues and two (sigmoid) / three (tanh) plain VALU operations per call; both saturate cleanly for large |x|
 // (2^(+big) = inf, rcp(inf) = 0).  tanh x = 2 sigmoid(2x) - 1: the recurrent kernels are bound by VALU issue, and

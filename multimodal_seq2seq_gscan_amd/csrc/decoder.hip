@@ -236,6 +236,7 @@ __device__ __forceinline__ void quad_offset(int u_off, int pk_off, int u2_off, i
 // ------------------------------------------------------------------------------------------
 template <int H, bool COND>
 __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a) {
+    TraceScope trace_scope(TK_DECODER_FWD);
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
                   HP = 2 * K0;
     constexpr int NQT = (COND ? 6 : 5) * H / 4;   // column quads of the textual images [U_t | PK_t | U2_t]
@@ -654,6 +655,7 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
 // ------------------------------------------------------------------------------------------
 template <int H, bool COND>
 __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a) {
+    TraceScope trace_scope(TK_DECODER_BWD);
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
                   HP = 2 * K0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1062,5 +1064,7 @@ int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hi
     }
     GSCAN_CHECK(false, "decoder_hidden_size %d has no compiled kernel (supported: 20 32 64 100)", H);
 }
+
+GSCAN_TRACE_TU(decoder)
 
 }  // namespace gscan

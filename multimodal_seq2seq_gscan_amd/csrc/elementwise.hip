@@ -44,6 +44,7 @@ constexpr int kEmbedRows = 64;
 __global__ void embed_grad_kernel(const int64_t *__restrict__ tok, const float *__restrict__ g, int64_t ldg,
                                   const float *__restrict__ mask, int rows, int D, int vocab, int pad,
                                   float *__restrict__ dtable) {
+    TraceScope trace_scope(TK_EMBED_GRAD);
     extern __shared__ float table[];
     const int n = vocab * D;
     for (int i = threadIdx.x; i < n; i += blockDim.x) table[i] = 0.f;
@@ -97,6 +98,7 @@ __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float 
                             float *__restrict__ v, size_t n, float step_size, float beta1, float beta2, float eps,
                             float inv_sqrt_bc2, const float *__restrict__ grad_scale,
                             const float *__restrict__ dev_scalars, int zero_grad) {
+    TraceScope trace_scope(TK_ADAM);
     const float gs = grad_scale ? ((zero_grad & 2) ? 1.f / grad_scale[0] : grad_scale[0]) : 1.f;
     if (dev_scalars) { step_size = dev_scalars[0]; inv_sqrt_bc2 = dev_scalars[1]; }   // graph replay: per-step values
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -154,6 +156,7 @@ struct MaskSegments { size_t end[3]; float p[3]; };
 
 __global__ void dropout_mask_kernel(float *__restrict__ out, MaskSegments seg, uint64_t seed, uint64_t stream_id,
                                     const uint64_t *__restrict__ dev_stream_id) {
+    TraceScope trace_scope(TK_DROPOUT);
     const size_t n = seg.end[2];
     const size_t nquad = (n + 3) / 4;
     if (dev_stream_id) stream_id = dev_stream_id[0];
@@ -218,6 +221,7 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 // ------------------------------------------------------------------------------------------
 
 __global__ void prologue_kernel(PrologueArgs a) {
+    TraceScope trace_scope(TK_PROLOGUE);
     const int64_t total = a.end[9];
     const int H = a.H;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -281,6 +285,7 @@ int step_prologue(const PrologueArgs &args, hipStream_t stream) {
 
 // g_w_o2h[row, original column] += dwo_perm[row, S-order column]
 __global__ void unpermute_add_kernel(const float *__restrict__ dwo_perm, float *__restrict__ g_w_o2h, int H) {
+    TraceScope trace_scope(TK_UNPERMUTE);
     const int n = H * 4 * H;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int row = i / (4 * H), col = i % (4 * H);
@@ -314,6 +319,7 @@ __device__ __forceinline__ int conv_kernel_size(int i, int K3) { return i == 0 ?
 // cells per blockIdx.y, a thread per feature f; the extra last row writes the replicated bias.  All index
 // arithmetic that involves a division is block- or loop-uniform (scalar): the kernel is a pure store stream.
 __global__ void toeplitz_build_kernel(ToeplitzArgs a, float *__restrict__ wt, float *__restrict__ bias_rep) {
+    TraceScope trace_scope(TK_TOEPLITZ_BUILD);
     const int G = a.G, C = a.C, Co = a.Co, F = 3 * Co, N = G * G * F, J = G * G * C;
     const int j = blockIdx.x;
     const int cell = j / C, ch = j - cell * C, r2 = cell / G, c2 = cell - r2 * G;
@@ -357,6 +363,7 @@ struct ToeplitzGradArgs {
     int wcount[3];
 };
 __global__ void toeplitz_fold_kernel(ToeplitzGradArgs a, const float *__restrict__ dwt, const float *__restrict__ dfeat) {
+    TraceScope trace_scope(TK_TOEPLITZ_FOLD);
     const int G = a.G, C = a.C, Co = a.Co, F = 3 * Co, N = G * G * F;
     if ((int)blockIdx.x < a.nw_blocks) {
         int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -403,5 +410,7 @@ int toeplitz_fold(float *const (&gw)[3], float *const (&gb)[3], int G, int C, in
     GSCAN_LAUNCHED("toeplitz_fold_kernel");
     return 0;
 }
+
+GSCAN_TRACE_TU(elementwise)
 
 }  // namespace gscan

@@ -179,11 +179,21 @@ struct PanelIter {
     }
 };
 
+#ifdef GSCAN_GEMM_STAMPS   // experiment build: cycle stamps of one workgroup's life, in the tail of the trace buffer
+#define GST(i) { const long long n_ = clock64(); gst_acc[i] += (unsigned)(n_ - gst_prev); gst_prev = n_; }
+#else
+#define GST(i)
+#endif
+
 template <int TMW, int BK, int KCA, int KCB, int VWA, int VWB>
 __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float (&lds_a)[2][TileM<TMW, BK>::A_FLOATS],
                                           float (&lds_b)[2][b_floats<BK>()]) {
     constexpr int BM = TileM<TMW, BK>::BM, LDR_A = TileM<TMW, BK>::LDR_A;
     constexpr int LDK = BK + 4;
+#ifdef GSCAN_GEMM_STAMPS
+    unsigned gst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long gst_prev = clock64();
+#endif
     const int bz = local / g.tiles_mn, rem = local % g.tiles_mn;
     // Tile order inside a problem: M tiles slowest by default; N tiles slowest (flag 16) when B is the larger operand,
     // so that an XCD's contiguous share of the tiles reads a slice of the LARGE operand and all of the small one.
@@ -217,11 +227,14 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
     const int fb = pb.is_kc() ? (wn * 16 * TNW + fr) * LDK + 8 * fg : (8 * fg) * LDR_B + wn * 16 * TNW + TNW * fr;
 
     float ra[BM * BK / 256], rb[BN * BK / 256];
+    GST(0)                                   // index math and iterator set-up
     uint32_t ma = pa.load(ra, kbeg);
     uint32_t mb = pb.load(rb, kbeg);
+    GST(1)                                   // first loads issued
     pa.template store<LDR_A>(lds_a[0], ra, ma, tid);
     pb.template store<LDR_B>(lds_b[0], rb, mb, tid);
     __syncthreads();
+    GST(2)                                   // first panels landed and staged
 
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -230,6 +243,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
             ma = pa.load(ra, k0 + BK);
             mb = pb.load(rb, k0 + BK);
         }
+        GST(3)
 #pragma unroll
         for (int kh = 0; kh < BK; kh += 32) {
         const float *la = lds_a[buf] + fa + (pa.is_kc() ? kh : kh * LDR_A), *lb = lds_b[buf] + fb + (pb.is_kc() ? kh : kh * LDR_B);
@@ -294,11 +308,14 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
             asum += (t0 + t1) + (t2 + t3);
         }
         }
+        GST(4)                               // fragment reads + MFMAs
         if (more) {
             pa.template store<LDR_A>(lds_a[buf ^ 1], ra, ma, tid);
             pb.template store<LDR_B>(lds_b[buf ^ 1], rb, mb, tid);
         }
+        GST(5)                               // wait for the next panels + LDS stores
         __syncthreads();
+        GST(6)
         buf ^= 1;
     }
 
@@ -352,10 +369,16 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
                 }
             }
         }
+    GST(7)                                   // epilogue
+#ifdef GSCAN_GEMM_STAMPS
+    if (g_trace_buf && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) g_trace_buf[1500 + i] += gst_acc[i];
+#endif
 }
 
 template <int TMW, int BK>
 __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
+    TraceScope trace_scope(TK_GEMM);
     constexpr int A_FLOATS = TileM<TMW, BK>::A_FLOATS, B_FLOATS = b_floats<BK>();
     int pi = 0;
 #pragma unroll
@@ -488,5 +511,7 @@ int gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int6
               alpha);
     return batch.launch(stream);
 }
+
+GSCAN_TRACE_TU(gemm)
 
 }  // namespace gscan

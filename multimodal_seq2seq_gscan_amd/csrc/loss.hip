@@ -81,6 +81,7 @@ int position_nll(const float *aux, const int64_t *pos, int B, int M, float *loss
 __global__ void step_losses_kernel(const float *__restrict__ logp, const int64_t *__restrict__ targets,
                                    const float *__restrict__ aux, const int64_t *__restrict__ pos, int B, int T, int V,
                                    int M, int pad, float *stats, float *__restrict__ dlogp, float *__restrict__ daux) {
+    TraceScope trace_scope(TK_LOSS);
     __shared__ float s_sum[16], s_cnt[16], s_aux[16];
     float acc = 0.f, cnt = 0.f, acc_aux = 0.f;
     const int n = B * T;
@@ -120,6 +121,7 @@ int step_losses(const float *logp, const int64_t *targets, const float *aux, con
 
 // seeds[0] = 1/tokens, seeds[1] = w/rows, seeds[2] = loss = sum NLL / tokens (+ w * sum aux NLL / rows)
 __global__ void loss_seeds_kernel(const float *stats, float w, int auxiliary, float *seeds) {
+    TraceScope trace_scope(TK_LOSS);
     if (threadIdx.x == 0) {
         const float s0 = 1.f / stats[1];
         const float s1 = auxiliary ? w / stats[3] : 0.f;
@@ -170,5 +172,7 @@ int sequence_metrics(const float *logp, const int64_t *targets, int B, int T, in
     GSCAN_LAUNCHED("sequence_metrics_kernel");
     return 0;
 }
+
+GSCAN_TRACE_TU(loss)
 
 }  // namespace gscan

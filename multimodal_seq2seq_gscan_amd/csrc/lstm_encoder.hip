@@ -72,6 +72,7 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
                                         float *__restrict__ h_final, float *__restrict__ gates,
                                         float *__restrict__ cells, float *__restrict__ hprev,
                                         const float *__restrict__ w_image) {
+    TraceScope trace_scope(TK_ENCODER_FWD);
     constexpr int R = EncShape<HE>::R, NT = 4 * HE / R;              // owning threads
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x, nthr = blockDim.x;
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_ke
                                         const float *__restrict__ gates, const float *__restrict__ cells,
                                         const float *__restrict__ d_out, const float *__restrict__ d_h_final,
                                         float *__restrict__ delta) {
+    TraceScope trace_scope(TK_ENCODER_BWD);
     constexpr int R = EncShape<HE>::R, KQ = HE / R, NT = 4 * KQ;
     static_assert(HE % R == 0, "hidden size must divide by the columns per thread");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -335,5 +337,7 @@ int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, c
     }
     GSCAN_CHECK(false, "encoder_hidden_size %d has no compiled kernel (supported: 20 32 64 100 128)", He);
 }
+
+GSCAN_TRACE_TU(lstm_encoder)
 
 }  // namespace gscan

@@ -130,6 +130,13 @@ void adam_scalars(float lr, float beta1, float beta2, float lr_decay, float lr_d
 int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream);
 int dropout_masks(float *out, const size_t (&n)[3], const float (&p)[3], uint64_t seed, uint64_t stream_id,
                   const uint64_t *dev_stream_id, hipStream_t stream);
+// in-kernel timeline (common.h): one setter per translation unit with kernels
+int trace_set_gemm(unsigned long long *buf);
+int trace_set_elementwise(unsigned long long *buf);
+int trace_set_loss(unsigned long long *buf);
+int trace_set_lstm_encoder(unsigned long long *buf);
+int trace_set_decoder(unsigned long long *buf);
+int trace_set_attention_grad(unsigned long long *buf);
 
 // loss.hip
 int step_losses(const float *logp, const int64_t *targets, const float *aux, const int64_t *pos, int B, int T, int V,

@@ -1,6 +1,6 @@
 """Development aid: build experimental copies of libgscan_hip.so that differ in -D flags for one source file.
 
-    python tools/variants.py name1:decoder.hip:-DFOO=1 name2:gemm.hip:-DBAR=2,-DBAZ ...
+    python tools/variants.py name1:decoder.hip:-DFOO=1 name2:gemm.hip:-DBAR=2,-DBAZ name3:all:-DQUX ...
 
 Each variant relinks the objects of the normal build with the one recompiled source and lands in
 variants/libgscan_hip.<name>.so (git-ignored; it travels with gpurun).  Select one at run time with
@@ -24,14 +24,21 @@ def main():
     procs = []
     for spec in sys.argv[1:]:
         name, src, flags = (spec.split(":") + [""])[:3]
-        obj = os.path.join(OUT, f"{name}.{src.replace('.hip', '.o')}")
-        cmd = [hipcc, *B.FLAGS, *[f for f in flags.split(",") if f], "-c", os.path.join(B.CSRC, src), "-o", obj]
-        procs.append((name, src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
-    for name, src, obj, p in procs:
-        out, err = p.communicate()
-        if p.returncode != 0:
-            raise SystemExit(f"{name}: hipcc failed\n{err}")
-        objs = [obj if s == src else os.path.join(B.OBJ, s.replace(".hip", ".o")) for s in B.SOURCES]
+        srcs = B.SOURCES if src == "all" else [src]          # "all": every source with the flags
+        jobs = []
+        for one in srcs:
+            obj = os.path.join(OUT, f"{name}.{one.replace('.hip', '.o')}")
+            cmd = [hipcc, *B.FLAGS, *[f for f in flags.split(",") if f], "-c", os.path.join(B.CSRC, one), "-o", obj]
+            jobs.append((one, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        procs.append((name, jobs))
+    for name, jobs in procs:
+        built = {}
+        for one, obj, p in jobs:
+            out, err = p.communicate()
+            if p.returncode != 0:
+                raise SystemExit(f"{name}: hipcc failed\n{err}")
+            built[one] = obj
+        objs = [built.get(s, os.path.join(B.OBJ, s.replace(".hip", ".o"))) for s in B.SOURCES]
         lib = os.path.join(OUT, f"libgscan_hip.{name}.so")
         subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib], check=True)
         print(lib)
