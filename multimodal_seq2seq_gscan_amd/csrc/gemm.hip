@@ -380,17 +380,27 @@ template <int TMW, int BK>
 __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
     TraceScope trace_scope(TK_GEMM);
     constexpr int A_FLOATS = TileM<TMW, BK>::A_FLOATS, B_FLOATS = b_floats<BK>();
-    int pi = 0;
+    // two scalar-load round trips before the first global load: the header (unused entries hold INT_MAX), then the
+    // problem's whole descriptor by value
+    int pi = 0, first = grp.tile_begin[0], per = grp.xcd_per[0];
 #pragma unroll
     for (int i = 1; i < kMaxGroup; ++i)
-        if (i < grp.count && (int)blockIdx.x >= grp.p[i].tile_begin) pi = i;
-    const GemmProblem &g = grp.p[pi];
+        if ((int)blockIdx.x >= grp.tile_begin[i]) { pi = i; first = grp.tile_begin[i]; per = grp.xcd_per[i]; }
+    asm volatile("" : "+s"(pi), "+s"(first));                 // selected from the header's registers
+    GemmProblem g = grp.p[pi];
+    // every field is wanted NOW (one batch of scalar loads, one wait), not each at its first use behind the
+    // previous one's wait
+    asm volatile("" : "+s"(g.M), "+s"(g.N), "+s"(g.K), "+s"(g.alpha), "+s"(g.beta), "+s"(g.a), "+s"(g.sam), "+s"(g.sak),
+                      "+s"(g.b), "+s"(g.sbk), "+s"(g.sbn), "+s"(g.c), "+s"(g.ldc));
+    asm volatile("" : "+s"(g.bias), "+s"(g.act), "+s"(g.mask), "+s"(g.gate), "+s"(g.k_chunk), "+s"(g.atomic),
+                      "+s"(g.asum1), "+s"(g.asum2), "+s"(g.tiles_n), "+s"(g.tiles_mn), "+s"(g.nsplit), "+s"(g.flags),
+                      "+s"(per));
     // XCD-aware order (GSCAN_GEMM_XCD=0 disables): workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.
     // Workgroup l of a problem takes tile (l % 8) * per + l / 8, so an XCD works on one contiguous eighth of the
     // tile space and its L2 sees each operand panel of that eighth once.
-    int local = blockIdx.x - g.tile_begin;
-    if (grp.xcd_per[pi] > 0) {
-        const int per = grp.xcd_per[pi], x = local & 7, j = local >> 3;
+    int local = blockIdx.x - first;
+    if (per > 0) {
+        const int x = local & 7, j = local >> 3;
         local = x * per + j;
         if (j >= per || local >= g.tiles_mn * g.nsplit) return;
     }
@@ -456,7 +466,7 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
     }
     GemmProblem &p = grp_.p[grp_.count++];
     p = GemmProblem{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, gate, chunk,
-                    split_k > 1 ? 1 : 0, asum1, asum2, 0, 0, 0, 0, flags};   // tile bookkeeping: at launch
+                    split_k > 1 ? 1 : 0, asum1, asum2, 0, 0, 0, flags};   // tile bookkeeping: at launch
     tiles_ += cdiv(N, BN) * cdiv(M, 64) * split_k;                            // in 64-row tiles
     flops_ += 2.0 * M * N * K;
 }
@@ -475,13 +485,14 @@ int GemmBatch::launch(hipStream_t stream) {
     static const int xcd = [] { const char *e = getenv("GSCAN_GEMM_XCD"); return e ? atoi(e) : 1; }();   // on by default
     static const int order = [] { const char *e = getenv("GSCAN_GEMM_ORDER"); return e ? atoi(e) : 1; }();
     int total = 0;
+    for (int i = 0; i < kMaxGroup; ++i) grp_.tile_begin[i] = INT_MAX;
     for (int i = 0; i < grp_.count; ++i) {
         GemmProblem &p = grp_.p[i];
         p.tiles_n = cdiv(p.N, BN);
         p.tiles_mn = p.tiles_n * cdiv(p.M, 32 * tmw);
         p.nsplit = cdiv(p.K, p.k_chunk);
         if (order && p.nsplit == 1 && p.N > p.M) p.flags |= 16;
-        p.tile_begin = total;
+        grp_.tile_begin[i] = total;
         const int n = p.tiles_mn * p.nsplit;
         grp_.xcd_per[i] = (xcd && n >= 16) ? cdiv(n, 8) : 0;
         total += grp_.xcd_per[i] ? 8 * grp_.xcd_per[i] : n;

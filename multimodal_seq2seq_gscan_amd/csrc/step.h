@@ -21,10 +21,13 @@ struct GemmProblem {
     const float *mask, *gate;             // elementwise, same indexing as C
     int k_chunk, atomic;                  // K range per k-slice; split-K accumulates with atomics
     float *asum1, *asum2;                 // optional: += sum_k A(m,k) (bias gradients)
-    int tiles_n, tiles_mn, tile_begin, nsplit;   // grid bookkeeping
+    int tiles_n, tiles_mn, nsplit;        // grid bookkeeping (the first workgroup id is in GemmGroup::tile_begin)
     int flags;                            // log2(floats per global load) of A | of B << 2
 };
-struct GemmGroup { int count; int xcd_per[kMaxGroup]; GemmProblem p[kMaxGroup]; };
+// tile_begin / xcd_per lead the kernel arguments as one contiguous header: a workgroup finds its problem with ONE
+// batch of scalar loads and fetches that problem's descriptor with a second one (the scan used to walk the
+// descriptors: six dependent scalar-load round trips, ~1500 cycles, before the first global load could be issued).
+struct GemmGroup { int count; int tile_begin[kMaxGroup]; int xcd_per[kMaxGroup]; GemmProblem p[kMaxGroup]; };
 
 // Builder for one grouped launch of independent products.
 class GemmBatch {
