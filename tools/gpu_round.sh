@@ -19,5 +19,11 @@ python tools/pmc_traffic.py "$(find $out/pmc_f -name '*counter_collection.csv' |
 cat "$out/pmc_traffic.json"
 cp "$(find $out/prof -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
 head -12 "$out/kernel_stats.csv"
+# timeline of an undisturbed step from in-kernel clock stamps (needs: python tools/variants.py trace:all:-DGSCAN_TRACE)
+if [ -f variants/libgscan_hip.trace.so ]; then
+  python tools/device_timeline.py > "$out/device_timeline_three_streams.txt" 2>&1
+  python tools/device_timeline.py --single-stream > "$out/device_timeline_single_stream.txt" 2>&1
+  tail -3 "$out/device_timeline_three_streams.txt"
+fi
 # raw traces are large: keep only the summaries
 rm -rf "$out/prof" "$out/pmc_f" "$out/pmc_w" "$out/pmc_m"
