@@ -1,0 +1,107 @@
+"""Size-independent properties of the HIP training step at the benchmark's full size (256 rows, 6x6x16 grid, hidden
+100, T = 20; BASELINE.json configs[1]), where the CPU oracle is too slow to be the checker:
+
+  * rows do not interact: permuting the batch permutes the log-probabilities bit for bit and leaves loss and gradients
+    unchanged (up to the summation order of the loss and of the split-K atomics);
+  * a row computed alone, or in a small batch, has the log-probabilities it has in the full batch;
+  * padding is inert: extra PAD columns on the targets or the commands change neither the loss nor the live
+    log-probabilities (the reference masks by length, seq2seq_model.py:62-88,129-137, and ignores PAD targets,
+    model.py:100);
+  * the backward pass is linear in the upstream gradient.
+
+Run: pytest -m gpu."""
+import pytest
+import torch
+
+from multimodal_seq2seq_gscan_amd.config import model_kwargs
+from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+
+pytestmark = pytest.mark.gpu
+PAD = 0
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from multimodal_seq2seq_gscan_amd.model import Model
+    torch.manual_seed(7)
+    cfg = model_kwargs("compositional", auxiliary_task=True)
+    model = Model(**cfg).cuda().eval()
+    batch = make_batch(Shape(batch=256, ragged=True), seed=11)
+    return model, batch
+
+
+def flat_grad(model):
+    return torch.cat([p.grad.detach().flatten() for _, p in model.named_parameters()]).cpu()
+
+
+def step(model, batch, rows=None, weight=0.3):
+    b = batch if rows is None else {k: v[rows] for k, v in batch.items()}
+    d = {k: v.cuda() for k, v in b.items()}
+    model.zero_grad()
+    logp, aux = model(commands_input=d["commands"], commands_lengths=b["cmd_lengths"].tolist(),
+                      situations_input=d["world"], target_batch=d["targets"], target_lengths=b["tgt_lengths"].tolist())
+    loss = model.get_loss(logp, d["targets"]) + weight * model.get_auxiliary_loss(aux, d["target_positions"])
+    loss.backward()
+    torch.cuda.synchronize()
+    return logp.detach().cpu(), aux.detach().cpu(), loss.item(), flat_grad(model)
+
+
+def test_batch_permutation(setup):
+    model, batch = setup
+    logp, aux, loss, grad = step(model, batch)
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(3))
+    logp_p, aux_p, loss_p, grad_p = step(model, batch, rows=perm)
+    assert torch.equal(logp_p, logp[perm]), "a row's log-probabilities depend on its position in the batch"
+    assert torch.equal(aux_p, aux[perm])
+    assert abs(loss_p - loss) < 1e-5
+    assert (grad_p - grad).abs().max().item() < 1e-5 + 1e-4 * grad.abs().max().item()
+
+
+def test_rows_are_independent_of_the_batch_they_sit_in(setup):
+    model, batch = setup
+    logp, aux, _, _ = step(model, batch)
+    for rows in (torch.tensor([0]), torch.tensor([5, 17, 200]), torch.arange(100, 133)):
+        sub = {k: v[rows] for k, v in batch.items()}
+        # the sub-batch keeps the full padded widths, so only the batch size changes
+        logp_s, aux_s, _, _ = step(model, sub)
+        assert (logp_s - logp[rows]).abs().max().item() < 2e-6
+        assert (aux_s - aux[rows]).abs().max().item() < 2e-6
+
+
+def test_padding_is_inert(setup):
+    model, batch = setup
+    logp, aux, loss, grad = step(model, batch, weight=0.0)
+    T, L = batch["targets"].shape[1], batch["commands"].shape[1]
+    wide = dict(batch)
+    wide["targets"] = torch.cat([batch["targets"], torch.full((256, 4), PAD, dtype=torch.long)], dim=1)
+    wide["commands"] = torch.cat([batch["commands"], torch.full((256, 2), PAD, dtype=torch.long)], dim=1)
+    logp_w, aux_w, loss_w, grad_w = step(model, wide, weight=0.0)
+    assert logp_w.shape[1] == T + 4 and wide["commands"].shape[1] == L + 2
+    # positions whose target is a live token: identical up to the changed GEMM tiling of the wider products
+    live = torch.arange(T).unsqueeze(0) < (batch["tgt_lengths"] - 1).unsqueeze(1)
+    assert (logp_w[:, :T][live] - logp[live]).abs().max().item() < 1e-5
+    assert abs(loss_w - loss) < 1e-5
+    assert (grad_w - grad).abs().max().item() < 1e-5 + 1e-4 * grad.abs().max().item()
+    # the auxiliary head sums the visual attention over ALL decoder steps, padded ones included (seq2seq_model.py:479,
+    # model.py:205): wider targets change it in the reference too, so the auxiliary term is left out here (weight 0)
+
+
+def test_backward_is_linear_in_the_upstream_gradient(setup):
+    model, batch = setup
+    d = {k: v.cuda() for k, v in batch.items()}
+
+    def grad_for(scale_logp, scale_aux):
+        model.zero_grad()
+        logp, aux = model(commands_input=d["commands"], commands_lengths=batch["cmd_lengths"].tolist(),
+                          situations_input=d["world"], target_batch=d["targets"],
+                          target_lengths=batch["tgt_lengths"].tolist())
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        up_logp = torch.randn(logp.shape, device="cuda", generator=gen) * 1e-3
+        up_aux = torch.randn(aux.shape, device="cuda", generator=gen) * 1e-3
+        torch.autograd.backward([logp, aux], [scale_logp * up_logp, scale_aux * up_aux])
+        torch.cuda.synchronize()
+        return flat_grad(model)
+
+    g10, g01, g23 = grad_for(1.0, 0.0), grad_for(0.0, 1.0), grad_for(2.0, 3.0)
+    ref = 2.0 * g10 + 3.0 * g01
+    assert (g23 - ref).abs().max().item() < 1e-6 + 1e-4 * ref.abs().max().item()
