@@ -89,38 +89,53 @@ def lstm_cell(x_proj: torch.Tensor, h: torch.Tensor, c: torch.Tensor, w_hh: torc
 # a2  EncoderRNN.forward                  seq2seq/seq2seq_model.py:47-89
 # ----------------------------------------------------------------------------------
 def command_encoder(p: Params, tokens: torch.Tensor, lengths, bidirectional: bool = True,
-                    mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                    mask: Optional[torch.Tensor] = None, layer_masks: Optional[Sequence[torch.Tensor]] = None,
+                    ) -> Tuple[torch.Tensor, torch.Tensor]:
     """tokens [B,L] -> (final hidden [B,He], per-step outputs [B,L,He]).
 
     The reference sorts, packs, runs nn.LSTM and unpacks (:62-88).  Equivalent
     statement used here: each direction walks only the first len_b tokens of row b
     (the reverse direction starts at token len_b-1), outputs at padded positions
-    are zero, and the two directions are summed (:77-80).
+    are zero, and the two directions are summed (:77-80).  With more than one layer
+    (nn.LSTM(num_layers=n), :44-45) the input of layer l+1 is the concatenation
+    [forward | reverse] of layer l's outputs, dropped out in training
+    (``layer_masks[l]``: scaled keep mask [B,L,D*He]); the direction sums and the
+    final hidden state are taken from the LAST layer only (:76-82).
     """
     B, L = tokens.shape
     lens = _lengths(lengths, tokens.device)
-    emb = p["encoder.embedding.weight"][tokens]                    # padding row is zero at init
+    x = p["encoder.embedding.weight"][tokens]                      # padding row is zero at init
     if mask is not None:
-        emb = emb * mask.view_as(emb)
+        x = x * mask.view_as(x)
     He = p["encoder.lstm.weight_hh_l0"].shape[1]
-    out = torch.zeros(B, L, He, dtype=emb.dtype)
-    hN = torch.zeros(B, He, dtype=emb.dtype)
-    for suffix in ([""] + (["_reverse"] if bidirectional else [])):
-        w_ih = p[f"encoder.lstm.weight_ih_l0{suffix}"]
-        w_hh = p[f"encoder.lstm.weight_hh_l0{suffix}"]
-        b = p[f"encoder.lstm.bias_ih_l0{suffix}"] + p[f"encoder.lstm.bias_hh_l0{suffix}"]
-        xp = emb @ w_ih.t() + b
-        h = torch.zeros(B, He, dtype=emb.dtype)
-        c = torch.zeros(B, He, dtype=emb.dtype)
-        steps = range(L - 1, -1, -1) if suffix else range(L)
-        for t in steps:
-            live = (t < lens).to(emb.dtype).unsqueeze(1)
-            h2, c2, _ = lstm_cell(xp[:, t], h, c, w_hh)
-            h = live * h2 + (1 - live) * h
-            c = live * c2 + (1 - live) * c
-            out[:, t] = out[:, t] + live * h2
-        hN = hN + h
-    return hN, out
+    layers = 1
+    while f"encoder.lstm.weight_hh_l{layers}" in p:
+        layers += 1
+    suffixes = [""] + (["_reverse"] if bidirectional else [])
+    for layer in range(layers):
+        per_dir, finals = [], []
+        for suffix in suffixes:
+            w_ih = p[f"encoder.lstm.weight_ih_l{layer}{suffix}"]
+            w_hh = p[f"encoder.lstm.weight_hh_l{layer}{suffix}"]
+            b = p[f"encoder.lstm.bias_ih_l{layer}{suffix}"] + p[f"encoder.lstm.bias_hh_l{layer}{suffix}"]
+            xp = x @ w_ih.t() + b
+            h = torch.zeros(B, He, dtype=x.dtype)
+            c = torch.zeros(B, He, dtype=x.dtype)
+            out = torch.zeros(B, L, He, dtype=x.dtype)
+            steps = range(L - 1, -1, -1) if suffix else range(L)
+            for t in steps:
+                live = (t < lens).to(x.dtype).unsqueeze(1)
+                h2, c2, _ = lstm_cell(xp[:, t], h, c, w_hh)
+                h = live * h2 + (1 - live) * h
+                c = live * c2 + (1 - live) * c
+                out[:, t] = live * h2
+            per_dir.append(out)
+            finals.append(h)
+        if layer + 1 < layers:
+            x = torch.cat(per_dir, dim=2)
+            if layer_masks is not None and layer_masks[layer] is not None:
+                x = x * layer_masks[layer].view_as(x)
+    return sum(finals), sum(per_dir)
 
 
 # ----------------------------------------------------------------------------------

@@ -73,8 +73,25 @@ def save(name: str, arrays: dict):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def deep_encoder_case():
+    """Two encoder layers (nn.LSTM(num_layers=2), seq2seq_model.py:44-45,76-82): demo dims, all gradients."""
+    cfg = model_kwargs("demo", num_encoder_layers=2, auxiliary_task=True)
+    shape = Shape(batch=5, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=7, max_target=9,
+                  ragged=True)
+    _, out, grads = run_case(cfg, shape, seed_weights=17, seed_data=27)
+    out.update({"grad/" + k: v for k, v in grads.items()})
+    save("demo_enc2.npz", out)
+    cfg = model_kwargs("demo", num_encoder_layers=3, conditional_attention=False, encoder_bidirectional=False)
+    _, out, grads = run_case(cfg, shape, seed_weights=18, seed_data=28)
+    out.update({"grad/" + k: v for k, v in grads.items()})
+    save("demo_enc3_unidirectional.npz", out)
+
+
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "deep_encoder":      # add these fixtures without touching the others
+        deep_encoder_case()
+        return
     # ---- 1. demo dims, every head variant, all gradients -------------------------------------
     for cond in (True, False):
         for aux in (True, False):
@@ -165,6 +182,9 @@ def main():
     out.update(logp=logp.detach().numpy(), loss=np.float32(loss.item()), seed_weights=np.int64(15),
                mask_cnn=m_cnn.numpy(), mask_enc=m_enc.numpy(), mask_dec=m_dec.numpy())
     save("demo_dropout_hostmask.npz", out)
+
+    # ---- 6b. more than one encoder layer ---------------------------------------------------------
+    deep_encoder_case()
 
     # ---- 7. seeded initialisation (train.py:27,58-64) and published parameter totals --------
     init = {}

@@ -25,11 +25,13 @@ def parameter_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
     s["visual_attention.query_layer.weight"] = (H, H)
     s["visual_attention.energy_layer.weight"] = (1, H)
     s["encoder.embedding.weight"] = (Vi, E)
-    for suffix in ([""] + (["_reverse"] if cfg["encoder_bidirectional"] else [])):
-        s[f"encoder.lstm.weight_ih_l0{suffix}"] = (4 * He, E)
-        s[f"encoder.lstm.weight_hh_l0{suffix}"] = (4 * He, He)
-        s[f"encoder.lstm.bias_ih_l0{suffix}"] = (4 * He,)
-        s[f"encoder.lstm.bias_hh_l0{suffix}"] = (4 * He,)
+    D = 2 if cfg["encoder_bidirectional"] else 1
+    for layer in range(int(cfg.get("num_encoder_layers", 1))):         # nn.LSTM order: layer, then direction
+        for suffix in ([""] + (["_reverse"] if cfg["encoder_bidirectional"] else [])):
+            s[f"encoder.lstm.weight_ih_l{layer}{suffix}"] = (4 * He, E if layer == 0 else D * He)
+            s[f"encoder.lstm.weight_hh_l{layer}{suffix}"] = (4 * He, He)
+            s[f"encoder.lstm.bias_ih_l{layer}{suffix}"] = (4 * He,)
+            s[f"encoder.lstm.bias_hh_l{layer}{suffix}"] = (4 * He,)
     s["enc_hidden_to_dec_hidden.weight"] = (H, He)
     s["enc_hidden_to_dec_hidden.bias"] = (H,)
     s["textual_attention.key_layer.weight"] = (H, He)

@@ -23,6 +23,7 @@ def _check_case(name, cfg, grads="full"):
     batch = fixture_batch(fx)
     loss, g, logp = oracle.loss_and_grads(p, batch, conditional=cfg["conditional_attention"],
                                           auxiliary=cfg["auxiliary_task"],
+                                          bidirectional=cfg["encoder_bidirectional"],
                                           weight_target_loss=float(fx["weight_target_loss"]))
     assert torch.allclose(logp, torch.from_numpy(fx["logp"]), atol=TOL, rtol=0)
     assert abs(loss.item() - float(fx["loss"])) < TOL
@@ -53,6 +54,20 @@ def test_geca_aux():
 
 def test_target_length_t120():
     _check_case("target_length_t120.npz", model_kwargs("target_length"))
+
+
+DEEP_ENCODERS = {
+    "demo_enc2.npz": dict(num_encoder_layers=2, auxiliary_task=True),
+    "demo_enc3_unidirectional.npz": dict(num_encoder_layers=3, conditional_attention=False,
+                                         encoder_bidirectional=False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(DEEP_ENCODERS))
+def test_more_than_one_encoder_layer(name):
+    """nn.LSTM(num_layers=n): layer inputs are the concatenated directions of the layer below, the direction sums
+    and the final state come from the last layer (seq2seq_model.py:44-45,76-82)."""
+    _check_case(name, model_kwargs("demo", **DEEP_ENCODERS[name]))
 
 
 def test_dropout_host_masks():
