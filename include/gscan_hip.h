@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 5
+#define GSCAN_ABI_VERSION 6
+#define GSCAN_MAX_ENC_LAYERS 4
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
 typedef struct gscan_dims {
@@ -48,6 +49,7 @@ typedef struct gscan_dims {
     int32_t bidirectional; /* encoder_bidirectional                                */
     int32_t pad_in;        /* input_padding_idx                                    */
     int32_t pad_tgt;       /* target_pad_idx                                       */
+    int32_t enc_layers;    /* num_encoder_layers (0 or 1: one layer; at most GSCAN_MAX_ENC_LAYERS) */
 } gscan_dims;
 
 /* One pointer per reference parameter (named_parameters() order, seq2seq/model.py:47-87).
@@ -65,6 +67,11 @@ typedef struct gscan_params {
     float *dec_emb;
     float *dec_w_ih, *dec_w_hh, *dec_b_ih, *dec_b_hh;
     float *out2hid_w, *hid2out_w;
+    /* encoder layers 1.. (nn.LSTM(num_layers=n), seq2seq_model.py:44-45): per layer weight_ih [4He, D*He],
+     * weight_hh [4He, He], bias_ih, bias_hh, then the same four of the reverse direction; NULL where absent.
+     * enc_w_* above are layer 0.  (In named_parameters() order these sit right behind layer 0; they are at the
+     * end of this struct so that one-layer callers keep their field offsets.) */
+    float *enc_deep[GSCAN_MAX_ENC_LAYERS - 1][8];
 } gscan_params;
 
 /* The reference's batch tuple (seq2seq/gSCAN_dataset.py:229-231) as device arrays. */
@@ -78,10 +85,11 @@ typedef struct gscan_batch {
 } gscan_batch;
 
 /* Scaled dropout masks (0 or 1/(1-p)), or NULL for "no dropout" (eval mode / p = 0).
- * cnn [B,G*G,3*Co], enc [B,L,E], dec [B,T,H] in batch-row order.  The caller either draws
+ * cnn [B,G*G,3*Co], enc [B,L,E], dec [B,T,H] in batch-row order; enc_deep only with more than one encoder layer.  The caller either draws
  * them with gscan_dropout_mask() or supplies masks of its own (host-mask parity mode). */
 typedef struct gscan_masks {
     const float *cnn, *enc, *dec;
+    const float *enc_deep;   /* [enc_layers-1, B, L, D*He]: inputs of encoder layers 1.. (nn.LSTM's inter-layer dropout) */
 } gscan_masks;
 
 int         gscan_abi_version(void);

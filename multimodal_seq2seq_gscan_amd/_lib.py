@@ -11,14 +11,15 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # GSCAN_HIP_LIB: development override, used by tools/variants.py to time experimental builds side by side
 LIB_PATH = os.environ.get("GSCAN_HIP_LIB") or os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
+MAX_ENC_LAYERS = 4
 
 _f32p = C.POINTER(C.c_float)
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)
 
 DIM_FIELDS = ("B", "L", "T", "G", "C", "Co", "K3", "E", "He", "H", "Vi", "V", "conditional", "auxiliary",
-              "bidirectional", "pad_in", "pad_tgt")
+              "bidirectional", "pad_in", "pad_tgt", "enc_layers")
 
 # (C field, reference state_dict name) in named_parameters() order; see include/gscan_hip.h
 PARAM_FIELDS = (
@@ -48,8 +49,13 @@ class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in DIM_FIELDS]
 
 
+# encoder layers 1..: (slot in gscan_params.enc_deep[layer-1], state_dict name pattern)
+ENC_DEEP_FIELDS = ("weight_ih_l{}", "weight_hh_l{}", "bias_ih_l{}", "bias_hh_l{}", "weight_ih_l{}_reverse",
+                   "weight_hh_l{}_reverse", "bias_ih_l{}_reverse", "bias_hh_l{}_reverse")
+
+
 class Params(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n, _ in PARAM_FIELDS]
+    _fields_ = [(n, C.c_void_p) for n, _ in PARAM_FIELDS] + [("enc_deep", (C.c_void_p * 8) * (MAX_ENC_LAYERS - 1))]
 
 
 class Batch(C.Structure):
@@ -58,7 +64,7 @@ class Batch(C.Structure):
 
 
 class Masks(C.Structure):
-    _fields_ = [("cnn", C.c_void_p), ("enc", C.c_void_p), ("dec", C.c_void_p)]
+    _fields_ = [("cnn", C.c_void_p), ("enc", C.c_void_p), ("dec", C.c_void_p), ("enc_deep", C.c_void_p)]
 
 
 _vp, _i, _f, _sz, _i64, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64, C.c_uint64

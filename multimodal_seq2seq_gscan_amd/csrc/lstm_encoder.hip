@@ -62,6 +62,9 @@ inline size_t encoder_fwd_lds(int L, int HE) { return ((size_t)L * 6 * HE + HE) 
 inline size_t encoder_bwd_lds(int L, int HE) { return ((size_t)L * 6 * HE + 4 * HE) * sizeof(float); }
 
 // grid (B, D): the two directions of a row run as two workgroups (they only meet in the sums below).
+// The LAST encoder layer passes `out` / `h_final` (direction sums), a layer below it passes `hcat` instead: its h per
+// direction, [B, L, D*He] = the next layer's input (nn.LSTM concatenates the directions), times `hcat_mask` (the
+// inter-layer dropout, or NULL), zero at padded positions.
 // `out` and `h_final` must be zero on entry: each direction ADDS its h (0 + h_f + h_r in either order is the same
 // float: two-operand addition commutes), which is how the directions are summed (seq2seq_model.py:77-81).
 // Thread j < 4He/R owns gate rows j + r*(4He/R), r < R  (R = 2: [i | f] rows and the matching [g | o] rows).
@@ -71,7 +74,8 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
                                         const float *__restrict__ b_hh_r, float *__restrict__ out,
                                         float *__restrict__ h_final, float *__restrict__ gates,
                                         float *__restrict__ cells, float *__restrict__ hprev,
-                                        const float *__restrict__ w_image) {
+                                        const float *__restrict__ w_image, float *__restrict__ hcat,
+                                        const float *__restrict__ hcat_mask) {
     TraceScope trace_scope(TK_ENCODER_FWD);
     constexpr int R = EncShape<HE>::R, NT = 4 * HE / R;              // owning threads
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
     for (int idx = j; idx < (L - len) * HE; idx += nthr) {
         const int t = len + idx / HE, k = idx % HE;
         hprev[((row0 + t) * D + dir) * HE + k] = 0.f;
+        if (hcat) hcat[((row0 + t) * D + dir) * HE + k] = 0.f;
     }
     // register image [dir][r][k][thread]: consecutive lanes read consecutive floats (a row per lane straight from
     // W_hh would touch 64 cache lines per load)
@@ -147,9 +152,10 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
         const bool first = dir ? (t == len - 1) : (t == 0);
         cells[row * HE + k] = c_s[idx];
         hprev[row * HE + k] = first ? 0.f : h_s[(dir ? t + 1 : t - 1) * HE + k];
-        atomicAdd(out + (row0 + t) * HE + k, h_s[idx]);
+        if (out) atomicAdd(out + (row0 + t) * HE + k, h_s[idx]);
+        if (hcat) hcat[row * HE + k] = hcat_mask ? h_s[idx] * hcat_mask[row * HE + k] : h_s[idx];
     }
-    if (is_unit && len > 0) atomicAdd(h_final + (int64_t)b * HE + j, h_s[(dir ? 0 : len - 1) * HE + j]);
+    if (h_final && is_unit && len > 0) atomicAdd(h_final + (int64_t)b * HE + j, h_s[(dir ? 0 : len - 1) * HE + j]);
 }
 
 // Backward: thread (seg, q) owns columns q + r*(He/R), r < R, of block seg of W_hh (its R dot products share the
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_ke
                                         const float *__restrict__ w_hh_f, const float *__restrict__ w_hh_r,
                                         const float *__restrict__ gates, const float *__restrict__ cells,
                                         const float *__restrict__ d_out, const float *__restrict__ d_h_final,
-                                        float *__restrict__ delta) {
+                                        float *__restrict__ delta, int d_out_row, int d_out_dir,
+                                        const float *__restrict__ d_out_mask) {
     TraceScope trace_scope(TK_ENCODER_BWD);
     constexpr int R = EncShape<HE>::R, KQ = HE / R, NT = 4 * KQ;
     static_assert(HE % R == 0, "hidden size must divide by the columns per thread");
@@ -181,10 +188,18 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_ke
         const int t = idx / (HE / 4), k4 = idx - t * (HE / 4);
         *reinterpret_cast<float4 *>(c_s + t * HE + 4 * k4) =
             *reinterpret_cast<const float4 *>(cells + ((row0 + t) * D + dir) * HE + 4 * k4);
-        *reinterpret_cast<float4 *>(o_s + t * HE + 4 * k4) =
-            *reinterpret_cast<const float4 *>(d_out + (row0 + t) * HE + 4 * k4);
+        // gradient wrt this direction's h_t: the shared sum [B,L,He] for the last layer (row stride He, direction
+        // offset 0), the direction's half of d(next layer's input) [B,L,D*He] times the dropout mask below it
+        const int64_t at = (row0 + t) * d_out_row + dir * d_out_dir + 4 * k4;
+        float4 g4 = *reinterpret_cast<const float4 *>(d_out + at);
+        if (d_out_mask) {
+            const float4 m4 = *reinterpret_cast<const float4 *>(d_out_mask + at);
+            g4 = float4{g4.x * m4.x, g4.y * m4.y, g4.z * m4.z, g4.w * m4.w};
+        }
+        *reinterpret_cast<float4 *>(o_s + t * HE + 4 * k4) = g4;
     }
-    for (int i = tid; i < 4 * HE; i += nthr) part_s[i] = (i < HE) ? d_h_final[(int64_t)b * HE + i] : 0.f;
+    for (int i = tid; i < 4 * HE; i += nthr)
+        part_s[i] = (i < HE && d_h_final) ? d_h_final[(int64_t)b * HE + i] : 0.f;
     for (int idx = tid; idx < (L - len) * HE; idx += nthr) {          // padded positions get delta = 0
         const int t = len + idx / HE, k4 = idx % HE;
         *reinterpret_cast<float4 *>(delta + ((row0 + t) * D + dir) * 4 * HE + 4 * k4) = float4{0.f, 0.f, 0.f, 0.f};
@@ -246,27 +261,27 @@ static int encoder_lds_attr(K kernel, size_t bytes, bool &attr_set) {
 template <int HE>
 static int launch_fwd(int B, int L, int D, const float *gx, const int32_t *lengths, const float *bf, const float *br,
                       float *out, float *hfin, float *gates, float *cells, float *hprev, const float *w_image,
-                      hipStream_t stream) {
+                      float *hcat, const float *hcat_mask, hipStream_t stream) {
     const int nt = EncShape<HE>::kThreads;
     static bool attr_set = false;
     if (int rc = encoder_lds_attr(encoder_lstm_fwd_kernel<HE>, encoder_fwd_lds(L, HE), attr_set)) return rc;
     // algorithmic work: the recurrent product h.W_hh^T per (row, step, direction); padded steps counted
     ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * HE * HE);
     hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B, D), dim3(nt), encoder_fwd_lds(L, HE), stream, L, D, gx, lengths,
-                       bf, br, out, hfin, gates, cells, hprev, w_image);
+                       bf, br, out, hfin, gates, cells, hprev, w_image, hcat, hcat_mask);
     GSCAN_LAUNCHED("encoder_lstm_fwd_kernel");
     return 0;
 }
 template <int HE>
 static int launch_bwd(int B, int L, int D, const int32_t *lengths, const float *wf, const float *wr,
                       const float *gates, const float *cells, const float *d_out, const float *d_hfin, float *delta,
-                      hipStream_t stream) {
+                      int d_out_row, int d_out_dir, const float *d_out_mask, hipStream_t stream) {
     const int nt = EncShape<HE>::kThreads;
     static bool attr_set = false;
     if (int rc = encoder_lds_attr(encoder_lstm_bwd_kernel<HE>, encoder_bwd_lds(L, HE), attr_set)) return rc;
     ProbeScope probe(P_ENCODER_BWD, stream, 2.0 * B * L * D * 4 * HE * HE);
     hipLaunchKernelGGL(encoder_lstm_bwd_kernel<HE>, dim3(B, D), dim3(nt), encoder_bwd_lds(L, HE), stream, L, D, lengths, wf,
-                       wr, gates, cells, d_out, d_hfin, delta);
+                       wr, gates, cells, d_out, d_hfin, delta, d_out_row, d_out_dir, d_out_mask);
     GSCAN_LAUNCHED("encoder_lstm_bwd_kernel");
     return 0;
 }
@@ -309,13 +324,15 @@ int encoder_rows_per_thread(int He) {
 
 int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths, const float *w_hh_f,
                          const float *b_hh_f, const float *w_hh_r, const float *b_hh_r, float *out, float *h_final,
-                         float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream) {
+                         float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream,
+                         float *hcat, const float *hcat_mask) {
     GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm: bad dims B=%d L=%d D=%d", B, L, D);
+    GSCAN_CHECK(hcat || (out && h_final), "encoder lstm: neither direction sums nor per-direction outputs requested");
     GSCAN_CHECK(D == 1 || (w_hh_r && b_hh_r), "encoder lstm: reverse weights missing");
     GSCAN_CHECK(w_image, "encoder lstm: weight image missing");
     GSCAN_CHECK(((uintptr_t)gx | (uintptr_t)gates) % 16 == 0, "encoder lstm: gx and gates must be 16-byte aligned");
     switch (He) {
-#define X(n) case n: return launch_fwd<n>(B, L, D, gx, lengths, b_hh_f, b_hh_r, out, h_final, gates, cells, hprev, w_image, stream);
+#define X(n) case n: return launch_fwd<n>(B, L, D, gx, lengths, b_hh_f, b_hh_r, out, h_final, gates, cells, hprev, w_image, hcat, hcat_mask, stream);
         GSCAN_HIDDEN_SIZES(X)
 #undef X
         default: break;
@@ -325,12 +342,16 @@ int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int
 
 int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_f,
                           const float *w_hh_r, const float *gates, const float *cells, const float *d_out,
-                          const float *d_h_final, float *delta, hipStream_t stream) {
+                          const float *d_h_final, float *delta, hipStream_t stream, int d_out_row, int d_out_dir,
+                          const float *d_out_mask) {
     GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm bwd: bad dims B=%d L=%d D=%d", B, L, D);
+    if (d_out_row == 0) d_out_row = He;                      // the last layer: one gradient for both directions
+    GSCAN_CHECK(d_out_row % 4 == 0 && d_out_dir % 4 == 0 && ((uintptr_t)d_out_mask % 16) == 0,
+                "encoder lstm bwd: d_out strides / mask must keep 16-byte alignment");
     GSCAN_CHECK(((uintptr_t)gates | (uintptr_t)cells | (uintptr_t)d_out | (uintptr_t)delta) % 16 == 0,
                 "encoder lstm bwd: gates, cells, d_out and delta must be 16-byte aligned");
     switch (He) {
-#define X(n) case n: return launch_bwd<n>(B, L, D, lengths, w_hh_f, w_hh_r, gates, cells, d_out, d_h_final, delta, stream);
+#define X(n) case n: return launch_bwd<n>(B, L, D, lengths, w_hh_f, w_hh_r, gates, cells, d_out, d_h_final, delta, d_out_row, d_out_dir, d_out_mask, stream);
         GSCAN_HIDDEN_SIZES(X)
 #undef X
         default: break;

@@ -156,12 +156,14 @@ int sequence_metrics(const float *logp, const int64_t *targets, int B, int T, in
 bool hidden_size_supported(int h);
 int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths, const float *w_hh_f,
                          const float *b_hh_f, const float *w_hh_r, const float *b_hh_r, float *out, float *h_final,
-                         float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream);
+                         float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream,
+                         float *hcat = nullptr, const float *hcat_mask = nullptr);
 int encoder_rows_per_thread(int He);   // rows of W_hh a thread of the forward kernel keeps (layout of its image)
 int encoder_weight_image(const float *w_hh_f, const float *w_hh_r, int He, int D, float *image, hipStream_t stream);
 int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_f,
                           const float *w_hh_r, const float *gates, const float *cells, const float *d_out,
-                          const float *d_h_final, float *delta, hipStream_t stream);
+                          const float *d_h_final, float *delta, hipStream_t stream, int d_out_row = 0,
+                          int d_out_dir = 0, const float *d_out_mask = nullptr);
 
 // decoder.hip (geometry and weight images: declared above, next to the prologue that writes the images)
 constexpr int kHeadChunk = 32;     // target steps per pass of the fused output head (two 16-row MFMA tiles)
@@ -242,7 +244,8 @@ struct Workspace {
     int64_t feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, row_stats, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
-        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, wt, dwt, bias_rep, wcat5;
+        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, wt, dwt, bias_rep, wcat5,
+        deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image;   // encoder layers below the last
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;

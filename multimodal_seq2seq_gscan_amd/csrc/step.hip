@@ -12,6 +12,17 @@
 
 namespace gscan {
 
+static inline int enc_layers(const gscan_dims &d) { return d.enc_layers > 1 ? d.enc_layers : 1; }
+
+// Parameters of encoder layer l: layer 0 sits in the named fields, layers 1.. in enc_deep (include/gscan_hip.h).
+struct EncLayer { float *w_ih, *w_hh, *b_ih, *b_hh, *w_ih_rev, *w_hh_rev, *b_ih_rev, *b_hh_rev; };
+static inline EncLayer enc_layer(const gscan_params &p, int l) {
+    if (l == 0) return {p.enc_w_ih, p.enc_w_hh, p.enc_b_ih, p.enc_b_hh, p.enc_w_ih_rev, p.enc_w_hh_rev, p.enc_b_ih_rev,
+                        p.enc_b_hh_rev};
+    float *const *q = p.enc_deep[l - 1];
+    return {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
+}
+
 // --------------------------------------------------------------------------------------
 // workspace
 // --------------------------------------------------------------------------------------
@@ -93,6 +104,16 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(enc_delta, B * L * D * 4 * He);
     SLOT(dfeat, B * M * F);
     SLOT(stamps, 64);
+    // encoder layers below the last one (num_encoder_layers > 1): saved activations, outputs (= the next layer's
+    // input, [B,L,D*He]) and their gradients per layer; register images of W_hh for layers 1..
+    const int64_t deep = enc_layers(d) - 1;
+    SLOT(deep_gates, deep * B * L * D * 4 * He);
+    SLOT(deep_cells, deep * B * L * D * He);
+    SLOT(deep_hprev, deep * B * L * D * He);
+    SLOT(deep_y, deep * B * L * D * He);
+    SLOT(deep_dy, deep * B * L * D * He);
+    SLOT(deep_delta, deep * B * L * D * 4 * He);
+    SLOT(deep_image, deep * D * 4 * He * He);
 #undef SLOT
     ws->nslots = n;
     ws->total_floats = p;
@@ -110,6 +131,8 @@ int check_dims(const gscan_dims &d) {
                 d.H);
     GSCAN_CHECK((int64_t)d.B * d.T * 4 * d.H < (1ll << 31) && (int64_t)d.B * d.G * d.G * 4 * d.H < (1ll << 31),
                 "dims: batch too large for 32-bit activation offsets (B=%d T=%d H=%d)", d.B, d.T, d.H);
+    GSCAN_CHECK(d.enc_layers >= 0 && d.enc_layers <= GSCAN_MAX_ENC_LAYERS,
+                "dims: at most %d encoder layers are supported (got %d)", GSCAN_MAX_ENC_LAYERS, d.enc_layers);
     GSCAN_CHECK(d.L <= 64, "dims: commands longer than 64 tokens are not supported (L=%d)", d.L);
     GSCAN_CHECK(d.G * d.G <= 64, "dims: grids larger than 8x8 are not supported (G=%d)", d.G);
     const size_t lds = decoder_lds_bytes(d.H, d.L, d.G * d.G, d.V, d.conditional != 0, true);
@@ -285,10 +308,41 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         if (cond) g.add(H, He, H, p.q2k_w + H, 2 * H, 1, p.txt_key_w, He, 1, w + ws.w_2kk, He);
         TRY(g.launch(st));
     }
-    // command encoder recurrence (seq2seq_model.py:62-88)
-    TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, p.enc_w_hh, p.enc_b_hh, p.enc_w_hh_rev,
-                             p.enc_b_hh_rev, w + ws.enc_out, w + ws.hN, w + ws.enc_gates, w + ws.enc_cells,
-                             w + ws.enc_hprev, w + ws.enc_w_image, st));
+    // command encoder recurrence (seq2seq_model.py:62-88).  With more than one layer (nn.LSTM(num_layers=n), :44-45)
+    // a layer below the last writes its h per direction, [B,L,D*He] times the inter-layer dropout mask: the next
+    // layer's input; the direction sums and the final state come from the last layer (:76-82).
+    const int NL = enc_layers(d);
+    const int64_t lay_h = (int64_t)B * L * D * He, lay_g = 4 * lay_h, lay_img = (int64_t)D * 4 * He * He;
+    for (int l = 0; l < NL; ++l) {
+        const EncLayer q = enc_layer(p, l);
+        const bool last = l == NL - 1;
+        GSCAN_CHECK(q.w_ih && q.w_hh && q.b_ih && q.b_hh && (D == 1 || (q.w_ih_rev && q.w_hh_rev && q.b_ih_rev && q.b_hh_rev)),
+                    "forward: parameters of encoder layer %d are missing", l);
+        const float *image = w + ws.enc_w_image;                 // layer 0: written by the prologue
+        if (l > 0) {
+            const int Din = D * He;
+            const float *x = w + ws.deep_y + (l - 1) * lay_h;    // the layer below, already dropped out
+            GemmBatch g;
+            g.add(B * L, 4 * He, Din, x, Din, 1, q.w_ih, 1, Din, w + ws.gx, (int64_t)D * 4 * He, 0.f, q.b_ih);
+            if (D == 2)
+                g.add(B * L, 4 * He, Din, x, Din, 1, q.w_ih_rev, 1, Din, w + ws.gx + 4 * He, (int64_t)D * 4 * He, 0.f,
+                      q.b_ih_rev);
+            TRY(g.launch(st));
+            float *img = w + ws.deep_image + (l - 1) * lay_img;
+            TRY(encoder_weight_image(q.w_hh, q.w_hh_rev, He, D, img, st));
+            image = img;
+        }
+        if (last) {
+            TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, q.w_hh, q.b_hh, q.w_hh_rev, q.b_hh_rev,
+                                     w + ws.enc_out, w + ws.hN, w + ws.enc_gates, w + ws.enc_cells, w + ws.enc_hprev,
+                                     image, st));
+        } else {
+            TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, q.w_hh, q.b_hh, q.w_hh_rev, q.b_hh_rev,
+                                     nullptr, nullptr, w + ws.deep_gates + l * lay_g, w + ws.deep_cells + l * lay_h,
+                                     w + ws.deep_hprev + l * lay_h, image, st, w + ws.deep_y + l * lay_h,
+                                     mk.enc_deep ? mk.enc_deep + l * lay_h : nullptr));
+        }
+    }
     {   // projected textual keys (:468-469), their images, and the bridge (model.py:195)
         GemmBatch g;
         g.add(B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H);
@@ -454,24 +508,44 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         float *const gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
         TRY(toeplitz_fold(gw, gb, d.G, C, Co, d.K3, B, w + ws.dwt, w + ws.dfeat, sd2));
     }
-    // ---- command encoder BPTT (chain)
-    TRY(encoder_lstm_backward(B, L, He, D, bt.cmd_lengths, p.enc_w_hh, p.enc_w_hh_rev, w + ws.enc_gates,
-                              w + ws.enc_cells, w + ws.denc, w + ws.dhN, w + ws.enc_delta, st));
-    const int64_t ldd = (int64_t)D * 4 * He;
-    {   // tail, on the caller's stream (the leaf streams are still busy with the key / conv gradients and would
-        // finish last otherwise): the encoder LSTM weight gradients and d(embedded command) for both directions
-        // (K = 8He split eight ways onto the zeroed buffer) in one launch, then the embedding table
+    // ---- command encoder BPTT (chain), last layer first.  Per layer: the reverse recurrence, then ONE launch on the
+    // caller's stream (the leaf streams are still busy with the key / conv gradients and would finish last
+    // otherwise) with the layer's weight gradients for both directions and the gradient wrt its input: the embedded
+    // command for layer 0 (K = 8He split eight ways onto the zeroed buffer), the layer below's [B,L,D*He] output
+    // otherwise (one product per direction, both accumulating with atomics onto the zeroed buffer).
+    const int NL = enc_layers(d);
+    const int64_t ldd = (int64_t)D * 4 * He, lay_h = (int64_t)B * L * D * He, lay_g = 4 * lay_h;
+    if (NL > 1) GSCAN_HIP(hipMemsetAsync(w + ws.deep_dy, 0, (size_t)(NL - 1) * lay_h * sizeof(float), st));
+    for (int l = NL - 1; l >= 0; --l) {
+        const EncLayer q = enc_layer(p, l), gq = enc_layer(g, l);
+        const bool last = l == NL - 1;
+        const float *lgates = last ? w + ws.enc_gates : w + ws.deep_gates + l * lay_g;
+        const float *lcells = last ? w + ws.enc_cells : w + ws.deep_cells + l * lay_h;
+        const float *lhprev = last ? w + ws.enc_hprev : w + ws.deep_hprev + l * lay_h;
+        float *ldelta = last ? w + ws.enc_delta : w + ws.deep_delta + l * lay_g;
+        if (last) {
+            TRY(encoder_lstm_backward(B, L, He, D, bt.cmd_lengths, q.w_hh, q.w_hh_rev, lgates, lcells, w + ws.denc,
+                                      w + ws.dhN, ldelta, st));
+        } else {
+            TRY(encoder_lstm_backward(B, L, He, D, bt.cmd_lengths, q.w_hh, q.w_hh_rev, lgates, lcells,
+                                      w + ws.deep_dy + l * lay_h, nullptr, ldelta, st, D * He, He,
+                                      mk.enc_deep ? mk.enc_deep + l * lay_h : nullptr));
+        }
+        const int Din = l == 0 ? E : D * He;
+        const float *x = l == 0 ? w + ws.xe : w + ws.deep_y + (l - 1) * lay_h;
         GemmBatch b;
         for (int dir = 0; dir < D; ++dir) {
-            const float *dl = w + ws.enc_delta + dir * 4 * He;
-            float *gw_ih = dir ? g.enc_w_ih_rev : g.enc_w_ih, *gw_hh = dir ? g.enc_w_hh_rev : g.enc_w_hh;
-            float *gb_ih = dir ? g.enc_b_ih_rev : g.enc_b_ih, *gb_hh = dir ? g.enc_b_hh_rev : g.enc_b_hh;
-            add_grad(b, 4 * He, He, BL, dl, 1, ldd, w + ws.enc_hprev + dir * He, (int64_t)D * He, 1, gw_hh, He, gb_ih,
-                     gb_hh);
-            add_grad(b, 4 * He, E, BL, dl, 1, ldd, w + ws.xe, E, 1, gw_ih, E);
+            const float *dl = ldelta + dir * 4 * He;
+            float *gw_ih = dir ? gq.w_ih_rev : gq.w_ih, *gw_hh = dir ? gq.w_hh_rev : gq.w_hh;
+            float *gb_ih = dir ? gq.b_ih_rev : gq.b_ih, *gb_hh = dir ? gq.b_hh_rev : gq.b_hh;
+            add_grad(b, 4 * He, He, BL, dl, 1, ldd, lhprev + dir * He, (int64_t)D * He, 1, gw_hh, He, gb_ih, gb_hh);
+            add_grad(b, 4 * He, Din, BL, dl, 1, ldd, x, Din, 1, gw_ih, Din);
+            if (l > 0)
+                b.add(BL, Din, 4 * He, dl, ldd, 1, dir ? q.w_ih_rev : q.w_ih, Din, 1, w + ws.deep_dy + (l - 1) * lay_h, Din,
+                      1.f, nullptr, 0, nullptr, 2);
         }
-        b.add(BL, E, D * 4 * He, w + ws.enc_delta, ldd, 1, w + ws.wih_stack, E, 1, w + ws.dxe, E, 1.f, nullptr, 0, nullptr,
-              8);
+        if (l == 0)
+            b.add(BL, E, D * 4 * He, ldelta, ldd, 1, w + ws.wih_stack, E, 1, w + ws.dxe, E, 1.f, nullptr, 0, nullptr, 8);
         TRY(b.launch(st));
     }
     TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));

@@ -187,7 +187,7 @@ class _PositionNLL(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------
 class Model(nn.Module):
     """Drop-in for `seq2seq.model.Model`.  Only the configuration the reference itself can run is
-    supported: Bahdanau attention, simple situation representation, one encoder/decoder layer."""
+    supported: Bahdanau attention, simple situation representation, one decoder layer (up to four encoder layers)."""
 
     def __init__(self, input_vocabulary_size: int, embedding_dimension: int, encoder_hidden_size: int,
                  num_encoder_layers: int, target_vocabulary_size: int, encoder_dropout_p: float,
@@ -204,8 +204,11 @@ class Model(nn.Module):
         if not simple_situation_representation:
             raise NotImplementedError("image situation representation is rejected by the reference CLI "
                                       "(__main__.py:112-114)")
-        if num_decoder_layers != 1 or num_encoder_layers != 1:
-            raise NotImplementedError("one encoder layer and one decoder layer are supported")
+        if num_decoder_layers != 1:
+            raise NotImplementedError("one decoder layer is supported (more cannot work in the reference either, "
+                                      "SURVEY.md App. B)")
+        if not 1 <= num_encoder_layers <= _lib.MAX_ENC_LAYERS:
+            raise NotImplementedError(f"1 to {_lib.MAX_ENC_LAYERS} encoder layers are supported")
 
         # construction order = RNG consumption order of the reference (model.py:47-87)
         self.situation_encoder = _WorldEncoderParams(num_cnn_channels, cnn_hidden_num_channels, cnn_kernel_size)
@@ -236,7 +239,7 @@ class Model(nn.Module):
         self.best_accuracy = 0
         self._hyper = dict(C=num_cnn_channels, Co=cnn_hidden_num_channels, K3=cnn_kernel_size,
                            E=embedding_dimension, He=encoder_hidden_size, H=decoder_hidden_size,
-                           Vi=input_vocabulary_size, V=target_vocabulary_size)
+                           Vi=input_vocabulary_size, V=target_vocabulary_size, NL=int(num_encoder_layers))
 
         self._flat: Optional[torch.Tensor] = None
         self._flat_grad: Optional[torch.Tensor] = None
@@ -247,6 +250,7 @@ class Model(nn.Module):
         self._dropout_seed = int(kwargs.get("seed", 42))
         self._dropout_calls = 0
         self._mask_buffer = None
+        self._mask_buffer_deep = None
         self._dummy_aux = None
         self._mask_key = None
         self._mask_stream_id = None      # device uint64 holding the Philox stream id (graph replay), or None
@@ -292,6 +296,10 @@ class Model(nn.Module):
                 setattr(s, field, base + 4 * self._offsets[name][0])
             else:
                 setattr(s, field, None)
+        for layer in range(1, self._hyper["NL"]):
+            for slot, pattern in enumerate(_lib.ENC_DEEP_FIELDS):
+                name = "encoder.lstm." + pattern.format(layer)
+                s.enc_deep[layer - 1][slot] = (base + 4 * self._offsets[name][0]) if name in self._offsets else None
         return s
 
     def _apply(self, fn, *args, **kwargs):
@@ -326,10 +334,11 @@ class Model(nn.Module):
 
     # ---- dropout ----------------------------------------------------------------------------
     def set_dropout_masks(self, cnn: Optional[torch.Tensor], enc: Optional[torch.Tensor],
-                          dec: Optional[torch.Tensor]) -> None:
-        """Host-mask parity mode: use these scaled keep-masks ([B,G*G,3Co], [B,L,E], [B,T,H]) for the
-        next forward call instead of drawing them on the device (SURVEY.md §7 hard part 3)."""
-        self._host_masks = (cnn, enc, dec)
+                          dec: Optional[torch.Tensor], enc_deep: Optional[torch.Tensor] = None) -> None:
+        """Host-mask parity mode: use these scaled keep-masks ([B,G*G,3Co], [B,L,E], [B,T,H] and, with more than
+        one encoder layer, [layers-1,B,L,D*He] for the inputs of layers 1..) for the next forward call instead of
+        drawing them on the device (SURVEY.md §7 hard part 3)."""
+        self._host_masks = (cnn, enc, dec, enc_deep)
 
     def _draw_masks(self, B: int, L: int, T: int, M: int, device) -> Tuple[Optional[torch.Tensor], ...]:
         if self._host_masks is not None:
@@ -357,6 +366,20 @@ class Model(nn.Module):
         for shape, n, p in zip(shapes, sizes, self.dropout_p):
             out.append(buf[off:off + n].view(shape) if p > 0.0 else None)
             off += n
+        if h["NL"] > 1 and self.dropout_p[1] > 0.0:
+            # nn.LSTM(dropout=p) drops the outputs of every layer but the last (seq2seq_model.py:44-45)
+            if self._mask_stream_id is not None:
+                raise NotImplementedError("graph replay with more than one encoder layer: the inter-layer masks "
+                                          "are drawn with a host-side Philox stream id")
+            D = 2 if self.encoder_bidirectional else 1
+            shape = (h["NL"] - 1, B, L, D * h["He"])
+            n = shape[0] * shape[1] * shape[2] * shape[3]
+            if self._mask_buffer_deep is None or self._mask_buffer_deep.numel() != n:
+                self._mask_buffer_deep = torch.empty(n, dtype=torch.float32, device=device)
+            _lib.check(lib.gscan_dropout_mask(self._mask_buffer_deep.data_ptr(), n, self.dropout_p[1],
+                                              self._dropout_seed, (1 << 40) + self._dropout_calls,
+                                              torch.cuda.current_stream().cuda_stream), "gscan_dropout_mask")
+            out.append(self._mask_buffer_deep.view(shape))
         return tuple(out)
 
     # ---- the two launches ---------------------------------------------------------------------
@@ -365,7 +388,7 @@ class Model(nn.Module):
         return _lib.Dims(B=B, L=L, T=T, G=G, C=h["C"], Co=h["Co"], K3=h["K3"], E=h["E"], He=h["He"], H=h["H"],
                          Vi=h["Vi"], V=h["V"], conditional=int(self.conditional_attention),
                          auxiliary=int(self.auxiliary_task), bidirectional=int(self.encoder_bidirectional),
-                         pad_in=self.input_padding_idx, pad_tgt=self.target_pad_idx)
+                         pad_in=self.input_padding_idx, pad_tgt=self.target_pad_idx, enc_layers=h["NL"])
 
     def _require_device(self, *tensors) -> None:
         if not (self._flat.is_cuda and all(t.is_cuda for t in tensors)):

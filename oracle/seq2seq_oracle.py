@@ -264,12 +264,13 @@ def forward(p: Params, commands: torch.Tensor, cmd_lengths, world: torch.Tensor,
             ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """Returns (log-probs [B,T,V], aux log-scores [B,G*G] or None).
 
-    ``masks`` = (cnn, encoder-embedding, decoder-embedding) scaled dropout masks
+    ``masks`` = (cnn, encoder-embedding, decoder-embedding[, inputs of encoder layers 1..]) scaled dropout masks
     (value 0 or 1/(1-p)) or None for no dropout.  Decoder mask is in batch row order.
     """
-    m_cnn, m_enc, m_dec = masks if masks is not None else (None, None, None)
+    m_cnn, m_enc, m_dec = tuple(masks[:3]) if masks is not None else (None, None, None)
+    m_deep = masks[3] if masks is not None and len(masks) > 3 else None        # [layers-1, B, L, D*He]
     feats = world_encoder(p, world, m_cnn)
-    hN, enc_out = command_encoder(p, commands, cmd_lengths, bidirectional, m_enc)
+    hN, enc_out = command_encoder(p, commands, cmd_lengths, bidirectional, m_enc, m_deep)
     logits, att_sum = decoder(p, hN, enc_out, cmd_lengths, feats, targets, conditional, m_dec, keep)
     if keep is not None:
         keep.update(feats=feats, hN=hN, enc_out=enc_out, logits=logits, att_sum=att_sum)
