@@ -87,7 +87,7 @@ def _test_on_dataset(flags) -> None:
     from .config import model_kwargs
     from .dataset import GroundedScanDataset
     from .model import Model
-    from .predict import predict, sequence_accuracy
+    from .predict import predict_and_save
     data_path = os.path.join(flags["data_directory"], "dataset.txt")
     assert os.path.exists(os.path.join(flags["data_directory"], flags["input_vocab_path"])) and os.path.exists(
         os.path.join(flags["data_directory"], flags["target_vocab_path"])), \
@@ -114,21 +114,9 @@ def _test_on_dataset(flags) -> None:
         logger.info("Loading checkpoint from file at '{}'".format(flags["resume_from_file"]))
         model.load_model(flags["resume_from_file"])
         logger.info("Loaded checkpoint '{}' (iter {})".format(flags["resume_from_file"], model.trained_iterations))
-        vocab, output = test_set.target_vocabulary, []
-        for (inp, derivation, situation, out_seq, tgt, aw_c, aw_s, pos_acc) in predict(
-                test_set.get_data_iterator(batch_size=256), model=model, max_decoding_steps=flags["max_decoding_steps"],
-                pad_idx=vocab.pad_idx, sos_idx=vocab.sos_idx, eos_idx=vocab.eos_idx,
-                max_examples_to_evaluate=flags["max_testing_examples"]):
-            accuracy = sequence_accuracy(out_seq, tgt[0].tolist()[1:-1])
-            output.append({"input": test_set.array_to_sentence(inp[0].tolist(), "input")[1:-1],
-                           "prediction": test_set.array_to_sentence(out_seq, "target"), "derivation": derivation,
-                           "target": test_set.array_to_sentence(tgt[0].tolist(), "target")[1:-1], "situation": situation,
-                           "attention_weights_input": aw_c, "attention_weights_situation": aw_s, "accuracy": accuracy,
-                           "exact_match": True if accuracy == 100 else False, "position_accuracy": pos_acc})
         output_file_path = os.path.join(flags["output_directory"], "_".join([split, flags["output_file_name"]]))
-        with open(output_file_path, mode="w") as outfile:
-            json.dump(output, outfile, indent=4)
-        logger.info("Wrote predictions for {} examples.".format(len(output)))
+        predict_and_save(test_set, model, output_file_path, flags["max_decoding_steps"],
+                         max_testing_examples=flags["max_testing_examples"])
         logger.info("Saved predictions to {}".format(output_file_path))
 
 

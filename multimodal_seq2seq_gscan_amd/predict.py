@@ -7,6 +7,7 @@ per-example loop gives it.  The generator yields the reference's 8-tuple per EXA
 `predict_and_save`-style writer consume it unchanged."""
 from __future__ import annotations
 
+import json
 import logging
 import time
 from typing import Iterator, List, Tuple
@@ -117,3 +118,25 @@ def evaluate(data_iterator: Iterator, model, max_decoding_steps: int, pad_idx: i
         target_accuracies.append(aux_acc_target)
     return (float(np.mean(np.array(accuracies))), (exact / len(accuracies)) * 100,
             float(np.mean(np.array(target_accuracies))))
+
+
+def predict_and_save(dataset, model, output_file_path: str, max_decoding_steps: int, max_testing_examples=None,
+                     batch_size: int = 256, **kwargs) -> str:
+    """seq2seq/predict.py:16-54: decode every example of `dataset` and write the reference's record schema
+    (input, prediction, derivation, target, situation, both attention traces, accuracy, exact_match,
+    position_accuracy) as JSON.  Batched (the reference iterates with batch_size=1)."""
+    vocab, output = dataset.target_vocabulary, []
+    for (inp, derivation, situation, out_seq, tgt, aw_c, aw_s, pos_acc) in predict(
+            dataset.get_data_iterator(batch_size=batch_size), model=model, max_decoding_steps=max_decoding_steps,
+            pad_idx=vocab.pad_idx, sos_idx=vocab.sos_idx, eos_idx=vocab.eos_idx,
+            max_examples_to_evaluate=max_testing_examples):
+        accuracy = sequence_accuracy(out_seq, tgt[0].tolist()[1:-1])
+        output.append({"input": dataset.array_to_sentence(inp[0].tolist(), "input")[1:-1],
+                       "prediction": dataset.array_to_sentence(out_seq, "target"), "derivation": derivation,
+                       "target": dataset.array_to_sentence(tgt[0].tolist(), "target")[1:-1], "situation": situation,
+                       "attention_weights_input": aw_c, "attention_weights_situation": aw_s, "accuracy": accuracy,
+                       "exact_match": True if accuracy == 100 else False, "position_accuracy": pos_acc})
+    with open(output_file_path, mode="w") as outfile:
+        json.dump(output, outfile, indent=4)
+    logger.info("Wrote predictions for {} examples.".format(len(output)))
+    return output_file_path

@@ -131,3 +131,23 @@ def test_reference_checkpoint_loads_and_round_trips(tmp_path):
     for i in ref["optimizer_state_dict"]["state"]:
         a, b = again["optimizer_state_dict"]["state"][i], ref["optimizer_state_dict"]["state"][i]
         assert torch.equal(a["exp_avg"], b["exp_avg"]) and float(a["step"]) == float(b["step"])
+
+
+def test_drop_in_package_exposes_the_reference_module_names():
+    """`seq2seq.{model,train,predict,evaluate,gSCAN_dataset,helpers}` resolve here with the names the reference's
+    own callers import (train.py:8-12, predict.py:1-10, __main__.py:5-9)."""
+    import importlib
+    import torch
+    wanted = {"seq2seq.model": ["Model"], "seq2seq.train": ["train"],
+              "seq2seq.predict": ["predict", "predict_and_save"], "seq2seq.evaluate": ["evaluate"],
+              "seq2seq.gSCAN_dataset": ["GroundedScanDataset", "Vocabulary"],
+              "seq2seq.helpers": ["sequence_mask", "log_parameters", "sequence_accuracy"]}
+    for module, names in wanted.items():
+        m = importlib.import_module(module)
+        for n in names:
+            assert hasattr(m, n), f"{module}.{n}"
+    from seq2seq.helpers import sequence_accuracy, sequence_mask
+    assert sequence_mask(torch.tensor([1, 3])).tolist() == [[True, False, False], [True, True, True]]
+    assert sequence_mask(torch.tensor([2]), max_len=4).tolist() == [[True, True, False, False]]
+    assert sequence_accuracy([1, 2, 3], [1, 2, 3]) == 100 and abs(sequence_accuracy([1, 2, 3], [1, 2]) - 200 / 3) < 1e-9
+    assert sequence_accuracy([1], [1, 2]) == 50
