@@ -605,6 +605,13 @@ class Model(nn.Module):
                                          torch.cuda.current_stream().cuda_stream), "gscan_decode_step")
         return logits, (h_out.unsqueeze(0), c_out.unsqueeze(0)), alpha_vis, alpha_text, alpha_vis
 
+    def decode_input_batched(self, *args, **kwargs):
+        """model.py:190-204 is the second half of the reference's forward() (its only caller, :209-213).  Here
+        forward() is one fused library call, so the teacher-forced decoder cannot be entered with encodings handed
+        in from outside; call forward() (training / scoring) or encode_input() + decode_input() (stepwise)."""
+        raise NotImplementedError("decode_input_batched is fused into Model.forward() on the HIP path; use forward(), "
+                                  "or encode_input() followed by decode_input() steps")
+
     # ---- checkpoints (model.py:228-261): same dictionary keys, same file names ----------------
     def get_current_state(self) -> dict:
         return {"iteration": self.trained_iterations, "state_dict": self.state_dict(),
