@@ -1,0 +1,79 @@
+"""Randomised parity sweep (GPU): random model configurations and batch shapes, HIP step against the CPU oracle
+(log-probabilities, loss, every gradient; tolerance of tests/test_parity_gpu.py).  Not part of the test-suite: run it
+after changes to a kernel's indexing.
+    python tools/fuzz_parity.py [--cases 40] [--seed 0]"""
+import argparse
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+import torch
+
+from multimodal_seq2seq_gscan_amd.config import model_kwargs
+from multimodal_seq2seq_gscan_amd.model import Model
+from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+from oracle import seq2seq_oracle as oracle
+from weights import golden_weights
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=40)
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+rng = random.Random(args.seed)
+TOL = 1e-4
+bad = 0
+for case in range(args.cases):
+    H = rng.choice([20, 32, 64, 100])
+    He = rng.choice([20, 32, 64, 100])
+    cfg = model_kwargs("demo", cnn_dropout_p=0.0, encoder_dropout_p=0.0, decoder_dropout_p=0.0,
+                       decoder_hidden_size=H, encoder_hidden_size=He, embedding_dimension=rng.choice([4, 5, 8, 25]),
+                       cnn_kernel_size=rng.choice([1, 3, 5, 7, 13]), cnn_hidden_num_channels=rng.choice([8, 20, 50]),
+                       conditional_attention=rng.random() < 0.6, auxiliary_task=rng.random() < 0.5,
+                       encoder_bidirectional=rng.random() < 0.7, num_encoder_layers=rng.choice([1, 1, 2, 3]),
+                       input_vocabulary_size=rng.choice([8, 14, 21]), target_vocabulary_size=rng.choice([5, 6, 9]),
+                       num_cnn_channels=rng.choice([15, 16]))
+    shape = Shape(batch=rng.choice([1, 2, 3, 5, 9]), grid=rng.choice([2, 3, 4, 6, 8]), channels=cfg["num_cnn_channels"],
+                  input_vocab=cfg["input_vocabulary_size"], target_vocab=cfg["target_vocabulary_size"],
+                  max_command=rng.choice([2, 3, 7, 10, 17]), max_target=rng.choice([2, 3, 10, 17, 33]),
+                  ragged=rng.random() < 0.7)
+    batch = make_batch(shape, seed=1000 + case)
+    params = {k: torch.from_numpy(v) for k, v in golden_weights(cfg, 100 + case).items()}
+    try:
+        model = Model(**cfg)
+        model.load_state_dict(params, strict=False)
+        model = model.cuda().eval()
+        d = {k: v.cuda() for k, v in batch.items()}
+        logp, aux = model(commands_input=d["commands"], commands_lengths=batch["cmd_lengths"].tolist(),
+                          situations_input=d["world"], target_batch=d["targets"],
+                          target_lengths=batch["tgt_lengths"].tolist())
+        loss = model.get_loss(logp, d["targets"])
+        if cfg["auxiliary_task"]:
+            loss = loss + 0.3 * model.get_auxiliary_loss(aux, d["target_positions"])
+        loss.backward()
+        torch.cuda.synchronize()
+        ref_loss, ref_grads, ref_logp = oracle.loss_and_grads(params, batch, conditional=cfg["conditional_attention"],
+                                                              auxiliary=cfg["auxiliary_task"],
+                                                              bidirectional=cfg["encoder_bidirectional"])
+        e_logp = (logp.detach().cpu() - ref_logp).abs().max().item()
+        e_loss = abs(loss.item() - ref_loss.item())
+        worst, worst_name = 0.0, ""
+        for n, p in model.named_parameters():
+            g, r = p.grad.cpu(), ref_grads[n]
+            e = ((g - r).abs() - 1e-3 * r.abs()).max().item()
+            if e > worst:
+                worst, worst_name = e, n
+        ok = e_logp < TOL and e_loss < TOL and worst < TOL
+    except Exception as exc:                                   # a configuration the library rejects is reported, not fatal
+        print(f"case {case}: {type(exc).__name__}: {str(exc)[:150]}")
+        ok, e_logp, e_loss, worst, worst_name = True, -1, -1, -1, "rejected"
+    tag = "ok " if ok else "BAD"
+    bad += 0 if ok else 1
+    print(f"{tag} case {case}: H={H} He={He} E={cfg['embedding_dimension']} k={cfg['cnn_kernel_size']} Co={cfg['cnn_hidden_num_channels']} "
+          f"cond={int(cfg['conditional_attention'])} aux={int(cfg['auxiliary_task'])} bi={int(cfg['encoder_bidirectional'])} "
+          f"layers={cfg['num_encoder_layers']} B={shape.batch} G={shape.grid} L={shape.max_command} T={shape.max_target} "
+          f"| logp {e_logp:.1e} loss {e_loss:.1e} grad {worst:.1e} {worst_name}", flush=True)
+print("failures:", bad)
+sys.exit(1 if bad else 0)
