@@ -194,12 +194,14 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
     unsigned gst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long gst_prev = clock64();
 #endif
-    const int bz = local / g.tiles_mn, rem = local % g.tiles_mn;
+    // quotients by multiply-high with the host's reciprocals: four integer divisions (each a float-reciprocal sequence
+    // through the vector unit) used to sit between the descriptor and the first global load
+    const int bz = g.inv_mn ? (int)__umulhi((uint32_t)local, g.inv_mn) : local, rem = local - bz * g.tiles_mn;   // inv 0: d = 1
     // Tile order inside a problem: M tiles slowest by default; N tiles slowest (flag 16) when B is the larger operand,
     // so that an XCD's contiguous share of the tiles reads a slice of the LARGE operand and all of the small one.
-    const int tiles_m = g.tiles_mn / g.tiles_n;
     const bool n_major = (g.flags & 16) != 0;
-    const int by = n_major ? rem % tiles_m : rem / g.tiles_n, bx = n_major ? rem / tiles_m : rem % g.tiles_n;
+    const int inner = g.inv_in ? (int)__umulhi((uint32_t)rem, g.inv_in) : rem;   // rem / tiles_m (N-major) or rem / tiles_n
+    const int by = n_major ? rem - inner * (int)g.tiles_m : inner, bx = n_major ? inner : rem - inner * g.tiles_n;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
                       "+s"(g.b), "+s"(g.sbk), "+s"(g.sbn), "+s"(g.c), "+s"(g.ldc));
     asm volatile("" : "+s"(g.bias), "+s"(g.act), "+s"(g.mask), "+s"(g.gate), "+s"(g.k_chunk), "+s"(g.atomic),
                       "+s"(g.asum1), "+s"(g.asum2), "+s"(g.tiles_n), "+s"(g.tiles_mn), "+s"(g.nsplit), "+s"(g.flags),
+                      "+s"(g.inv_mn), "+s"(g.inv_in), "+s"(g.tiles_m),
                       "+s"(per));
     // XCD-aware order (GSCAN_GEMM_XCD=0 disables): workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.
     // Workgroup l of a problem takes tile (l % 8) * per + l / 8, so an XCD works on one contiguous eighth of the
@@ -466,7 +469,7 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
     }
     GemmProblem &p = grp_.p[grp_.count++];
     p = GemmProblem{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, gate, chunk,
-                    split_k > 1 ? 1 : 0, asum1, asum2, 0, 0, 0, flags};   // tile bookkeeping: at launch
+                    split_k > 1 ? 1 : 0, asum1, asum2, 0, 0, 0, 0u, 0u, flags, 0};   // tile bookkeeping: at launch
     tiles_ += cdiv(N, BN) * cdiv(M, 64) * split_k;                            // in 64-row tiles
     flops_ += 2.0 * M * N * K;
 }
@@ -492,6 +495,15 @@ int GemmBatch::launch(hipStream_t stream) {
         p.tiles_mn = p.tiles_n * cdiv(p.M, 32 * tmw);
         p.nsplit = cdiv(p.K, p.k_chunk);
         if (order && p.nsplit == 1 && p.N > p.M) p.flags |= 16;
+        p.tiles_m = p.tiles_mn / p.tiles_n;
+        const uint32_t inner = (p.flags & 16) ? (uint32_t)p.tiles_m : (uint32_t)p.tiles_n;
+        p.inv_mn = p.tiles_mn > 1 ? (uint32_t)((1ull << 32) / (uint32_t)p.tiles_mn) + 1u : 0u;    // 0 stands for d = 1
+        p.inv_in = inner > 1 ? (uint32_t)((1ull << 32) / inner) + 1u : 0u;
+        if (((int64_t)p.tiles_mn * p.nsplit + p.tiles_mn) * p.tiles_mn >= (1ll << 32)) {   // exactness of umulhi(x, inv)
+            bad_ = true;
+            set_error("gemm batch: problem %d has too many tiles for the reciprocal index arithmetic", i);
+            return 1;
+        }
         grp_.tile_begin[i] = total;
         const int n = p.tiles_mn * p.nsplit;
         grp_.xcd_per[i] = (xcd && n >= 16) ? cdiv(n, 8) : 0;

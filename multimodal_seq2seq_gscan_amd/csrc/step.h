@@ -22,7 +22,10 @@ struct GemmProblem {
     int k_chunk, atomic;                  // K range per k-slice; split-K accumulates with atomics
     float *asum1, *asum2;                 // optional: += sum_k A(m,k) (bias gradients)
     int tiles_n, tiles_mn, nsplit;        // grid bookkeeping (the first workgroup id is in GemmGroup::tile_begin)
-    int flags;                            // log2(floats per global load) of A | of B << 2
+    uint32_t inv_mn, inv_in;              // floor(2^32 / d) + 1 for d = tiles_mn and for the inner tile count (tiles_n,
+                                          // or tiles_m when N tiles run slowest): x / d = umulhi(x, inv) for x * d < 2^32
+    int flags;                            // log2(floats per global load) of A | of B << 2 | 16: N tiles run slowest
+    int tiles_m;
 };
 // tile_begin / xcd_per lead the kernel arguments as one contiguous header: a workgroup finds its problem with ONE
 // batch of scalar loads and fetches that problem's descriptor with a second one (the scan used to walk the
