@@ -228,13 +228,12 @@ int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream) {
     GSCAN_CHECK(B > 0 && a.T > 0 && a.L > 0 && a.M > 0 && a.L <= 64 && a.M <= 64 && a.He > 0 && a.F > 0 && a.He <= 512,
                 "keys backward: bad dims B=%d T=%d L=%d cells=%d He=%d F=%d", B, a.T, a.L, a.M, a.He, a.F);
     switch (H) {
-        case 20: return launch_keys_backward<20>(B, a, stream);
-        case 32: return launch_keys_backward<32>(B, a, stream);
-        case 64: return launch_keys_backward<64>(B, a, stream);
-        case 100: return launch_keys_backward<100>(B, a, stream);
+#define X(n) case n: return launch_keys_backward<n>(B, a, stream);
+        GSCAN_DEC_HIDDEN_SIZES(X)
+#undef X
         default: break;
     }
-    GSCAN_CHECK(false, "keys backward: decoder_hidden_size %d has no compiled kernel (20 32 64 100)", H);
+    GSCAN_CHECK(false, "keys backward: decoder_hidden_size %d has no compiled kernel (" GSCAN_DEC_HIDDEN_LIST ")", H);
 }
 
 GSCAN_TRACE_TU(attention_grad)

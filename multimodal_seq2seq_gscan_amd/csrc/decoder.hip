@@ -1039,7 +1039,6 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
     return 0;
 }
 
-#define GSCAN_DEC_HIDDEN_SIZES(X) X(20) X(32) X(64) X(100)
 
 bool decoder_hidden_supported(int h) {
 #define X(n) if (h == n) return true;
@@ -1062,7 +1061,7 @@ int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hi
 #undef X
         default: break;
     }
-    GSCAN_CHECK(false, "decoder_hidden_size %d has no compiled kernel (supported: 20 32 64 100)", H);
+    GSCAN_CHECK(false, "decoder_hidden_size %d has no compiled kernel (supported: " GSCAN_DEC_HIDDEN_LIST ")", H);
 }
 
 GSCAN_TRACE_TU(decoder)

@@ -286,7 +286,7 @@ static int launch_bwd(int B, int L, int D, const int32_t *lengths, const float *
     return 0;
 }
 
-#define GSCAN_HIDDEN_SIZES(X) X(20) X(32) X(64) X(100) X(128)
+#define GSCAN_HIDDEN_SIZES(X) GSCAN_ENC_HIDDEN_SIZES(X)
 
 bool hidden_size_supported(int h) {
 #define X(n) if (h == n) return true;
@@ -337,7 +337,7 @@ int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int
 #undef X
         default: break;
     }
-    GSCAN_CHECK(false, "encoder_hidden_size %d has no compiled kernel (supported: 20 32 64 100 128)", He);
+    GSCAN_CHECK(false, "encoder_hidden_size %d has no compiled kernel (supported: " GSCAN_ENC_HIDDEN_LIST ")", He);
 }
 
 int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_f,
@@ -356,7 +356,7 @@ int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, c
 #undef X
         default: break;
     }
-    GSCAN_CHECK(false, "encoder_hidden_size %d has no compiled kernel (supported: 20 32 64 100 128)", He);
+    GSCAN_CHECK(false, "encoder_hidden_size %d has no compiled kernel (supported: " GSCAN_ENC_HIDDEN_LIST ")", He);
 }
 
 GSCAN_TRACE_TU(lstm_encoder)

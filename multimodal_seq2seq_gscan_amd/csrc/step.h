@@ -155,6 +155,14 @@ int position_nll(const float *aux, const int64_t *pos, int B, int M, float *loss
 int sequence_metrics(const float *logp, const int64_t *targets, int B, int T, int V, int pad, float *out3,
                      hipStream_t stream);
 
+// Hidden sizes with compiled kernels (the recurrent weights live in registers, so the size is a template parameter).
+// Decoder / keys kernels: multiples of 4 up to 100 (five column quads per unit must fit 128 threads, 7 H^2 weights the
+// register file); encoder: up to 128.
+#define GSCAN_DEC_HIDDEN_SIZES(X) X(20) X(32) X(40) X(48) X(64) X(80) X(96) X(100)
+#define GSCAN_DEC_HIDDEN_LIST "20 32 40 48 64 80 96 100"
+#define GSCAN_ENC_HIDDEN_SIZES(X) X(20) X(32) X(40) X(48) X(64) X(80) X(96) X(100) X(128)
+#define GSCAN_ENC_HIDDEN_LIST "20 32 40 48 64 80 96 100 128"
+
 // lstm_encoder.hip
 bool hidden_size_supported(int h);
 int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths, const float *w_hh_f,

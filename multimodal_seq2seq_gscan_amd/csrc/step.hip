@@ -125,9 +125,9 @@ int check_dims(const gscan_dims &d) {
                 "dims: non-positive dimension (B=%d L=%d T=%d G=%d C=%d Co=%d E=%d V=%d Vi=%d)", d.B, d.L, d.T, d.G,
                 d.C, d.Co, d.E, d.V, d.Vi);
     GSCAN_CHECK(d.K3 > 0 && (d.K3 & 1), "dims: cnn_kernel_size must be odd (got %d)", d.K3);
-    GSCAN_CHECK(hidden_size_supported(d.He), "dims: encoder_hidden_size %d has no compiled kernel (20 32 64 100 128)",
+    GSCAN_CHECK(hidden_size_supported(d.He), "dims: encoder_hidden_size %d has no compiled kernel (" GSCAN_ENC_HIDDEN_LIST ")",
                 d.He);
-    GSCAN_CHECK(decoder_hidden_supported(d.H), "dims: decoder_hidden_size %d has no compiled kernel (20 32 64 100)",
+    GSCAN_CHECK(decoder_hidden_supported(d.H), "dims: decoder_hidden_size %d has no compiled kernel (" GSCAN_DEC_HIDDEN_LIST ")",
                 d.H);
     GSCAN_CHECK((int64_t)d.B * d.T * 4 * d.H < (1ll << 31) && (int64_t)d.B * d.G * d.G * 4 * d.H < (1ll << 31),
                 "dims: batch too large for 32-bit activation offsets (B=%d T=%d H=%d)", d.B, d.T, d.H);

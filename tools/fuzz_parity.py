@@ -26,8 +26,8 @@ rng = random.Random(args.seed)
 TOL = 1e-4
 bad = 0
 for case in range(args.cases):
-    H = rng.choice([20, 32, 64, 100])
-    He = rng.choice([20, 32, 64, 100])
+    H = rng.choice([20, 32, 40, 48, 64, 80, 96, 100])
+    He = rng.choice([20, 32, 40, 48, 64, 80, 96, 100, 128])
     cfg = model_kwargs("demo", cnn_dropout_p=0.0, encoder_dropout_p=0.0, decoder_dropout_p=0.0,
                        decoder_hidden_size=H, encoder_hidden_size=He, embedding_dimension=rng.choice([4, 5, 8, 25]),
                        cnn_kernel_size=rng.choice([1, 3, 5, 7, 13]), cnn_hidden_num_channels=rng.choice([8, 20, 50]),
