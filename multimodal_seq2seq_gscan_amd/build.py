@@ -21,6 +21,8 @@ SOURCES = ["gemm.hip", "elementwise.hip", "loss.hip", "lstm_encoder.hip", "decod
            "probe.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          f"-I{INCLUDE}", f"-I{CSRC}"]
+# per-source extras: the grouped GEMM's problem lookup reads its header from preloaded kernel-argument SGPRs
+EXTRA_FLAGS = {"gemm.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=12"]}
 
 
 def _hipcc() -> str:
@@ -48,7 +50,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

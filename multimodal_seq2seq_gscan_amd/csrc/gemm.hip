@@ -379,16 +379,23 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
 }
 
 template <int TMW, int BK>
-__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup grp) {
+__global__ __launch_bounds__(256) void gemm_group_kernel(int tb0, int tb1, int tb2, int tb3, int tb4, int tb5, int tb6,
+                                                         int tb7, int tb8, int tb9, int tb10, int tb11, GemmGroup grp) {
+    // The first workgroup id of every problem arrives as twelve leading scalar arguments: this file is compiled with
+    // -mllvm -amdgpu-kernarg-preload-count=12 (build.py), so they sit in SGPRs when the wave starts and the problem
+    // lookup costs no memory round trip (firmware without kernarg preload runs the compiler's loading preamble).
+    const int tb[kMaxGroup] = {tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7, tb8, tb9, tb10, tb11};
+    static_assert(kMaxGroup == 12, "the preloaded header is twelve scalars");
     TraceScope trace_scope(TK_GEMM);
     constexpr int A_FLOATS = TileM<TMW, BK>::A_FLOATS, B_FLOATS = b_floats<BK>();
     // two scalar-load round trips before the first global load: the header (unused entries hold INT_MAX), then the
     // problem's whole descriptor by value
-    int pi = 0, first = grp.tile_begin[0], per = grp.xcd_per[0];
+    int pi = 0, first = tb[0];
 #pragma unroll
     for (int i = 1; i < kMaxGroup; ++i)
-        if ((int)blockIdx.x >= grp.tile_begin[i]) { pi = i; first = grp.tile_begin[i]; per = grp.xcd_per[i]; }
-    asm volatile("" : "+s"(pi), "+s"(first));                 // selected from the header's registers
+        if ((int)blockIdx.x >= tb[i]) { pi = i; first = tb[i]; }
+    asm volatile("" : "+s"(pi), "+s"(first));                 // selected from the preloaded registers
+    int per = grp.xcd_per[pi];
     GemmProblem g = grp.p[pi];
     // every field is wanted NOW (one batch of scalar loads, one wait), not each at its first use behind the
     // previous one's wait
@@ -509,16 +516,19 @@ int GemmBatch::launch(hipStream_t stream) {
         grp_.xcd_per[i] = (xcd && n >= 16) ? cdiv(n, 8) : 0;
         total += grp_.xcd_per[i] ? 8 * grp_.xcd_per[i] : n;
     }
+    const int *t = grp_.tile_begin;
+#define TB t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]
     ProbeScope probe(P_GEMM, stream, flops_);
     // 64-deep K rounds (GSCAN_GEMM_BK=64, experiments): isolated long-K split products gain 10-20 % (a round's
     // load latency is paid half as often), but the overlapped training step loses 3 % to the larger workgroups
     // (52 KB of LDS, +40 VGPRs), so 32 is what every launch uses.
     static const int forced_bk = [] { const char *e = getenv("GSCAN_GEMM_BK"); return e ? atoi(e) : 0; }();
     const bool deep = forced_bk == 64;
-    if (tmw == 1 && deep) hipLaunchKernelGGL((gemm_group_kernel<1, 64>), dim3(total), dim3(256), 0, stream, grp_);
-    else if (tmw == 1) hipLaunchKernelGGL((gemm_group_kernel<1, 32>), dim3(total), dim3(256), 0, stream, grp_);
-    else if (deep) hipLaunchKernelGGL((gemm_group_kernel<2, 64>), dim3(total), dim3(256), 0, stream, grp_);
-    else hipLaunchKernelGGL((gemm_group_kernel<2, 32>), dim3(total), dim3(256), 0, stream, grp_);
+    if (tmw == 1 && deep) hipLaunchKernelGGL((gemm_group_kernel<1, 64>), dim3(total), dim3(256), 0, stream, TB, grp_);
+    else if (tmw == 1) hipLaunchKernelGGL((gemm_group_kernel<1, 32>), dim3(total), dim3(256), 0, stream, TB, grp_);
+    else if (deep) hipLaunchKernelGGL((gemm_group_kernel<2, 64>), dim3(total), dim3(256), 0, stream, TB, grp_);
+    else hipLaunchKernelGGL((gemm_group_kernel<2, 32>), dim3(total), dim3(256), 0, stream, TB, grp_);
+#undef TB
     GSCAN_LAUNCHED("gemm_group_kernel");
     return 0;
 }

@@ -28,7 +28,8 @@ def main():
         jobs = []
         for one in srcs:
             obj = os.path.join(OUT, f"{name}.{one.replace('.hip', '.o')}")
-            cmd = [hipcc, *B.FLAGS, *[f for f in flags.split(",") if f], "-c", os.path.join(B.CSRC, one), "-o", obj]
+            cmd = [hipcc, *B.FLAGS, *B.EXTRA_FLAGS.get(one, []), *[f for f in flags.split(",") if f], "-c",
+                   os.path.join(B.CSRC, one), "-o", obj]
             jobs.append((one, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
         procs.append((name, jobs))
     for name, jobs in procs:
