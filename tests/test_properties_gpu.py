@@ -105,3 +105,26 @@ def test_backward_is_linear_in_the_upstream_gradient(setup):
     g10, g01, g23 = grad_for(1.0, 0.0), grad_for(0.0, 1.0), grad_for(2.0, 3.0)
     ref = 2.0 * g10 + 3.0 * g01
     assert (g23 - ref).abs().max().item() < 1e-6 + 1e-4 * ref.abs().max().item()
+
+
+def test_training_memorises_one_batch():
+    """End-to-end sanity of gradients + fused Adam/LR on the device: with dropout off, a few hundred steps on one
+    fixed batch of random targets drive the loss from ~log(V) to near zero and the exact-match rate to 100 %."""
+    from multimodal_seq2seq_gscan_amd.model import Model
+    from multimodal_seq2seq_gscan_amd.train import TrainStep
+    torch.manual_seed(3)
+    cfg = model_kwargs("compositional", cnn_dropout_p=0.0, encoder_dropout_p=0.0, decoder_dropout_p=0.0)
+    model = Model(**cfg).cuda()
+    batch = {k: v.cuda() for k, v in make_batch(Shape(batch=16, max_target=12, ragged=True), seed=5).items()}
+    step = TrainStep(model, learning_rate=3e-3, lr_decay_steps=100000.0)
+    first = float(step(batch)["loss"].item())
+    for _ in range(500):
+        out = step(batch)
+    last = float(out["loss"].item())
+    assert first > 1.0 and last < 0.05, (first, last)
+    model.eval()
+    logp, _ = model(commands_input=batch["commands"], commands_lengths=batch["cmd_lengths"].tolist(),
+                    situations_input=batch["world"], target_batch=batch["targets"],
+                    target_lengths=batch["tgt_lengths"].tolist())
+    accuracy, exact_match = model.get_metrics(logp, batch["targets"])
+    assert exact_match == 100.0 and accuracy > 99.9, (accuracy, exact_match)
