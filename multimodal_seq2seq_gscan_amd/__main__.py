@@ -150,11 +150,13 @@ def main(flags):
         cfg = model_kwargs("compositional")
         cfg.update({k: flags[k] for k in cfg if k in flags})
         model = Model(**cfg).cuda()
+        optimizer_state = None
         if flags["resume_from_file"]:
             assert os.path.isfile(flags["resume_from_file"]), "No checkpoint found at {}".format(flags["resume_from_file"])
-            model.load_model(flags["resume_from_file"])
+            optimizer_state = model.load_model(flags["resume_from_file"])      # train.py:81-82
         step = train(_synthetic_batches(flags, rank, world), model, flags["max_training_iterations"],
                      print_every=flags["print_every"], weight_target_loss=flags["weight_target_loss"], rank=rank,
+                     optimizer_state_dict=optimizer_state,
                      learning_rate=flags["learning_rate"], adam_beta_1=flags["adam_beta_1"],
                      adam_beta_2=flags["adam_beta_2"], lr_decay=flags["lr_decay"],
                      lr_decay_steps=flags["lr_decay_steps"])

@@ -20,7 +20,7 @@ import logging
 import os
 import random
 from collections import Counter, defaultdict
-from typing import Dict, Iterator, List, Optional
+from typing import Dict, Iterator, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -227,14 +227,17 @@ class GroundedScanDataset:
         self._order = self._order[np.random.permutation(len(self._order))]
 
     # ---- batches (:184-231) ---------------------------------------------------------------------
-    def get_data_iterator(self, batch_size=10, device: Optional[torch.device] = None) -> Iterator[tuple]:
+    def get_data_iterator(self, batch_size=10, device: Optional[torch.device] = None,
+                          shard: Tuple[int, int] = (0, 1)) -> Iterator[tuple]:
         """Yields (input_batch [B,L] i64, input_lengths, derivations, situation_batch [B,G,G,C] f32, situations,
         target_batch [B,T] i64, target_lengths, agent_positions [B] i64, target_positions [B] i64), every batch
         padded to ITS longest sequences, the last one short (as the reference)."""
         if device is None:
             device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         pin = device.type == "cuda"
-        for lo in range(0, len(self._order), batch_size):
+        for number, lo in enumerate(range(0, len(self._order), batch_size)):
+            if number % shard[1] != shard[0]:      # shard = (rank, world): every world-th batch (evaluation under DP)
+                continue
             idx = self._order[lo:lo + batch_size]
             in_len, tgt_len = self._input_lengths[idx], self._target_lengths[idx]
             L, T = int(in_len.max()), int(tgt_len.max())

@@ -12,7 +12,6 @@ import logging
 import time
 from typing import Iterator, List, Tuple
 
-import numpy as np
 import torch
 
 logger = logging.getLogger(__name__)
@@ -105,19 +104,28 @@ def predict(data_iterator: Iterator, model, max_decoding_steps: int, pad_idx: in
     logger.info("Done predicting in {} seconds.".format(time.time() - start))
 
 
-def evaluate(data_iterator: Iterator, model, max_decoding_steps: int, pad_idx: int, sos_idx: int, eos_idx: int,
-             max_examples_to_evaluate=None) -> Tuple[float, float, float]:
-    """evaluate.py:10-24: (mean token accuracy %, exact match %, mean target-position accuracy %)."""
-    accuracies, target_accuracies, exact = [], [], 0
+def evaluate_sums(data_iterator: Iterator, model, max_decoding_steps: int, pad_idx: int, sos_idx: int, eos_idx: int,
+                  max_examples_to_evaluate=None) -> Tuple[float, float, float, float]:
+    """The sums behind evaluate(): (sum of token accuracies %, exact matches, sum of target-position accuracies %,
+    examples) — additive over shards of a split, which is how data-parallel ranks share an evaluation."""
+    acc_sum, target_sum, exact, n = 0.0, 0.0, 0, 0
     for _, _, _, output_sequence, target_sequence, _, _, aux_acc_target in predict(
             data_iterator=data_iterator, model=model, max_decoding_steps=max_decoding_steps, pad_idx=pad_idx,
             sos_idx=sos_idx, eos_idx=eos_idx, max_examples_to_evaluate=max_examples_to_evaluate):
         accuracy = sequence_accuracy(output_sequence, target_sequence[0].tolist()[1:-1])
         exact += int(accuracy == 100)
-        accuracies.append(accuracy)
-        target_accuracies.append(aux_acc_target)
-    return (float(np.mean(np.array(accuracies))), (exact / len(accuracies)) * 100,
-            float(np.mean(np.array(target_accuracies))))
+        acc_sum += accuracy
+        target_sum += aux_acc_target
+        n += 1
+    return acc_sum, float(exact), target_sum, float(n)
+
+
+def evaluate(data_iterator: Iterator, model, max_decoding_steps: int, pad_idx: int, sos_idx: int, eos_idx: int,
+             max_examples_to_evaluate=None) -> Tuple[float, float, float]:
+    """evaluate.py:10-24: (mean token accuracy %, exact match %, mean target-position accuracy %)."""
+    acc_sum, exact, target_sum, n = evaluate_sums(data_iterator, model, max_decoding_steps, pad_idx, sos_idx, eos_idx,
+                                                  max_examples_to_evaluate)
+    return acc_sum / n, (exact / n) * 100, target_sum / n
 
 
 def predict_and_save(dataset, model, output_file_path: str, max_decoding_steps: int, max_testing_examples=None,

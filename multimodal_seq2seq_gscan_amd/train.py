@@ -43,7 +43,10 @@ class FlatAdam:
         self.model = model
         self.lr, self.betas, self.eps = float(learning_rate), (float(adam_beta_1), float(adam_beta_2)), float(eps)
         self.lr_decay, self.lr_decay_steps = float(lr_decay), float(lr_decay_steps)
-        self.steps_taken = 0
+        self.steps_taken = 0          # Adam's `step` (bias corrections); restored from a checkpoint
+        self.lr_steps = 0             # LambdaLR's counter; NOT restored on resume, as in the reference (train.py:68-84:
+                                      # the scheduler is built before optimizer.load_state_dict and is not checkpointed,
+                                      # so a resumed run starts again from the initial learning rate)
         flat = model.flat_parameters
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
@@ -52,13 +55,22 @@ class FlatAdam:
 
     def current_lr(self) -> float:
         """What scheduler.get_lr()[0] prints at train.py:123 after `steps_taken` scheduler steps."""
-        return self.lr * self.lr_decay ** (self.steps_taken / self.lr_decay_steps)
+        return self.lr * self.lr_decay ** (self.lr_steps / self.lr_decay_steps)
+
+    def advance(self) -> None:
+        """One more optimizer.step() + scheduler.step() (train.py:111-112)."""
+        self.steps_taken += 1
+        self.lr_steps += 1
+
+    def _lr_of_this_step(self) -> float:
+        """The learning rate optimizer.step() number `lr_steps` runs with: the scheduler has stepped lr_steps-1 times."""
+        return self.lr * self.lr_decay ** ((self.lr_steps - 1) / self.lr_decay_steps)
 
     def stage_scalars(self) -> None:
-        """Host side of one step: advance the counter, push [lr_t/(1-b1^t), 1/sqrt(1-b2^t)] to the device."""
+        """Host side of one step: advance the counters, push [lr_t/(1-b1^t), 1/sqrt(1-b2^t)] to the device."""
         lib = _lib.load()
-        self.steps_taken += 1
-        lib.gscan_adam_scalars(self.lr, self.betas[0], self.betas[1], self.lr_decay, self.lr_decay_steps,
+        self.advance()
+        lib.gscan_adam_scalars(self._lr_of_this_step(), self.betas[0], self.betas[1], 1.0, 1.0,
                                self.steps_taken, self._host_scalars.data_ptr())
         self._dev_scalars.copy_(self._host_scalars, non_blocking=True)
 
@@ -68,8 +80,8 @@ class FlatAdam:
         m = self.model
         _lib.check(lib.gscan_adam_step_mean(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(),
                                             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                            m.flat_parameters.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
-                                            self.lr_decay, self.lr_decay_steps, self.steps_taken, count.data_ptr(),
+                                            m.flat_parameters.numel(), self._lr_of_this_step(), self.betas[0],
+                                            self.betas[1], self.eps, 1.0, 1.0, self.steps_taken, count.data_ptr(),
                                             torch.cuda.current_stream().cuda_stream), "gscan_adam_step_mean")
 
     def launch(self, zero_grad: bool = True, device_scalars: bool = True) -> None:
@@ -78,8 +90,8 @@ class FlatAdam:
         if not device_scalars:
             fn = lib.gscan_adam_step_zero_grad if zero_grad else lib.gscan_adam_step
             _lib.check(fn(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(), self.exp_avg.data_ptr(),
-                          self.exp_avg_sq.data_ptr(), m.flat_parameters.numel(), self.lr, self.betas[0],
-                          self.betas[1], self.eps, self.lr_decay, self.lr_decay_steps, self.steps_taken, None,
+                          self.exp_avg_sq.data_ptr(), m.flat_parameters.numel(), self._lr_of_this_step(), self.betas[0],
+                          self.betas[1], self.eps, 1.0, 1.0, self.steps_taken, None,
                           torch.cuda.current_stream().cuda_stream), "gscan_adam_step")
             return
         _lib.check(lib.gscan_adam_step_graph(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(),
@@ -89,7 +101,7 @@ class FlatAdam:
                                              torch.cuda.current_stream().cuda_stream), "gscan_adam_step_graph")
 
     def step(self, zero_grad: bool = True) -> None:
-        self.steps_taken += 1
+        self.advance()
         self.launch(zero_grad, device_scalars=False)
 
     # ---- checkpoint interop with torch.optim.Adam (model.py:246-261 stores optimizer.state_dict()) ----
@@ -112,6 +124,7 @@ class FlatAdam:
             self.exp_avg[off:off + n].copy_(sd["state"][i]["exp_avg"].reshape(-1))
             self.exp_avg_sq[off:off + n].copy_(sd["state"][i]["exp_avg_sq"].reshape(-1))
             self.steps_taken = int(sd["state"][i]["step"])
+        self.lr_steps = 0
 
 
 class GradientExchange:
@@ -120,14 +133,26 @@ class GradientExchange:
     divisors): a 4-float statistics all-reduce before backward (`seeds`), one flat gradient all-reduce after it.
     With a single process all of them are no-ops."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, always_collective: bool = False):
         self.group = process_group
         active = dist.is_available() and dist.is_initialized()
         self.world_size = dist.get_world_size(process_group) if active else 1
         self.rank = dist.get_rank(process_group) if active else 0
+        # always_collective: issue the collectives even on a one-rank group (drives the real RCCL launch and its
+        # stream hand-over on a single device; tests)
+        self.collective = active and (self.world_size > 1 or always_collective)
+        # gloo has no device collectives: device buffers are staged through host memory (two processes sharing one
+        # GPU in the tests; RCCL refuses two ranks on one device).  "nccl" = RCCL reduces in place over xGMI.
+        self.host_staged = self.collective and dist.get_backend(process_group) == "gloo"
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world_size > 1:
+        if not self.collective:
+            return t
+        if t.is_cuda and self.host_staged:
+            host = t.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+        else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
@@ -166,21 +191,25 @@ class TrainStep:
     def __init__(self, model: Model, learning_rate: float = 1e-3, adam_beta_1: float = 0.9,
                  adam_beta_2: float = 0.999, lr_decay: float = 0.9, lr_decay_steps: float = 20000.0,
                  weight_target_loss: float = 0.3, process_group=None, graph: bool = False,
-                 fused_loss: Optional[bool] = None, single_exchange: Optional[bool] = None, **_):
+                 fused_loss: Optional[bool] = None, single_exchange: Optional[bool] = None,
+                 always_collective: bool = False, on_gradients=None, **_):
         self.model = model
         self.optimizer = FlatAdam(model, learning_rate, adam_beta_1, adam_beta_2, lr_decay, lr_decay_steps)
         self.weight_target_loss = float(weight_target_loss)
-        self.exchange = GradientExchange(process_group)
+        self.exchange = GradientExchange(process_group, always_collective)
         self.graph = bool(graph)
+        # on_gradients(flat mean-loss gradient of the global batch): called between the exchange and the optimiser
+        # (which clears the buffer); diagnostics and tests only — it costs a device pass in the one-collective form
+        self.on_gradients = on_gradients
         # A single process needs no statistics exchange between forward and backward: the backward kernels seed
         # themselves from the loss partials of the forward pass (gscan_backward_nll), two launches fewer.
-        self.fused_loss = (self.exchange.world_size == 1) if fused_loss is None else bool(fused_loss)
+        self.fused_loss = (not self.exchange.collective) if fused_loss is None else bool(fused_loss)
         if self.fused_loss and self.exchange.world_size > 1:
             raise ValueError("fused_loss needs the global token count: not available with more than one process")
         # Several processes, no auxiliary loss: every rank back-propagates its SUM loss, the statistics ride behind
         # the gradients in one all-reduce and Adam divides by the global token count.
         if single_exchange is None:
-            single_exchange = self.exchange.world_size > 1 and not model.auxiliary_task and not self.graph
+            single_exchange = self.exchange.collective and not model.auxiliary_task and not self.graph
         elif single_exchange and (model.auxiliary_task or self.graph):
             raise ValueError("the one-collective step needs a single loss term and eager launches")
         self.single_exchange = bool(single_exchange)
@@ -234,7 +263,7 @@ class TrainStep:
         """Per-step host work.  Eager: only the step counter moves (scalars travel as kernel arguments).
         Graph replay: optimizer scalars and the Philox stream id go to their device slots."""
         if not self.graph:
-            self.optimizer.steps_taken += 1
+            self.optimizer.advance()
             return
         self.optimizer.stage_scalars()
         self._host_stream_id[0] = self.model._dropout_calls
@@ -262,12 +291,16 @@ class TrainStep:
             store = model._grad_store
             model._launch_backward_nll(fw["call"], self.weight_target_loss, store[-4:], self.seeds, sum_reduction=True)
             _, count, loss = self.exchange.mean_from_sums(store)
+            if self.on_gradients is not None:
+                self.on_gradients(model.flat_gradients / count)
             self.optimizer.launch_mean(count)
             model.update_state(is_best=False)
             return {"loss": loss, "tokens": count[0], "logp": fw["logp"], "aux": fw["aux"]}
         self.exchange.all_reduce(self.stats)
         self._section_backward(fw)
         self.exchange.all_reduce(model.flat_gradients)
+        if self.on_gradients is not None:
+            self.on_gradients(model.flat_gradients)
         self.optimizer.launch(zero_grad=True, device_scalars=False)
         return self._result(fw)
 
@@ -290,8 +323,13 @@ class TrainStep:
 
     def _capture(self, batch) -> dict:
         static = {k: v.clone() for k, v in batch.items()}
+        # Captured launches keep the device addresses they were recorded with, so every shape's graphs get their OWN
+        # workspace and mask buffer, held by the entry: the model would otherwise replace (and the allocator recycle)
+        # the buffers of an earlier shape the moment a larger shape arrives.
+        model = self.model
+        model._workspace = model._mask_buffer = model._mask_key = None
         # warm-up on a side stream (first launches set kernel attributes, allocate the workspace and masks)
-        saved_steps, saved_calls = self.optimizer.steps_taken, self.model._dropout_calls
+        saved_steps, saved_calls = (self.optimizer.steps_taken, self.optimizer.lr_steps), self.model._dropout_calls
         params = self.model.flat_parameters.clone()
         m, v = self.optimizer.exp_avg.clone(), self.optimizer.exp_avg_sq.clone()
         side = torch.cuda.Stream()
@@ -307,7 +345,7 @@ class TrainStep:
         self.model.flat_parameters.copy_(params)
         self.optimizer.exp_avg.copy_(m)
         self.optimizer.exp_avg_sq.copy_(v)
-        self.optimizer.steps_taken, self.model._dropout_calls = saved_steps, saved_calls
+        (self.optimizer.steps_taken, self.optimizer.lr_steps), self.model._dropout_calls = saved_steps, saved_calls
         self.model.flat_gradients.zero_()
         g_forward, g_backward, g_adam = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         pool = torch.cuda.graph_pool_handle()
@@ -319,24 +357,31 @@ class TrainStep:
             self.optimizer.launch(zero_grad=True)
         self.model.flat_gradients.zero_()
         self.model._dropout_calls = saved_calls
-        return {"static": static, "fw": fw, "g_forward": g_forward, "g_backward": g_backward, "g_adam": g_adam}
+        return {"static": static, "fw": fw, "g_forward": g_forward, "g_backward": g_backward, "g_adam": g_adam,
+                "buffers": (model._workspace, model._mask_buffer)}
 
 
 def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world_size: int) -> Dict[str, torch.Tensor]:
-    """Rank r takes rows [r*B/W, (r+1)*B/W) of the global minibatch (last rank takes the remainder)."""
+    """Rank r takes rows [floor(r*B/W), floor((r+1)*B/W)) of the global minibatch: shard sizes differ by at most
+    one row.  Every rank needs at least one row (a rank without rows could not join the step's collectives and the
+    others would wait for it forever): B < W raises on EVERY rank, since all ranks see the same B."""
     B = batch["commands"].shape[0]
-    per = B // world_size
-    lo = rank * per
-    hi = B if rank == world_size - 1 else lo + per
+    if B < world_size:
+        raise ValueError(f"a global batch of {B} rows cannot be sharded over {world_size} ranks "
+                         f"(train_on_dataset drops such a trailing batch)")
+    lo, hi = rank * B // world_size, (rank + 1) * B // world_size
     return {k: v[lo:hi] for k, v in batch.items()}
 
 
 def train(batches: Iterable[Dict[str, torch.Tensor]], model: Model, max_training_iterations: int,
-          print_every: int = 100, weight_target_loss: float = 0.3, rank: int = 0, **optim_flags) -> TrainStep:
+          print_every: int = 100, weight_target_loss: float = 0.3, rank: int = 0, optimizer_state_dict=None,
+          **optim_flags) -> TrainStep:
     """The reference's `while training_iteration < max_training_iterations` loop (train.py:86-153) over an
     iterable of device batches; evaluation/checkpointing (train.py:129-149) belong to the callers' side
     of the hot path and are not repeated here."""
     step = TrainStep(model, weight_target_loss=weight_target_loss, **optim_flags)
+    if optimizer_state_dict is not None:
+        step.optimizer.load_state_dict(optimizer_state_dict)       # train.py:82
     it = 1
     for batch in batches:
         if it >= max_training_iterations + 1:
@@ -363,13 +408,15 @@ def train_on_dataset(data_path: str, data_directory: str, generate_vocabularies:
     log every `print_every`, greedy-decode the dev split every `evaluate_every` and checkpoint on a new best exact
     match — with the HIP step, the packed batcher (dataset.py) and batched evaluation.  Under torch.distributed
     every rank reads the same file, shuffles with the same seed and trains on its rows of each batch."""
+    import random
     import numpy as np
     from .config import model_kwargs
     from .dataset import GroundedScanDataset
-    from .predict import evaluate
+    from .predict import evaluate_sums
 
     torch.manual_seed(seed)                                     # train.py:27
     np.random.seed(seed)                                        # the same shuffle on every rank
+    random.seed(seed)                                           # the same k-shot sample on every rank (dataset.load_examples)
     logger.info("Loading Training set...")
     training_set = GroundedScanDataset(data_path, data_directory, split="train", input_vocabulary_file=input_vocab_path,
                                        target_vocabulary_file=target_vocab_path,
@@ -419,6 +466,10 @@ def train_on_dataset(data_path: str, data_directory: str, generate_vocabularies:
             batch = {"commands": commands, "cmd_lengths": torch.as_tensor(cmd_lengths), "world": world,
                      "targets": targets, "tgt_lengths": torch.as_tensor(tgt_lengths), "target_positions": positions}
             if world_size > 1:
+                # the epoch's short trailing batch (gSCAN_dataset.py:195-196) may hold fewer rows than there are
+                # ranks: every rank sees the same batch, so every rank drops it
+                if commands.shape[0] < world_size:
+                    continue
                 batch = {key: value.cuda() if key.endswith("lengths") else value
                          for key, value in shard_batch(batch, rank, world_size).items()}
             out = step(batch)
@@ -429,19 +480,30 @@ def train_on_dataset(data_path: str, data_directory: str, generate_vocabularies:
                 logger.info("Iteration %08d, loss %8.4f, accuracy %5.2f, exact match %5.2f, learning_rate %.5f,"
                             " aux. accuracy target pos %5.2f" % (training_iteration, out["loss"].item(), accuracy,
                                                                  exact_match, step.optimizer.current_lr(), aux_acc))
-            if training_iteration % evaluate_every == 0 and rank == 0:      # train.py:129-149
-                logger.info("Evaluating..")
-                accuracy, exact_match, target_accuracy = evaluate(
-                    dev_set.get_data_iterator(batch_size=evaluation_batch_size), model=model,
+            if training_iteration % evaluate_every == 0:                    # train.py:129-149
+                # Every rank decodes its share of the dev batches and the four sums are all-reduced, so no rank sits
+                # in the next step's collective while rank 0 decodes the whole split (and all ranks agree on "best").
+                if rank == 0:
+                    logger.info("Evaluating..")
+                limit = max_testing_examples and -(-max_testing_examples // world_size)
+                sums = torch.tensor(evaluate_sums(
+                    dev_set.get_data_iterator(batch_size=evaluation_batch_size, shard=(rank, world_size)), model=model,
                     max_decoding_steps=max_decoding_steps, pad_idx=vocab.pad_idx, sos_idx=vocab.sos_idx,
-                    eos_idx=vocab.eos_idx, max_examples_to_evaluate=max_testing_examples)
-                logger.info("  Evaluation Accuracy: %5.2f Exact Match: %5.2f "
-                            " Target Accuracy: %5.2f" % (accuracy, exact_match, target_accuracy))
+                    eos_idx=vocab.eos_idx, max_examples_to_evaluate=limit), dtype=torch.float64)
+                if world_size > 1:
+                    sums = step.exchange.all_reduce(sums.cuda()).cpu()
+                n = max(float(sums[3]), 1.0)
+                accuracy, exact_match, target_accuracy = (float(sums[0]) / n, 100.0 * float(sums[1]) / n,
+                                                          float(sums[2]) / n)
+                if rank == 0:
+                    logger.info("  Evaluation Accuracy: %5.2f Exact Match: %5.2f "
+                                " Target Accuracy: %5.2f" % (accuracy, exact_match, target_accuracy))
                 if exact_match > best_exact_match:
                     best_exact_match = exact_match
                     model.update_state(accuracy=accuracy, exact_match=exact_match, is_best=True)
-                    model.save_checkpoint(file_name="checkpoint.pth.tar", is_best=True,
-                                          optimizer_state_dict=step.optimizer.state_dict())
+                    if rank == 0:
+                        model.save_checkpoint(file_name="checkpoint.pth.tar", is_best=True,
+                                              optimizer_state_dict=step.optimizer.state_dict())
             training_iteration += 1
             if training_iteration > max_training_iterations:
                 break

@@ -28,6 +28,44 @@ def test_grid_encoding_matches_the_readme_known_answer():
     assert int(grid.sum()) == 4 * 3 + 2 and grid[0].sum() == 0
 
 
+def test_encode_situation_known_answer_of_the_reference_test():
+    """GroundedScan/dataset_test.py:666-693 (`test_encode_situation`) restated as data: the only test the reference
+    holds that pins what the hot path consumes.  15x15 grid, the agent (direction 0) AND a red circle of size 2 in the
+    SAME cell [7, 2], a green circle of size 4 at [3, 12].  Object vectors follow ObjectVocabulary.generate_objects
+    (world.py:415-434) for the test's vocabulary (dataset_test.py:29-41: nouns circle, cylinder, square; colours red,
+    blue, green, yellow; sizes 1-4): one-hot size | one-hot over shapes + colours -> 11 attributes, 16 channels.
+    The dictionary is what Situation.to_representation (world.py:269-281) writes into a dataset file."""
+    red_circle_2 = "01001001000"       # size 2 -> bit 1; circle -> bit 4 + 0; red -> bit 4 + 3
+    green_circle_4 = "00011000010"     # size 4 -> bit 3; circle -> bit 4;     green -> bit 4 + 5
+    situation = {
+        "grid_size": 15, "agent_position": {"row": "7", "column": "2"}, "agent_direction": 0,
+        "target_object": {"vector": red_circle_2, "position": {"row": "7", "column": "2"},
+                          "object": {"shape": "circle", "color": "red", "size": "2"}},
+        "distance_to_target": "0", "direction_to_target": "n",
+        "placed_objects": {
+            "0": {"vector": red_circle_2, "position": {"row": "7", "column": "2"},
+                  "object": {"shape": "circle", "color": "red", "size": "2"}},
+            "1": {"vector": green_circle_4, "position": {"row": "3", "column": "12"},
+                  "object": {"shape": "circle", "color": "green", "size": "4"}}},
+        "carrying_object": None}
+    expected = np.zeros([15, 15, 11 + 1 + 4], dtype="uint8")           # dataset_test.py:681-688
+    expected[7, 2, -5] = 1
+    expected[7, 2, -4:] = np.array([1, 0, 0, 0])
+    expected[7, 2, :-5] = [int(c) for c in red_circle_2]
+    expected[3, 12, :-5] = [int(c) for c in green_circle_4]
+    grid = encode_situation(situation)
+    assert grid.dtype == np.uint8 and np.array_equal(grid, expected)
+    # the counter-example: read_gscan/read_gscan.py:47,54 writes the object row OVER the agent's cell, erasing the agent
+    # bit and direction; Grid.encode (minigrid.py:389-398) keeps both, and so must this reader (SURVEY.md App. B-13)
+    overwritten = expected.copy()
+    overwritten[7, 2, -5:] = 0
+    assert not np.array_equal(grid, overwritten)
+    assert grid[7, 2, :11].sum() == 3 and grid[7, 2, 11] == 1 and grid[7, 2, 12:].tolist() == [1, 0, 0, 0]
+    # the order in which objects and agent are listed does not matter
+    situation["placed_objects"] = dict(reversed(list(situation["placed_objects"].items())))
+    assert np.array_equal(encode_situation(situation), expected)
+
+
 def test_vocabulary_indices_and_json_round_trip(tmp_path):
     v = Vocabulary()
     v.add_sentence(["walk", "to", "a", "red", "circle"])

@@ -116,6 +116,7 @@ def test_reference_checkpoint_loads_and_round_trips(tmp_path):
     opt = FlatAdam(model, 1e-3)
     opt.load_state_dict(opt_state)
     assert opt.steps_taken == 2
+    assert opt.lr_steps == 0 and opt.current_lr() == 1e-3      # the scheduler restarts on resume (train.py:68-84)
     names = [n for n, _ in model.named_parameters()]
     for i, n in enumerate(names):
         off, cnt = model._offsets[n]

@@ -264,6 +264,35 @@ def test_train_step_matches_reference_adam_steps():
         assert model.trained_iterations == 3
 
 
+def test_graph_replay_with_two_batch_shapes_matches_eager():
+    """Captured HIP graphs keep the addresses they were recorded with: a second (larger) batch shape must not
+    invalidate the graphs of the first.  Shapes alternate small, large, small, large, small; the loss of every step
+    and the final parameters must equal the eager TrainStep's on the same batches."""
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+    from multimodal_seq2seq_gscan_amd.train import TrainStep
+    cfg = model_kwargs("demo", cnn_dropout_p=0.0, encoder_dropout_p=0.0, decoder_dropout_p=0.0)
+    small = Shape(batch=3, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=5, max_target=6)
+    large = Shape(batch=9, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=7, max_target=12)
+    runs = {}
+    for graph in (False, True):
+        model = build_model(cfg, fixture_params(cfg, {"seed_weights": 13}))
+        step = TrainStep(model, learning_rate=1e-3, graph=graph)
+        losses = []
+        for i in range(5):
+            batch = {k: v.cuda() for k, v in make_batch(large if i % 2 else small, 500 + i).items()}
+            losses.append(step(batch)["loss"].item())
+            # churn the allocator between steps the way a training loop does
+            junk = [torch.empty(1 << (18 + j), device="cuda").fill_(float("nan")) for j in range(3)]
+            del junk
+        torch.cuda.synchronize()
+        runs[graph] = (losses, model.flat_parameters.detach().cpu().clone())
+        if graph:
+            assert len(step._graphs) == 2
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert a == a and abs(a - b) < 1e-5, (runs[False][0], runs[True][0])
+    assert torch.allclose(runs[False][1], runs[True][1], atol=2e-5, rtol=0)
+
+
 @pytest.mark.parametrize("auxiliary", [False, True])
 def test_fused_loss_backward_matches_two_phase_path(auxiliary):
     """gscan_backward_nll (loss seeded inside the backward kernels, the single-process TrainStep) against the
