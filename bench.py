@@ -29,20 +29,44 @@ import torch.distributed as dist  # noqa: E402
 
 # fp32 matrix peak of MI355X (v_mfma_f32_*_f32 = the fp32 vector rate), MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP32_TFLOPS = 157.3
-PROBES = ("decoder_forward", "decoder_backward", "encoder_forward", "encoder_backward", "gemm")
-# HBM-side bytes per launch of the GEMM family come from separate rocprofv3 PMC passes over this same workload
-# (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process): tools/pmc_traffic.py writes the file
+PROBES = ("decoder_forward", "decoder_backward", "encoder_forward", "encoder_backward", "gemm", "conv_forward",
+          "conv_backward", "keys_backward")
+# HBM-side bytes per launch of the GEMM family cannot be read from inside the process (FETCH_SIZE / WRITE_SIZE are
+# rocprofv3 PMC counters, collected in two separate passes over this same command by tools/gpu_round.sh, which writes
+# this file together with a hash of the kernel sources it profiled).  The number is reported only when that hash
+# equals the hash of the sources of the library that is running; a stale profile yields null and a warning.
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
 
 
-def pmc_traffic(kernel_family: str):
+def source_hash() -> str:
+    """sha256 over the kernel sources and the public header (what libgscan_hip.so is built from)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "multimodal_seq2seq_gscan_amd", "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    for path in [os.path.join(csrc, f) for f in files] + [os.path.join(ROOT, "include", "gscan_hip.h")]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_family: str, workload: str):
+    """(bytes per launch or None, provenance string)."""
     if kernel_family != "gemm" or not os.path.exists(PMC_TRAFFIC):
-        return None
+        return None, "no PMC profile for this kernel family"
     try:
         with open(PMC_TRAFFIC) as f:
-            return round(float(json.load(f)["traffic_bytes_per_launch"]))
-    except (OSError, ValueError, KeyError):
-        return None
+            prof = json.load(f)
+        if prof.get("source_sha") != source_hash():
+            print(f"bench.py: WARNING: {PMC_TRAFFIC} was collected on other kernel sources "
+                  f"({prof.get('source_sha')} != {source_hash()}): roofline.traffic is null; rerun tools/gpu_round.sh",
+                  file=sys.stderr, flush=True)
+            return None, "stale PMC profile (kernel sources changed since it was collected)"
+        if prof.get("workload", "compositional") != workload:
+            return None, f"PMC profile is of workload {prof.get('workload')}"
+        return round(float(prof["traffic_bytes_per_launch"])), f"profiles/pmc_traffic_latest.json ({prof.get('tag', '?')})"
+    except (OSError, ValueError, KeyError) as e:
+        return None, f"unreadable PMC profile: {e}"
 
 
 def algorithmic_mflop_per_example(cfg: dict, G: int, L: int, T: int) -> float:
@@ -66,9 +90,8 @@ def cpu_baseline(cfg: dict, shape, budget_s: float) -> dict:
     from oracle import seq2seq_oracle as oracle
     from weights import golden_weights
     # The path issues ~20k small ATen ops per step: beyond a few dozen threads it gets slower, not faster
-    # (256 threads: 0.9 examples/s on the MI355X host).  Use at most 32 of the cores we are allowed to run on.
-    cores = min(len(os.sched_getaffinity(0)), 32)
-    torch.set_num_threads(cores)
+    # (256 threads: 0.9 examples/s on the MI355X host).  The thread count is swept below and the best one reported.
+    allowed = len(os.sched_getaffinity(0))
     params = {k: torch.from_numpy(v) for k, v in golden_weights(cfg, 1).items()}
     names = list(params)
     m = [torch.zeros_like(params[k]) for k in names]
@@ -87,16 +110,29 @@ def cpu_baseline(cfg: dict, shape, budget_s: float) -> dict:
                                         auxiliary=cfg["auxiliary_task"], masks=masks)
         oracle.adam_step([params[k] for k in names], [g[k] for k in names], m, v, step, 1e-3)
 
-    one(1)                                   # warm-up (thread pools, allocator)
+    sweep, step_no = {}, 1
+    for cores in sorted({c for c in (8, 16, 32) if c <= allowed} or {allowed}):
+        torch.set_num_threads(cores)
+        one(step_no)                         # warm-up at this thread count (thread pools, allocator)
+        t0 = time.perf_counter()
+        one(step_no + 1)
+        one(step_no + 2)
+        sweep[cores] = 2 * B / (time.perf_counter() - t0)
+        step_no += 3
+    cores = max(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    one(step_no)
     n, t0 = 0, time.perf_counter()
     while True:
-        one(n + 2)
+        one(step_no + 1 + n)
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 64:
             break
     return {"value": round(n * B / el, 1), "unit": "examples/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of the same workload (B={B}, T={T}) after 1 warm-up step, torch {torch.__version__} CPU"}
+            "thread_sweep": {str(c): round(v, 1) for c, v in sweep.items()},
+            "sample": f"{n} steps of the same workload (B={B}, T={T}) at the best thread count of the sweep, after "
+                      f"warm-up, torch {torch.__version__} CPU, {allowed} cores allowed"}
 
 
 def main():
@@ -108,6 +144,9 @@ def main():
     ap.add_argument("--target-length", type=int, default=20)
     ap.add_argument("--command-length", type=int, default=10)
     ap.add_argument("--workload", default="compositional", choices=["compositional", "target_length", "demo"])
+    ap.add_argument("--auxiliary", action="store_true", help="S4: the GECA configuration (auxiliary target-position head)")
+    ap.add_argument("--ragged", action="store_true", help="ragged command / target lengths instead of dense ones")
+    ap.add_argument("--windows", type=int, default=4, help="extra timed windows of K steps for the spread (0 = none)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--graph", action="store_true",
                     help="replay captured HIP graphs instead of launching eagerly (pays off once the host is the limiter)")
@@ -132,11 +171,11 @@ def main():
     from multimodal_seq2seq_gscan_amd.train import TrainStep
 
     lib = _lib.load()
-    cfg = model_kwargs(args.workload)
+    cfg = model_kwargs(args.workload, auxiliary_task=args.auxiliary)
     grid = 4 if args.workload == "demo" else 6
     shape = Shape(batch=args.batch, grid=grid, channels=cfg["num_cnn_channels"],
                   input_vocab=cfg["input_vocabulary_size"], target_vocab=cfg["target_vocabulary_size"],
-                  max_command=args.command_length, max_target=args.target_length, ragged=False)
+                  max_command=args.command_length, max_target=args.target_length, ragged=args.ragged)
     torch.manual_seed(42)                                 # identical initialisation on every rank (train.py:27)
     model = Model(**cfg).cuda()
     batch = {k: v.cuda() for k, v in make_batch(shape, seed=1234 + rank).items()}   # resident in HBM
@@ -162,6 +201,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     loss = float(out["loss"].item())
+    # spread: further windows of the same K steps (the contract's number is the first window above)
+    windows = [1e3 * elapsed / args.steps]
+    for _ in range(args.windows):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(batch)
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        windows.append(1e3 * float(t.item()) / args.steps)
 
     # second pass over the same K steps, launched eagerly, with HIP-event probes around each kernel family
     # (events cannot be read back from inside a captured graph)
@@ -177,12 +228,16 @@ def main():
     lib.gscan_probe_enable(0)
     families = {}
     for name in PROBES:
-        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
-        _lib.check(lib.gscan_probe_read(name.encode(), C.byref(ms), C.byref(fl), C.byref(n)), "gscan_probe_read")
+        ms, xfl, fl, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(lib.gscan_probe_read(name.encode(), C.byref(ms), C.byref(xfl), C.byref(fl), C.byref(n)),
+                   "gscan_probe_read")
         if n.value:
+            per_s = 1.0 / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
             families[name] = {"ms_per_step": ms.value / args.steps, "launches_per_step": n.value / args.steps,
                               "avg_us": 1e3 * ms.value / n.value,
-                              "tflops": fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0}
+                              "tflops": fl.value * per_s,                    # ALGORITHMIC flops / time
+                              "executed_tflops": xfl.value * per_s,          # 2 M N K of what was launched
+                              "algorithmic_gflop_per_launch": fl.value / n.value / 1e9}
     fence()
 
     if rank == 0:
@@ -191,22 +246,34 @@ def main():
         dominant = max(families, key=lambda k: families[k]["ms_per_step"])
         d = families[dominant]
         mflop = algorithmic_mflop_per_example(cfg, grid, L, T)
+        traffic, traffic_source = pmc_traffic(dominant, args.workload if not args.auxiliary and T == 20 else "other")
+        windows_sorted = sorted(windows)
+        label = {"compositional": "S4 GECA-like (auxiliary head)" if args.auxiliary else "S1 compositional",
+                 "target_length": "S3 target_length", "demo": "S0 demo"}[args.workload]
         result = {
             "metric": "training examples/sec (forward+backward) on compositional_splits, 1/2/4/8 GPUs",
             "value": round(ex_per_s, 1), "unit": "examples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"S1 {args.workload}: {B} rows/GPU, {grid}x{grid}x{cfg['num_cnn_channels']} grid, "
-                                   f"k={cfg['cnn_kernel_size']}, hidden {cfg['decoder_hidden_size']}, L={L}, T={T} dense, "
+            "ms_per_step_windows": {"n": len(windows), "min": round(windows_sorted[0], 4),
+                                    "median": round(windows_sorted[len(windows) // 2], 4),
+                                    "max": round(windows_sorted[-1], 4)},
+            "config": {"workload": f"{label}: {B} rows/GPU, {grid}x{grid}x{cfg['num_cnn_channels']} grid, "
+                                   f"k={cfg['cnn_kernel_size']}, hidden {cfg['decoder_hidden_size']}, L={L}, T={T} "
+                                   f"{'ragged' if args.ragged else 'dense'}, "
                                    f"dropout {cfg['encoder_dropout_p']}/{cfg['decoder_dropout_p']}/{cfg['cnn_dropout_p']}, "
-                                   f"conditional attention, Adam+LR step included",
+                                   f"conditional attention{', auxiliary head' if args.auxiliary else ''}, Adam+LR step included",
                        "global_batch": world * B, "parallelism": f"dp{world}", "parameters": model.flat_parameters.numel(),
-                       "launch": "hipGraph replay (3 graphs per step)" if args.graph else "eager, 22 launches per step on 3 streams"},
+                       "launch": "hipGraph replay (3 graphs per step)" if args.graph else "eager, 24 launches per step on 3 streams"},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(d["tflops"], 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_FP32_TFLOPS, 4),
-                         "traffic": pmc_traffic(dominant), "avg_launch_us": round(d["avg_us"], 2),
-                         "note": "fp32 matrix peak = fp32 vector peak on gfx950; algorithmic flops per launch in "
-                                 "DESIGN.md; traffic = HBM-side bytes per launch from the PMC passes in profiles/"},
+                         "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": round(d["avg_us"], 2),
+                         "algorithmic_gflop_per_launch": round(d["algorithmic_gflop_per_launch"], 4),
+                         "executed_over_algorithmic": round(d["executed_tflops"] / d["tflops"], 3) if d["tflops"] > 0 else None,
+                         "note": "achieved = ALGORITHMIC flops of the family's launches (SURVEY.md 8d: composite-weight and "
+                                 "U-image products not counted; per-launch list in DESIGN.md 5) / their HIP-event time; fp32 "
+                                 "matrix peak = fp32 vector peak on gfx950; traffic = HBM-side bytes per launch from the "
+                                 "rocprofv3 PMC passes named in traffic_source, null when that profile is stale"},
             "kernel_families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in families.items()},
             "step_algorithmic_tflops": round(ex_per_s * mflop / 1e6, 3),
             "final_loss": round(loss, 4),

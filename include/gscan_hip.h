@@ -14,8 +14,8 @@
  *
  * Layouts are the reference's own: parameters are the tensors of Model.state_dict()
  * (row-major [out, in], LSTM gate order i,f,g,o); commands [B,L] and targets [B,T] are
- * int64 token ids; world is float32 [B,G,G,C] indexed [row][col][channel];
- * log-probabilities are float32 [B,T,V].
+ * int64 token ids; world is float32 — or uint8, the form the batcher ships — [B,G,G,C] indexed
+ * [row][col][channel]; log-probabilities are float32 [B,T,V].
  */
 #ifndef GSCAN_HIP_H
 #define GSCAN_HIP_H
@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 6
+#define GSCAN_ABI_VERSION 7
 #define GSCAN_MAX_ENC_LAYERS 4
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
@@ -78,10 +78,13 @@ typedef struct gscan_params {
 typedef struct gscan_batch {
     const int64_t *commands;     /* [B,L]                                           */
     const int32_t *cmd_lengths;  /* [B]  number of real tokens per command          */
-    const float   *world;        /* [B,G,G,C]                                       */
+    const float   *world;        /* [B,G,G,C] float32, or NULL when world_u8 is given */
     const int64_t *targets;      /* [B,T]                                           */
     const int64_t *target_positions; /* [B] flat grid cell of the target object (gSCAN_dataset.py:216-219),
                                       * or NULL; only the auxiliary loss of gscan_backward_nll reads it */
+    const uint8_t *world_u8;     /* [B,G,G,C] the same tensor as bytes (Grid.encode writes uint8, minigrid.py:384): when
+                                  * not NULL it is read INSTEAD of `world` and widened inside the kernels — 1 byte per
+                                  * element crosses PCIe and HBM instead of 4 */
 } gscan_batch;
 
 /* Scaled dropout masks (0 or 1/(1-p)), or NULL for "no dropout" (eval mode / p = 0).
@@ -224,10 +227,13 @@ int gscan_dropout_masks(float *out, size_t n_cnn, size_t n_enc, size_t n_dec, fl
 int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, void *stream);
 
 /* Per-kernel-family timing for roofline reports: when enabled, every launch of a family
- * ("decoder_forward", "decoder_backward", "encoder_forward", "encoder_backward", "gemm") is
- * bracketed by HIP events on its launch stream.  gscan_probe_read synchronises on those events
- * and returns the summed duration, the summed ALGORITHMIC flops (DESIGN.md states the per-launch
- * formulas) and the launch count since the last reset.  Do not enable during graph capture. */
+ * ("decoder_forward", "decoder_backward", "encoder_forward", "encoder_backward", "gemm", "conv_forward",
+ * "conv_backward", "keys_backward") is bracketed by HIP events on its launch stream.  gscan_probe_read synchronises
+ * on those events and returns the summed duration, the summed EXECUTED flops (2 M N K of every product launched,
+ * tile padding excluded; 0 for the input-sparse convolution kernels, whose work depends on the data), the summed
+ * ALGORITHMIC flops (the launch's share of SURVEY.md 8(d)'s count: valid convolution taps only, composite-weight
+ * and U-image products not counted; DESIGN.md states the per-launch formulas) and the launch count since the last
+ * reset.  Do not enable during graph capture. */
 int gscan_probe_enable(int on);
 /* In-kernel timeline (diagnostic): with a device buffer of GSCAN_TRACE_WORDS uint64 set (zeroed by the caller), the
  * first workgroup of every kernel launch appends (kernel id, grid size, 100 MHz device clock) to the start list and
@@ -240,7 +246,8 @@ int gscan_probe_enable(int on);
 #define GSCAN_TRACE_WORDS (2 + 2 * 3 * GSCAN_TRACE_RECORDS)
 int gscan_trace_set(unsigned long long *device_buffer);
 int gscan_probe_reset(void);
-int gscan_probe_read(const char *name, double *total_ms, double *flops, int64_t *launches);
+int gscan_probe_read(const char *name, double *total_ms, double *executed_flops, double *algorithmic_flops,
+                     int64_t *launches);
 
 /* ---- building blocks, exported so that each kernel can be parity-tested on its own ---- */
 
@@ -254,17 +261,19 @@ int gscan_gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam
 
 /* ConvolutionalNet.forward (seq2seq/cnn_model.py:22-36) on its own: the three same-padded convolutions (kernels
  * 1, 5, K3; kh walks grid columns and kw grid rows because the reference convolves the transposed image), bias,
- * ReLU and dropout mask, as ONE product world[B, G*G*C] . Wt[G*G*C, G*G*3Co] with the Toeplitz image Wt of the
- * kernels.  conv_w[i] [Co,C,k_i,k_i], conv_b[i] [Co]; mask [B,G*G,3Co] or NULL; feat [B,G*G,3Co].
- * wt_scratch: (G*G*C + 1) * G*G*3Co floats. */
-int gscan_world_encoder_forward(const float *world, const float *const conv_w[3], const float *const conv_b[3], int B,
-                                int G, int C, int Co, int K3, const float *mask, float *wt_scratch, float *feat,
-                                void *stream);
+ * ReLU and dropout mask, computed from the NON-ZEROS of the world tensor (csrc/conv.hip; exact for any input).
+ * world: [B,G,G,C] float32, or uint8 when world_is_u8 != 0.  conv_w[i] [Co,C,k_i,k_i], conv_b[i] [Co];
+ * mask [B,G*G,3Co] or NULL; feat [B,G*G,3Co].  image_scratch: (1 + 25 + K3*K3) * C * roundup(Co, 32) floats. */
+int gscan_world_encoder_forward(const void *world, int world_is_u8, const float *const conv_w[3],
+                                const float *const conv_b[3], int B, int G, int C, int Co, int K3, const float *mask,
+                                float *image_scratch, float *feat, void *stream);
 /* Its weight gradients: given d(loss)/d(conv output before ReLU/dropout) `dfeat` [B,G*G,3Co], ADDS the kernel and
- * bias gradients into grad_w[i] / grad_b[i] (d Wt = world^T . dfeat folded back onto the kernels).
- * dwt_scratch: G*G*C * G*G*3Co floats. */
-int gscan_world_encoder_backward(const float *world, const float *dfeat, int B, int G, int C, int Co, int K3,
-                                 float *dwt_scratch, float *const grad_w[3], float *const grad_b[3], void *stream);
+ * bias gradients into grad_w[i] / grad_b[i].  list_scratch: gscan_world_encoder_backward_scratch_floats(B, G, C)
+ * floats (the per-channel lists of non-zeros). */
+size_t gscan_world_encoder_backward_scratch_floats(int B, int G, int C);
+int gscan_world_encoder_backward(const void *world, int world_is_u8, const float *dfeat, int B, int G, int C, int Co,
+                                 int K3, float *list_scratch, float *const grad_w[3], float *const grad_b[3],
+                                 void *stream);
 
 /* Masked per-row LSTM over the command (seq2seq/seq2seq_model.py:62-88).
  * gx [B,L,D,4He] = W_ih x + b_ih (D directions); out [B,L,He] = sum of directions,

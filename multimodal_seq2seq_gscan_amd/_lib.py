@@ -11,7 +11,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # GSCAN_HIP_LIB: development override, used by tools/variants.py to time experimental builds side by side
 LIB_PATH = os.environ.get("GSCAN_HIP_LIB") or os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_ENC_LAYERS = 4
 
 _f32p = C.POINTER(C.c_float)
@@ -60,7 +60,7 @@ class Params(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [("commands", C.c_void_p), ("cmd_lengths", C.c_void_p), ("world", C.c_void_p),
-                ("targets", C.c_void_p), ("target_positions", C.c_void_p)]
+                ("targets", C.c_void_p), ("target_positions", C.c_void_p), ("world_u8", C.c_void_p)]
 
 
 class Masks(C.Structure):
@@ -100,10 +100,13 @@ PROTOTYPES = {
     "gscan_dropout_masks": (_i, [_vp, _sz, _sz, _sz, _f, _f, _f, _u64, _u64, _vp, _vp]),
     "gscan_probe_enable": (_i, [_i]),
     "gscan_probe_reset": (_i, []),
-    "gscan_probe_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "gscan_probe_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                              C.POINTER(_i64)]),
     "gscan_gemm_f32": (_i, [_i, _i, _i, _f, _vp, _i64, _i64, _vp, _i64, _i64, _f, _vp, _i64, _vp, _i, _vp, _i, _vp]),
-    "gscan_world_encoder_forward": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "gscan_world_encoder_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    "gscan_world_encoder_forward": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp, _vp,
+                                         _vp]),
+    "gscan_world_encoder_backward_scratch_floats": (_sz, [_i, _i, _i]),
+    "gscan_world_encoder_backward": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "gscan_encoder_lstm_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _vp]),
     "gscan_encoder_lstm_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

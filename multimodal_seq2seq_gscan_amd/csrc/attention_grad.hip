@@ -227,6 +227,12 @@ static int launch_keys_backward(int B, const KeysBackwardArgs &a, hipStream_t st
 int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream) {
     GSCAN_CHECK(B > 0 && a.T > 0 && a.L > 0 && a.M > 0 && a.L <= 64 && a.M <= 64 && a.He > 0 && a.F > 0 && a.He <= 512,
                 "keys backward: bad dims B=%d T=%d L=%d cells=%d He=%d F=%d", B, a.T, a.L, a.M, a.He, a.F);
+    // algorithmic flops: the data-gradient halves of the key layers and of the bridge (SURVEY.md 8d counts backward as
+    // 2 x forward MACs: half of it data gradients), 2 * B * (L He H + M F H + He H); the value-path sums
+    // dPK += alpha^T . dctx are the data-gradient halves of the context reductions, 2 * B * T * (L + M) * H
+    const double alg = 2.0 * B * ((double)a.L * a.He * H + (double)a.M * a.F * H + (double)a.He * H) +
+                       2.0 * B * a.T * (double)(a.L + a.M) * H;
+    ProbeScope probe(P_KEYS_BWD, stream, alg, alg);
     switch (H) {
 #define X(n) case n: return launch_keys_backward<n>(B, a, stream);
         GSCAN_DEC_HIDDEN_SIZES(X)

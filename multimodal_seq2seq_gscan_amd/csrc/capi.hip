@@ -48,7 +48,7 @@ int gscan_workspace_find(const gscan_dims *dims, const char *name, size_t *offse
 int gscan_forward(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
                   const gscan_masks *masks, void *workspace, float *logp, float *aux_logp, void *stream) {
     ARG(dims && params && batch && workspace, "forward: NULL argument");
-    ARG(batch->commands && batch->cmd_lengths && batch->world && batch->targets, "forward: NULL batch array");
+    ARG(batch->commands && batch->cmd_lengths && (batch->world || batch->world_u8) && batch->targets, "forward: NULL batch array");
     gscan_masks none{nullptr, nullptr, nullptr};
     return step_forward(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, logp, aux_logp,
                         (hipStream_t)stream);
@@ -143,7 +143,7 @@ int gscan_trace_set(unsigned long long *device_buffer) {
     GSCAN_HIP(hipDeviceSynchronize());
     int rc = trace_set_gemm(device_buffer) | trace_set_elementwise(device_buffer) | trace_set_loss(device_buffer) |
              trace_set_lstm_encoder(device_buffer) | trace_set_decoder(device_buffer) |
-             trace_set_attention_grad(device_buffer);
+             trace_set_attention_grad(device_buffer) | trace_set_conv(device_buffer);
     GSCAN_CHECK(rc == 0, "trace_set: hipMemcpyToSymbol failed");
     GSCAN_HIP(hipDeviceSynchronize());
     return 0;
@@ -198,9 +198,10 @@ int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t st
 
 int gscan_probe_enable(int on) { return probe_enable(on); }
 int gscan_probe_reset(void) { return probe_reset(); }
-int gscan_probe_read(const char *name, double *total_ms, double *flops, int64_t *launches) {
-    ARG(name && total_ms && flops && launches, "probe_read: NULL argument");
-    return probe_read(name, total_ms, flops, launches);
+int gscan_probe_read(const char *name, double *total_ms, double *executed_flops, double *algorithmic_flops,
+                     int64_t *launches) {
+    ARG(name && total_ms && executed_flops && algorithmic_flops && launches, "probe_read: NULL argument");
+    return probe_read(name, total_ms, executed_flops, algorithmic_flops, launches);
 }
 
 int gscan_gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
@@ -210,32 +211,28 @@ int gscan_gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam
                     (hipStream_t)stream);
 }
 
-int gscan_world_encoder_forward(const float *world, const float *const conv_w[3], const float *const conv_b[3], int B,
-                                int G, int C, int Co, int K3, const float *mask, float *wt_scratch, float *feat,
-                                void *stream) {
-    ARG(world && conv_w && conv_b && wt_scratch && feat, "world_encoder_forward: NULL argument");
+int gscan_world_encoder_forward(const void *world, int world_is_u8, const float *const conv_w[3],
+                                const float *const conv_b[3], int B, int G, int C, int Co, int K3, const float *mask,
+                                float *image_scratch, float *feat, void *stream) {
+    ARG(world && conv_w && conv_b && image_scratch && feat, "world_encoder_forward: NULL argument");
     ARG(B > 0 && G > 0 && C > 0 && Co > 0 && K3 > 0 && (K3 & 1), "world_encoder_forward: bad dims");
-    const int M = G * G, F = 3 * Co;
-    float *wt = wt_scratch, *bias_rep = wt_scratch + (size_t)M * C * M * F;
     const float *const cw[3] = {conv_w[0], conv_w[1], conv_w[2]};
     const float *const cb[3] = {conv_b[0], conv_b[1], conv_b[2]};
-    if (int rc = toeplitz_build(cw, cb, G, C, Co, K3, wt, bias_rep, (hipStream_t)stream)) return rc;
-    GemmBatch g;
-    g.add(B, M * F, M * C, world, (int64_t)M * C, 1, wt, (int64_t)M * F, 1, feat, (int64_t)M * F, 0.f, bias_rep, 1, mask);
-    return g.launch((hipStream_t)stream);
+    if (int rc = conv_weight_image(cw, C, Co, K3, image_scratch, (hipStream_t)stream)) return rc;
+    return world_conv_forward(world, world_is_u8, image_scratch, cb, mask, B, G, C, Co, K3, feat, (hipStream_t)stream);
 }
 
-int gscan_world_encoder_backward(const float *world, const float *dfeat, int B, int G, int C, int Co, int K3,
-                                 float *dwt_scratch, float *const grad_w[3], float *const grad_b[3], void *stream) {
-    ARG(world && dfeat && dwt_scratch && grad_w && grad_b, "world_encoder_backward: NULL argument");
+size_t gscan_world_encoder_backward_scratch_floats(int B, int G, int C) {
+    return (B > 0 && G > 0 && C > 0) ? world_conv_backward_scratch_floats(B, G, C) : 0;
+}
+
+int gscan_world_encoder_backward(const void *world, int world_is_u8, const float *dfeat, int B, int G, int C, int Co,
+                                 int K3, float *list_scratch, float *const grad_w[3], float *const grad_b[3], void *stream) {
+    ARG(world && dfeat && list_scratch && grad_w && grad_b, "world_encoder_backward: NULL argument");
     ARG(B > 0 && G > 0 && C > 0 && Co > 0 && K3 > 0 && (K3 & 1), "world_encoder_backward: bad dims");
-    const int M = G * G, F = 3 * Co;
-    GemmBatch g;
-    g.add(M * C, M * F, B, world, 1, (int64_t)M * C, dfeat, (int64_t)M * F, 1, dwt_scratch, (int64_t)M * F);
-    if (int rc = g.launch((hipStream_t)stream)) return rc;
     float *const gw[3] = {grad_w[0], grad_w[1], grad_w[2]};
     float *const gb[3] = {grad_b[0], grad_b[1], grad_b[2]};
-    return toeplitz_fold(gw, gb, G, C, Co, K3, B, dwt_scratch, dfeat, (hipStream_t)stream);
+    return world_conv_backward(world, world_is_u8, dfeat, B, G, C, Co, K3, list_scratch, gw, gb, (hipStream_t)stream);
 }
 
 int gscan_encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths,

@@ -36,11 +36,13 @@ void set_error(const char *fmt, ...);
         }                                                                           \
     } while (0)
 
+#define TRY_RC(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Kernel ids of the in-kernel timeline (diagnostic, tools/device_timeline.py).
-enum TraceKernel { TK_DROPOUT = 1, TK_TOEPLITZ_BUILD, TK_PROLOGUE, TK_GEMM, TK_ENCODER_FWD, TK_DECODER_FWD, TK_DECODER_BWD,
-                   TK_KEYS_BWD, TK_UNPERMUTE, TK_EMBED_GRAD, TK_ENCODER_BWD, TK_TOEPLITZ_FOLD, TK_ADAM, TK_LOSS, TK_OTHER };
+enum TraceKernel { TK_DROPOUT = 1, TK_CONV_FWD, TK_PROLOGUE, TK_GEMM, TK_ENCODER_FWD, TK_DECODER_FWD, TK_DECODER_BWD,
+                   TK_KEYS_BWD, TK_UNPERMUTE, TK_EMBED_GRAD, TK_ENCODER_BWD, TK_CONV_BWD, TK_ADAM, TK_LOSS, TK_OTHER };
 constexpr int kTraceRecords = 256;     // per list; buffer = 2 counters + 2 lists of kTraceRecords x (kid, grid, ticks)
 
 #if defined(__HIPCC__)

@@ -1,0 +1,362 @@
+// World encoder (seq2seq/cnn_model.py:22-36): three same-padded convolutions (kernels 1, 5, K3) over the
+// [B, G, G, C] world tensor, concatenated along the channel dimension, ReLU, dropout — and their weight / bias
+// gradients — as INPUT-SPARSE kernels.
+//
+// A gSCAN world is a grid of one-hot attribute vectors: one agent cell (2 ones) and up to a dozen objects (3 ones
+// each) on 36 cells x 16 channels, i.e. <= ~40 non-zeros among 576 inputs (gym_minigrid/minigrid.py:380-399,
+// gSCAN_dataset.py:229-231).  And the grid (6x6) is smaller than the kernels (7x7, 13x13), so the "convolution"
+// is almost a fully connected layer: every non-zero input reaches most output cells.  Hence
+//     out[b, q, f] = bias[f] + sum over the non-zeros (p, ch, v) of example b within reach of q of
+//                    v * W_conv(f)[o(f), ch, kh = col(p) - col(q) + pad, kw = row(p) - row(q) + pad]
+// costs ~80 k multiply-adds per example instead of the 1.21 M of the dense form (3.11 M as a Toeplitz product,
+// which is what round 1 ran on the matrix cores, 61 % of it multiplying zeros), with no 12.4 MB weight image to
+// rebuild and no 12.4 MB gradient image to fold.  The result is exact for ANY input (a zero contributes nothing to a
+// sum), dense worlds just take proportionally longer.  kh walks grid columns and kw grid rows because the reference
+// convolves the transposed image (cnn_model.py:28,34).  The world may arrive as float32 or as uint8 (the batcher
+// ships 576 B per example and nothing widens it in HBM).
+//
+// Forward: four workgroups per example.  Each compacts the example's non-zeros into LDS with ballots (scan order,
+// deterministic), then every wave walks (output cell, convolution) pairs with a lane per output channel: the
+// 64 lanes test 64 non-zeros against the pair's kernel window at once, and the hits are consumed four at a time
+// (v_readlane of value and weight-row offset, one coalesced load of a Co-float weight row each, one FMA).  The
+// weight rows come from a [tap][ch][o] image of the three kernels written by the step prologue (60 k floats,
+// L2-resident).  Bound: L2 -> CU traffic of the weight rows, ~400 KB per example.
+//
+// Backward: d W_conv[o, ch, kh, kw] = sum over b, non-zeros (p, ch, v) of v * dfeat[b, q(p, tap), conv, o].  A first
+// small kernel compacts the non-zeros per (input channel, quarter of the batch); in the second a workgroup owns two
+// kernel taps of one input channel, a wave per (tap, batch quarter), a lane per output channel: one Co-float row of
+// dfeat per hit, the four quarter sums added in LDS, and the tap's gradients leave as plain adds into the reference's
+// [Co, C, k, k] layout — no atomics, fixed summation order.  Extra workgroups add the bias gradients (column sums of
+// dfeat).
+#include "step.h"
+
+namespace gscan {
+
+constexpr int kConvThreads = 512;
+constexpr int kConvWaves = kConvThreads / 64;
+constexpr int kConvSegments = 4;       // the batch is cut into this many segments for the backward kernel's lists
+
+__global__ void conv_image_kernel(const float *__restrict__ w1, const float *__restrict__ w2,
+                                  const float *__restrict__ w3, int C, int Co, int K3, float *__restrict__ img) {
+    const int total = (26 + K3 * K3) * C * conv_row_floats(Co);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
+        img[i] = conv_image_element(w1, w2, w3, C, Co, K3, i);
+}
+
+int conv_weight_image(const float *const (&w)[3], int C, int Co, int K3, float *img, hipStream_t stream) {
+    const int total = (int)conv_image_floats(C, Co, K3);
+    hipLaunchKernelGGL(conv_image_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, stream, w[0], w[1], w[2],
+                       C, Co, K3, img);
+    GSCAN_LAUNCHED("conv_image_kernel");
+    return 0;
+}
+
+struct ConvArgs {
+    int B, G, C, Co, K3;
+    const float *img;            // forward: [tap][ch][o]
+    const float *b[3];           // forward: biases
+    const float *mask;           // forward: [B, G*G, 3Co] scaled keep mask or NULL
+    float *feat;                 // forward: [B, G*G, 3Co]
+    const float *dfeat;          // backward: [B, G*G, 3Co] gradient wrt the pre-activation
+    float *gw[3], *gb[3];        // backward: gradients (added to)
+    int slice, nw_blocks;       // backward: examples per list segment, workgroups that own weight gradients
+    uint32_t *seg_keys;          // backward: per (channel, segment) lists of non-zeros [C][kConvSegments][slice * G*G]
+    float *seg_vals;
+    int *seg_count;              // [C][kConvSegments]
+};
+
+// Compaction of the non-zeros among n elements into LDS by the whole workgroup, in scan order (deterministic).
+// get(e) -> value, key(e) -> packed coordinates.  Wave w takes a contiguous range of the elements; pass 1 counts its
+// non-zeros, pass 2 (after the counts of the waves in front are known) writes them.  A pass fetches eight 64-element
+// rows before it looks at any of them: the scan is a chain of global-load latencies otherwise (one wave alone over a
+// 576-byte example: 9 dependent round trips to HBM, most of the kernel).  Returns the count; ends with a barrier.
+template <typename Get, typename Key>
+__device__ __forceinline__ int compact_nonzeros(int n, uint32_t *keys, float *vals, int *wave_counts, Get get, Key key) {
+    constexpr int U = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (((n + kConvWaves - 1) / kConvWaves) + 63) / 64 * 64;
+    const int lo = wave * per, hi = min(n, lo + per);
+    int cnt = 0;
+    for (int base = lo; base < hi; base += 64 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * 64 + lane;
+            v[u] = e < hi ? get(e) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cnt += __popcll(__ballot(v[u] != 0.f));
+    }
+    if (lane == 0) wave_counts[wave] = cnt;
+    __syncthreads();
+    int at = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kConvWaves; ++w) {
+        const int c = wave_counts[w];
+        at += w < wave ? c : 0;
+        total += c;
+    }
+    for (int base = lo; base < hi; base += 64 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * 64 + lane;
+            v[u] = e < hi ? get(e) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool nz = v[u] != 0.f;
+            const unsigned long long m = __ballot(nz);
+            if (nz) {
+                const int i = at + __popcll(m & ((1ull << lane) - 1ull));
+                keys[i] = key(base + u * 64 + lane);
+                vals[i] = v[u];
+            }
+            at += __popcll(m);
+        }
+    }
+    __syncthreads();
+    return total;
+}
+
+// acc += sum over the set lanes j of `hits` of val_j * src[row_j + o].  A hit costs one load of a short row and nothing
+// is reused, so what matters is how many loads a wave keeps in flight: R hits per round (a missing hit repeats
+// the round's first address with a zero value), value and row offset fetched from the hit lanes with v_readlane.
+template <int R>
+__device__ __forceinline__ float consume_hits(unsigned long long hits, int row, float v, const float *__restrict__ src,
+                                              int o) {
+    float acc[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) acc[u] = 0.f;
+    while (hits) {
+        int j[R];
+        bool has[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            has[u] = hits != 0;
+            j[u] = has[u] ? __builtin_ctzll(hits) : j[0];
+            hits = has[u] ? (hits & (hits - 1)) : hits;
+        }
+        float w[R], x[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int r = __builtin_amdgcn_readlane(row, j[u]);
+            x[u] = has[u] ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j[u])) : 0.f;
+            w[u] = src[r + o];
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) acc[u] = fmaf(x[u], w[u], acc[u]);
+    }
+#pragma unroll
+    for (int w = R / 2; w > 0; w >>= 1)
+#pragma unroll
+        for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
+    return acc[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kConvThreads) void world_conv_fwd_kernel(ConvArgs a, const T *__restrict__ world) {
+    TraceScope trace_scope(TK_CONV_FWD);
+    extern __shared__ uint32_t conv_lds[];
+    const int G = a.G, C = a.C, Co = a.Co, M = G * G, F = 3 * Co, MC = M * C;
+    uint32_t *keys = conv_lds;
+    float *vals = reinterpret_cast<float *>(conv_lds + MC);
+    int *wave_counts = reinterpret_cast<int *>(conv_lds + 2 * MC);
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T *x = world + (int64_t)b * MC;
+    const int count = compact_nonzeros(
+        MC, keys, vals, wave_counts, [&](int e) { return (float)x[e]; },
+        [&](int e) { const int p = e / C, ch = e - p * C, pr = p / G; return (uint32_t)(pr | ((p - pr * G) << 8) | (ch << 16)); });
+    // an example's (output cell, convolution) pairs are dealt to gridDim.y workgroups x 8 waves
+    const int ochunks = (Co + 63) >> 6, npairs = M * 3 * ochunks, CoP = conv_row_floats(Co);
+    for (int pair = blockIdx.y * kConvWaves + wave; pair < npairs; pair += gridDim.y * kConvWaves) {
+        const int q = pair / (3 * ochunks), rem = pair - q * 3 * ochunks, conv = rem / ochunks, oc = rem - conv * ochunks;
+        const int o = oc * 64 + lane, oo = min(o, Co - 1);
+        const int k = conv_ksize(conv, a.K3), h = k >> 1, tap0 = conv_tap0(conv, a.K3);
+        const int qr = q / G, qc = q - qr * G;
+        float acc = 0.f;
+        for (int c0 = 0; c0 < count; c0 += 64) {
+            const int i = c0 + lane;
+            const bool live = i < count;
+            const uint32_t key = live ? keys[i] : 0u;
+            const float v = live ? vals[i] : 0.f;
+            const int kw = (int)(key & 255u) - qr + h, kh = (int)((key >> 8) & 255u) - qc + h, ch = (int)(key >> 16);
+            const bool hit = live && (unsigned)kw < (unsigned)k && (unsigned)kh < (unsigned)k;
+            const int row = ((tap0 + kh * k + kw) * C + ch) * CoP;
+            acc += consume_hits<8>(__ballot(hit), row, v, a.img, oo);
+        }
+        if (o < Co) {
+            const int f = conv * Co + o;
+            const int64_t at = ((int64_t)b * M + q) * F + f;
+            float val = fmaxf(acc + a.b[conv][o], 0.f);
+            if (a.mask) val *= a.mask[at];
+            a.feat[at] = val;
+        }
+    }
+}
+
+// Backward, pass 1: the non-zeros of input channel ch among the examples of batch segment s, compacted in scan
+// order into seg_keys / seg_vals [ch][s][...] (key = cell row | cell column << 8 | example << 16).
+template <typename T>
+__global__ __launch_bounds__(kConvThreads) void world_channel_lists_kernel(ConvArgs a, const T *__restrict__ world) {
+    TraceScope trace_scope(TK_CONV_BWD);
+    __shared__ int wave_counts[kConvWaves];
+    const int G = a.G, C = a.C, M = G * G;
+    const int ch = blockIdx.x, sg = blockIdx.y, b0 = sg * a.slice, nb = max(0, min(a.B, b0 + a.slice) - b0);
+    const int64_t base = ((int64_t)ch * kConvSegments + sg) * a.slice * M;
+    const T *x = world + (int64_t)b0 * M * C + ch;
+    const int count = compact_nonzeros(
+        nb * M, a.seg_keys + base, a.seg_vals + base, wave_counts, [&](int e) { return (float)x[(int64_t)e * C]; },
+        [&](int e) { const int bl = e / M, p = e - bl * M, pr = p / G; return (uint32_t)(pr | ((p - pr * G) << 8) | ((b0 + bl) << 16)); });
+    if (threadIdx.x == 0) a.seg_count[ch * kConvSegments + sg] = count;
+}
+
+// Backward, pass 2.  Workgroup (ch, y): its 8 waves are 2 kernel taps (x output-channel chunk) times the 4 batch
+// segments; wave (tap, segment) walks that segment's list of channel ch in chunks of 64 (a lane per non-zero tests it
+// against the tap), consumes the hits 16 row loads at a time with a lane per output channel, and the four segment
+// sums of a tap are added in LDS in a fixed order: the workgroup OWNS the tap's Co gradients, which leave as plain adds.
+template <int DUMMY>
+__global__ __launch_bounds__(kConvThreads) void world_conv_bwd_kernel(ConvArgs a) {
+    TraceScope trace_scope(TK_CONV_BWD);
+    __shared__ float partial[kConvWaves][64];
+    const int G = a.G, C = a.C, Co = a.Co, M = G * G, F = 3 * Co;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= a.nw_blocks) {
+        if (blockIdx.y != 0) return;
+        // bias gradients: db_i[o] += sum over rows of dfeat[row, f] for a chunk of 64 rows of the [B*G*G, F] view
+        const int chunk = blockIdx.x - a.nw_blocks, rows = a.B * M;
+        const int r0 = chunk * 64, r1 = min(rows, r0 + 64);
+        for (int f = threadIdx.x; f < F; f += kConvThreads) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int r = r0;
+            for (; r + 3 < r1; r += 4) {
+                s0 += a.dfeat[(int64_t)r * F + f];
+                s1 += a.dfeat[(int64_t)(r + 1) * F + f];
+                s2 += a.dfeat[(int64_t)(r + 2) * F + f];
+                s3 += a.dfeat[(int64_t)(r + 3) * F + f];
+            }
+            for (; r < r1; ++r) s0 += a.dfeat[(int64_t)r * F + f];
+            atomicAdd(&a.gb[f / Co][f % Co], (s0 + s1) + (s2 + s3));
+        }
+        return;
+    }
+    constexpr int kTapsPerGroup = kConvWaves / kConvSegments;
+    const int ch = blockIdx.x, sg = wave % kConvSegments;
+    const int ochunks = (Co + 63) >> 6, npairs = (26 + a.K3 * a.K3) * ochunks;
+    const int pair = blockIdx.y * kTapsPerGroup + wave / kConvSegments;
+    const bool owns = pair < npairs;
+    const int tg = owns ? pair / ochunks : 0, oc = owns ? pair - tg * ochunks : 0;
+    const int o = oc * 64 + lane, oo = min(o, Co - 1);
+    const int conv = tg < 1 ? 0 : (tg < 26 ? 1 : 2), k = conv_ksize(conv, a.K3), h = k >> 1;
+    const int t = tg - conv_tap0(conv, a.K3), kh = t / k, kw = t - kh * k;
+    float acc = 0.f;
+    if (owns) {
+        const int64_t base = ((int64_t)ch * kConvSegments + sg) * a.slice * M;
+        const int count = a.seg_count[ch * kConvSegments + sg];
+        // the non-zero at (pr, pc) reaches output cell (pr - (kw - h), pc - (kh - h)) through this tap
+        for (int c0 = 0; c0 < count; c0 += 64) {
+            const int i = c0 + lane;
+            const bool live = i < count;
+            const uint32_t key = live ? a.seg_keys[base + i] : 0u;
+            const float v = live ? a.seg_vals[base + i] : 0.f;
+            const int qr = (int)(key & 255u) - (kw - h), qc = (int)((key >> 8) & 255u) - (kh - h), b = (int)(key >> 16);
+            const bool hit = live && (unsigned)qr < (unsigned)G && (unsigned)qc < (unsigned)G;
+            const int row = (b * M + qr * G + qc) * F + conv * Co;
+            acc += consume_hits<16>(__ballot(hit), row, v, a.dfeat, oo);
+        }
+    }
+    partial[wave][lane] = acc;
+    __syncthreads();
+    if (owns && sg == 0 && o < Co) {
+        const int w0 = wave;          // waves w0 .. w0 + 3 hold the four segment sums of this tap
+        const float sum = (partial[w0][lane] + partial[w0 + 1][lane]) + (partial[w0 + 2][lane] + partial[w0 + 3][lane]);
+        a.gw[conv][(o * C + ch) * k * k + t] += sum;
+    }
+}
+
+// MAC_conv = C * Co * sum over the three kernels of valid(G, k)^2, valid = taps that hit real cells
+static double conv_algorithmic_flops(int B, int G, int C, int Co, int K3) {
+    double mac = 0.0;
+    for (int k : {1, 5, K3}) {
+        int valid = 0;
+        for (int i = 0; i < G; ++i)
+            for (int j = 0; j < G; ++j) valid += (i - j <= k / 2 && j - i <= k / 2);
+        mac += (double)valid * valid;
+    }
+    return 2.0 * B * C * Co * mac;
+}
+
+static int conv_check(int B, int G, int C, int Co, int K3) {
+    GSCAN_CHECK(B > 0 && G > 0 && G <= 255 && C > 0 && C <= 255 && Co > 0 && K3 > 0 && (K3 & 1),
+                "world encoder: unsupported dimensions (B=%d G=%d C=%d Co=%d K3=%d)", B, G, C, Co, K3);
+    GSCAN_CHECK((int64_t)B * G * G * 3 * Co < (1ll << 31) && (int64_t)(26 + K3 * K3) * C * Co < (1ll << 31),
+                "world encoder: batch or kernels too large for 32-bit offsets (B=%d G=%d Co=%d K3=%d)", B, G, Co, K3);
+    return 0;
+}
+
+int world_conv_forward(const void *world, int world_is_u8, const float *img, const float *const (&b)[3],
+                       const float *mask, int B, int G, int C, int Co, int K3, float *feat, hipStream_t stream) {
+    TRY_RC(conv_check(B, G, C, Co, K3));
+    const size_t lds = (size_t)G * G * C * 8 + 4 * kConvWaves;
+    GSCAN_CHECK(lds <= 128 * 1024, "world encoder: a %dx%dx%d world does not fit the non-zero list in LDS", G, G, C);
+    ConvArgs a{};
+    a.B = B; a.G = G; a.C = C; a.Co = Co; a.K3 = K3; a.img = img; a.mask = mask; a.feat = feat;
+    for (int i = 0; i < 3; ++i) a.b[i] = b[i];
+    static bool attr_set = false;
+    if (!attr_set) {
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&world_conv_fwd_kernel<float>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&world_conv_fwd_kernel<uint8_t>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    ProbeScope probe(P_CONV_FWD, stream, 0.0, conv_algorithmic_flops(B, G, C, Co, K3));
+    // four workgroups per example: 32 waves per CU keep ~256 row loads in flight, and the examples' unequal numbers
+    // of non-zeros (5 ... 38) spread over the chip instead of one CU carrying the heaviest example alone
+    const dim3 grid(B, 4);
+    if (world_is_u8)
+        hipLaunchKernelGGL(world_conv_fwd_kernel<uint8_t>, grid, dim3(kConvThreads), lds, stream, a,
+                           static_cast<const uint8_t *>(world));
+    else
+        hipLaunchKernelGGL(world_conv_fwd_kernel<float>, grid, dim3(kConvThreads), lds, stream, a,
+                           static_cast<const float *>(world));
+    GSCAN_LAUNCHED("world_conv_fwd_kernel");
+    return 0;
+}
+
+size_t world_conv_backward_scratch_floats(int B, int G, int C) {
+    const size_t seg = (size_t)cdiv(B, kConvSegments) * G * G;
+    return 2 * (size_t)C * kConvSegments * seg + (size_t)C * kConvSegments + 64;
+}
+
+int world_conv_backward(const void *world, int world_is_u8, const float *dfeat, int B, int G, int C, int Co, int K3,
+                        float *scratch, float *const (&gw)[3], float *const (&gb)[3], hipStream_t stream) {
+    TRY_RC(conv_check(B, G, C, Co, K3));
+    GSCAN_CHECK(B < 65536, "world encoder: more than 65535 examples per call (B=%d)", B);
+    ConvArgs a{};
+    a.B = B; a.G = G; a.C = C; a.Co = Co; a.K3 = K3; a.dfeat = dfeat;
+    for (int i = 0; i < 3; ++i) { a.gw[i] = gw[i]; a.gb[i] = gb[i]; }
+    a.slice = cdiv(B, kConvSegments);
+    a.nw_blocks = C;
+    const size_t seg = (size_t)a.slice * G * G;
+    a.seg_keys = reinterpret_cast<uint32_t *>(scratch);
+    a.seg_vals = scratch + (size_t)C * kConvSegments * seg;
+    a.seg_count = reinterpret_cast<int *>(scratch + 2 * (size_t)C * kConvSegments * seg);
+    const int npairs = (26 + K3 * K3) * cdiv(Co, 64);
+    const dim3 lists(C, kConvSegments), grid(C + cdiv((int64_t)B * G * G, 64), cdiv(npairs, kConvWaves / kConvSegments));
+    ProbeScope probe(P_CONV_BWD, stream, 0.0, conv_algorithmic_flops(B, G, C, Co, K3));
+    if (world_is_u8)
+        hipLaunchKernelGGL(world_channel_lists_kernel<uint8_t>, lists, dim3(kConvThreads), 0, stream, a,
+                           static_cast<const uint8_t *>(world));
+    else
+        hipLaunchKernelGGL(world_channel_lists_kernel<float>, lists, dim3(kConvThreads), 0, stream, a,
+                           static_cast<const float *>(world));
+    GSCAN_LAUNCHED("world_channel_lists_kernel");
+    hipLaunchKernelGGL(world_conv_bwd_kernel<0>, grid, dim3(kConvThreads), 0, stream, a);
+    GSCAN_LAUNCHED("world_conv_bwd_kernel");
+    return 0;
+}
+
+GSCAN_TRACE_TU(conv)
+
+}  // namespace gscan

@@ -1,6 +1,5 @@
 // Small memory-bound kernels of the training step: embedding gather / gradient scatter, the step
-// prologue (weight images, embeddings, zeroing), the Toeplitz image of the convolutions and its
-// gradient fold, fused Adam and the Philox dropout-mask generator.
+// prologue (weight images, embeddings, zeroing), fused Adam and the Philox dropout-mask generator.
 // All are one-pass, coalesced along the innermost (feature) dimension.
 #include "step.h"
 
@@ -218,11 +217,12 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 //   seg 7  zero_extra          = 0   (accumulation targets: encoder direction sums enc_out / hN, split-K dxe)
 //   seg 8  register images of the decoder's recurrent weights and of the output head (step.h)
 //   seg 9  register image of the encoder's recurrent weights: [dir][r][k][thread] = W_hh_dir[thread + r*NT][k]
+//   seg 10 [tap][ch][o] image of the three convolution kernels (conv.hip)
 // ------------------------------------------------------------------------------------------
 
 __global__ void prologue_kernel(PrologueArgs a) {
     TraceScope trace_scope(TK_PROLOGUE);
-    const int64_t total = a.end[9];
+    const int64_t total = a.end[10];
     const int H = a.H;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -267,16 +267,20 @@ __global__ void prologue_kernel(PrologueArgs a) {
             a.zero_extra[idx - a.end[6]] = 0.f;
         } else if (idx < a.end[8]) {
             decoder_image_element(a.img, (int)(idx - a.end[7]));
-        } else {
+        } else if (idx < a.end[9]) {
             const int i = (int)(idx - a.end[8]), He = a.He, nt = 4 * He / a.enc_rows;
             const int j = i % nt, k = (i / nt) % He, r = (i / (nt * He)) % a.enc_rows, dir = i / (4 * He * He);
             a.enc_image[i] = (dir ? a.enc_w_hh_r : a.enc_w_hh_f)[(int64_t)(j + r * nt) * He + k];
+        } else {
+            const int i = (int)(idx - a.end[9]);
+            a.conv_img[i] = conv_image_element(a.conv_w[0], a.conv_w[1], a.conv_w[2], a.cC, a.cCo, a.cK3, i);
         }
     }
 }
 
 int step_prologue(const PrologueArgs &args, hipStream_t stream) {
-    const int64_t total = args.end[9];
+    const int64_t total = args.end[10];
+    if (total == 0) return 0;
     hipLaunchKernelGGL(prologue_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, stream,
                        args);
     GSCAN_LAUNCHED("prologue_kernel");
@@ -298,136 +302,6 @@ __global__ void unpermute_add_kernel(const float *__restrict__ dwo_perm, float *
 int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream) {
     hipLaunchKernelGGL(unpermute_add_kernel, dim3(cdiv(H * 4 * H, 256)), dim3(256), 0, stream, dwo_perm, g_w_o2h, H);
     GSCAN_LAUNCHED("unpermute_add_kernel");
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// World encoder as ONE dense product (seq2seq/cnn_model.py:22-36).  The grid is tiny (G*G = 36 cells, 576
-// inputs per example), so the three same-padded convolutions are expanded into a Toeplitz matrix
-//   Wt[(r',c',ch), (r,c,f)] = W_conv(f)[o(f), ch, kh = c'-c+p, kw = r'-r+p]   (0 outside the kernel window)
-// and  features[b, (r,c,f)] = relu(world[b,:] . Wt[:, (r,c,f)] + bias[f]) : no im2col buffer (44 MB at B=256),
-// K = 576 instead of 16*(1+25+49) = 1200 gathered taps, and the output is already [B, G*G, 3*Co].
-// kh walks grid columns and kw grid rows because the reference convolves the transposed image.
-// ------------------------------------------------------------------------------------------
-struct ToeplitzArgs {
-    const float *w[3], *b[3];
-    int G, C, Co, K3;
-};
-__device__ __forceinline__ int conv_kernel_size(int i, int K3) { return i == 0 ? 1 : (i == 1 ? 5 : K3); }
-
-// grid (G*G*C + 1, 4): row j of Wt per blockIdx.x (its cell / channel are block-uniform), a quarter of the output
-// cells per blockIdx.y, a thread per feature f; the extra last row writes the replicated bias.  All index
-// arithmetic that involves a division is block- or loop-uniform (scalar): the kernel is a pure store stream.
-__global__ void toeplitz_build_kernel(ToeplitzArgs a, float *__restrict__ wt, float *__restrict__ bias_rep) {
-    TraceScope trace_scope(TK_TOEPLITZ_BUILD);
-    const int G = a.G, C = a.C, Co = a.Co, F = 3 * Co, N = G * G * F, J = G * G * C;
-    const int j = blockIdx.x;
-    const int cell = j / C, ch = j - cell * C, r2 = cell / G, c2 = cell - r2 * G;
-    const int per = (G * G + gridDim.y - 1) / gridDim.y, pos0 = blockIdx.y * per, pos1 = min(G * G, pos0 + per);
-    for (int f = threadIdx.x; f < F; f += blockDim.x) {
-        const int i = (f >= Co) + (f >= 2 * Co), o = f - i * Co;
-        if (j == J) {                                         // bias replicated over the G*G positions
-            const float bv = a.b[i][o];
-            for (int pos = pos0; pos < pos1; ++pos) bias_rep[pos * F + f] = bv;
-            continue;
-        }
-        const int k = conv_kernel_size(i, a.K3), p = k / 2;
-        const float *wrow = a.w[i] + (o * C + ch) * k * k;
-        float *dst = wt + (int64_t)j * N + f;
-        int r = pos0 / G, c = pos0 - r * G;
-        for (int pos = pos0; pos < pos1; ++pos) {
-            const int kw = r2 - r + p, kh = c2 - c + p;
-            dst[pos * F] = (kw >= 0 && kw < k && kh >= 0 && kh < k) ? wrow[kh * k + kw] : 0.f;
-            if (++c == G) { c = 0; ++r; }
-        }
-    }
-}
-
-int toeplitz_build(const float *const (&w)[3], const float *const (&b)[3], int G, int C, int Co, int K3, float *wt,
-                   float *bias_rep, hipStream_t stream) {
-    ToeplitzArgs a{{w[0], w[1], w[2]}, {b[0], b[1], b[2]}, G, C, Co, K3};
-    const int F = 3 * Co, J = G * G * C;
-    hipLaunchKernelGGL(toeplitz_build_kernel, dim3(J + 1, 4), dim3(std::min(256, cdiv(F, 64) * 64)), 0, stream, a, wt,
-                       bias_rep);
-    GSCAN_LAUNCHED("toeplitz_build_kernel");
-    return 0;
-}
-
-// Fold d(Wt) back onto the three convolution kernels and sum d(features) into the three biases:
-//   dW_i[o,ch,kh,kw] += sum over output cells (r,c) with (r+kw-p, c+kh-p) inside the grid of dWt[(r',c',ch),(r,c,f)]
-//   db_i[o]          += sum over rows b and cells of dfeat[b, (r,c), f]
-// Blocks [0, nw) fold weights (thread -> (o fastest, tap)), the remaining blocks sum 64-row chunks of dfeat.
-struct ToeplitzGradArgs {
-    float *gw[3], *gb[3];
-    int G, C, Co, K3, rows, nw_blocks;
-    int wcount[3];
-};
-__global__ void toeplitz_fold_kernel(ToeplitzGradArgs a, const float *__restrict__ dwt, const float *__restrict__ dfeat) {
-    TraceScope trace_scope(TK_TOEPLITZ_FOLD);
-    const int G = a.G, C = a.C, Co = a.Co, F = 3 * Co, N = G * G * F;
-    if ((int)blockIdx.x < a.nw_blocks) {
-        int e = blockIdx.x * blockDim.x + threadIdx.x;
-        int i = 0;
-        while (i < 3 && e >= a.wcount[i]) { e -= a.wcount[i]; ++i; }
-        if (i >= 3) return;
-        const int k = conv_kernel_size(i, a.K3), p = k / 2;
-        const int o = e % Co, tap = e / Co;                    // tap = (ch*k + kh)*k + kw
-        const int kw = tap % k, kh = (tap / k) % k, ch = tap / (k * k);
-        // output cells (r, c) whose input cell (r + kw - p, c + kh - p) lies inside the grid: two index ranges, no
-        // tests inside the loops, and the loads of a grid row are independent (up to 8 in flight per thread: the
-        // loop used to be one dependent load per iteration, 18 us for 12 MB)
-        const int rlo = max(0, p - kw), rhi = min(G, G + p - kw), clo = max(0, p - kh), chi = min(G, G + p - kh);
-        const float *base = dwt + (int64_t)ch * N + i * Co + o + (int64_t)((kw - p) * G + (kh - p)) * C * N;
-        const int64_t cell_step = (int64_t)C * N + F;           // (r, c) -> (r, c+1): input row block and output column block
-        float acc0 = 0.f, acc1 = 0.f;
-        for (int r = rlo; r < rhi && clo < chi; ++r) {          // (taps that reach no cell of a small grid: k = 13 on 6x6)
-            const float *row = base + (int64_t)(r * G) * cell_step;
-            float x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = clo + u;
-                x[u] = row[(int64_t)min(c, chi - 1) * cell_step];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-                acc0 += (clo + u < chi) ? x[u] : 0.f;
-                acc1 += (clo + u + 1 < chi) ? x[u + 1] : 0.f;
-            }
-        }
-        const float acc = acc0 + acc1;
-        a.gw[i][((o * C + ch) * k + kh) * k + kw] += acc;
-    } else {
-        const int chunk = blockIdx.x - a.nw_blocks;
-        const int f = threadIdx.x;
-        if (f >= F) return;
-        const int r0 = chunk * 64, r1 = min(a.rows, r0 + 64);     // rows of the [B*G*G, F] view
-        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-        int r = r0;
-        for (; r + 3 < r1; r += 4) {
-            acc0 += dfeat[(int64_t)r * F + f];
-            acc1 += dfeat[(int64_t)(r + 1) * F + f];
-            acc2 += dfeat[(int64_t)(r + 2) * F + f];
-            acc3 += dfeat[(int64_t)(r + 3) * F + f];
-        }
-        for (; r < r1; ++r) acc0 += dfeat[(int64_t)r * F + f];
-        atomicAdd(&a.gb[f / Co][f % Co], (acc0 + acc1) + (acc2 + acc3));
-    }
-}
-
-int toeplitz_fold(float *const (&gw)[3], float *const (&gb)[3], int G, int C, int Co, int K3, int B, const float *dwt,
-                  const float *dfeat, hipStream_t stream) {
-    ToeplitzGradArgs a{{gw[0], gw[1], gw[2]}, {gb[0], gb[1], gb[2]}, G, C, Co, K3, B * G * G, 0, {0, 0, 0}};
-    int total = 0;
-    for (int i = 0; i < 3; ++i) {
-        const int k = i == 0 ? 1 : (i == 1 ? 5 : K3);
-        a.wcount[i] = Co * C * k * k;
-        total += a.wcount[i];
-    }
-    GSCAN_CHECK(3 * Co <= 256, "toeplitz_fold: more than 256 feature channels");
-    GSCAN_CHECK(G <= 8, "toeplitz_fold: grids wider than 8 cells are not supported (got %d)", G);
-    a.nw_blocks = cdiv(total, 256);
-    hipLaunchKernelGGL(toeplitz_fold_kernel, dim3(a.nw_blocks + cdiv(a.rows, 64)), dim3(256), 0, stream, a, dwt, dfeat);
-    GSCAN_LAUNCHED("toeplitz_fold_kernel");
     return 0;
 }
 

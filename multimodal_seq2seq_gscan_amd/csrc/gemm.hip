@@ -4,7 +4,7 @@
 //   C[M,N] = act(alpha * A.B + beta * C + bias[n]) * mask[m,n]           (+ optional  asum[m] += sum_k A(m,k))
 //
 // Every dense contraction of the training step that is not inside a per-row kernel goes through
-// this kernel: the Toeplitz-expanded convolutions, key/value projections, LSTM input projections,
+// this kernel: key/value projections, LSTM input projections, data-gradient products
 // and all weight-gradient products (K = B*T rows, split over workgroups).
 // Operands are addressed with (row, col) strides so the reference's [out,in] parameter
 // layout and its transposes are consumed in place; nothing is re-packed in HBM.
@@ -478,7 +478,9 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
     p = GemmProblem{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, gate, chunk,
                     split_k > 1 ? 1 : 0, asum1, asum2, 0, 0, 0, 0u, 0u, flags, 0};   // tile bookkeeping: at launch
     tiles_ += cdiv(N, BN) * cdiv(M, 64) * split_k;                            // in 64-row tiles
-    flops_ += 2.0 * M * N * K;
+    last_flops_ = 2.0 * M * N * K;
+    flops_ += last_flops_;
+    alg_flops_ += last_flops_;
 }
 
 // Launches whose 64-row tiling has fewer workgroups than this use 32-row tiles.  Measured on the training step's
@@ -518,7 +520,7 @@ int GemmBatch::launch(hipStream_t stream) {
     }
     const int *t = grp_.tile_begin;
 #define TB t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]
-    ProbeScope probe(P_GEMM, stream, flops_);
+    ProbeScope probe(P_GEMM, stream, flops_, alg_flops_);
     // 64-deep K rounds (GSCAN_GEMM_BK=64, experiments): isolated long-K split products gain 10-20 % (a round's
     // load latency is paid half as often), but the overlapped training step loses 3 % to the larger workgroups
     // (52 KB of LDS, +40 VGPRs), so 32 is what every launch uses.

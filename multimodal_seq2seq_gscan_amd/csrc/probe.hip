@@ -10,18 +10,19 @@
 namespace gscan {
 
 static const char *kProbeNames[P_COUNT] = {"decoder_forward", "decoder_backward", "encoder_forward",
-                                           "encoder_backward", "gemm"};
+                                           "encoder_backward", "gemm", "conv_forward", "conv_backward",
+                                           "keys_backward"};
 struct ProbeState {
     std::vector<hipEvent_t> begin, end;
     size_t used = 0;
-    double flops = 0.0;
+    double flops = 0.0, alg_flops = 0.0;
 };
 static bool g_probe_on = false;
 static bool g_stamps_on = false;
 static ProbeState g_probe[P_COUNT];
 constexpr size_t kMaxPairs = 1 << 15;
 
-ProbeScope::ProbeScope(int id, hipStream_t st, double flops) : id_(-1), st_(st) {
+ProbeScope::ProbeScope(int id, hipStream_t st, double flops, double alg_flops) : id_(-1), st_(st) {
     if (!g_probe_on) return;
     ProbeState &p = g_probe[id];
     if (p.used >= kMaxPairs) return;
@@ -33,6 +34,7 @@ ProbeScope::ProbeScope(int id, hipStream_t st, double flops) : id_(-1), st_(st) 
     }
     id_ = id;
     p.flops += flops;
+    p.alg_flops += alg_flops < 0.0 ? flops : alg_flops;
     hipEventRecord(p.begin[p.used], st);
 }
 ProbeScope::~ProbeScope() {
@@ -51,10 +53,10 @@ int probe_enable(int on) {
     return 0;
 }
 int probe_reset() {
-    for (auto &p : g_probe) { p.used = 0; p.flops = 0.0; }
+    for (auto &p : g_probe) { p.used = 0; p.flops = 0.0; p.alg_flops = 0.0; }
     return 0;
 }
-int probe_read(const char *name, double *total_ms, double *flops, int64_t *launches) {
+int probe_read(const char *name, double *total_ms, double *flops, double *alg_flops, int64_t *launches) {
     for (int i = 0; i < P_COUNT; ++i) {
         if (strcmp(name, kProbeNames[i]) != 0) continue;
         ProbeState &p = g_probe[i];
@@ -67,6 +69,7 @@ int probe_read(const char *name, double *total_ms, double *flops, int64_t *launc
         }
         *total_ms = ms;
         *flops = p.flops;
+        *alg_flops = p.alg_flops;
         *launches = (int64_t)p.used;
         return 0;
     }

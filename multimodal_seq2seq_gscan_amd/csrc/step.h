@@ -39,11 +39,15 @@ public:
              float *c, int64_t ldc, float beta = 0.f, const float *bias = nullptr, int act = 0,
              const float *mask = nullptr, int split_k = 1, float *asum1 = nullptr, float *asum2 = nullptr,
              const float *gate = nullptr, float alpha = 1.f);
+    // The product added last is NOT part of the algorithmic flop count of SURVEY.md 8(d) (composite weights, U
+    // images computed in place of per-step context products that the decoder kernel is charged with): it still
+    // counts as executed work.
+    void overhead() { alg_flops_ -= last_flops_; last_flops_ = 0.0; }
     int launch(hipStream_t stream);
 private:
     GemmGroup grp_{};
     int tiles_ = 0;
-    double flops_ = 0.0;
+    double flops_ = 0.0, alg_flops_ = 0.0, last_flops_ = 0.0;
     bool bad_ = false;
 };
 
@@ -115,18 +119,18 @@ struct PrologueArgs {
     int cond;
     int64_t zero_extra_count;
     int H, He, E, D, BL, BT, Vi, V;
-    int64_t end[10];
+    int64_t end[11];
     DecoderImageArgs img;
     // seg 9: register image of the encoder's recurrent weights, [dir][r][k][thread] (lstm_encoder.hip)
     const float *enc_w_hh_f, *enc_w_hh_r;
     float *enc_image;
     int enc_rows;                          // weight rows per thread
+    // seg 10: [tap][ch][o] image of the three convolution kernels (conv.hip)
+    const float *conv_w[3];
+    float *conv_img;
+    int cC, cCo, cK3;
 };
 int step_prologue(const PrologueArgs &args, hipStream_t stream);
-int toeplitz_build(const float *const (&w)[3], const float *const (&b)[3], int G, int C, int Co, int K3, float *wt,
-                   float *bias_rep, hipStream_t stream);
-int toeplitz_fold(float *const (&gw)[3], float *const (&gb)[3], int G, int C, int Co, int K3, int B, const float *dwt,
-                  const float *dfeat, hipStream_t stream);
 int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream);
 int adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
               float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
@@ -143,6 +147,35 @@ int trace_set_loss(unsigned long long *buf);
 int trace_set_lstm_encoder(unsigned long long *buf);
 int trace_set_decoder(unsigned long long *buf);
 int trace_set_attention_grad(unsigned long long *buf);
+
+// conv.hip: the world encoder (cnn_model.py:22-36) and its weight gradients, input-sparse
+#ifdef __HIPCC__
+__device__ __forceinline__ int conv_ksize(int conv, int K3) { return conv == 0 ? 1 : (conv == 1 ? 5 : K3); }
+__device__ __forceinline__ int conv_tap0(int conv, int K3) { return conv == 0 ? 0 : (conv == 1 ? 1 : 26); }
+#endif
+// [tap][ch][o] image of the three kernels (taps of conv_1, conv_2, conv_3 one after the other), rows padded with
+// zeros to a multiple of 32 floats so that a row starts on a 128-byte line: element i of (1 + 25 + K3^2) * C * CoP.
+// Written by the step prologue, read by the forward kernel as coalesced rows.
+__host__ __device__ static inline int conv_row_floats(int Co) { return (Co + 31) / 32 * 32; }
+static inline int64_t conv_image_floats(int C, int Co, int K3) { return (int64_t)(26 + K3 * K3) * C * conv_row_floats(Co); }
+#ifdef __HIPCC__
+__device__ __forceinline__ float conv_image_element(const float *w1, const float *w2, const float *w3, int C, int Co,
+                                                    int K3, int i) {
+    const int CoP = conv_row_floats(Co);
+    const int o = i % CoP, ch = (i / CoP) % C, tg = i / (CoP * C);
+    if (o >= Co) return 0.f;
+    const int conv = tg < 1 ? 0 : (tg < 26 ? 1 : 2), k = conv_ksize(conv, K3), t = tg - conv_tap0(conv, K3);
+    const float *w = conv == 0 ? w1 : (conv == 1 ? w2 : w3);
+    return w[(o * C + ch) * k * k + t];                      // t = kh * k + kw, the reference's own tap order
+}
+#endif
+int conv_weight_image(const float *const (&w)[3], int C, int Co, int K3, float *img, hipStream_t stream);
+int world_conv_forward(const void *world, int world_is_u8, const float *img, const float *const (&b)[3],
+                       const float *mask, int B, int G, int C, int Co, int K3, float *feat, hipStream_t stream);
+size_t world_conv_backward_scratch_floats(int B, int G, int C);
+int world_conv_backward(const void *world, int world_is_u8, const float *dfeat, int B, int G, int C, int Co, int K3,
+                        float *scratch, float *const (&gw)[3], float *const (&gb)[3], hipStream_t stream);
+int trace_set_conv(unsigned long long *buf);
 
 // loss.hip
 int step_losses(const float *logp, const int64_t *targets, const float *aux, const int64_t *pos, int B, int T, int V,
@@ -237,9 +270,11 @@ struct KeysBackwardArgs {
 int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream);
 
 // probe.hip
-enum ProbeId { P_DECODER_FWD = 0, P_DECODER_BWD, P_ENCODER_FWD, P_ENCODER_BWD, P_GEMM, P_COUNT };
+enum ProbeId { P_DECODER_FWD = 0, P_DECODER_BWD, P_ENCODER_FWD, P_ENCODER_BWD, P_GEMM, P_CONV_FWD, P_CONV_BWD, P_KEYS_BWD, P_COUNT };
 struct ProbeScope {
-    ProbeScope(int id, hipStream_t st, double flops);
+    // flops: executed by the launch (2 M N K, padding excluded); alg_flops: its share of SURVEY.md 8(d)'s
+    // algorithmic count (negative: same as flops)
+    ProbeScope(int id, hipStream_t st, double flops, double alg_flops = -1.0);
     ~ProbeScope();
     int id_;
     hipStream_t st_;
@@ -247,7 +282,7 @@ struct ProbeScope {
 int probe_enable(int on);
 bool probe_stamps_enabled();
 int probe_reset();
-int probe_read(const char *name, double *total_ms, double *flops, int64_t *launches);
+int probe_read(const char *name, double *total_ms, double *flops, double *alg_flops, int64_t *launches);
 
 // step.hip
 struct WorkspaceSlot { const char *name; int64_t offset, count; };
@@ -255,7 +290,7 @@ struct Workspace {
     int64_t feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, row_stats, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
-        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, wt, dwt, bias_rep, wcat5,
+        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, conv_img, conv_lists, wcat5,
         deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image;   // encoder layers below the last
     WorkspaceSlot slot[96];
     int nslots;

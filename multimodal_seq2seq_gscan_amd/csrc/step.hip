@@ -40,9 +40,8 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
         return ws->slot[n - 1].offset;
     };
 #define SLOT(field, count) ws->field = take(#field, (count))
-    SLOT(wt, M * d.C * M * F);
-    SLOT(dwt, M * d.C * M * F);
-    SLOT(bias_rep, M * F);
+    SLOT(conv_img, conv_image_floats(d.C, d.Co, d.K3));
+    SLOT(conv_lists, (int64_t)world_conv_backward_scratch_floats(d.B, d.G, d.C));
     SLOT(feat, B * M * F);
     SLOT(pkv, B * M * H);
     SLOT(uv, B * M * 4 * H);
@@ -182,7 +181,7 @@ static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, cons
 
 // --------------------------------------------------------------------------------------
 // Two-stream schedule.  Most launches of the step are small and latency-bound, and the dependency graph has
-// width: in forward the world branch (Toeplitz conv -> visual keys) and the command branch (input projection
+// width: in forward the world branch (sparse conv -> visual keys) and the command branch (input projection
 // -> BiLSTM -> textual keys) are independent until the decoder; in backward every weight-gradient product is
 // a leaf that nothing waits for except the optimiser.  The main stream (the caller's) carries the critical
 // chain; a side stream carries the other branch / the leaves, tied together with HIP events.  Event and
@@ -238,37 +237,28 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     GSCAN_CHECK(!cond || (p.q2k_w && p.q2k_b), "forward: conditional attention needs queries_to_keys parameters");
     GSCAN_CHECK(D == 1 || (p.enc_w_ih_rev && p.enc_w_hh_rev && p.enc_b_ih_rev && p.enc_b_hh_rev),
                 "forward: bidirectional encoder needs the *_reverse parameters");
-    GSCAN_CHECK(bt.commands && bt.cmd_lengths && bt.world && (!teacher_forced || bt.targets),
+    GSCAN_CHECK(bt.commands && bt.cmd_lengths && (bt.world || bt.world_u8) && (!teacher_forced || bt.targets),
                 "forward: NULL array in the batch");
     TRY(side_init());
     hipStream_t sd = g_side.single ? st : g_side.stream;
 
-    // ================= side stream: world branch (needs only the batch, the parameters and the CNN mask) ==========
-    TRY(order_after(sd, st));          // whatever produced the inputs / masks on the caller's stream
-    {   // Toeplitz image of the three convolutions (12.4 MB at G=6, C=16, Co=50), rebuilt from the live weights
-        const float *const cw[3] = {p.conv1_w, p.conv2_w, p.conv3_w};
-        const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
-        TRY(toeplitz_build(cw, cb, d.G, C, Co, d.K3, w + ws.wt, w + ws.bias_rep, sd));
-    }
-    {
-        GemmBatch g;
-        // world encoder (cnn_model.py:22-36) as one product world[B, G*G*C] . Wt[G*G*C, G*G*3Co]; bias + ReLU +
-        // dropout in the epilogue; the result IS feat[B, G*G, 3Co]
-        g.add(B, M * F, M * C, bt.world, (int64_t)M * C, 1, w + ws.wt, (int64_t)M * F, 1, w + ws.feat, (int64_t)M * F, 0.f,
-              w + ws.bias_rep, 1, mk.cnn);
-        // composite weight W_ih[:, ctx_vis] . W_key_vis, so that U_vis = feat . (.)^T needs no extra level
-        g.add(4 * H, F, H, p.dec_w_ih + 2 * H, 3 * H, 1, p.vis_key_w, F, 1, w + ws.w_sk, F);
-        TRY(g.launch(sd));
-    }
-    {   // projected visual keys (seq2seq_model.py:466-467) and their gate images
-        GemmBatch g;
-        g.add(B * M, H, F, w + ws.feat, F, 1, p.vis_key_w, 1, F, w + ws.pkv, H);
-        g.add(B * M, 4 * H, F, w + ws.feat, F, 1, w + ws.w_sk, 1, F, w + ws.uv, 4 * H);
-        TRY(g.launch(sd));
-    }
-
-    // ================= main stream: command branch and decoder inputs ==========================================
-    {   // prologue: bias sum, permuted / stacked weight images, both embedding gathers (one launch)
+    // ================= prelude schedule ============================================================================
+    // Critical chain on the caller's stream: prologue -> L1 (command projections) -> BiLSTM -> L3 (textual keys, bridge).
+    // Everything only the DECODER waits for runs on two side streams behind ONE fork event at the very start:
+    //   side 2: a mini prologue (convolution weight image) -> the input-sparse world encoder;
+    //   side 1: a mini prologue (embedded targets S[:, 0:H], decoder bias sum) -> ONE GEMM launch with the embedding
+    //           part of the decoder gates `ge` and the composite weight W_ih[:, ctx_vis] . W_key_vis -> (the world
+    //           features of side 2) -> ONE GEMM launch with the visual keys and their gate images.
+    // Round 1 had `ge` in L1 in front of the recurrence and the world branch as two chip-filling launches racing it:
+    // one workgroup of the recurrence wants 128 VGPRs per SIMD, i.e. two GEMM slots freed on the same CU at once, and
+    // loses that race for as long as 96-VGPR GEMM workgroups keep arriving (it started 55 us after its inputs were
+    // ready).  Now L1 is five small products, and the 10-25 us a cross-stream event takes to release the side streams
+    // are a head start for the command chain.  Measured and dropped (profiles/r02_ab_*): forking the side streams
+    // behind L1 instead (+30 us: the event latency lands on the critical path), composite weights as dot-product
+    // segments of the prologue instead of GEMM products (+12 us: a 26 us prologue in front of the world encoder).
+    hipStream_t sd2 = g_side.single ? st : g_side.stream2;
+    // one prologue launch with the segments of `which` (0: caller's stream, 1: side 1, 2: side 2); the others stay empty
+    auto prologue = [&](int which, hipStream_t stream) -> int {
         PrologueArgs a{};
         a.b_ih = p.dec_b_ih; a.b_hh = p.dec_b_hh; a.w_o2h = p.out2hid_w;
         a.w_ih_f = p.enc_w_ih; a.w_ih_r = p.enc_w_ih_rev; a.enc_emb = p.enc_emb; a.dec_emb = p.dec_emb;
@@ -285,73 +275,110 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
                                  w + ws.dec_w_bwd, w + ws.dec_w_head, H, cond ? 1 : 0, geo.slots, geo.k0};
         a.enc_w_hh_f = p.enc_w_hh; a.enc_w_hh_r = p.enc_w_hh_rev; a.enc_image = w + ws.enc_w_image;
         a.enc_rows = encoder_rows_per_thread(He);
-        const int64_t n[10] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
+        a.conv_w[0] = p.conv1_w; a.conv_w[1] = p.conv2_w; a.conv_w[2] = p.conv3_w;
+        a.conv_img = w + ws.conv_img; a.cC = C; a.cCo = Co; a.cK3 = d.K3;
+        const int64_t n[11] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
                                (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
                                a.zero_extra_count, 2 * geo.image_floats + (int64_t)H * kDecThreads,
-                               (int64_t)D * 4 * He * He};
+                               (int64_t)D * 4 * He * He, conv_image_floats(C, Co, d.K3)};
         int64_t acc = 0;
-        for (int i = 0; i < 10; ++i) { acc += n[i]; a.end[i] = acc; }
-        TRY(step_prologue(a, st));
-    }
+        for (int i = 0; i < 11; ++i) {
+            // side 1: decoder bias sum, embedded targets; side 2: convolution weight image
+            const int owner = (i == 0 || i == 5) ? 1 : (i == 10 ? 2 : 0);
+            acc += owner == which ? n[i] : 0;
+            a.end[i] = acc;
+        }
+        return step_prologue(a, stream);
+    };
     {
-        GemmBatch g;
-        // encoder input projections W_ih x + b_ih, both directions (seq2seq_model.py:70)
-        g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih, 1, E, w + ws.gx, (int64_t)D * 4 * He, 0.f, p.enc_b_ih);
-        if (D == 2)
-            g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih_rev, 1, E, w + ws.gx + 4 * He, (int64_t)D * 4 * He, 0.f,
-                  p.enc_b_ih_rev);
-        // decoder: embedding part of the gate pre-activations for all t (teacher forcing)
-        if (teacher_forced)
-            g.add(B * T, 4 * H, H, w + ws.S, 4 * H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge, 4 * H, 0.f, w + ws.bsum);
-        // composite weights for the textual memories
-        g.add(4 * H, He, H, p.dec_w_ih + H, 3 * H, 1, p.txt_key_w, He, 1, w + ws.w_ck, He);
-        if (cond) g.add(H, He, H, p.q2k_w + H, 2 * H, 1, p.txt_key_w, He, 1, w + ws.w_2kk, He);
-        TRY(g.launch(st));
-    }
-    // command encoder recurrence (seq2seq_model.py:62-88).  With more than one layer (nn.LSTM(num_layers=n), :44-45)
-    // a layer below the last writes its h per direction, [B,L,D*He] times the inter-layer dropout mask: the next
-    // layer's input; the direction sums and the final state come from the last layer (:76-82).
-    const int NL = enc_layers(d);
-    const int64_t lay_h = (int64_t)B * L * D * He, lay_g = 4 * lay_h, lay_img = (int64_t)D * 4 * He * He;
-    for (int l = 0; l < NL; ++l) {
-        const EncLayer q = enc_layer(p, l);
-        const bool last = l == NL - 1;
-        GSCAN_CHECK(q.w_ih && q.w_hh && q.b_ih && q.b_hh && (D == 1 || (q.w_ih_rev && q.w_hh_rev && q.b_ih_rev && q.b_hh_rev)),
-                    "forward: parameters of encoder layer %d are missing", l);
-        const float *image = w + ws.enc_w_image;                 // layer 0: written by the prologue
-        if (l > 0) {
-            const int Din = D * He;
-            const float *x = w + ws.deep_y + (l - 1) * lay_h;    // the layer below, already dropped out
+        auto side_work = [&]() -> int {
+            {   // ---- side 2: world encoder (cnn_model.py:22-36), input-sparse kernel (conv.hip)
+                TRY(prologue(2, sd2));
+                const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
+                TRY(world_conv_forward(bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world, bt.world_u8 != nullptr,
+                                       w + ws.conv_img, cb, mk.cnn, B, d.G, C, Co, d.K3, w + ws.feat, sd2));
+            }
+            {   // ---- side 1: the embedding part of the decoder gate pre-activations for all t (teacher forcing) and the
+                // composite weight W_ih[:, ctx_vis] . W_key_vis (so that U_vis = feat . (.)^T needs no extra level) in one
+                // launch; then, behind the world features of side 2, the visual keys and their gate images
+                TRY(prologue(1, sd));
+                GemmBatch g;
+                if (teacher_forced)
+                    g.add(B * T, 4 * H, H, w + ws.S, 4 * H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge, 4 * H, 0.f, w + ws.bsum);
+                g.add(4 * H, F, H, p.dec_w_ih + 2 * H, 3 * H, 1, p.vis_key_w, F, 1, w + ws.w_sk, F);
+                g.overhead();
+                TRY(g.launch(sd));
+                TRY(order_after(sd, sd2));
+                GemmBatch k;      // projected visual keys (seq2seq_model.py:466-467)
+                k.add(B * M, H, F, w + ws.feat, F, 1, p.vis_key_w, 1, F, w + ws.pkv, H);
+                k.add(B * M, 4 * H, F, w + ws.feat, F, 1, w + ws.w_sk, 1, F, w + ws.uv, 4 * H);
+                k.overhead();     // U image: its algorithmic counterpart, W_ih[:, ctx_vis] . ctx_vis per step, is charged to the decoder kernel
+                TRY(k.launch(sd));
+            }
+            return 0;
+        };
+        TRY(order_after(sd, st, sd2));   // fork: whatever produced the inputs / masks on the caller's stream
+        TRY(prologue(0, st));
+        TRY(side_work());
+        {
             GemmBatch g;
-            g.add(B * L, 4 * He, Din, x, Din, 1, q.w_ih, 1, Din, w + ws.gx, (int64_t)D * 4 * He, 0.f, q.b_ih);
+            // encoder input projections W_ih x + b_ih, both directions (seq2seq_model.py:70)
+            g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih, 1, E, w + ws.gx, (int64_t)D * 4 * He, 0.f, p.enc_b_ih);
             if (D == 2)
-                g.add(B * L, 4 * He, Din, x, Din, 1, q.w_ih_rev, 1, Din, w + ws.gx + 4 * He, (int64_t)D * 4 * He, 0.f,
-                      q.b_ih_rev);
+                g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih_rev, 1, E, w + ws.gx + 4 * He, (int64_t)D * 4 * He, 0.f,
+                      p.enc_b_ih_rev);
+            // composite weights for the textual memories
+            g.add(4 * H, He, H, p.dec_w_ih + H, 3 * H, 1, p.txt_key_w, He, 1, w + ws.w_ck, He);
+            g.overhead();
+            if (cond) { g.add(H, He, H, p.q2k_w + H, 2 * H, 1, p.txt_key_w, He, 1, w + ws.w_2kk, He); g.overhead(); }
             TRY(g.launch(st));
-            float *img = w + ws.deep_image + (l - 1) * lay_img;
-            TRY(encoder_weight_image(q.w_hh, q.w_hh_rev, He, D, img, st));
-            image = img;
         }
-        if (last) {
-            TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, q.w_hh, q.b_hh, q.w_hh_rev, q.b_hh_rev,
-                                     w + ws.enc_out, w + ws.hN, w + ws.enc_gates, w + ws.enc_cells, w + ws.enc_hprev,
-                                     image, st));
-        } else {
-            TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, q.w_hh, q.b_hh, q.w_hh_rev, q.b_hh_rev,
-                                     nullptr, nullptr, w + ws.deep_gates + l * lay_g, w + ws.deep_cells + l * lay_h,
-                                     w + ws.deep_hprev + l * lay_h, image, st, w + ws.deep_y + l * lay_h,
-                                     mk.enc_deep ? mk.enc_deep + l * lay_h : nullptr));
+        // command encoder recurrence (seq2seq_model.py:62-88).  With more than one layer (nn.LSTM(num_layers=n), :44-45)
+        // a layer below the last writes its h per direction, [B,L,D*He] times the inter-layer dropout mask: the next
+        // layer's input; the direction sums and the final state come from the last layer (:76-82).
+        const int NL = enc_layers(d);
+        const int64_t lay_h = (int64_t)B * L * D * He, lay_g = 4 * lay_h, lay_img = (int64_t)D * 4 * He * He;
+        for (int l = 0; l < NL; ++l) {
+            const EncLayer q = enc_layer(p, l);
+            const bool last = l == NL - 1;
+            GSCAN_CHECK(q.w_ih && q.w_hh && q.b_ih && q.b_hh && (D == 1 || (q.w_ih_rev && q.w_hh_rev && q.b_ih_rev && q.b_hh_rev)),
+                        "forward: parameters of encoder layer %d are missing", l);
+            const float *image = w + ws.enc_w_image;                 // layer 0: written by the prologue
+            if (l > 0) {
+                const int Din = D * He;
+                const float *x = w + ws.deep_y + (l - 1) * lay_h;    // the layer below, already dropped out
+                GemmBatch g;
+                g.add(B * L, 4 * He, Din, x, Din, 1, q.w_ih, 1, Din, w + ws.gx, (int64_t)D * 4 * He, 0.f, q.b_ih);
+                if (D == 2)
+                    g.add(B * L, 4 * He, Din, x, Din, 1, q.w_ih_rev, 1, Din, w + ws.gx + 4 * He, (int64_t)D * 4 * He, 0.f,
+                          q.b_ih_rev);
+                TRY(g.launch(st));
+                float *img = w + ws.deep_image + (l - 1) * lay_img;
+                TRY(encoder_weight_image(q.w_hh, q.w_hh_rev, He, D, img, st));
+                image = img;
+            }
+            if (last) {
+                TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, q.w_hh, q.b_hh, q.w_hh_rev, q.b_hh_rev,
+                                         w + ws.enc_out, w + ws.hN, w + ws.enc_gates, w + ws.enc_cells, w + ws.enc_hprev,
+                                         image, st));
+            } else {
+                TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, q.w_hh, q.b_hh, q.w_hh_rev, q.b_hh_rev,
+                                         nullptr, nullptr, w + ws.deep_gates + l * lay_g, w + ws.deep_cells + l * lay_h,
+                                         w + ws.deep_hprev + l * lay_h, image, st, w + ws.deep_y + l * lay_h,
+                                         mk.enc_deep ? mk.enc_deep + l * lay_h : nullptr));
+            }
+        }
+        {   // projected textual keys (:468-469), their images, and the bridge (model.py:195)
+            GemmBatch g;
+            g.add(B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H);
+            g.add(B * L, 4 * H, He, w + ws.enc_out, He, 1, w + ws.w_ck, 1, He, w + ws.ut, 4 * H);
+            g.overhead();     // U images of the textual memories: charged to the decoder kernel as the context terms they replace
+            if (cond) { g.add(B * L, H, He, w + ws.enc_out, He, 1, w + ws.w_2kk, 1, He, w + ws.u2t, H); g.overhead(); }
+            g.add(B, H, He, w + ws.hN, He, 1, p.bridge_w, 1, He, w + ws.hprev, (int64_t)T * H, 0.f, p.bridge_b, 2);
+            TRY(g.launch(st));
         }
     }
-    {   // projected textual keys (:468-469), their images, and the bridge (model.py:195)
-        GemmBatch g;
-        g.add(B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H);
-        g.add(B * L, 4 * H, He, w + ws.enc_out, He, 1, w + ws.w_ck, 1, He, w + ws.ut, 4 * H);
-        if (cond) g.add(B * L, H, He, w + ws.enc_out, He, 1, w + ws.w_2kk, 1, He, w + ws.u2t, H);
-        g.add(B, H, He, w + ws.hN, He, 1, p.bridge_w, 1, He, w + ws.hprev, (int64_t)T * H, 0.f, p.bridge_b, 2);
-        TRY(g.launch(st));
-    }
-    TRY(order_after(st, sd));          // join: the decoder needs both branches
+    TRY(order_after(st, sd));          // join: the decoder needs all three branches (side 1 has waited for side 2)
     return 0;
 }
 
@@ -500,13 +527,11 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         add_grad(b, H, F, BM_, w + ws.dpk_v, 1, H, w + ws.feat, F, 1, g.vis_key_w, F);
         TRY(b.launch(sd));
     }
-    {   // leaf: d(Wt) = world^T . dfeat (K = B only: no split, no atomics), folded onto the conv kernels
-        GemmBatch b;
-        b.add(M * C, M * F, B, bt.world, 1, (int64_t)M * C, w + ws.dfeat, (int64_t)M * F, 1, w + ws.dwt, (int64_t)M * F);
-        TRY(b.launch(sd2));
+    {   // leaf: convolution kernel and bias gradients from the non-zeros of the world and d(features) (conv.hip)
         float *const gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
         float *const gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
-        TRY(toeplitz_fold(gw, gb, d.G, C, Co, d.K3, B, w + ws.dwt, w + ws.dfeat, sd2));
+        TRY(world_conv_backward(bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world, bt.world_u8 != nullptr,
+                                w + ws.dfeat, B, d.G, C, Co, d.K3, w + ws.conv_lists, gw, gb, sd2));
     }
     // ---- command encoder BPTT (chain), last layer first.  Per layer: the reverse recurrence, then ONE launch on the
     // caller's stream (the leaf streams are still busy with the key / conv gradients and would finish last

@@ -119,6 +119,15 @@ def _as_int32_lengths(lengths, device) -> torch.Tensor:
     return torch.tensor([int(v) for v in lengths], dtype=torch.int32).to(device, non_blocking=True)
 
 
+def _world_operand(world: torch.Tensor) -> torch.Tensor:
+    """The world tensor as the kernels read it: uint8 stays uint8 (Grid.encode's own dtype, minigrid.py:384; the
+    batcher ships it that way, 1 byte per element, and the convolution kernels widen it in registers), everything
+    else becomes float32 as in the reference (gSCAN_dataset.py:262-264)."""
+    if world.dtype == torch.uint8:
+        return world.contiguous()
+    return world.to(torch.float32).contiguous()
+
+
 # ------------------------------------------------------------------------------------------
 # autograd glue: one node for the whole network, one for each loss
 # ------------------------------------------------------------------------------------------
@@ -412,11 +421,11 @@ class Model(nn.Module):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=commands.device)
         commands = commands.contiguous()
         targets = targets.contiguous()
-        world = world.to(torch.float32).contiguous()
+        world = _world_operand(world)
         if positions is not None:
             positions = positions.view(-1).contiguous()
-        batch = _lib.Batch(commands.data_ptr(), lengths.data_ptr(), world.data_ptr(), targets.data_ptr(),
-                           _lib.ptr(positions))
+        batch = _lib.Batch(commands.data_ptr(), lengths.data_ptr(), None if world.dtype == torch.uint8 else world.data_ptr(),
+                           targets.data_ptr(), _lib.ptr(positions), world.data_ptr() if world.dtype == torch.uint8 else None)
         mstruct = _lib.Masks(*[_lib.ptr(m) for m in masks])
         logp = torch.empty(B, T, self._hyper["V"], dtype=torch.float32, device=commands.device)
         aux = torch.empty(B, G * G, dtype=torch.float32, device=commands.device) if self.auxiliary_task else None
@@ -553,8 +562,9 @@ class Model(nn.Module):
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
         commands = commands_input.contiguous()
-        world = situations_input.to(torch.float32).contiguous()
-        batch = _lib.Batch(commands.data_ptr(), lengths.data_ptr(), world.data_ptr(), None, None)
+        world = _world_operand(situations_input)
+        batch = _lib.Batch(commands.data_ptr(), lengths.data_ptr(), None if world.dtype == torch.uint8 else world.data_ptr(),
+                           None, None, world.data_ptr() if world.dtype == torch.uint8 else None)
         masks = _lib.Masks(None, None, None)      # eval semantics: predict() calls model.eval() first (predict.py:70)
         _lib.check(lib.gscan_encode(C.byref(dims), C.byref(self._param_struct), C.byref(batch), C.byref(masks),
                                     self._workspace.data_ptr(), torch.cuda.current_stream().cuda_stream),

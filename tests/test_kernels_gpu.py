@@ -69,16 +69,28 @@ def test_gemm_epilogues_and_split_k(lib):
     assert got[:, :5].abs().max().item() == 0 and got[:, 5 + N:].abs().max().item() == 0
 
 
-def test_world_encoder_forward_and_weight_gradients(lib):
-    """The Toeplitz product equals the reference's three conv2d on the transposed image + ReLU + dropout mask
-    (cnn_model.py:28-35), and its gradient product folded back equals autograd's kernel / bias gradients."""
+@pytest.mark.parametrize("B,G,Cc,K3,Co,density,u8", [
+    (5, 6, 16, 7, 50, 0.2, False),        # the paper's shape, float32 world
+    (37, 6, 16, 13, 50, 0.07, True),      # k = 13 (every cell reaches every cell), uint8 world, two backward slices
+    (3, 4, 15, 7, 50, 1.0, False),        # a DENSE world: the sparse kernels are exact for any input
+    (2, 15, 16, 7, 70, 0.05, True),       # the reference's 15 x 15 test grid, Co > 64 (two output-channel chunks)
+    (4, 3, 5, 3, 7, 0.5, False),          # tiny everything
+])
+def test_world_encoder_forward_and_weight_gradients(lib, B, G, Cc, K3, Co, density, u8):
+    """The input-sparse world encoder equals the reference's three conv2d on the transposed image + ReLU + dropout
+    mask (cnn_model.py:28-35), and its backward kernel equals autograd's kernel / bias gradients; float32 and uint8
+    worlds, sparse and dense, non-{0,1} values included."""
     import ctypes as C
     import gpu_ops
     from multimodal_seq2seq_gscan_amd import _lib
     g = torch.Generator().manual_seed(3)
-    B, G, Cc, K3, Co = 5, 6, 16, 7, 50
     M, F = G * G, 3 * Co
-    world = (torch.rand(B, G, G, Cc, generator=g) > 0.8).float()
+    world = (torch.rand(B, G, G, Cc, generator=g) < density).float()
+    if u8:
+        world = world * torch.randint(1, 4, world.shape, generator=g).float()      # bytes other than 1 widen exactly
+    else:
+        world = world * (0.5 + torch.rand(world.shape, generator=g))               # arbitrary float values
+    world[0] = 0 if B > 1 else world[0]                                             # an example without non-zeros
     Ws = [(torch.randn(Co, Cc, k, k, generator=g) * 0.1).requires_grad_(True) for k in (1, 5, K3)]
     bs = [(torch.randn(Co, generator=g) * 0.1).requires_grad_(True) for _ in range(3)]
     mask = (torch.rand(B, M, F, generator=g) > 0.1).float() / 0.9
@@ -87,12 +99,12 @@ def test_world_encoder_forward_and_weight_gradients(lib):
     feat_ref = torch.relu(ref) * mask
     d_out = torch.randn(B, M, F, generator=g)
     feat_ref.backward(d_out)
-    world_d, mask_d = dev(world), dev(mask)
+    world_d, mask_d = dev(world.to(torch.uint8) if u8 else world), dev(mask)
     W_d, b_d = [dev(W.detach()) for W in Ws], [dev(b.detach()) for b in bs]
     ptrs = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
-    scratch = torch.empty((M * Cc + 1) * M * F, device="cuda")
+    scratch = torch.empty((26 + K3 * K3) * Cc * ((Co + 31) // 32 * 32), device="cuda")   # rows padded to 128 bytes
     feat = torch.empty(B, M, F, device="cuda")
-    _lib.check(lib.gscan_world_encoder_forward(world_d.data_ptr(), ptrs(W_d), ptrs(b_d), B, G, Cc, Co, K3,
+    _lib.check(lib.gscan_world_encoder_forward(world_d.data_ptr(), int(u8), ptrs(W_d), ptrs(b_d), B, G, Cc, Co, K3,
                                                mask_d.data_ptr(), scratch.data_ptr(), feat.data_ptr(),
                                                gpu_ops.stream()), "world_encoder_forward")
     assert (feat.cpu() - feat_ref.detach()).abs().max().item() < 1e-4
@@ -100,9 +112,10 @@ def test_world_encoder_forward_and_weight_gradients(lib):
     dpre = dev(d_out * mask * (ref > 0).float())
     gW = [torch.zeros_like(W) for W in W_d]
     gb = [torch.zeros_like(b) for b in b_d]
-    dwt = torch.empty(M * Cc * M * F, device="cuda")
-    _lib.check(lib.gscan_world_encoder_backward(world_d.data_ptr(), dpre.data_ptr(), B, G, Cc, Co, K3, dwt.data_ptr(),
-                                                ptrs(gW), ptrs(gb), gpu_ops.stream()), "world_encoder_backward")
+    lists = torch.empty(lib.gscan_world_encoder_backward_scratch_floats(B, G, Cc), device="cuda")
+    _lib.check(lib.gscan_world_encoder_backward(world_d.data_ptr(), int(u8), dpre.data_ptr(), B, G, Cc, Co, K3,
+                                                lists.data_ptr(), ptrs(gW), ptrs(gb), gpu_ops.stream()),
+               "world_encoder_backward")
     for W, b, gw_, gb_ in zip(Ws, bs, gW, gb):
         assert torch.allclose(gw_.cpu(), W.grad, atol=1e-4, rtol=1e-4), W.shape
         assert torch.allclose(gb_.cpu(), b.grad, atol=1e-4, rtol=1e-4)

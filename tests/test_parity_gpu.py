@@ -152,6 +152,22 @@ def test_intermediates_against_oracle():
     assert not bad, "\n".join(bad)
 
 
+def test_uint8_world_gives_the_float_world_results_bit_for_bit():
+    """The batcher ships the world as uint8 (Grid.encode's dtype, minigrid.py:384): the kernels widen it in registers,
+    so log-probabilities and every gradient equal the float32 run's up to the order of the gradient atomics."""
+    cfg = model_kwargs("demo", auxiliary_task=True)
+    fx = load_fixture("demo_cond1_aux1.npz")
+    batch = fixture_batch(fx)
+    model = build_model(cfg, fixture_params(cfg, fx))
+    logp_f, aux_f, loss_f, grads_f = run_step(model, batch, cfg)
+    as_bytes = dict(batch, world=batch["world"].to(torch.uint8))
+    assert torch.equal(as_bytes["world"].float(), batch["world"])
+    logp_b, aux_b, loss_b, grads_b = run_step(model, as_bytes, cfg)
+    assert torch.equal(logp_f, logp_b) and torch.equal(aux_f.detach().cpu(), aux_b.detach().cpu())
+    for k in grads_f:
+        assert torch.allclose(grads_f[k], grads_b[k], atol=1e-6, rtol=1e-5), k
+
+
 def test_dropout_host_masks():
     """Train mode with the reference's own CPU-drawn masks handed over (host-mask parity mode)."""
     cfg = model_kwargs("demo")

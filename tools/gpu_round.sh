@@ -10,12 +10,16 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>
 tail -3 "$out/pytest_gpu.log"
 timeout -k 10 300 python bench.py > "$out/bench_line.json" 2> "$out/bench.err" || { tail -30 "$out/bench.err"; exit 1; }
 cat "$out/bench_line.json"
+# the other single-GPU configurations of BASELINE.json: S3 (k=13, T=120) and S4 (auxiliary head)
+timeout -k 10 300 python bench.py --workload target_length --target-length 120 --steps 20 --warmup 5 --cpu-seconds 8 > "$out/bench_S3.json" 2>> "$out/bench.err" || { tail -30 "$out/bench.err"; exit 1; }
+timeout -k 10 300 python bench.py --auxiliary --cpu-seconds 0 > "$out/bench_S4.json" 2>> "$out/bench.err" || { tail -30 "$out/bench.err"; exit 1; }
+python -c "import json,sys; [print(f, json.load(open(f))['value'], json.load(open(f))['ms_per_step']) for f in sys.argv[1:]]" "$out/bench_S3.json" "$out/bench_S4.json"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -o run -- python3 bench.py --cpu-seconds 0 > "$out/prof_bench.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_f" -o run -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$out/pmc_f.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_w" -o run -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$out/pmc_w.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_m" -o run -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$out/pmc_m.log" 2>&1
 python tools/pmc_mfma.py "$(find $out/pmc_m -name '*counter_collection.csv' | head -1)" > "$out/pmc_mfma.json"
-python tools/pmc_traffic.py "$(find $out/pmc_f -name '*counter_collection.csv' | head -1)" "$(find $out/pmc_w -name '*counter_collection.csv' | head -1)" gemm_group_kernel > "$out/pmc_traffic.json"
+python tools/pmc_traffic.py "$(find $out/pmc_f -name '*counter_collection.csv' | head -1)" "$(find $out/pmc_w -name '*counter_collection.csv' | head -1)" gemm_group_kernel "$tag" > "$out/pmc_traffic.json"
 cat "$out/pmc_traffic.json"
 cp "$(find $out/prof -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
 head -12 "$out/kernel_stats.csv"

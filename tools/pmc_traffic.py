@@ -11,7 +11,10 @@ stores and float atomics.
 """
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def total(path, counter, kernel):
@@ -33,6 +36,10 @@ def main():
            "write_bytes_per_launch": 1024.0 * w / max(nw, 1),
            "corrections": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), unit 1 KB; WRITE_SIZE x1"}
     out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+    from bench import source_hash          # the profile is valid for exactly these kernel sources (bench.py checks)
+    out["source_sha"] = source_hash()
+    out["tag"] = sys.argv[4] if len(sys.argv) > 4 else ""
+    out["workload"] = "compositional"
     print(json.dumps(out))
 
 
