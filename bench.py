@@ -135,6 +135,70 @@ def cpu_baseline(cfg: dict, shape, budget_s: float) -> dict:
                       f"warm-up, torch {torch.__version__} CPU, {allowed} cores allowed"}
 
 
+def batcher_leg(args, cfg: dict, n_params: int) -> dict:
+    """End-to-end examples/s with the dataset reader and batcher in the loop: a dataset FILE of
+    --batcher-examples examples in the reference's format is generated, read by GroundedScanDataset, shuffled, and
+    every batch is gathered on the host, copied to the device (uint8 world, one pinned slab) and trained on.  The
+    same model dims / step as the headline number; compared with a run of the same batches resident in HBM."""
+    import tempfile
+    from multimodal_seq2seq_gscan_amd.dataset import BatchStager, GroundedScanDataset
+    from multimodal_seq2seq_gscan_amd.model import Model
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, write_dataset_file
+    from multimodal_seq2seq_gscan_amd.train import TrainStep
+    B = args.batch
+    keys = ("commands", "cmd_lengths", "world", "targets", "tgt_lengths", "target_positions")
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "dataset.txt")
+        t0 = time.perf_counter()
+        write_dataset_file(path, {"train": args.batcher_examples}, Shape(batch=1, max_command=args.command_length,
+                                                                         max_target=args.target_length), seed=7)
+        t_write = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        data = GroundedScanDataset(path, tmp, k=0, split="train", generate_vocabulary=True)
+        data.read_dataset()
+        t_read = time.perf_counter() - t0
+    cfg = dict(cfg, input_vocabulary_size=data.input_vocabulary_size, target_vocabulary_size=data.target_vocabulary_size,
+               num_cnn_channels=data.image_channels)
+    torch.manual_seed(42)
+    model = Model(**cfg).cuda()
+    step = TrainStep(model, learning_rate=1e-3)
+    stager = BatchStager(torch.device("cuda"), data.slab_bytes(B))
+    results = {}
+    for bucket in (0, 8):
+        data.shuffle_data(bucket_batches=bucket, batch_size=B)
+        it = data.batches(B, stager=stager)
+        for _ in range(args.warmup):
+            step({k: v for k, v in next(it).items() if k in keys})
+        torch.cuda.synchronize()
+        n, rows, full, t0 = 0, 0, None, time.perf_counter()
+        for b in it:
+            if b["commands"].shape[0] != B:            # the split's short trailing batch
+                continue
+            step({k: b[k] for k in keys})
+            n, rows, full = n + 1, rows + B, b
+            if n >= 4 * args.steps:
+                break
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        # the same number of steps on ONE of those batches kept resident (what `value` measures, on these shapes)
+        resident = {k: full[k].clone() for k in keys}
+        for _ in range(args.warmup):
+            step(resident)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(resident)
+        torch.cuda.synchronize()
+        el_res = time.perf_counter() - t0
+        results["length_buckets_8" if bucket else "reference_order"] = {
+            "examples_per_s": round(rows / el, 1), "ms_per_step": round(1e3 * el / n, 4), "steps": n,
+            "resident_examples_per_s": round(rows / el_res, 1), "fraction_of_resident": round(el_res / el, 3)}
+    return {"examples": data.num_examples, "file_write_s": round(t_write, 1), "file_read_s": round(t_read, 1),
+            "h2d_bytes_per_batch": data.slab_bytes(B), "parameters": model.flat_parameters.numel(), **results,
+            "note": "ragged lengths from the file (every batch padded to ITS longest rows, gSCAN_dataset.py:200-220); "
+                    "resident = the last full batch of the run repeated from HBM"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,6 +210,9 @@ def main():
     ap.add_argument("--workload", default="compositional", choices=["compositional", "target_length", "demo"])
     ap.add_argument("--auxiliary", action="store_true", help="S4: the GECA configuration (auxiliary target-position head)")
     ap.add_argument("--ragged", action="store_true", help="ragged command / target lengths instead of dense ones")
+    ap.add_argument("--with-batcher", action="store_true",
+                    help="also time the step fed by the dataset reader / batcher on a generated dataset file (SURVEY 8 f1)")
+    ap.add_argument("--batcher-examples", type=int, default=100000)
     ap.add_argument("--windows", type=int, default=4, help="extra timed windows of K steps for the spread (0 = none)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--graph", action="store_true",
@@ -240,6 +307,9 @@ def main():
                               "algorithmic_gflop_per_launch": fl.value / n.value / 1e9}
     fence()
 
+    batcher = None
+    if args.with_batcher and rank == 0 and world == 1:
+        batcher = batcher_leg(args, cfg, model.flat_parameters.numel())
     if rank == 0:
         B, L, T = args.batch, args.command_length, args.target_length
         ex_per_s = world * B * args.steps / elapsed
@@ -278,6 +348,8 @@ def main():
             "step_algorithmic_tflops": round(ex_per_s * mflop / 1e6, 3),
             "final_loss": round(loss, 4),
         }
+        if batcher is not None:
+            result["with_batcher"] = batcher
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(cfg, shape, args.cpu_seconds)
         else:

@@ -33,6 +33,8 @@ _VALUE_FLAGS = [
     ("decoder_hidden_size", int, 100), ("seed", int, 42),
     # additive: synthetic data (no dataset file ships with the reference checkout)
     ("synthetic_batches", int, 1000),
+    # additive: order every window of this many batches by target length after the shuffle (0 = the reference's order)
+    ("length_bucket_batches", int, 0),
 ]
 # paired switches: (destination, flag that sets True, flag that sets False, default)
 _SWITCHES = [

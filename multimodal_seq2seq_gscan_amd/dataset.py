@@ -10,8 +10,12 @@ its attribute vector (`"vector": "0001010100"` = sizes | shapes + colours one-ho
 and the agent cell / direction are plain numbers, so the `[G, G, C]` tensor of `Grid.encode` — object vector, then
 one agent bit, then a one-hot of the four directions, indexed `[row, column, :]` — is filled without `gym`.
 Examples are packed ONCE into contiguous host arrays (tokens int64 padded to the split's longest sequence, grids
-uint8: 240 bytes per 4x4x15 example), a batch is a slice of them: one pinned staging buffer, asynchronous copies,
-the grid expanded to fp32 on the device.  The yielded tuple is the reference's 9-tuple (gSCAN_dataset.py:229-231).
+uint8: 576 bytes per 6x6x16 example).  A batch is gathered straight into ONE pinned slab of a small ring
+(`BatchStager`), crosses PCIe as ONE asynchronous copy on a copy stream that runs a batch ahead of the consumer, and
+its tensors are views of the device slab.  The world stays uint8 all the way: the convolution kernels widen it in
+registers (csrc/conv.hip), so 576 B per example move over PCIe and through HBM instead of 2 304.
+`batches()` yields the dictionaries `TrainStep` consumes; `get_data_iterator()` yields the reference's 9-tuple
+(gSCAN_dataset.py:229-231), with a float32 world unless asked otherwise.
 """
 from __future__ import annotations
 
@@ -222,31 +226,175 @@ class GroundedScanDataset:
         self._derivations = [e.get("derivation") for e in raw]
         self._order = np.arange(n, dtype=np.int64)
 
-    def shuffle_data(self) -> None:
-        """:177-183 (np.random.permutation, unseeded there as well)."""
-        self._order = self._order[np.random.permutation(len(self._order))]
-
     # ---- batches (:184-231) ---------------------------------------------------------------------
-    def get_data_iterator(self, batch_size=10, device: Optional[torch.device] = None,
-                          shard: Tuple[int, int] = (0, 1)) -> Iterator[tuple]:
-        """Yields (input_batch [B,L] i64, input_lengths, derivations, situation_batch [B,G,G,C] f32, situations,
-        target_batch [B,T] i64, target_lengths, agent_positions [B] i64, target_positions [B] i64), every batch
-        padded to ITS longest sequences, the last one short (as the reference)."""
-        if device is None:
-            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        pin = device.type == "cuda"
+    def shuffle_data(self, bucket_batches: int = 0, batch_size: int = 0) -> None:
+        """:177-183 (np.random.permutation, unseeded there as well).  bucket_batches > 0 (additive): after the shuffle,
+        every window of bucket_batches * batch_size examples is ordered by target length, so that the batches cut
+        from it hold rows of similar length and pad less (the decoder runs T = longest row steps for every row,
+        seq2seq_model.py:473); windows and their contents are still random."""
+        order = self._order[np.random.permutation(len(self._order))]
+        if bucket_batches > 0 and batch_size > 0:
+            window = bucket_batches * batch_size
+            for lo in range(0, len(order), window):
+                part = order[lo:lo + window]
+                order[lo:lo + window] = part[np.argsort(self._target_lengths[part], kind="stable")]
+            # the batches of a window in random order (otherwise lengths would rise steadily inside every window)
+            nb = (len(order) + batch_size - 1) // batch_size
+            perm = np.random.permutation(nb)
+            order = np.concatenate([order[b * batch_size:(b + 1) * batch_size] for b in perm])
+        self._order = order
+
+    def _index_batches(self, batch_size: int, shard: Tuple[int, int]):
         for number, lo in enumerate(range(0, len(self._order), batch_size)):
             if number % shard[1] != shard[0]:      # shard = (rank, world): every world-th batch (evaluation under DP)
                 continue
-            idx = self._order[lo:lo + batch_size]
+            yield self._order[lo:lo + batch_size]
+
+    def batches(self, batch_size: int, device: Optional[torch.device] = None, shard: Tuple[int, int] = (0, 1),
+                stager: Optional["BatchStager"] = None) -> Iterator[Dict[str, torch.Tensor]]:
+        """Device batches for TrainStep / greedy_decode: commands, targets, target_positions, agent_positions (int64),
+        cmd_lengths, tgt_lengths (int32), world (UINT8 [B,G,G,C]) — views of one device slab that arrived in one
+        asynchronous copy, a batch ahead of the consumer; plus `index` (host int64: the examples' positions in the
+        split).  A batch's tensors stay valid until the iterator is advanced twice more."""
+        if device is None:
+            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if device.type != "cuda":
+            raise RuntimeError("batches() stages through pinned memory onto the HIP device; use get_data_iterator() "
+                               "for host tensors")
+        own = stager is None
+        if own:
+            stager = BatchStager(device, self.slab_bytes(batch_size))
+        pending = None
+        for idx in self._index_batches(batch_size, shard):
+            staged = stager.stage(self, idx)          # host gather + asynchronous copy of the NEXT batch ...
+            if pending is not None:
+                yield stager.deliver(pending)         # ... while the consumer works on this one
+            pending = staged
+        if pending is not None:
+            yield stager.deliver(pending)
+
+    def slab_bytes(self, batch_size: int) -> int:
+        """Bytes of one staging slab for batches of up to batch_size rows of this split."""
+        L, T = self._commands.shape[1], self._targets.shape[1]
+        cell = int(np.prod(self._grids.shape[1:])) if self._grids.ndim == 4 else 0
+        return _Slab.layout(batch_size, L, T, cell)[1]
+
+    def get_data_iterator(self, batch_size=10, device: Optional[torch.device] = None,
+                          shard: Tuple[int, int] = (0, 1), world_dtype: torch.dtype = torch.float32) -> Iterator[tuple]:
+        """Yields (input_batch [B,L] i64, input_lengths, derivations, situation_batch [B,G,G,C], situations,
+        target_batch [B,T] i64, target_lengths, agent_positions [B] i64, target_positions [B] i64), every batch
+        padded to ITS longest sequences, the last one short (as the reference).  situation_batch is float32 as in the
+        reference (gSCAN_dataset.py:262-264) unless world_dtype=torch.uint8 is asked for (the HIP Model takes both)."""
+        if device is None:
+            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if device.type == "cuda":
+            # the reference yields tensors of their own (a caller may keep them): copies of the ring's views
+            for b in self.batches(batch_size, device, shard):
+                idx = b["index"]
+                world = b["world"].clone() if world_dtype == torch.uint8 else b["world"].to(world_dtype)
+                yield (b["commands"].clone(), self._input_lengths[idx], [self._derivations[i] for i in idx], world,
+                       [self._situations[i] for i in idx], b["targets"].clone(), self._target_lengths[idx],
+                       b["agent_positions"].clone(), b["target_positions"].clone())
+            return
+        for idx in self._index_batches(batch_size, shard):      # host tensors (tests without a GPU)
             in_len, tgt_len = self._input_lengths[idx], self._target_lengths[idx]
             L, T = int(in_len.max()), int(tgt_len.max())
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+            yield (t(self._commands[idx, :L]), in_len, [self._derivations[i] for i in idx],
+                   t(self._grids[idx]).to(world_dtype), [self._situations[i] for i in idx], t(self._targets[idx, :T]),
+                   tgt_len, t(self._agent_positions[idx]), t(self._target_positions[idx]))
 
-            def ship(array: np.ndarray) -> torch.Tensor:
-                t = torch.from_numpy(np.ascontiguousarray(array))
-                return (t.pin_memory() if pin else t).to(device, non_blocking=True)
 
-            yield (ship(self._commands[idx, :L]), in_len, [self._derivations[i] for i in idx],
-                   ship(self._grids[idx]).to(torch.float32), [self._situations[i] for i in idx],
-                   ship(self._targets[idx, :T]), tgt_len, ship(self._agent_positions[idx]),
-                   ship(self._target_positions[idx]))
+class _Slab:
+    """Section offsets of one staging slab: [commands i64 | targets i64 | agent i64 | target pos i64 | cmd len i32 |
+    tgt len i32 | grids u8], every section 64-byte aligned."""
+
+    @staticmethod
+    def layout(B: int, L: int, T: int, cell_bytes: int):
+        sizes = (("commands", 8 * B * L), ("targets", 8 * B * T), ("agent_positions", 8 * B),
+                 ("target_positions", 8 * B), ("cmd_lengths", 4 * B), ("tgt_lengths", 4 * B), ("world", B * cell_bytes))
+        offsets, at = {}, 0
+        for name, n in sizes:
+            offsets[name] = (at, n)
+            at += (n + 63) // 64 * 64
+        return offsets, at
+
+
+class BatchStager:
+    """A ring of `depth` pinned host slabs and as many device slabs, and a copy stream.
+
+    stage(): gathers the rows of a batch from the packed arrays straight into the next pinned slab (numpy writes
+    into the pinned memory: no intermediate tensors, no per-array pin_memory() allocations) and enqueues ONE
+    host-to-device copy of the used part of the slab on the copy stream.  deliver(): makes the consumer's stream
+    wait for that copy and returns views of the device slab.  A device slab is reused `depth` batches later, after
+    the copy stream has waited for the event the consumer's stream recorded when it moved on."""
+
+    def __init__(self, device: torch.device, slab_bytes: int, depth: int = 3):
+        self.device, self.depth, self.slab_bytes = device, depth, slab_bytes
+        self.host = [torch.empty(slab_bytes, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        self.host_np = [h.numpy() for h in self.host]
+        self.dev = [torch.empty(slab_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.copy_stream = torch.cuda.Stream(device)
+        self.copied = [torch.cuda.Event() for _ in range(depth)]
+        self.released = [None] * depth
+        self.count = 0
+        self._last = None
+        self._views = {}              # (slot, B, L, T, grid shape) -> (used bytes, host numpy views, device tensor views)
+
+    _SECTIONS = (("commands", np.int64, torch.int64), ("targets", np.int64, torch.int64),
+                 ("agent_positions", np.int64, torch.int64), ("target_positions", np.int64, torch.int64),
+                 ("cmd_lengths", np.int32, torch.int32), ("tgt_lengths", np.int32, torch.int32),
+                 ("world", np.uint8, torch.uint8))
+
+    def _layout(self, slot: int, B: int, L: int, T: int, grid_shape: tuple):
+        """Views of slab `slot` for a batch shape, built once per shape (slicing / viewing tensors costs more host time
+        than gathering the rows)."""
+        key = (slot, B, L, T, grid_shape)
+        hit = self._views.get(key)
+        if hit is None:
+            offsets, used = _Slab.layout(B, L, T, int(np.prod(grid_shape)))
+            if used > self.slab_bytes:
+                raise ValueError(f"batch of {B} rows needs {used} bytes, the staging slabs hold {self.slab_bytes}")
+            shapes = {"commands": (B, L), "targets": (B, T), "agent_positions": (B,), "target_positions": (B,),
+                      "cmd_lengths": (B,), "tgt_lengths": (B,), "world": (B,) + grid_shape}
+            host, dev = {}, {}
+            for name, np_type, torch_type in self._SECTIONS:
+                off, n = offsets[name]
+                host[name] = self.host_np[slot][off:off + n].view(np_type).reshape(shapes[name])
+                dev[name] = self.dev[slot][off:off + n].view(torch_type).view(shapes[name])
+            hit = self._views[key] = (used, host, dev, self.host[slot][:used], self.dev[slot][:used])
+        return hit
+
+    def stage(self, data: "GroundedScanDataset", idx: np.ndarray) -> tuple:
+        slot = self.count % self.depth
+        self.count += 1
+        in_len, tgt_len = data._input_lengths[idx], data._target_lengths[idx]
+        L, T = int(in_len.max()), int(tgt_len.max())
+        used, host, dev, host_used, dev_used = self._layout(slot, len(idx), L, T, tuple(data._grids.shape[1:]))
+        if self.count > self.depth:
+            self.copied[slot].synchronize()            # the slab's previous copy has long left the host buffer
+        np.take(data._commands[:, :L], idx, axis=0, out=host["commands"], mode="clip")   # mode: no buffering of out
+        np.take(data._targets[:, :T], idx, axis=0, out=host["targets"], mode="clip")
+        np.take(data._agent_positions, idx, out=host["agent_positions"], mode="clip")
+        np.take(data._target_positions, idx, out=host["target_positions"], mode="clip")
+        host["cmd_lengths"][:] = in_len
+        host["tgt_lengths"][:] = tgt_len
+        np.take(data._grids, idx, axis=0, out=host["world"], mode="clip")
+        copy = self.copy_stream
+        if self.released[slot] is not None:
+            copy.wait_event(self.released[slot])       # the consumer is done with this device slab
+        with torch.cuda.stream(copy):
+            dev_used.copy_(host_used, non_blocking=True)
+        self.copied[slot].record(copy)
+        return slot, dev, idx
+
+    def deliver(self, staged: tuple) -> Dict[str, torch.Tensor]:
+        slot, dev, idx = staged
+        current = torch.cuda.current_stream(self.device)
+        if self._last is not None:                    # everything the consumer launched on the previous batch
+            if self.released[self._last] is None:
+                self.released[self._last] = torch.cuda.Event()
+            self.released[self._last].record(current)
+        self._last = slot
+        current.wait_event(self.copied[slot])
+        return dict(dev, index=idx)

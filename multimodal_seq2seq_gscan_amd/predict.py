@@ -135,7 +135,8 @@ def predict_and_save(dataset, model, output_file_path: str, max_decoding_steps: 
     position_accuracy) as JSON.  Batched (the reference iterates with batch_size=1)."""
     vocab, output = dataset.target_vocabulary, []
     for (inp, derivation, situation, out_seq, tgt, aw_c, aw_s, pos_acc) in predict(
-            dataset.get_data_iterator(batch_size=batch_size), model=model, max_decoding_steps=max_decoding_steps,
+            dataset.get_data_iterator(batch_size=batch_size, world_dtype=torch.uint8), model=model,
+            max_decoding_steps=max_decoding_steps,
             pad_idx=vocab.pad_idx, sos_idx=vocab.sos_idx, eos_idx=vocab.eos_idx,
             max_examples_to_evaluate=max_testing_examples):
         accuracy = sequence_accuracy(out_seq, tgt[0].tolist()[1:-1])

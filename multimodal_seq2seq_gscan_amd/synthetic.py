@@ -84,3 +84,52 @@ def make_batch(shape: Shape, seed: int = 1234) -> Dict[str, torch.Tensor]:
     positions = torch.randint(0, shape.grid * shape.grid, (shape.batch,), generator=gen)
     return {"commands": commands, "cmd_lengths": cmd_lengths, "world": world, "targets": targets,
             "tgt_lengths": tgt_lengths, "target_positions": positions}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# A dataset FILE of the same distribution, in the reference's format (GroundedScan/dataset.py:487-514 reads it;
+# the situation dictionaries follow Situation.to_representation, world.py:269-281): input for the reader / batcher
+# (dataset.py here) when no gSCAN download is at hand — tests and `bench.py --with-batcher`.
+# ------------------------------------------------------------------------------------------------------------------
+_COMMAND_WORDS = ["walk", "push", "pull", "to", "a", "the", "red", "green", "blue", "yellow", "big", "small", "circle",
+                  "square", "cylinder", "cautiously", "hesitantly", "while", "spinning", "zigzagging"]
+_ACTIONS = ["walk", "turn left", "turn right", "push", "pull", "stay"]
+_SHAPES, _COLOURS = ["circle", "square", "cylinder"], ["red", "green", "blue", "yellow"]
+
+
+def write_dataset_file(path: str, examples: Dict[str, int], shape: Shape = Shape(batch=1), seed: int = 0) -> None:
+    """Write {"examples": {split: [...]}} with examples[split] random examples per split: commands of
+    4..max_command-2 words, targets of 2..max_target-2 actions (ragged), grids of shape.grid cells with one agent
+    and 1..12 objects (4 sizes + 3 shapes + 4 colours -> 11 attributes, 16 channels)."""
+    import json
+    import random
+    rng = random.Random(seed)
+    G = shape.grid
+    out = {"grid_size": G, "type_grammar": "adverb", "min_object_size": 1, "max_object_size": 4, "max_recursion": 2,
+           "percentage_train": 0.8, "examples": {}}
+    for split, count in examples.items():
+        rows = []
+        for _ in range(count):
+            cells = rng.sample(range(G * G), min(G * G, 1 + rng.randint(1, 12)))
+            placed = {}
+            for j, cell in enumerate(cells[1:]):
+                size, sh, co = rng.randint(1, 4), rng.randrange(3), rng.randrange(4)
+                vector = ["0"] * 11
+                vector[size - 1], vector[4 + sh], vector[7 + co] = "1", "1", "1"
+                placed[str(j)] = {"vector": "".join(vector),
+                                  "position": {"row": str(cell // G), "column": str(cell % G)},
+                                  "object": {"shape": _SHAPES[sh], "color": _COLOURS[co], "size": str(size)}}
+            target = placed["0"]
+            situation = {"grid_size": G, "agent_position": {"row": str(cells[0] // G), "column": str(cells[0] % G)},
+                         "agent_direction": rng.randrange(4), "target_object": target, "distance_to_target": "1",
+                         "direction_to_target": "n", "placed_objects": placed, "carrying_object": None}
+            command = [rng.choice(_COMMAND_WORDS) for _ in range(rng.randint(min(4, shape.max_command - 2),
+                                                                             shape.max_command - 2))]
+            actions = [rng.choice(_ACTIONS) for _ in range(rng.randint(min(2, shape.max_target - 2),
+                                                                       shape.max_target - 2))]
+            rows.append({"command": ",".join(command), "meaning": ",".join(command), "derivation": "",
+                         "situation": situation, "target_commands": ",".join(actions), "verb_in_command": command[0],
+                         "manner": "", "referred_target": ""})
+        out["examples"][split] = rows
+    with open(path, "w") as f:
+        json.dump(out, f)

@@ -403,7 +403,7 @@ def train_on_dataset(data_path: str, data_directory: str, generate_vocabularies:
                      print_every: int, evaluate_every: int, max_decoding_steps: int, output_directory: str,
                      resume_from_file: str = "", k: int = 0, max_training_examples=None, max_testing_examples=None,
                      weight_target_loss: float = 0.3, seed: int = 42, rank: int = 0, world_size: int = 1,
-                     evaluation_batch_size: int = 256, **flags) -> Model:
+                     evaluation_batch_size: int = 256, length_bucket_batches: int = 0, **flags) -> Model:
     """seq2seq/train.py:17-154 on a gSCAN dataset file: the reference's loop — shuffle, iterate batches, step,
     log every `print_every`, greedy-decode the dev split every `evaluate_every` and checkpoint on a new best exact
     match — with the HIP step, the packed batcher (dataset.py) and batched evaluation.  Under torch.distributed
@@ -411,7 +411,7 @@ def train_on_dataset(data_path: str, data_directory: str, generate_vocabularies:
     import random
     import numpy as np
     from .config import model_kwargs
-    from .dataset import GroundedScanDataset
+    from .dataset import BatchStager, GroundedScanDataset
     from .predict import evaluate_sums
 
     torch.manual_seed(seed)                                     # train.py:27
@@ -459,19 +459,20 @@ def train_on_dataset(data_path: str, data_directory: str, generate_vocabularies:
     logger.info("Training starts..")
     training_iteration = model.trained_iterations if resume_from_file else 1
     vocab = dev_set.target_vocabulary
+    # one ring of pinned / device slabs for the whole run: a batch is gathered into a slab, crosses PCIe in one
+    # asynchronous copy a batch ahead of the step, and stays uint8 (the kernels widen the world in registers)
+    stager = BatchStager(model.flat_parameters.device, training_set.slab_bytes(training_batch_size))
+    keys = ("commands", "cmd_lengths", "world", "targets", "tgt_lengths", "target_positions")
     while training_iteration < max_training_iterations:          # train.py:88
-        training_set.shuffle_data()
-        for (commands, cmd_lengths, _, world, _, targets, tgt_lengths, _, positions) in training_set.get_data_iterator(
-                batch_size=training_batch_size):
-            batch = {"commands": commands, "cmd_lengths": torch.as_tensor(cmd_lengths), "world": world,
-                     "targets": targets, "tgt_lengths": torch.as_tensor(tgt_lengths), "target_positions": positions}
+        training_set.shuffle_data(bucket_batches=length_bucket_batches, batch_size=training_batch_size)
+        for staged in training_set.batches(training_batch_size, stager=stager):
+            batch = {key: staged[key] for key in keys}
             if world_size > 1:
                 # the epoch's short trailing batch (gSCAN_dataset.py:195-196) may hold fewer rows than there are
                 # ranks: every rank sees the same batch, so every rank drops it
-                if commands.shape[0] < world_size:
+                if batch["commands"].shape[0] < world_size:
                     continue
-                batch = {key: value.cuda() if key.endswith("lengths") else value
-                         for key, value in shard_batch(batch, rank, world_size).items()}
+                batch = shard_batch(batch, rank, world_size)
             out = step(batch)
             if training_iteration % print_every == 0 and rank == 0:
                 accuracy, exact_match = model.get_metrics(out["logp"], batch["targets"])
@@ -487,7 +488,8 @@ def train_on_dataset(data_path: str, data_directory: str, generate_vocabularies:
                     logger.info("Evaluating..")
                 limit = max_testing_examples and -(-max_testing_examples // world_size)
                 sums = torch.tensor(evaluate_sums(
-                    dev_set.get_data_iterator(batch_size=evaluation_batch_size, shard=(rank, world_size)), model=model,
+                    dev_set.get_data_iterator(batch_size=evaluation_batch_size, shard=(rank, world_size),
+                                              world_dtype=torch.uint8), model=model,
                     max_decoding_steps=max_decoding_steps, pad_idx=vocab.pad_idx, sos_idx=vocab.sos_idx,
                     eos_idx=vocab.eos_idx, max_examples_to_evaluate=limit), dtype=torch.float64)
                 if world_size > 1:

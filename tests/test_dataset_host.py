@@ -121,3 +121,59 @@ def test_k_shot_moves_adverb_examples_into_train_and_dev():
     assert len(base["adverb_1"]) == 3 and len(base["train"]) == 8 and len(base["dev"]) == 3
     moved = load_examples(DATA, k=2)
     assert len(moved["adverb_1"]) == 1 and len(moved["train"]) == 10 and len(moved["dev"]) == 5
+
+
+def test_generated_dataset_file_round_trips_through_the_reader(tmp_path):
+    """synthetic.write_dataset_file writes the reference's file format (GroundedScan/dataset.py:487-514): the reader
+    packs it, the grids follow Grid.encode (one agent cell, three bits per object) and the iterator keeps the
+    9-tuple contract."""
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, write_dataset_file
+    path = str(tmp_path / "dataset.txt")
+    write_dataset_file(path, {"train": 50, "dev": 7}, Shape(batch=1, max_command=9, max_target=12), seed=3)
+    data = GroundedScanDataset(path, str(tmp_path), k=0, split="train", generate_vocabulary=True)
+    data.read_dataset()
+    assert data.num_examples == 50 and data.image_channels == 16 and data.image_dimensions == 6
+    grids = data._grids
+    assert grids.dtype == np.uint8 and grids.max() == 1
+    assert (grids[..., 11].reshape(50, -1).sum(1) == 1).all()               # exactly one agent cell
+    assert (grids[..., 12:].reshape(50, -1).sum(1) == 1).all()              # with exactly one direction bit
+    objects = grids[..., :11].reshape(50, -1).sum(1)
+    assert ((objects % 3) == 0).all() and objects.min() >= 3                # three bits per placed object
+    batches = list(data.get_data_iterator(batch_size=16, device=torch.device("cpu")))
+    assert [b[0].shape[0] for b in batches] == [16, 16, 16, 2]
+    for b in batches:
+        assert b[0].shape[1] == int(b[1].max()) and b[5].shape[1] == int(b[6].max())      # padded to ITS longest rows
+        assert b[3].dtype == torch.float32 and tuple(b[3].shape[1:]) == (6, 6, 16)
+
+
+def test_length_buckets_permute_the_split_and_cut_padding(tmp_path):
+    """shuffle_data(bucket_batches=k): still a permutation of the split, batches hold rows of similar target length
+    (fewer padded decoder steps), and bucket_batches=0 is the reference's plain shuffle."""
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, write_dataset_file
+    path = str(tmp_path / "dataset.txt")
+    write_dataset_file(path, {"train": 400}, Shape(batch=1, max_target=30), seed=5)
+    data = GroundedScanDataset(path, str(tmp_path), k=0, split="train", generate_vocabulary=True)
+    data.read_dataset()
+
+    def padded_steps():
+        return sum(int(b[6].max()) * len(b[6]) for b in data.get_data_iterator(batch_size=20, device=torch.device("cpu")))
+
+    np.random.seed(0)
+    data.shuffle_data()
+    assert sorted(data._order.tolist()) == list(range(400))
+    plain = padded_steps()
+    data.shuffle_data(bucket_batches=5, batch_size=20)
+    assert sorted(data._order.tolist()) == list(range(400))
+    bucketed = padded_steps()
+    live = int(data._target_lengths.sum())
+    assert live <= bucketed < plain and (bucketed - live) < 0.5 * (plain - live)
+
+
+def test_staging_slab_layout():
+    from multimodal_seq2seq_gscan_amd.dataset import _Slab
+    offsets, total = _Slab.layout(256, 10, 20, 576)
+    assert all(off % 64 == 0 for off, _ in offsets.values()) and total % 64 == 0
+    assert offsets["world"][1] == 256 * 576 and offsets["commands"][1] == 256 * 10 * 8
+    ends = sorted((off, off + n) for off, n in offsets.values())
+    assert all(a[1] <= b[0] for a, b in zip(ends, ends[1:])) and ends[-1][1] <= total      # no overlap
+    assert total < 256 * (576 + 8 * 30 + 16 + 8) + 7 * 64

@@ -585,3 +585,56 @@ def test_command_line_on_a_dataset_file(tmp_path):
     assert records[0]["target"] == ["turn left", "turn left", "walk", "turn left", "walk"]
     assert all(w in ("turn left", "turn right", "walk", "<EOS>", "<SOS>", "<PAD>") for w in records[0]["prediction"])
     assert len(json.load(open(f"{out}/test_predict.json"))) == 2
+
+
+def test_staged_batcher_delivers_the_packed_rows_while_the_step_runs(tmp_path):
+    """batches gathered into a ring of pinned slabs, copied a batch ahead on a copy stream, world kept
+    uint8.  Over several epochs (the ring of three slabs is reused many times, with training steps in flight on the
+    delivered views) every delivered tensor equals the packed rows it was cut from; the reference-contract iterator
+    on the device equals the host one; and training on staged uint8 batches gives the loss of training on the
+    same rows shipped as float32 tensors."""
+    from multimodal_seq2seq_gscan_amd.dataset import BatchStager, GroundedScanDataset
+    from multimodal_seq2seq_gscan_amd.model import Model
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, write_dataset_file
+    from multimodal_seq2seq_gscan_amd.train import TrainStep
+    path = str(tmp_path / "dataset.txt")
+    write_dataset_file(path, {"train": 150}, Shape(batch=1, max_command=8, max_target=12), seed=11)
+    data = GroundedScanDataset(path, str(tmp_path), k=0, split="train", generate_vocabulary=True)
+    data.read_dataset()
+    cfg = model_kwargs("demo", input_vocabulary_size=data.input_vocabulary_size, num_cnn_channels=16,
+                       target_vocabulary_size=data.target_vocabulary_size, cnn_dropout_p=0.0, encoder_dropout_p=0.0,
+                       decoder_dropout_p=0.0)
+    torch.manual_seed(3)
+    staged_model, plain_model = Model(**cfg).cuda(), Model(**cfg).cuda()
+    plain_model.load_state_dict(staged_model.state_dict())
+    staged_step, plain_step = TrainStep(staged_model, learning_rate=1e-3), TrainStep(plain_model, learning_rate=1e-3)
+    keys = ("commands", "cmd_lengths", "world", "targets", "tgt_lengths", "target_positions")
+    stager = BatchStager(torch.device("cuda"), data.slab_bytes(16))
+    np.random.seed(4)
+    seen = 0
+    for epoch in range(3):
+        data.shuffle_data()
+        for b in data.batches(16, stager=stager):
+            idx = b["index"]
+            L, T = int(data._input_lengths[idx].max()), int(data._target_lengths[idx].max())
+            assert b["world"].dtype == torch.uint8 and b["cmd_lengths"].dtype == torch.int32
+            out = staged_step({k: b[k] for k in keys})                      # the step runs on the views ...
+            host = {"commands": torch.from_numpy(data._commands[idx, :L]), "targets": torch.from_numpy(data._targets[idx, :T]),
+                    "world": torch.from_numpy(data._grids[idx]).float(),
+                    "cmd_lengths": torch.from_numpy(data._input_lengths[idx]), "tgt_lengths": torch.from_numpy(data._target_lengths[idx]),
+                    "target_positions": torch.from_numpy(data._target_positions[idx])}
+            ref = plain_step({k: v.cuda() for k, v in host.items()})         # ... and equals the float32 route
+            assert torch.equal(b["commands"].cpu(), host["commands"]) and torch.equal(b["targets"].cpu(), host["targets"])
+            assert torch.equal(b["world"].cpu(), torch.from_numpy(data._grids[idx]))
+            assert torch.equal(b["cmd_lengths"].cpu().long(), host["cmd_lengths"])
+            assert torch.equal(b["target_positions"].cpu(), host["target_positions"])
+            assert abs(out["loss"].item() - ref["loss"].item()) < 1e-5
+            seen += len(idx)
+    assert seen == 3 * 150 and stager.count == 3 * 10
+    assert torch.allclose(staged_model.flat_parameters, plain_model.flat_parameters, atol=1e-4)
+    data._order = np.arange(150)
+    on_device = list(data.get_data_iterator(batch_size=32))
+    on_host = list(data.get_data_iterator(batch_size=32, device=torch.device("cpu")))
+    for d, h in zip(on_device, on_host):
+        assert d[3].dtype == torch.float32 and torch.equal(d[3].cpu(), h[3]) and torch.equal(d[0].cpu(), h[0])
+        assert torch.equal(d[5].cpu(), h[5]) and torch.equal(d[8].cpu(), h[8]) and (d[1] == h[1]).all()
