@@ -140,6 +140,17 @@ int gscan_decode_step(const gscan_dims *dims, const gscan_params *params, const 
                       const int64_t *tokens, const float *h_in, const float *c_in, void *workspace, float *logits,
                       float *h_out, float *c_out, float *alpha_text, float *alpha_vis, void *stream);
 
+/* predict.py:82-115 for all B rows in ONE call: gscan_encode, then the persistent decoder kernel with the argmax fed
+ * back in-kernel (eval mode) — every row decodes from <SOS> until it emits <EOS> or max_steps steps have run
+ * (max_steps = max_decoding_steps + 1: the reference's `while token != eos and i <= max_decoding_steps`).
+ * dims->T must be 1 (workspace of gscan_workspace_bytes(dims)).  Outputs: tokens [B,max_steps] (the tokens produced,
+ * the final <EOS> included; entries behind a row's own steps are not written), steps [B], the attention rows of
+ * every step alpha_text [B,max_steps,L] and alpha_vis [B,max_steps,G*G], and att_sum [B,G*G] = the row's visual
+ * attention summed over its steps (the auxiliary head's input, predict.py:118-120).  No host synchronisation. */
+int gscan_greedy_decode(const gscan_dims *dims, int max_steps, const gscan_params *params, const gscan_batch *batch,
+                        void *workspace, int sos_idx, int eos_idx, int64_t *tokens, int32_t *steps, float *alpha_text,
+                        float *alpha_vis, float *att_sum, void *stream);
+
 /* Model.get_loss (seq2seq/model.py:147-160): NLL of targets shifted left by one with a PAD
  * appended, over positions whose shifted target != pad.  Writes loss_sum[0] = sum of -logp
  * and count[0] = number of such positions (as float); the reference's loss is

@@ -102,6 +102,15 @@ int gscan_decode_step(const gscan_dims *dims, const gscan_params *params, const 
                            alpha_text, alpha_vis, (hipStream_t)stream);
 }
 
+int gscan_greedy_decode(const gscan_dims *dims, int max_steps, const gscan_params *params, const gscan_batch *batch,
+                        void *workspace, int sos_idx, int eos_idx, int64_t *tokens, int32_t *steps, float *alpha_text,
+                        float *alpha_vis, float *att_sum, void *stream) {
+    ARG(dims && params && batch && workspace, "greedy_decode: NULL argument");
+    ARG(batch->commands && batch->cmd_lengths && (batch->world || batch->world_u8), "greedy_decode: NULL batch array");
+    return step_greedy(*dims, max_steps, *params, *batch, (float *)workspace, sos_idx, eos_idx, tokens, steps,
+                       alpha_text, alpha_vis, att_sum, (hipStream_t)stream);
+}
+
 int gscan_step_losses(const float *logp, const int64_t *targets, const float *aux_logp, const int64_t *positions, int B,
                       int T, int V, int M, int pad, float *stats, float *dlogp, float *daux, void *stream) {
     ARG(logp && targets && stats && dlogp && B > 0 && T > 0 && V > 0, "step_losses: bad argument");

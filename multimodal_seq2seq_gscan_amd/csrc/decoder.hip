@@ -234,7 +234,11 @@ __device__ __forceinline__ void quad_offset(int u_off, int pk_off, int u2_off, i
 }
 
 // ------------------------------------------------------------------------------------------
-template <int H, bool COND>
+// GREEDY = false: teacher forcing over the T given target tokens, everything backward needs is saved (training /
+// scoring).  GREEDY = true (predict.py:101-112): the row feeds its own argmax back for up to T steps and stops at
+// <EOS>; the embedding part of the gates is a row of a [V, 4H] table, the output head is the composite
+// W_h2o . W_o2h ([V, 4H], in LDS) applied every step, nothing is saved but tokens and attention rows.
+template <int H, bool COND, bool GREEDY>
 __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a) {
     TraceScope trace_scope(TK_DECODER_FWD);
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
@@ -258,6 +262,10 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     float *part_s = q2_s + HP;                              // [4][kPartStride] visual partial column sums
     float *sc_s = part_s + 4 * kPartStride, *bq_s = sc_s + 64, *stamp_acc = sc_s + 192;
     static_assert(H <= 128, "bq_s holds one bias per hidden unit in 128 floats");
+    // greedy decoding only: composite head [V,4H] (S order), embedding part of the logits [V,V], visual context,
+    // logits, current token (behind everything else in LDS)
+    float *wc_s = smem + o.total, *le_s = wc_s + a.V * 4 * H, *ctxv_s = le_s + a.V * a.V, *logit_s = ctxv_s + H;
+    int *tok_s = reinterpret_cast<int *>(logit_s + 64);
     long long stamp_prev = a.stamps ? clock64() : 0;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
@@ -281,8 +289,13 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     if (tid < 16) stamp_acc[tid] = 0.f;
     lds_barrier();
     float c = 0.f;
+    if (GREEDY) {
+        const int V = a.V;
+        for (int i = tid; i < V * 4 * H; i += kDecThreads) wc_s[i] = a.head_wc[i];
+        if (tid == 0) tok_s[0] = a.sos;
+    }
     if (tid < H) {
-        const float h0 = a.hprev[(int64_t)b * T * H + tid];
+        const float h0 = a.hprev[(int64_t)b * (GREEDY ? 1 : T) * H + tid];
         c = a.c0 ? a.c0[(int64_t)b * H + tid] : h0;         // c0 = h0 unless given (seq2seq_model.py:494-504)
         h_s[tid] = h0;
         vt_s[tid] = a.v_t[tid];
@@ -291,6 +304,17 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     if (COND && tid < H) bq_s[tid] = a.b_q2k[tid];
     float att_acc = 0.f;                                    // wave 0, lane m
     lds_barrier();
+    if (GREEDY) {   // le[v][v'] = Wc[v', 0:H] . Emb[v]: what the token fed in contributes to the logits
+        const int V = a.V;
+        for (int i = tid; i < V * V; i += kDecThreads) {
+            const int v = i / V, vo = i - v * V;
+            float acc = 0.f;
+            for (int k = 0; k < H; ++k) acc = fmaf(wc_s[vo * 4 * H + k], a.dec_emb[v * H + k], acc);
+            le_s[i] = acc;
+        }
+        lds_barrier();
+    }
+    int steps_done = 0;
     // The weight registers are complete from here on, and the compiler's wait-count bookkeeping is told so: without
     // this explicit wait it re-checks "the first weight load may still be in flight" at the top of EVERY iteration
     // with s_waitcnt vmcnt(2), which in steady state drains the previous step's stores (vmcnt counts in order).
@@ -301,11 +325,12 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         GSCAN_STAMP(0)
         const unsigned bt = (unsigned)b * T + t;            // 32-bit offsets: B*T*4H < 2^31 is checked on the host
         float ge[NS], gh[NS];
+        const unsigned ge_row = GREEDY ? (unsigned)tok_s[0] : bt;     // greedy: row of the [V, 4H] table of the token fed in
 #pragma unroll
         for (int s = 0; s < NS; ++s) {                      // embedding part of the gates: issued early, used in C2
             const int r = s * kDecPairs + pair;
             // unconditional in the slots that hold gate rows: a guarded load makes the compiler drain vmcnt first
-            ge[s] = (s * kDecPairs < 4 * H) ? a.ge[bt * 4 * H + min(r, 4 * H - 1)] : 0.f;
+            ge[s] = (s * kDecPairs < 4 * H) ? a.ge[ge_row * 4 * H + min(r, 4 * H - 1)] : 0.f;
         }
 
         // ---- A: everything that multiplies h_{t-1} -------------------------------------------
@@ -367,14 +392,16 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
                 if (r < 4 * H) {
                     gsum_s[r] = ge[s] + col_s[r];
                 } else if (r < 5 * H) {
-                    a.s[bt * 4 * H + H + (r - 4 * H)] = col_s[r];
-                    a.qt[bt * H + r - 4 * H] = gh[s];
+                    if (!GREEDY) {
+                        a.s[bt * 4 * H + H + (r - 4 * H)] = col_s[r];
+                        a.qt[bt * H + r - 4 * H] = gh[s];
+                    }
                 } else if (r < 6 * H) {
                     if (COND) {
                         const float q = tanhf_(gh[s] + col_s[r] + bq_s[r - 5 * H]);   // seq2seq_model.py:394-396
                         q2_s[r - 5 * H] = q;
-                        a.q2[bt * H + r - 5 * H] = q;
-                    } else {
+                        if (!GREEDY) a.q2[bt * H + r - 5 * H] = q;
+                    } else if (!GREEDY) {
                         a.qv[bt * H + r - 5 * H] = gh[s];
                     }
                 }
@@ -390,7 +417,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
                 const int r = s * kDecPairs + pair;
                 if (r >= 6 * H && r < 7 * H) {
                     const float acc = pair_sum(half_dot<K0>(w[s], q2_s + half * K0));
-                    if (half == 0) { qv_s[r - 6 * H] = acc; a.qv[bt * H + r - 6 * H] = acc; }
+                    if (half == 0) { qv_s[r - 6 * H] = acc; if (!GREEDY) a.qv[bt * H + r - 6 * H] = acc; }
                 }
             }
         }
@@ -436,21 +463,54 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
                 const float pre = gsum_s[r] + (part_s[r] + part_s[kPartStride + r]) +
                                   (part_s[2 * kPartStride + r] + part_s[3 * kPartStride + r]);
                 g4[gi] = (gi == 2) ? tanhf_(pre) : sigmoidf_(pre);
-                a.gates[bt * 4 * H + r] = g4[gi];
+                if (!GREEDY) a.gates[bt * 4 * H + r] = g4[gi];
             }
             c = g4[1] * c + g4[0] * g4[2];
             const float h = g4[3] * tanhf_(c);
             h_s[tid] = h;
-            a.cells[bt * H + tid] = c;
-            a.s[bt * 4 * H + 3 * H + tid] = h;
-            if (t + 1 < T) a.hprev[(bt + 1) * H + tid] = h;
+            if (!GREEDY) {
+                a.cells[bt * H + tid] = c;
+                a.s[bt * 4 * H + 3 * H + tid] = h;
+                if (t + 1 < T) a.hprev[(bt + 1) * H + tid] = h;
+            }
         } else if (tid >= 128 && tid < 128 + H) {
             const int r = 4 * H + (tid - 128);
-            a.s[bt * 4 * H + 2 * H + (tid - 128)] = (part_s[r] + part_s[kPartStride + r]) +
-                                                    (part_s[2 * kPartStride + r] + part_s[3 * kPartStride + r]);
+            const float cv = (part_s[r] + part_s[kPartStride + r]) + (part_s[2 * kPartStride + r] + part_s[3 * kPartStride + r]);
+            if (GREEDY) ctxv_s[tid - 128] = cv;
+            else a.s[bt * 4 * H + 2 * H + (tid - 128)] = cv;
         }
         lds_barrier();
         GSCAN_STAMP(8)
+        if (GREEDY) {
+            // output head on [e | ctx_text | ctx_vis | h] (seq2seq_model.py:421-424) as the composite W_h2o . W_o2h,
+            // argmax (= argmax of log_softmax, predict.py:106-107; the first of equal maxima), feed back, stop at <EOS>
+            const int V = a.V, tok = tok_s[0];
+            for (int v = wave; v < V; v += nwave) {
+                const float *wrow = wc_s + v * 4 * H;
+                float p = 0.f;
+                for (int k = lane; k < H; k += 64)
+                    p += wrow[H + k] * col_s[4 * H + k] + wrow[2 * H + k] * ctxv_s[k] + wrow[3 * H + k] * h_s[k];
+                p = wave_sum(p);
+                if (lane == 0) logit_s[v] = p + le_s[tok * V + v];
+            }
+            lds_barrier();
+            if (tid == 0) {
+                int best = 0;
+                float top = logit_s[0];
+                for (int v = 1; v < V; ++v)
+                    if (logit_s[v] > top) { top = logit_s[v]; best = v; }
+                tok_s[0] = best;
+                a.tokens_out[(int64_t)b * T + t] = best;
+            }
+            steps_done = t + 1;
+            lds_barrier();
+            if (tok_s[0] == a.eos) break;                  // uniform: every thread reads the same LDS word
+        }
+    }
+    if (GREEDY) {
+        if (tid == 0) a.steps_out[b] = steps_done;
+        if (wave == 0 && lane < M) a.att_sum[(int64_t)b * M + lane] = att_acc;
+        return;
     }
     if (a.h_last && tid < H) a.h_last[(int64_t)b * H + tid] = h_s[tid];   // h_T (own LDS write, no barrier needed)
     if (wave == 0) {
@@ -1006,7 +1066,8 @@ constexpr size_t kLdsLimit = 160 * 1024;
 template <int H, bool COND>
 static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_t stream) {
     const DecoderLds o = decoder_lds(H, a.L, a.M, a.V, COND, backward);
-    const size_t bytes = (size_t)o.total * sizeof(float);
+    const bool greedy = !backward && a.tokens_out != nullptr;
+    const size_t bytes = ((size_t)o.total + (greedy ? (size_t)a.V * 4 * H + (size_t)a.V * a.V + H + 64 + 16 : 0)) * sizeof(float);
     GSCAN_CHECK(bytes <= kLdsLimit,
                 "decoder: a row's memories need %zu bytes of LDS (> 160 KiB): grid cells=%d command length=%d hidden=%d",
                 bytes, a.M, a.L, H);
@@ -1029,11 +1090,18 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
     } else {
         static bool attr_set = false;
         if (!attr_set) {
-            GSCAN_HIP(hipFuncSetAttribute((const void *)decoder_fwd_kernel<H, COND>,
+            GSCAN_HIP(hipFuncSetAttribute((const void *)decoder_fwd_kernel<H, COND, false>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+            GSCAN_HIP(hipFuncSetAttribute((const void *)decoder_fwd_kernel<H, COND, true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
             attr_set = true;
         }
-        hipLaunchKernelGGL((decoder_fwd_kernel<H, COND>), dim3(B), dim3(kDecThreads), bytes, stream, a);
+        if (greedy) {
+            GSCAN_CHECK(a.V <= 64 && a.head_wc && a.dec_emb && a.steps_out, "greedy decoder: missing tables or V > 64");
+            hipLaunchKernelGGL((decoder_fwd_kernel<H, COND, true>), dim3(B), dim3(kDecThreads), bytes, stream, a);
+        } else {
+            hipLaunchKernelGGL((decoder_fwd_kernel<H, COND, false>), dim3(B), dim3(kDecThreads), bytes, stream, a);
+        }
         GSCAN_LAUNCHED("decoder_fwd_kernel");
     }
     return 0;

@@ -252,6 +252,13 @@ struct DecoderArgs {
     float *dv_t, *dv_v;                // [H] energy-vector gradients, accumulated with atomics
     float *dh0;                        // [B,H] gradient wrt the bridge pre-activation
     float *stamps;                     // diagnostics: [2][16] per-phase cycle sums of workgroup 0, or NULL
+    // greedy decoding (forward kernel, GREEDY instantiation; selected by tokens_out != NULL): T = step limit,
+    // ge = [V,4H] table Emb . W_ih[:, :H]^T + biases, hprev = h0 [B,H]
+    const float *head_wc;              // [V,4H] composite W_h2o . W_o2h with columns in S order
+    const float *dec_emb;              // [V,H]
+    int sos, eos;
+    int64_t *tokens_out;               // [B,T] tokens produced (the <EOS> included)
+    int32_t *steps_out;                // [B] steps taken
 };
 bool decoder_hidden_supported(int h);
 size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward);
@@ -291,7 +298,8 @@ struct Workspace {
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, row_stats, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
         wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, conv_img, conv_lists, wcat5,
-        deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image;   // encoder layers below the last
+        deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image,   // encoder layers below the last
+        ge_table, head_wc;        // greedy decoding: [V,4H] tables
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;
@@ -306,6 +314,9 @@ int step_encode(const gscan_dims &d, const gscan_params &p, const gscan_batch &b
 int step_decode_one(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const int64_t *tokens,
                     const float *h_in, const float *c_in, float *w, float *logits, float *h_out, float *c_out,
                     float *alpha_text, float *alpha_vis, hipStream_t st);
+int step_greedy(const gscan_dims &d, int max_steps, const gscan_params &p, const gscan_batch &bt, float *w, int sos,
+                int eos, int64_t *tokens, int32_t *steps, float *alpha_text, float *alpha_vis, float *att_sum,
+                hipStream_t st);
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                   const float *dlogp, const float *daux, const float *seeds, const NllSeed *nll, const gscan_params &g,
                   hipStream_t st);

@@ -113,6 +113,8 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(deep_dy, deep * B * L * D * He);
     SLOT(deep_delta, deep * B * L * D * 4 * He);
     SLOT(deep_image, deep * D * 4 * He * He);
+    SLOT(ge_table, V * 4 * H);                       // greedy decoding: Emb . W_ih[:, :H]^T + biases
+    SLOT(head_wc, V * 4 * H);                        // greedy decoding: W_h2o . W_o2h (S order)
 #undef SLOT
     ws->nslots = n;
     ws->total_floats = p;
@@ -443,6 +445,39 @@ int step_decode_one(const gscan_dims &d, const gscan_params &p, const gscan_batc
     a.logp_out = w + ws.logp_saved;
     a.aux_saved = nullptr; a.aux_out = nullptr; a.row_stats = nullptr;
     a.stamps = nullptr;
+    return decoder_run(false, B, H, d.conditional != 0, a, st);
+}
+
+// Greedy decoding of a whole batch in ONE launch (predict.py:82-115): encode, two tiny table products, then the
+// persistent decoder with the argmax fed back in-kernel, every row until its own <EOS> or max_steps steps.
+int step_greedy(const gscan_dims &d, int max_steps, const gscan_params &p, const gscan_batch &bt, float *w, int sos,
+                int eos, int64_t *tokens, int32_t *steps, float *alpha_text, float *alpha_vis, float *att_sum,
+                hipStream_t st) {
+    TRY(check_dims(d));
+    GSCAN_CHECK(d.T == 1, "greedy_decode: dims.T must be 1 (the workspace holds no per-step activations), got %d", d.T);
+    GSCAN_CHECK(max_steps > 0 && tokens && steps && alpha_text && alpha_vis && att_sum, "greedy_decode: bad arguments");
+    GSCAN_CHECK(sos >= 0 && sos < d.V && eos >= 0 && eos < d.V, "greedy_decode: <SOS>/<EOS> outside the vocabulary");
+    Workspace ws;
+    TRY(workspace_layout(d, &ws));
+    gscan_masks none{};
+    TRY(encode_branches(d, p, bt, none, w, ws, false, st));
+    const int B = d.B, H = d.H, V = d.V;
+    {
+        GemmBatch g;
+        g.add(V, 4 * H, H, p.dec_emb, H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge_table, 4 * H, 0.f, w + ws.bsum);
+        g.add(V, 4 * H, H, p.hid2out_w, H, 1, w + ws.wo_perm, 4 * H, 1, w + ws.head_wc, 4 * H);
+        TRY(g.launch(st));
+    }
+    DecoderArgs a = decoder_args(d, p, bt, w, ws);
+    a.T = max_steps;
+    a.w_image = w + ws.dec_w_fwd;
+    a.ge = w + ws.ge_table;
+    a.head_wc = w + ws.head_wc;
+    a.dec_emb = p.dec_emb;
+    a.sos = sos; a.eos = eos;
+    a.tokens_out = tokens; a.steps_out = steps;
+    a.alpha_c = alpha_text; a.alpha_s = alpha_vis; a.att_sum = att_sum;
+    a.aux_saved = nullptr; a.aux_out = nullptr; a.row_stats = nullptr; a.stamps = nullptr;
     return decoder_run(false, B, H, d.conditional != 0, a, st);
 }
 

@@ -615,6 +615,47 @@ class Model(nn.Module):
                                          torch.cuda.current_stream().cuda_stream), "gscan_decode_step")
         return logits, (h_out.unsqueeze(0), c_out.unsqueeze(0)), alpha_vis, alpha_text, alpha_vis
 
+    def greedy_decode(self, commands_input: torch.LongTensor, commands_lengths: List[int],
+                      situations_input: torch.Tensor, sos_idx: int, eos_idx: int, max_decoding_steps: int):
+        """predict.py:82-115 for every row of a batch in ONE library call (`gscan_greedy_decode`): encode, then the
+        persistent decoder kernel feeds its own argmax back, each row until its <EOS> or max_decoding_steps + 1
+        steps — no launch and no host synchronisation per token.  Returns device tensors (tokens [B,S] int64, steps
+        [B] int32, alpha_text [B,S,L], alpha_vis [B,S,G*G], att_sum [B,G*G]), S = max_decoding_steps + 1; entries of
+        a row behind its own `steps` are undefined."""
+        lib = _lib.load()
+        self._require_device(commands_input, situations_input)
+        device = commands_input.device
+        lengths = _as_int32_lengths(commands_lengths, device)
+        B, L = commands_input.shape
+        G = situations_input.shape[1]
+        if situations_input.shape != (B, G, G, self._hyper["C"]):
+            raise ValueError(f"situations_input must be [B,G,G,{self._hyper['C']}], got {tuple(situations_input.shape)}")
+        assert lengths.numel() == B, "Wrong amount of lengths passed to .forward()"   # seq2seq_model.py:57
+        dims = self._dims(B, L, 1, G)
+        need = lib.gscan_workspace_bytes(C.byref(dims))
+        if need == 0:
+            raise _lib.GscanError("unsupported dimensions: " + lib.gscan_last_error().decode())
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        commands = commands_input.contiguous()
+        world = _world_operand(situations_input)
+        batch = _lib.Batch(commands.data_ptr(), lengths.data_ptr(), None if world.dtype == torch.uint8 else world.data_ptr(),
+                           None, None, world.data_ptr() if world.dtype == torch.uint8 else None)
+        S, M = int(max_decoding_steps) + 1, G * G
+        tokens = torch.zeros(B, S, dtype=torch.int64, device=device)
+        steps = torch.zeros(B, dtype=torch.int32, device=device)
+        alpha_text = torch.zeros(B, S, L, dtype=torch.float32, device=device)
+        alpha_vis = torch.zeros(B, S, M, dtype=torch.float32, device=device)
+        att_sum = torch.zeros(B, M, dtype=torch.float32, device=device)
+        _lib.check(lib.gscan_greedy_decode(C.byref(dims), S, C.byref(self._param_struct), C.byref(batch),
+                                           self._workspace.data_ptr(), int(sos_idx), int(eos_idx), tokens.data_ptr(),
+                                           steps.data_ptr(), alpha_text.data_ptr(), alpha_vis.data_ptr(),
+                                           att_sum.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "gscan_greedy_decode")
+        self._generation += 1
+        self._decode_state = None
+        return tokens, steps, alpha_text, alpha_vis, att_sum
+
     def decode_input_batched(self, *args, **kwargs):
         """model.py:190-204 is the second half of the reference's forward() (its only caller, :209-213).  Here
         forward() is one fused library call, so the teacher-forced decoder cannot be entered with encodings handed

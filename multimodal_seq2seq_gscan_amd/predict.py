@@ -29,8 +29,30 @@ def sequence_accuracy(prediction: List[int], target: List[int]) -> float:
 
 def greedy_decode(model, commands: torch.Tensor, cmd_lengths, world: torch.Tensor, sos_idx: int, eos_idx: int,
                   max_decoding_steps: int) -> dict:
-    """predict.py:82-115 for all rows of a batch.  Returns per-row python lists `tokens` (the trailing <EOS>
-    still included, as the loop produces it), `alpha_text`, `alpha_vis` and the summed visual attention [B, G*G]."""
+    """predict.py:82-115 for all rows of a batch: ONE library call (Model.greedy_decode: encode + the persistent
+    decoder kernel with the argmax fed back in-kernel), one device-to-host copy of the results.  Returns per-row
+    python lists `tokens` (the trailing <EOS> still included, as the loop produces it), `alpha_text`, `alpha_vis`
+    and the summed visual attention [B, G*G]."""
+    B = commands.shape[0]
+    tokens, steps, alpha_text, alpha_vis, att_sum = model.greedy_decode(commands, cmd_lengths, world, sos_idx, eos_idx,
+                                                                        max_decoding_steps)
+    lengths = list(cmd_lengths) if not isinstance(cmd_lengths, torch.Tensor) else cmd_lengths.tolist()
+    tok, n_steps, at, av = tokens.cpu(), steps.cpu().tolist(), alpha_text.cpu(), alpha_vis.cpu()
+    rows = {"tokens": [], "alpha_text": [], "alpha_vis": [], "att_sum": att_sum}
+    for r in range(B):
+        n, L = int(n_steps[r]), int(lengths[r])
+        rows["tokens"].append(tok[r, :n].tolist())
+        rows["alpha_text"].append([at[r, s, :L].tolist() for s in range(n)])    # batch size 1 has no padding columns
+        rows["alpha_vis"].append([av[r, s].tolist() for s in range(n)])
+    return rows
+
+
+def greedy_decode_stepwise(model, commands: torch.Tensor, cmd_lengths, world: torch.Tensor, sos_idx: int, eos_idx: int,
+                           max_decoding_steps: int) -> dict:
+    """The same decoding through the reference's own call sequence (encode_input, key_layer, initialize_hidden,
+    decode_input per token: predict.py:82-112) with every row stepped until the last one has stopped: one launch and
+    one host synchronisation per token.  Kept as the drop-in surface check of those methods; predict() uses
+    greedy_decode above."""
     B = commands.shape[0]
     device = commands.device
     encoded = model.encode_input(commands_input=commands, commands_lengths=cmd_lengths, situations_input=world)

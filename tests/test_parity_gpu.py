@@ -414,6 +414,40 @@ def test_greedy_predict_matches_reference_loop():
     assert 0.0 <= acc <= 100.0 and 0.0 <= exact <= 100.0 and 0.0 <= aux <= 100.0
 
 
+def test_persistent_greedy_decoder_equals_the_stepwise_loop_and_stops_at_the_limit():
+    """One launch per batch (gscan_greedy_decode: argmax and <EOS> test fed back in-kernel) against the reference's
+    own call sequence driven token by token (encode_input / decode_input, predict.py:82-112): same tokens, stopping
+    steps, attention rows and summed visual attention, at the paper's dims for a ragged batch; and the T = 120 limit
+    of the target-length configuration (max_decoding_steps = 119: rows that never emit <EOS> stop after exactly 120
+    steps, predict.py:101)."""
+    from multimodal_seq2seq_gscan_amd.model import Model
+    from multimodal_seq2seq_gscan_amd.predict import greedy_decode, greedy_decode_stepwise
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+    # (with seeded random weights every row of a batch behaves alike: which token plays <EOS> decides whether the
+    # rows stop early or run into the limit; the CPU oracle's greedy_decode gives the same lengths for these seeds)
+    for workload, limit, uint8, eos, expect in (("compositional", 12, False, 5, "early"), ("compositional", 12, True, 2, "limit"),
+                                                ("target_length", 119, True, 6, "early"), ("target_length", 119, False, 2, "limit")):
+        torch.manual_seed(5)
+        cfg = model_kwargs(workload, auxiliary_task=True)
+        model = Model(**cfg).cuda().eval()
+        batch = make_batch(Shape(batch=37, input_vocab=cfg["input_vocabulary_size"],
+                                 target_vocab=cfg["target_vocabulary_size"], ragged=True), seed=21)
+        world = batch["world"].to(torch.uint8).cuda() if uint8 else batch["world"].cuda()
+        args = (model, batch["commands"].cuda(), batch["cmd_lengths"].tolist(), world, 1, eos, limit)
+        with torch.no_grad():
+            one, ref = greedy_decode(*args), greedy_decode_stepwise(*args)
+        assert one["tokens"] == ref["tokens"]
+        lengths = [len(t) for t in one["tokens"]]
+        if expect == "limit":
+            assert lengths == [limit + 1] * 37 and all(eos not in t for t in one["tokens"])
+        else:
+            assert max(lengths) <= limit and all(t[-1] == eos and eos not in t[:-1] for t in one["tokens"])
+        for r in range(37):
+            assert torch.allclose(torch.tensor(one["alpha_text"][r]), torch.tensor(ref["alpha_text"][r]), atol=1e-5)
+            assert torch.allclose(torch.tensor(one["alpha_vis"][r]), torch.tensor(ref["alpha_vis"][r]), atol=1e-5)
+        assert torch.allclose(one["att_sum"], ref["att_sum"], atol=1e-4)
+
+
 def test_command_line_train_then_test_modes(tmp_path):
     """`python -m seq2seq --mode=train ... --synthetic_data` then `--mode=test` (seq2seq/__main__.py:21-167): the
     training loop runs, writes the reference's checkpoint dictionary, and the test mode decodes greedily from it
