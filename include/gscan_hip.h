@@ -140,6 +140,16 @@ int gscan_decode_step(const gscan_dims *dims, const gscan_params *params, const 
                       const int64_t *tokens, const float *h_in, const float *c_in, void *workspace, float *logits,
                       float *h_out, float *c_out, float *alpha_text, float *alpha_vis, void *stream);
 
+/* Model.decode_input_batched (model.py:190-204), the second half of the reference's forward(): teacher-forced decoding
+ * from encodings HANDED IN — encoded_situations [B,G*G,3Co] (ConvolutionalNet output), encoder_outputs [B,L,He]
+ * (batch-major; the reference holds them time-major), hidden_states [B,He] — through the bridge, both key layers,
+ * the decoder over all T steps, the output head and log_softmax.  Eval semantics (no dropout), inference only: no
+ * backward call may follow.  batch->commands / world are not read.  Writes logp [B,T,V] and att_sum [B,G*G] (the
+ * visual attention summed over the T steps, seq2seq_model.py:490).  `workspace` as for gscan_forward. */
+int gscan_decode_batched(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                         const float *encoded_situations, const float *encoder_outputs, const float *hidden_states,
+                         void *workspace, float *logp, float *att_sum, void *stream);
+
 /* predict.py:82-115 for all B rows in ONE call: gscan_encode, then the persistent decoder kernel with the argmax fed
  * back in-kernel (eval mode) — every row decodes from <SOS> until it emits <EOS> or max_steps steps have run
  * (max_steps = max_decoding_steps + 1: the reference's `while token != eos and i <= max_decoding_steps`).

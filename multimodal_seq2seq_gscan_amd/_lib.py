@@ -89,6 +89,7 @@ PROTOTYPES = {
     "gscan_encode": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp]),
     "gscan_decode_step": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp]),
+    "gscan_decode_batched": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gscan_greedy_decode": (_i, [C.POINTER(Dims), _i, C.POINTER(Params), C.POINTER(Batch), _vp, _i, _i, _vp, _vp, _vp, _vp,
                                  _vp, _vp]),
     "gscan_backward_nll": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _f, _i,

@@ -102,6 +102,24 @@ int gscan_decode_step(const gscan_dims *dims, const gscan_params *params, const 
                            alpha_text, alpha_vis, (hipStream_t)stream);
 }
 
+int gscan_decode_batched(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                         const float *encoded_situations, const float *encoder_outputs, const float *hidden_states,
+                         void *workspace, float *logp, float *att_sum, void *stream) {
+    ARG(dims && params && batch && workspace && logp && att_sum, "decode_batched: NULL argument");
+    ARG(batch->cmd_lengths && batch->targets && encoded_situations && encoder_outputs && hidden_states,
+        "decode_batched: NULL array");
+    gscan_dims d = *dims;
+    d.auxiliary = 0;                        // the summed visual attention itself is returned, not its log_softmax
+    gscan_masks none{};
+    if (int rc = step_forward(d, *params, *batch, none, (float *)workspace, logp, nullptr, (hipStream_t)stream,
+                              encoded_situations, encoder_outputs, hidden_states)) return rc;
+    size_t off = 0, cnt = 0;
+    if (int rc = gscan_workspace_find(&d, "att_sum", &off, &cnt)) return rc;
+    GSCAN_HIP(hipMemcpyAsync(att_sum, (const char *)workspace + off, cnt * sizeof(float), hipMemcpyDeviceToDevice,
+                             (hipStream_t)stream));
+    return 0;
+}
+
 int gscan_greedy_decode(const gscan_dims *dims, int max_steps, const gscan_params *params, const gscan_batch *batch,
                         void *workspace, int sos_idx, int eos_idx, int64_t *tokens, int32_t *steps, float *alpha_text,
                         float *alpha_vis, float *att_sum, void *stream) {

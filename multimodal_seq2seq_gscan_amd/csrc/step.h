@@ -307,7 +307,8 @@ struct Workspace {
 int check_dims(const gscan_dims &d);
 int workspace_layout(const gscan_dims &d, Workspace *ws);
 int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
-                 float *logp, float *aux_logp, hipStream_t st);
+                 float *logp, float *aux_logp, hipStream_t st, const float *given_feat = nullptr,
+                 const float *given_enc_out = nullptr, const float *given_hN = nullptr);
 struct NllSeed { float w_aux; bool sum; float *stats_out, *seeds_out; };   // backward of the training loss itself
 int step_encode(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                 hipStream_t st);

@@ -231,15 +231,19 @@ static int order_after(hipStream_t waiter, hipStream_t signaller, hipStream_t wa
 // Everything before the decoder: both encoders, the projected keys and their gate images, the bridge, and the
 // per-step weight images.  teacher_forced = the target tokens of all T steps are known (training / scoring):
 // their embeddings and the embedding part of the gate pre-activations are computed here too.
+// `given` (Model.decode_input_batched, model.py:190-204): the encodings come from the caller — the two encoders are
+// skipped, the given tensors take the place of their outputs in the workspace and everything behind them runs.
+struct GivenEncodings { const float *feat, *enc_out, *hN; };   // [B,G*G,3Co] [B,L,He] [B,He]
 static int encode_branches(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk,
-                           float *w, const Workspace &ws, bool teacher_forced, hipStream_t st) {
+                           float *w, const Workspace &ws, bool teacher_forced, hipStream_t st,
+                           const GivenEncodings *given = nullptr) {
     const int B = d.B, L = d.L, T = d.T, M = d.G * d.G, C = d.C, Co = d.Co, F = 3 * Co, E = d.E, He = d.He, H = d.H,
               V = d.V, D = d.bidirectional ? 2 : 1;
     const bool cond = d.conditional != 0;
     GSCAN_CHECK(!cond || (p.q2k_w && p.q2k_b), "forward: conditional attention needs queries_to_keys parameters");
     GSCAN_CHECK(D == 1 || (p.enc_w_ih_rev && p.enc_w_hh_rev && p.enc_b_ih_rev && p.enc_b_hh_rev),
                 "forward: bidirectional encoder needs the *_reverse parameters");
-    GSCAN_CHECK(bt.commands && bt.cmd_lengths && (bt.world || bt.world_u8) && (!teacher_forced || bt.targets),
+    GSCAN_CHECK(bt.cmd_lengths && (given || (bt.commands && (bt.world || bt.world_u8))) && (!teacher_forced || bt.targets),
                 "forward: NULL array in the batch");
     TRY(side_init());
     hipStream_t sd = g_side.single ? st : g_side.stream;
@@ -280,7 +284,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.conv_w[0] = p.conv1_w; a.conv_w[1] = p.conv2_w; a.conv_w[2] = p.conv3_w;
         a.conv_img = w + ws.conv_img; a.cC = C; a.cCo = Co; a.cK3 = d.K3;
         const int64_t n[11] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
-                               (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
+                               given ? 0 : (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
                                a.zero_extra_count, 2 * geo.image_floats + (int64_t)H * kDecThreads,
                                (int64_t)D * 4 * He * He, conv_image_floats(C, Co, d.K3)};
         int64_t acc = 0;
@@ -295,10 +299,16 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     {
         auto side_work = [&]() -> int {
             {   // ---- side 2: world encoder (cnn_model.py:22-36), input-sparse kernel (conv.hip)
-                TRY(prologue(2, sd2));
-                const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
-                TRY(world_conv_forward(bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world, bt.world_u8 != nullptr,
-                                       w + ws.conv_img, cb, mk.cnn, B, d.G, C, Co, d.K3, w + ws.feat, sd2));
+                if (given) {
+                    GSCAN_HIP(hipMemcpyAsync(w + ws.feat, given->feat, sizeof(float) * (size_t)B * M * F,
+                                             hipMemcpyDeviceToDevice, sd2));
+                } else {
+                    TRY(prologue(2, sd2));
+                    const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
+                    TRY(world_conv_forward(bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world,
+                                           bt.world_u8 != nullptr, w + ws.conv_img, cb, mk.cnn, B, d.G, C, Co, d.K3,
+                                           w + ws.feat, sd2));
+                }
             }
             {   // ---- side 1: the embedding part of the decoder gate pre-activations for all t (teacher forcing) and the
                 // composite weight W_ih[:, ctx_vis] . W_key_vis (so that U_vis = feat . (.)^T needs no extra level) in one
@@ -325,10 +335,12 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         {
             GemmBatch g;
             // encoder input projections W_ih x + b_ih, both directions (seq2seq_model.py:70)
-            g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih, 1, E, w + ws.gx, (int64_t)D * 4 * He, 0.f, p.enc_b_ih);
-            if (D == 2)
-                g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih_rev, 1, E, w + ws.gx + 4 * He, (int64_t)D * 4 * He, 0.f,
-                      p.enc_b_ih_rev);
+            if (!given) {
+                g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih, 1, E, w + ws.gx, (int64_t)D * 4 * He, 0.f, p.enc_b_ih);
+                if (D == 2)
+                    g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih_rev, 1, E, w + ws.gx + 4 * He, (int64_t)D * 4 * He,
+                          0.f, p.enc_b_ih_rev);
+            }
             // composite weights for the textual memories
             g.add(4 * H, He, H, p.dec_w_ih + H, 3 * H, 1, p.txt_key_w, He, 1, w + ws.w_ck, He);
             g.overhead();
@@ -338,7 +350,12 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         // command encoder recurrence (seq2seq_model.py:62-88).  With more than one layer (nn.LSTM(num_layers=n), :44-45)
         // a layer below the last writes its h per direction, [B,L,D*He] times the inter-layer dropout mask: the next
         // layer's input; the direction sums and the final state come from the last layer (:76-82).
-        const int NL = enc_layers(d);
+        const int NL = given ? 0 : enc_layers(d);
+        if (given) {
+            GSCAN_HIP(hipMemcpyAsync(w + ws.enc_out, given->enc_out, sizeof(float) * (size_t)B * L * He,
+                                     hipMemcpyDeviceToDevice, st));
+            GSCAN_HIP(hipMemcpyAsync(w + ws.hN, given->hN, sizeof(float) * (size_t)B * He, hipMemcpyDeviceToDevice, st));
+        }
         const int64_t lay_h = (int64_t)B * L * D * He, lay_g = 4 * lay_h, lay_img = (int64_t)D * 4 * He * He;
         for (int l = 0; l < NL; ++l) {
             const EncLayer q = enc_layer(p, l);
@@ -385,7 +402,8 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
 }
 
 int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk,
-                 float *w, float *logp, float *aux_logp, hipStream_t st) {
+                 float *w, float *logp, float *aux_logp, hipStream_t st, const float *given_feat,
+                 const float *given_enc_out, const float *given_hN) {
     TRY(check_dims(d));
     Workspace ws;
     TRY(workspace_layout(d, &ws));
@@ -393,7 +411,10 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     const bool cond = d.conditional != 0;
     GSCAN_CHECK(logp != nullptr, "forward: logp is NULL");
     GSCAN_CHECK(!d.auxiliary || aux_logp, "forward: auxiliary task set but aux_logp is NULL");
-    TRY(encode_branches(d, p, bt, mk, w, ws, true, st));
+    const GivenEncodings given{given_feat, given_enc_out, given_hN};
+    const bool have = given_feat || given_enc_out || given_hN;
+    GSCAN_CHECK(!have || (given_feat && given_enc_out && given_hN), "decode_batched: all three encodings must be given");
+    TRY(encode_branches(d, p, bt, mk, w, ws, true, st, have ? &given : nullptr));
 
     // ---- the T-step recurrence; its epilogue is the output head, which does not feed back
     // (seq2seq_model.py:421-424: S . wo_perm^T, then W_h2o) and log_softmax (model.py:203, :166-170) of the row's

@@ -656,12 +656,48 @@ class Model(nn.Module):
         self._decode_state = None
         return tokens, steps, alpha_text, alpha_vis, att_sum
 
-    def decode_input_batched(self, *args, **kwargs):
-        """model.py:190-204 is the second half of the reference's forward() (its only caller, :209-213).  Here
-        forward() is one fused library call, so the teacher-forced decoder cannot be entered with encodings handed
-        in from outside; call forward() (training / scoring) or encode_input() + decode_input() (stepwise)."""
-        raise NotImplementedError("decode_input_batched is fused into Model.forward() on the HIP path; use forward(), "
-                                  "or encode_input() followed by decode_input() steps")
+    def decode_input_batched(self, target_batch: torch.LongTensor, target_lengths: List[int],
+                             initial_hidden: torch.Tensor, encoded_commands: torch.Tensor,
+                             command_lengths: List[int], encoded_situations: torch.Tensor):
+        """model.py:190-204, the second half of the reference's forward(): teacher-forced decoding from encodings
+        handed in (the dictionary entries of encode_input: hidden_states [B,He], encoder_outputs [L,B,He],
+        encoded_situations [B,G*G,3Co]).  Returns the reference's pair (log-probabilities [T,B,V] TIME-major,
+        summed visual attention [B,G*G]).  One library call (`gscan_decode_batched`); eval semantics, no autograd —
+        training goes through forward(), which fuses both halves."""
+        lib = _lib.load()
+        self._require_device(target_batch, initial_hidden, encoded_commands, encoded_situations)
+        device = target_batch.device
+        B, T = target_batch.shape
+        L, M = encoded_commands.shape[0], encoded_situations.shape[1]
+        G = int(round(M ** 0.5))
+        h = self._hyper
+        if (tuple(encoded_commands.shape) != (L, B, h["He"]) or tuple(initial_hidden.shape) != (B, h["He"]) or
+                tuple(encoded_situations.shape) != (B, G * G, 3 * h["Co"])):
+            raise ValueError("decode_input_batched: expected hidden [B,He], encoder_outputs [L,B,He] and "
+                             f"encoded_situations [B,G*G,{3 * h['Co']}], got {tuple(initial_hidden.shape)}, "
+                             f"{tuple(encoded_commands.shape)}, {tuple(encoded_situations.shape)}")
+        lengths = _as_int32_lengths(command_lengths, device)
+        assert lengths.numel() == B                                       # seq2seq_model.py:120
+        dims = self._dims(B, L, T, G)
+        need = lib.gscan_workspace_bytes(C.byref(dims))
+        if need == 0:
+            raise _lib.GscanError("unsupported dimensions: " + lib.gscan_last_error().decode())
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        targets = target_batch.contiguous()
+        enc_out = encoded_commands.detach().to(torch.float32).transpose(0, 1).contiguous()
+        feat = encoded_situations.detach().to(torch.float32).contiguous()
+        hN = initial_hidden.detach().to(torch.float32).contiguous()
+        batch = _lib.Batch(None, lengths.data_ptr(), None, targets.data_ptr(), None, None)
+        logp = torch.empty(B, T, h["V"], dtype=torch.float32, device=device)
+        att_sum = torch.empty(B, G * G, dtype=torch.float32, device=device)
+        _lib.check(lib.gscan_decode_batched(C.byref(dims), C.byref(self._param_struct), C.byref(batch), feat.data_ptr(),
+                                            enc_out.data_ptr(), hN.data_ptr(), self._workspace.data_ptr(),
+                                            logp.data_ptr(), att_sum.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "gscan_decode_batched")
+        self._generation += 1
+        self._decode_state = None
+        return logp.transpose(0, 1), att_sum
 
     # ---- checkpoints (model.py:228-261): same dictionary keys, same file names ----------------
     def get_current_state(self) -> dict:

@@ -376,6 +376,35 @@ def test_decode_input_steps_match_teacher_forced_forward():
     assert torch.allclose(enc["hidden_states"].cpu(), hN, atol=5e-5)
 
 
+def test_decode_input_batched_from_handed_in_encodings_equals_forward():
+    """Model.decode_input_batched (model.py:190-204) fed with the dictionary of encode_input gives forward()'s
+    log-probabilities (time-major, as the reference returns them) and the summed visual attention behind the
+    auxiliary head; encodings that were modified by the caller are honoured."""
+    cfg = model_kwargs("demo", auxiliary_task=True)
+    fx = load_fixture("demo_cond1_aux1.npz")
+    model = build_model(cfg, fixture_params(cfg, fx))
+    batch = fixture_batch(fx)
+    d = {k: v.cuda() for k, v in batch.items()}
+    lens = batch["cmd_lengths"].tolist()
+    with torch.no_grad():
+        logp, aux = model(commands_input=d["commands"], commands_lengths=lens, situations_input=d["world"],
+                          target_batch=d["targets"], target_lengths=batch["tgt_lengths"].tolist())
+        enc = model.encode_input(commands_input=d["commands"], commands_lengths=lens, situations_input=d["world"])
+        out, att = model.decode_input_batched(
+            target_batch=d["targets"], target_lengths=batch["tgt_lengths"].tolist(), initial_hidden=enc["hidden_states"],
+            encoded_commands=enc["encoded_commands"]["encoder_outputs"], command_lengths=lens,
+            encoded_situations=enc["encoded_situations"])
+        assert tuple(out.shape) == (logp.shape[1], logp.shape[0], logp.shape[2])
+        assert (out.transpose(0, 1) - logp).abs().max().item() < 1e-6
+        assert (model.auxiliary_task_forward(att) - aux).abs().max().item() < 1e-5
+        assert (out.transpose(0, 1).cpu() - torch.from_numpy(fx["logp"])).abs().max().item() < TOL
+        other, _ = model.decode_input_batched(
+            target_batch=d["targets"], target_lengths=batch["tgt_lengths"].tolist(),
+            initial_hidden=enc["hidden_states"] * 0.5, encoded_commands=enc["encoded_commands"]["encoder_outputs"],
+            command_lengths=lens, encoded_situations=enc["encoded_situations"])
+        assert (other - out).abs().max().item() > 1e-3
+
+
 def test_greedy_predict_matches_reference_loop():
     """predict() (batched greedy decoding on the HIP path) against the reference's own per-example
     encode_input / decode_input loop (tests/golden/demo_greedy.npz): same tokens, stopping steps, attention."""
