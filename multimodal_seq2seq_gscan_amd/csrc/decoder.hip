@@ -197,11 +197,14 @@ struct DecoderLds {
     int uv, pkv, ut, pkt, u2t, dpkv, dpkt, vec, total;
 };
 constexpr int kPartStride = 512;   // columns per m-group slab of partial sums (>= 5H)
-__host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bool cond, bool backward) {
+// uv_in_lds = false: the gate images of the visual memories U_vis [M,4H] (the largest resident block: 102 KB for an
+// 8x8 grid at H = 100) stay in global memory and the two phases that read them stream them from L2 every step.
+__host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bool cond, bool backward,
+                                                  bool uv_in_lds = true) {
     const int HP = 2 * (((H / 2 + 3) / 4) * 4);       // padded length of every vector a half_dot reads
     DecoderLds o;
     int p = 0;
-    o.uv = p;  p += M * 4 * H;
+    o.uv = p;  p += uv_in_lds ? M * 4 * H : 0;
     o.pkv = p; p += M * H;
     o.ut = p;  p += L * 4 * H;
     o.pkt = p; p += L * H;
@@ -238,7 +241,9 @@ __device__ __forceinline__ void quad_offset(int u_off, int pk_off, int u2_off, i
 // scoring).  GREEDY = true (predict.py:101-112): the row feeds its own argmax back for up to T steps and stops at
 // <EOS>; the embedding part of the gates is a row of a [V, 4H] table, the output head is the composite
 // W_h2o . W_o2h ([V, 4H], in LDS) applied every step, nothing is saved but tokens and attention rows.
-template <int H, bool COND, bool GREEDY>
+// UVL = false: the visual gate images are streamed from L2 (decoder_lds); compiled for the hidden sizes whose 8x8-grid
+// memories overflow LDS only.
+template <int H, bool COND, bool GREEDY, bool UVL = true>
 __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a) {
     TraceScope trace_scope(TK_DECODER_FWD);
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
@@ -250,7 +255,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = kDecThreads / 64;
     const int pair = tid >> 1, half = tid & 1;
     const int T = a.T, L = a.L, M = a.M;
-    const DecoderLds o = decoder_lds(H, L, M, a.V, COND, false);
+    constexpr bool uv_lds = UVL;
+    const DecoderLds o = decoder_lds(H, L, M, a.V, COND, false, uv_lds);
     float *Uv = smem + o.uv, *PKv = smem + o.pkv, *Ut = smem + o.ut, *PKt = smem + o.pkt, *U2t = smem + o.u2t;
     float *vec = smem + o.vec;
     float *h_s = vec;                                       // dot input, zero-padded to HP
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int i = 0; i < K0; ++i) w[s][i] = a.w_image[(s * K0 + i) * kDecThreads + tid];
-    stage(Uv, a.u_v + (int64_t)b * M * 4 * H, M * 4 * H, tid, kDecThreads);
+    if (uv_lds) stage(Uv, a.u_v + (int64_t)b * M * 4 * H, M * 4 * H, tid, kDecThreads);
     stage(PKv, a.pk_v + (int64_t)b * M * H, M * H, tid, kDecThreads);
     stage(Ut, a.u_t + (int64_t)b * L * 4 * H, L * 4 * H, tid, kDecThreads);
     stage(PKt, a.pk_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
@@ -443,11 +449,20 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             const int grp = wave >> 1, q = tid & 127;          // the m range is wave-uniform
             const int m_lo = grp * mg, m_hi = min(M, m_lo + mg);
             float4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float *src = smem + qv_off;
+            if (uv_lds || q >= H) {                            // LDS-resident images (always: the PK columns)
+                const float *src = smem + qv_off;
 #pragma unroll 3
-            for (int m = m_lo; m < m_hi; ++m) {
-                const float am = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), m));
-                acc = fma4(am, *reinterpret_cast<const float4 *>(src + m * qv_stride), acc);
+                for (int m = m_lo; m < m_hi; ++m) {
+                    const float am = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), m));
+                    acc = fma4(am, *reinterpret_cast<const float4 *>(src + m * qv_stride), acc);
+                }
+            } else {                                           // U_vis streamed from L2 (it did not fit LDS)
+                const float *src = a.u_v + (int64_t)b * M * 4 * H + 4 * q;
+#pragma unroll 4
+                for (int m = m_lo; m < m_hi; ++m) {
+                    const float am = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), m));
+                    acc = fma4(am, *reinterpret_cast<const float4 *>(src + (int64_t)m * 4 * H), acc);
+                }
             }
             if (q < NQV) *reinterpret_cast<float4 *>(part_s + grp * kPartStride + 4 * q) = acc;
         }
@@ -659,10 +674,11 @@ __device__ __forceinline__ void score_backward(float dsm, const float *q_s, cons
 // memory, 16-byte LDS reads.  float4 index idx < H covers the four delta blocks against U, the next H/4 the
 // external context gradient against PK, the last H/4 (conditional, textual only) dzq against U2.  The left-hand
 // vectors do not depend on m: each lane reads its (up to three) float4 of them once.
+// u_global != NULL: the U rows are read from global memory ([n, 4H]) instead of LDS.
 template <int H, int HP, bool WITH_U2>
 __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s, const float *ext_s, int u_off,
                                             int pk_off, int u2_off, int n, const float *add, float *sc_s, int wave,
-                                            int nwave, int lane) {
+                                            int nwave, int lane, const float *u_global = nullptr) {
     constexpr int Q = H / 4, NQ = (WITH_U2 ? 6 : 5) * Q, NI = (NQ + 63) / 64;
     lane = opaque(lane);
     float4 x[NI];
@@ -690,9 +706,19 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
         for (int i = 0; i < 2; ++i) {
             const int m = min(m0 + i * nwave, n - 1);
             p[i] = 0.f;
+            if (u_global == nullptr) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
-                p[i] = dot4(x[j], *reinterpret_cast<const float4 *>(smem + yoff[j] + m * ystr[j]), p[i]);
+                for (int j = 0; j < NI; ++j)
+                    p[i] = dot4(x[j], *reinterpret_cast<const float4 *>(smem + yoff[j] + m * ystr[j]), p[i]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int idx = lane + 64 * j;
+                    const float4 y = idx < 4 * Q ? *reinterpret_cast<const float4 *>(u_global + (int64_t)m * 4 * H + 4 * idx)
+                                                 : *reinterpret_cast<const float4 *>(smem + yoff[j] + m * ystr[j]);
+                    p[i] = dot4(x[j], y, p[i]);
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -713,7 +739,7 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
 // (dPK += alpha^T . dctx) is a separate batched product outside (it needs W_ih^T . delta,
 // which is again a dense GEMM).
 // ------------------------------------------------------------------------------------------
-template <int H, bool COND>
+template <int H, bool COND, bool UVL = true>
 __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a) {
     TraceScope trace_scope(TK_DECODER_BWD);
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
@@ -722,7 +748,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = kDecThreads / 64;
     const int pair = tid >> 1, half = tid & 1;
     const int T = a.T, L = a.L, M = a.M;
-    const DecoderLds o = decoder_lds(H, L, M, a.V, COND, true);
+    constexpr bool uv_lds = UVL;
+    const DecoderLds o = decoder_lds(H, L, M, a.V, COND, true, uv_lds);
     float *Uv = smem + o.uv, *PKv = smem + o.pkv, *Ut = smem + o.ut, *PKt = smem + o.pkt, *U2t = smem + o.u2t;
     float *dPKv = smem + o.dpkv, *dPKt = smem + o.dpkt;
     float *vec = smem + o.vec;
@@ -839,7 +866,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int i = 0; i < K0; ++i) wt[s][i] = a.w_image[(s * K0 + i) * kDecThreads + tid];
-    stage(Uv, a.u_v + (int64_t)b * M * 4 * H, M * 4 * H, tid, kDecThreads);
+    if (uv_lds) stage(Uv, a.u_v + (int64_t)b * M * 4 * H, M * 4 * H, tid, kDecThreads);
     stage(PKv, a.pk_v + (int64_t)b * M * H, M * H, tid, kDecThreads);
     stage(Ut, a.u_t + (int64_t)b * L * 4 * H, L * 4 * H, tid, kDecThreads);
     stage(PKt, a.pk_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
@@ -944,7 +971,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         GSCAN_STAMP(1)
 
         // ---- 2: d alpha_vis[m] = delta . U_vis[m] + dctx_vis(ext) . PK_vis[m] + d att_sum[m] ---
-        dalpha_rows<H, HP, false>(smem, d_s, exs_s, o.uv, o.pkv, o.pkv, M, datt_s, sc_s, wave, nwave, lane);
+        dalpha_rows<H, HP, false>(smem, d_s, exs_s, o.uv, o.pkv, o.pkv, M, datt_s, sc_s, wave, nwave, lane,
+                                  uv_lds ? nullptr : a.u_v + (int64_t)b * M * 4 * H);
         lds_barrier();
         GSCAN_STAMP(2)
         // ---- 3: softmax backward in every wave's registers (lane m: ds_m = alpha_m (dalpha_m - sum alpha dalpha)),
@@ -1063,14 +1091,21 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
 // ------------------------------------------------------------------------------------------
 constexpr size_t kLdsLimit = 160 * 1024;
 
+constexpr int kStreamMinHidden = 84;   // hidden sizes from here on have a U_vis-streaming instantiation
+
 template <int H, bool COND>
 static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_t stream) {
-    const DecoderLds o = decoder_lds(H, a.L, a.M, a.V, COND, backward);
     const bool greedy = !backward && a.tokens_out != nullptr;
-    const size_t bytes = ((size_t)o.total + (greedy ? (size_t)a.V * 4 * H + (size_t)a.V * a.V + H + 64 + 16 : 0)) * sizeof(float);
+    const size_t extra = greedy ? (size_t)a.V * 4 * H + (size_t)a.V * a.V + H + 64 + 16 : 0;
+    // the row's memories stay in LDS for all T steps; when they do not fit, the largest block (the gate images of
+    // the visual memories) stays in global memory and is streamed from L2 by the two phases that read it
+    DecoderLds o = decoder_lds(H, a.L, a.M, a.V, COND, backward, true);
+    const bool uvl = ((size_t)o.total + extra) * sizeof(float) <= kLdsLimit || H < kStreamMinHidden;
+    if (!uvl) o = decoder_lds(H, a.L, a.M, a.V, COND, backward, false);
+    const size_t bytes = ((size_t)o.total + extra) * sizeof(float);
     GSCAN_CHECK(bytes <= kLdsLimit,
-                "decoder: a row's memories need %zu bytes of LDS (> 160 KiB): grid cells=%d command length=%d hidden=%d",
-                bytes, a.M, a.L, H);
+                "decoder: a row's memories need %zu bytes of LDS (> 160 KiB)%s: grid cells=%d command length=%d hidden=%d",
+                bytes, uvl ? "" : " even with the visual gate images left in global memory", a.M, a.L, H);
     GSCAN_CHECK(a.w_image != nullptr, "decoder: weight image missing");
     // Algorithmic MACs of one decoder step that this kernel owns (SURVEY.md §8d MAC_step minus the
     // embedding part of the LSTM input and the output head, which run as GEMMs outside the loop):
@@ -1078,33 +1113,28 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
     const double macs = (double)H * H + 2.0 * a.L * H + (COND ? 2.0 * H * H : 0.0) + (double)H * H +
                         2.0 * a.M * H + 4.0 * H * 3.0 * H + 4.0 * H * H + (double)H * a.V;   // + the fused head
     ProbeScope probe(backward ? P_DECODER_BWD : P_DECODER_FWD, stream, 2.0 * macs * B * a.T);
-    if (backward) {
-        static bool attr_set = false;
+    auto launch = [&](auto kernel, const char *name) -> int {
+        static bool attr_set = false;                          // one flag per kernel instantiation (generic lambda)
         if (!attr_set) {
-            GSCAN_HIP(hipFuncSetAttribute((const void *)decoder_bwd_kernel<H, COND>,
+            GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
             attr_set = true;
         }
-        hipLaunchKernelGGL((decoder_bwd_kernel<H, COND>), dim3(B), dim3(kDecThreads), bytes, stream, a);
-        GSCAN_LAUNCHED("decoder_bwd_kernel");
-    } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            GSCAN_HIP(hipFuncSetAttribute((const void *)decoder_fwd_kernel<H, COND, false>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-            GSCAN_HIP(hipFuncSetAttribute((const void *)decoder_fwd_kernel<H, COND, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-            attr_set = true;
+        hipLaunchKernelGGL(kernel, dim3(B), dim3(kDecThreads), bytes, stream, a);
+        GSCAN_LAUNCHED(name);
+        return 0;
+    };
+    if (greedy) GSCAN_CHECK(a.V <= 64 && a.head_wc && a.dec_emb && a.steps_out, "greedy decoder: missing tables or V > 64");
+    if constexpr (H >= kStreamMinHidden) {
+        if (!uvl) {
+            if (backward) return launch(decoder_bwd_kernel<H, COND, false>, "decoder_bwd_kernel");
+            if (greedy) return launch(decoder_fwd_kernel<H, COND, true, false>, "decoder_fwd_kernel");
+            return launch(decoder_fwd_kernel<H, COND, false, false>, "decoder_fwd_kernel");
         }
-        if (greedy) {
-            GSCAN_CHECK(a.V <= 64 && a.head_wc && a.dec_emb && a.steps_out, "greedy decoder: missing tables or V > 64");
-            hipLaunchKernelGGL((decoder_fwd_kernel<H, COND, true>), dim3(B), dim3(kDecThreads), bytes, stream, a);
-        } else {
-            hipLaunchKernelGGL((decoder_fwd_kernel<H, COND, false>), dim3(B), dim3(kDecThreads), bytes, stream, a);
-        }
-        GSCAN_LAUNCHED("decoder_fwd_kernel");
     }
-    return 0;
+    if (backward) return launch(decoder_bwd_kernel<H, COND, true>, "decoder_bwd_kernel");
+    if (greedy) return launch(decoder_fwd_kernel<H, COND, true, true>, "decoder_fwd_kernel");
+    return launch(decoder_fwd_kernel<H, COND, false, true>, "decoder_fwd_kernel");
 }
 
 
@@ -1116,7 +1146,9 @@ bool decoder_hidden_supported(int h) {
 }
 
 size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward) {
-    return (size_t)decoder_lds(H, L, M, V, cond, backward).total * sizeof(float);
+    const size_t full = (size_t)decoder_lds(H, L, M, V, cond, backward, true).total * sizeof(float);
+    if (full <= kLdsLimit || H < kStreamMinHidden) return full;
+    return (size_t)decoder_lds(H, L, M, V, cond, backward, false).total * sizeof(float);
 }
 
 int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream) {

@@ -188,13 +188,13 @@ int position_nll(const float *aux, const int64_t *pos, int B, int M, float *loss
 int sequence_metrics(const float *logp, const int64_t *targets, int B, int T, int V, int pad, float *out3,
                      hipStream_t stream);
 
-// Hidden sizes with compiled kernels (the recurrent weights live in registers, so the size is a template parameter).
-// Decoder / keys kernels: multiples of 4 up to 100 (five column quads per unit must fit 128 threads, 7 H^2 weights the
-// register file); encoder: up to 128.
-#define GSCAN_DEC_HIDDEN_SIZES(X) X(20) X(32) X(40) X(48) X(64) X(80) X(96) X(100)
-#define GSCAN_DEC_HIDDEN_LIST "20 32 40 48 64 80 96 100"
-#define GSCAN_ENC_HIDDEN_SIZES(X) X(20) X(32) X(40) X(48) X(64) X(80) X(96) X(100) X(128)
-#define GSCAN_ENC_HIDDEN_LIST "20 32 40 48 64 80 96 100 128"
+// Hidden sizes with compiled kernels (the recurrent weights live in registers, so the size is a template parameter):
+// EVERY multiple of 4 — decoder / keys kernels up to 100 (five column quads per unit must fit 128 threads, 7 H^2
+// weights the register file), encoder up to 128.
+#define GSCAN_DEC_HIDDEN_SIZES(X) X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64) X(68) X(72) X(76) X(80) X(84) X(88) X(92) X(96) X(100)
+#define GSCAN_DEC_HIDDEN_LIST "multiples of 4 from 4 to 100"
+#define GSCAN_ENC_HIDDEN_SIZES(X) X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64) X(68) X(72) X(76) X(80) X(84) X(88) X(92) X(96) X(100) X(104) X(108) X(112) X(116) X(120) X(124) X(128)
+#define GSCAN_ENC_HIDDEN_LIST "multiples of 4 from 4 to 128"
 
 // lstm_encoder.hip
 bool hidden_size_supported(int h);

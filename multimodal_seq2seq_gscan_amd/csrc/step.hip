@@ -137,8 +137,8 @@ int check_dims(const gscan_dims &d) {
     GSCAN_CHECK(d.L <= 64, "dims: commands longer than 64 tokens are not supported (L=%d)", d.L);
     GSCAN_CHECK(d.G * d.G <= 64, "dims: grids larger than 8x8 are not supported (G=%d)", d.G);
     const size_t lds = decoder_lds_bytes(d.H, d.L, d.G * d.G, d.V, d.conditional != 0, true);
-    GSCAN_CHECK(lds <= 160 * 1024, "dims: the decoder needs %zu bytes of LDS per row (limit 163840): L=%d G=%d H=%d", lds,
-                d.L, d.G, d.H);
+    GSCAN_CHECK(lds <= 160 * 1024, "dims: the decoder needs %zu bytes of LDS per row (limit 163840) even with the visual "
+                "gate images streamed from L2: L=%d G=%d H=%d", lds, d.L, d.G, d.H);
     return 0;
 }
 

@@ -582,6 +582,16 @@ EDGE_CASES = [
     ("hidden64_k3_nocond", {"encoder_hidden_size": 64, "decoder_hidden_size": 64, "cnn_kernel_size": 3,
                             "conditional_attention": False, "embedding_dimension": 8}, dict(batch=2), None),
     ("length_one_commands", {}, dict(batch=4), "short_commands"),
+    # hidden sizes that got kernels in round 2 (every multiple of 4: decoder up to 100, encoder up to 128)
+    ("hidden24_encoder72", {"encoder_hidden_size": 72, "decoder_hidden_size": 24, "embedding_dimension": 7}, dict(batch=3), None),
+    ("hidden72_encoder128_aux", {"encoder_hidden_size": 128, "decoder_hidden_size": 72, "auxiliary_task": True},
+     dict(batch=2), None),
+    ("hidden4", {"encoder_hidden_size": 4, "decoder_hidden_size": 4, "embedding_dimension": 3}, dict(batch=2), None),
+    # 8x8 grid at hidden 100: the visual gate images (102 KB per row) do not fit LDS next to the rest and are
+    # streamed from L2 by the decoder kernels (round 1 refused this shape)
+    ("grid8_hidden100_streamed_gate_images", {"encoder_hidden_size": 100, "decoder_hidden_size": 100,
+                                              "embedding_dimension": 25, "auxiliary_task": True},
+     dict(batch=3, grid=8, max_target=6), None),
     ("all_pad_targets_row", {}, dict(batch=3), "pad_row"),
 ]
 
