@@ -218,11 +218,12 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 //   seg 8  register images of the decoder's recurrent weights and of the output head (step.h)
 //   seg 9  register image of the encoder's recurrent weights: [dir][r][k][thread] = W_hh_dir[thread + r*NT][k]
 //   seg 10 [tap][ch][o] image of the three convolution kernels (conv.hip)
+//   seg 11-13 composite weights W_ih[:, ctx] . W_key (visual, textual) and W_q2k[:, ctx_text] . W_key_text
 // ------------------------------------------------------------------------------------------
 
 __global__ void prologue_kernel(PrologueArgs a) {
     TraceScope trace_scope(TK_PROLOGUE);
-    const int64_t total = a.end[10];
+    const int64_t total = a.end[13];
     const int H = a.H;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -271,15 +272,39 @@ __global__ void prologue_kernel(PrologueArgs a) {
             const int i = (int)(idx - a.end[8]), He = a.He, nt = 4 * He / a.enc_rows;
             const int j = i % nt, k = (i / nt) % He, r = (i / (nt * He)) % a.enc_rows, dir = i / (4 * He * He);
             a.enc_image[i] = (dir ? a.enc_w_hh_r : a.enc_w_hh_f)[(int64_t)(j + r * nt) * He + k];
-        } else {
+        } else if (idx < a.end[10]) {
             const int i = (int)(idx - a.end[9]);
             a.conv_img[i] = conv_image_element(a.conv_w[0], a.conv_w[1], a.conv_w[2], a.cC, a.cCo, a.cK3, i);
+        } else {
+            // composite weights: out[r, c] = sum_h A[r, col0 + h] * Wk[h, c].  Consecutive threads take consecutive c
+            // (coalesced Wk rows, A broadcast); eight products are fetched before they are added, so the loop is
+            // not a chain of load latencies
+            const float *__restrict__ A, *__restrict__ Wk;
+            float *out;
+            int lda, col0, N, i;
+            if (idx < a.end[11]) { i = (int)(idx - a.end[10]); A = a.w_ih_dec; lda = 3 * H; col0 = 2 * H; Wk = a.w_key_vis; N = a.F; out = a.w_sk; }
+            else if (idx < a.end[12]) { i = (int)(idx - a.end[11]); A = a.w_ih_dec; lda = 3 * H; col0 = H; Wk = a.w_key_txt; N = a.He; out = a.w_ck; }
+            else { i = (int)(idx - a.end[12]); A = a.w_q2k; lda = 2 * H; col0 = H; Wk = a.w_key_txt; N = a.He; out = a.w_2kk; }
+            const int r = i / N, c = i - r * N;
+            const float *arow = A + (int64_t)r * lda + col0;
+            const float *wcol = Wk + c;
+            float acc0 = 0.f, acc1 = 0.f;
+            int h = 0;
+            for (; h + 7 < H; h += 8) {
+                float x[8], y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { x[u] = arow[h + u]; y[u] = wcol[(int64_t)(h + u) * N]; }
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) { acc0 = fmaf(x[u], y[u], acc0); acc1 = fmaf(x[u + 1], y[u + 1], acc1); }
+            }
+            for (; h < H; ++h) acc0 = fmaf(arow[h], wcol[(int64_t)h * N], acc0);
+            out[i] = acc0 + acc1;
         }
     }
 }
 
 int step_prologue(const PrologueArgs &args, hipStream_t stream) {
-    const int64_t total = args.end[10];
+    const int64_t total = args.end[13];
     if (total == 0) return 0;
     hipLaunchKernelGGL(prologue_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, stream,
                        args);

@@ -58,7 +58,7 @@ template <int HE> struct EncShape {
 //   backward  d_s [len][4He] gate activations  ->  gate pre-activation gradients (in place)
 //             c_s [len][He] cells, o_s [len][He] gradient wrt the summed outputs, part_s [4He] partial dh
 constexpr size_t kEncLdsLimit = 160 * 1024;
-inline size_t encoder_fwd_lds(int L, int HE) { return ((size_t)L * 6 * HE + HE) * sizeof(float); }
+inline size_t encoder_fwd_lds(int L, int HE, int E = 0) { return ((size_t)L * 6 * HE + HE + (size_t)((L + 7) & ~7) * E) * sizeof(float); }
 inline size_t encoder_bwd_lds(int L, int HE) { return ((size_t)L * 6 * HE + 4 * HE) * sizeof(float); }
 
 // grid (B, D): the two directions of a row run as two workgroups (they only meet in the sums below).
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
                                         float *__restrict__ h_final, float *__restrict__ gates,
                                         float *__restrict__ cells, float *__restrict__ hprev,
                                         const float *__restrict__ w_image, float *__restrict__ hcat,
-                                        const float *__restrict__ hcat_mask) {
+                                        const float *__restrict__ hcat_mask, EncInput in) {
     TraceScope trace_scope(TK_ENCODER_FWD);
     constexpr int R = EncShape<HE>::R, NT = 4 * HE / R;              // owning threads
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -86,8 +86,48 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
     const bool is_gate = j < NT, is_unit = j < HE;
     const int64_t row0 = (int64_t)b * L;                             // row of (b, t, dir) = (row0 + t) * D + dir
 
-    // stage the input projections of the whole command, recurrent bias added (seq2seq_model.py:74)
-    {
+    if (in.x) {
+        // the first layer projects its own input: g_s[t][row] = W_ih[row] . x[b,t] + b_ih[row] + b_hh[row]
+        // (seq2seq_model.py:70,74).  x = the embedded, dropped-out command (E floats per token, staged in LDS); a
+        // thread computes the projections of the gate rows it owns, so nothing crosses threads but x — and the
+        // launch that used to compute them for the whole batch is off the critical chain of the step.
+        const int E = in.E;
+        float *x_s = z_s + HE;                                       // [E][LP] time-contiguous, LP = len rounded up to 8
+        const int LP = (len + 7) & ~7;
+        for (int idx = j; idx < LP * E; idx += nthr) {
+            const int e = idx / LP, t = idx - e * LP;
+            x_s[idx] = t < len ? in.x[(row0 + t) * E + e] : 0.f;
+        }
+        lds_barrier();
+        if (is_gate) {
+            const float *w_ih = dir ? in.w_ih_r : in.w_ih_f, *b_ih = dir ? in.b_ih_r : in.b_ih_f;
+            const float *b_hh = dir ? b_hh_r : b_hh_f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int gr = j + r * NT;
+                const float *wrow = w_ih + (int64_t)gr * E;
+                const float bias = b_ih[gr] + b_hh[gr];
+                for (int t0 = 0; t0 < len; t0 += 8) {                // eight time steps per pass over the weight row
+                    float acc[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[u] = bias;
+                    for (int e = 0; e < E; ++e) {
+                        const float wv = wrow[e];
+                        const float4 x0 = *reinterpret_cast<const float4 *>(x_s + e * LP + t0);
+                        const float4 x1 = *reinterpret_cast<const float4 *>(x_s + e * LP + t0 + 4);
+                        acc[0] = fmaf(wv, x0.x, acc[0]); acc[1] = fmaf(wv, x0.y, acc[1]);
+                        acc[2] = fmaf(wv, x0.z, acc[2]); acc[3] = fmaf(wv, x0.w, acc[3]);
+                        acc[4] = fmaf(wv, x1.x, acc[4]); acc[5] = fmaf(wv, x1.y, acc[5]);
+                        acc[6] = fmaf(wv, x1.z, acc[6]); acc[7] = fmaf(wv, x1.w, acc[7]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (t0 + u < len) g_s[(t0 + u) * 4 * HE + gr] = acc[u];
+                }
+            }
+        }
+    } else {
+        // stage the input projections of the whole command, recurrent bias added (seq2seq_model.py:74)
         const float *bias = dir ? b_hh_r : b_hh_f;                   // a parameter: no 16-byte alignment promised
         for (int idx = j; idx < len * HE; idx += nthr) {
             const int t = idx / HE, q = idx - t * HE;
@@ -261,14 +301,16 @@ static int encoder_lds_attr(K kernel, size_t bytes, bool &attr_set) {
 template <int HE>
 static int launch_fwd(int B, int L, int D, const float *gx, const int32_t *lengths, const float *bf, const float *br,
                       float *out, float *hfin, float *gates, float *cells, float *hprev, const float *w_image,
-                      float *hcat, const float *hcat_mask, hipStream_t stream) {
+                      float *hcat, const float *hcat_mask, const EncInput &in, hipStream_t stream) {
     const int nt = EncShape<HE>::kThreads;
     static bool attr_set = false;
-    if (int rc = encoder_lds_attr(encoder_lstm_fwd_kernel<HE>, encoder_fwd_lds(L, HE), attr_set)) return rc;
-    // algorithmic work: the recurrent product h.W_hh^T per (row, step, direction); padded steps counted
-    ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * HE * HE);
-    hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B, D), dim3(nt), encoder_fwd_lds(L, HE), stream, L, D, gx, lengths,
-                       bf, br, out, hfin, gates, cells, hprev, w_image, hcat, hcat_mask);
+    const size_t lds = encoder_fwd_lds(L, HE, in.x ? in.E : 0);
+    if (int rc = encoder_lds_attr(encoder_lstm_fwd_kernel<HE>, lds, attr_set)) return rc;
+    // algorithmic work: the recurrent product h.W_hh^T per (row, step, direction), plus the input projection when the
+    // kernel computes it itself; padded steps counted
+    ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * HE * (HE + (in.x ? in.E : 0)));
+    hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B, D), dim3(nt), lds, stream, L, D, gx, lengths,
+                       bf, br, out, hfin, gates, cells, hprev, w_image, hcat, hcat_mask, in);
     GSCAN_LAUNCHED("encoder_lstm_fwd_kernel");
     return 0;
 }
@@ -325,14 +367,19 @@ int encoder_rows_per_thread(int He) {
 int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths, const float *w_hh_f,
                          const float *b_hh_f, const float *w_hh_r, const float *b_hh_r, float *out, float *h_final,
                          float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream,
-                         float *hcat, const float *hcat_mask) {
+                         float *hcat, const float *hcat_mask, const EncInput *input) {
     GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm: bad dims B=%d L=%d D=%d", B, L, D);
+    EncInput in{};
+    if (input) in = *input;
+    GSCAN_CHECK(!in.x || (in.E > 0 && in.w_ih_f && in.b_ih_f && (D == 1 || (in.w_ih_r && in.b_ih_r))),
+                "encoder lstm: input projection requested without its weights");
+    GSCAN_CHECK(in.x || gx, "encoder lstm: neither input projections nor inputs given");
     GSCAN_CHECK(hcat || (out && h_final), "encoder lstm: neither direction sums nor per-direction outputs requested");
     GSCAN_CHECK(D == 1 || (w_hh_r && b_hh_r), "encoder lstm: reverse weights missing");
     GSCAN_CHECK(w_image, "encoder lstm: weight image missing");
-    GSCAN_CHECK(((uintptr_t)gx | (uintptr_t)gates) % 16 == 0, "encoder lstm: gx and gates must be 16-byte aligned");
+    GSCAN_CHECK(((in.x ? 0 : (uintptr_t)gx) | (uintptr_t)gates) % 16 == 0, "encoder lstm: gx and gates must be 16-byte aligned");
     switch (He) {
-#define X(n) case n: return launch_fwd<n>(B, L, D, gx, lengths, b_hh_f, b_hh_r, out, h_final, gates, cells, hprev, w_image, hcat, hcat_mask, stream);
+#define X(n) case n: return launch_fwd<n>(B, L, D, gx, lengths, b_hh_f, b_hh_r, out, h_final, gates, cells, hprev, w_image, hcat, hcat_mask, in, stream);
         GSCAN_HIDDEN_SIZES(X)
 #undef X
         default: break;

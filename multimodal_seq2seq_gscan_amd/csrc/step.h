@@ -119,7 +119,7 @@ struct PrologueArgs {
     int cond;
     int64_t zero_extra_count;
     int H, He, E, D, BL, BT, Vi, V;
-    int64_t end[11];
+    int64_t end[14];
     DecoderImageArgs img;
     // seg 9: register image of the encoder's recurrent weights, [dir][r][k][thread] (lstm_encoder.hip)
     const float *enc_w_hh_f, *enc_w_hh_r;
@@ -129,6 +129,12 @@ struct PrologueArgs {
     const float *conv_w[3];
     float *conv_img;
     int cC, cCo, cK3;
+    // seg 11-13: composite weights, so that the gate images U = memory . (.)^T of the attention memories need no
+    // second level of products: w_sk [4H, F] = W_ih[:, 2H:3H] . W_key_vis, w_ck [4H, He] = W_ih[:, H:2H] . W_key_text,
+    // w_2kk [H, He] = W_q2k[:, H:2H] . W_key_text
+    const float *w_key_vis, *w_key_txt;
+    float *w_sk, *w_ck, *w_2kk;
+    int F;
 };
 int step_prologue(const PrologueArgs &args, hipStream_t stream);
 int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream);
@@ -198,10 +204,12 @@ int sequence_metrics(const float *logp, const int64_t *targets, int B, int T, in
 
 // lstm_encoder.hip
 bool hidden_size_supported(int h);
+// x != NULL: the kernel projects its own input x [B,L,E] through W_ih (+ b_ih) instead of reading gx (first layer)
+struct EncInput { const float *x; int E; const float *w_ih_f, *b_ih_f, *w_ih_r, *b_ih_r; };
 int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths, const float *w_hh_f,
                          const float *b_hh_f, const float *w_hh_r, const float *b_hh_r, float *out, float *h_final,
                          float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream,
-                         float *hcat = nullptr, const float *hcat_mask = nullptr);
+                         float *hcat = nullptr, const float *hcat_mask = nullptr, const EncInput *input = nullptr);
 int encoder_rows_per_thread(int He);   // rows of W_hh a thread of the forward kernel keeps (layout of its image)
 int encoder_weight_image(const float *w_hh_f, const float *w_hh_r, int He, int D, float *image, hipStream_t stream);
 int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_f,

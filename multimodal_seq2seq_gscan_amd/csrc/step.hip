@@ -249,19 +249,13 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     hipStream_t sd = g_side.single ? st : g_side.stream;
 
     // ================= prelude schedule ============================================================================
-    // Critical chain on the caller's stream: prologue -> L1 (command projections) -> BiLSTM -> L3 (textual keys, bridge).
-    // Everything only the DECODER waits for runs on two side streams behind ONE fork event at the very start:
-    //   side 2: a mini prologue (convolution weight image) -> the input-sparse world encoder;
-    //   side 1: a mini prologue (embedded targets S[:, 0:H], decoder bias sum) -> ONE GEMM launch with the embedding
-    //           part of the decoder gates `ge` and the composite weight W_ih[:, ctx_vis] . W_key_vis -> (the world
-    //           features of side 2) -> ONE GEMM launch with the visual keys and their gate images.
-    // Round 1 had `ge` in L1 in front of the recurrence and the world branch as two chip-filling launches racing it:
-    // one workgroup of the recurrence wants 128 VGPRs per SIMD, i.e. two GEMM slots freed on the same CU at once, and
-    // loses that race for as long as 96-VGPR GEMM workgroups keep arriving (it started 55 us after its inputs were
-    // ready).  Now L1 is five small products, and the 10-25 us a cross-stream event takes to release the side streams
-    // are a head start for the command chain.  Measured and dropped (profiles/r02_ab_*): forking the side streams
-    // behind L1 instead (+30 us: the event latency lands on the critical path), composite weights as dot-product
-    // segments of the prologue instead of GEMM products (+12 us: a 26 us prologue in front of the world encoder).
+    // prologue -> world encoder -> command recurrence (its first layer projects its own input) -> ONE GEMM launch
+    // {textual keys + gate images, bridge, visual keys + gate images, embedding part of the decoder gates} -> decoder.
+    // Round 1 ran the world branch on a side stream as two chip-filling GEMM launches racing the recurrence, whose
+    // workgroups (two GEMM slots freed on the same CU at once) started 55 us late; round 2 first moved everything only
+    // the decoder waits for onto two side streams (the three-stream schedule kept below for A/B runs), then found the
+    // cross-stream events themselves to be the cost.  Measured and dropped (profiles/r02_ab_*): forking behind L1 or
+    // behind the prologue (+20..30 us: the event latency lands on the critical path), host issue order (no effect).
     hipStream_t sd2 = g_side.single ? st : g_side.stream2;
     // one prologue launch with the segments of `which` (0: caller's stream, 1: side 1, 2: side 2); the others stay empty
     auto prologue = [&](int which, hipStream_t stream) -> int {
@@ -283,69 +277,77 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.enc_rows = encoder_rows_per_thread(He);
         a.conv_w[0] = p.conv1_w; a.conv_w[1] = p.conv2_w; a.conv_w[2] = p.conv3_w;
         a.conv_img = w + ws.conv_img; a.cC = C; a.cCo = Co; a.cK3 = d.K3;
-        const int64_t n[11] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
+        a.w_key_vis = p.vis_key_w; a.w_key_txt = p.txt_key_w; a.F = F;
+        a.w_sk = w + ws.w_sk; a.w_ck = w + ws.w_ck; a.w_2kk = w + ws.w_2kk;
+        const int64_t n[14] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
                                given ? 0 : (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
                                a.zero_extra_count, 2 * geo.image_floats + (int64_t)H * kDecThreads,
-                               (int64_t)D * 4 * He * He, conv_image_floats(C, Co, d.K3)};
+                               (int64_t)D * 4 * He * He, given ? 0 : conv_image_floats(C, Co, d.K3),
+                               (int64_t)4 * H * F, (int64_t)4 * H * He, cond ? (int64_t)H * He : 0};
         int64_t acc = 0;
-        for (int i = 0; i < 11; ++i) {
-            // side 1: decoder bias sum, embedded targets; side 2: convolution weight image
-            const int owner = (i == 0 || i == 5) ? 1 : (i == 10 ? 2 : 0);
-            acc += owner == which ? n[i] : 0;
+        for (int i = 0; i < 14; ++i) {
+            // side 1: decoder bias sum, embedded targets; side 2: convolution weight image, visual composite weight
+            const int owner = (i == 0 || i == 5) ? 1 : ((i == 10 || i == 11) ? 2 : 0);
+            acc += (owner == which || which == 3) ? n[i] : 0;   // which 3: every segment in one launch
             a.end[i] = acc;
         }
         return step_prologue(a, stream);
     };
+    // the dense products of the prelude, each added to whichever launch the schedule below puts it in
+    auto add_visual = [&](GemmBatch &k) {     // projected visual keys (seq2seq_model.py:466-467) and their gate images
+        k.add(B * M, H, F, w + ws.feat, F, 1, p.vis_key_w, 1, F, w + ws.pkv, H);
+        k.add(B * M, 4 * H, F, w + ws.feat, F, 1, w + ws.w_sk, 1, F, w + ws.uv, 4 * H);
+        k.overhead();     // U image: its algorithmic counterpart, W_ih[:, ctx_vis] . ctx_vis per step, is charged to the decoder kernel
+    };
+    auto add_ge = [&](GemmBatch &g) {         // embedding part of the decoder gate pre-activations for all t (teacher forcing)
+        if (teacher_forced)
+            g.add(B * T, 4 * H, H, w + ws.S, 4 * H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge, 4 * H, 0.f, w + ws.bsum);
+    };
+    auto add_textual = [&](GemmBatch &g) {    // projected textual keys (:468-469), their images, and the bridge (model.py:195)
+        g.add(B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H);
+        g.add(B * L, 4 * H, He, w + ws.enc_out, He, 1, w + ws.w_ck, 1, He, w + ws.ut, 4 * H);
+        g.overhead();     // U images of the textual memories: charged to the decoder kernel as the context terms they replace
+        if (cond) { g.add(B * L, H, He, w + ws.enc_out, He, 1, w + ws.w_2kk, 1, He, w + ws.u2t, H); g.overhead(); }
+        g.add(B, H, He, w + ws.hN, He, 1, p.bridge_w, 1, He, w + ws.hprev, (int64_t)T * H, 0.f, p.bridge_b, 2);
+    };
+    auto world_encoder = [&](hipStream_t stream) -> int {      // cnn_model.py:22-36, input-sparse kernel (conv.hip)
+        if (given) {
+            GSCAN_HIP(hipMemcpyAsync(w + ws.feat, given->feat, sizeof(float) * (size_t)B * M * F, hipMemcpyDeviceToDevice,
+                                     stream));
+            return 0;
+        }
+        const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
+        return world_conv_forward(bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world, bt.world_u8 != nullptr,
+                                  w + ws.conv_img, cb, mk.cnn, B, d.G, C, Co, d.K3, w + ws.feat, stream);
+    };
+    // Default: the whole prelude on the caller's stream — one prologue, the world encoder, the recurrence, and ONE GEMM
+    // launch with every dense product.  No cross-stream event: each costs 25-30 us of latency on this stack (record ->
+    // the other queue's first kernel), more than overlapping the now short kernels buys, and the recurrence (128+
+    // VGPRs per SIMD for one workgroup) no longer races floods of GEMM workgroups for CUs.  Measured: 0.553 ms per step
+    // against 0.572 for the three-stream schedule below (profiles/r02_ab_forward_streams.txt), which
+    // GSCAN_FORWARD_STREAMS=3 selects for A/B runs.
+    static const int fwd_streams = [] { const char *e = getenv("GSCAN_FORWARD_STREAMS"); return e ? atoi(e) : 1; }();
+    const bool merged = fwd_streams == 1 || g_side.single;
     {
-        auto side_work = [&]() -> int {
-            {   // ---- side 2: world encoder (cnn_model.py:22-36), input-sparse kernel (conv.hip)
-                if (given) {
-                    GSCAN_HIP(hipMemcpyAsync(w + ws.feat, given->feat, sizeof(float) * (size_t)B * M * F,
-                                             hipMemcpyDeviceToDevice, sd2));
-                } else {
-                    TRY(prologue(2, sd2));
-                    const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
-                    TRY(world_conv_forward(bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world,
-                                           bt.world_u8 != nullptr, w + ws.conv_img, cb, mk.cnn, B, d.G, C, Co, d.K3,
-                                           w + ws.feat, sd2));
-                }
+        if (merged) {
+            TRY(prologue(3, st));
+            TRY(world_encoder(st));
+        } else {
+            TRY(order_after(sd, st, sd2));   // fork: whatever produced the inputs / masks on the caller's stream
+            TRY(prologue(0, st));
+            {   // ---- side 2: world encoder, then ONE GEMM launch with the visual keys and their gate images
+                TRY(prologue(2, sd2));
+                TRY(world_encoder(sd2));
+                GemmBatch k;
+                add_visual(k);
+                TRY(k.launch(sd2));
             }
-            {   // ---- side 1: the embedding part of the decoder gate pre-activations for all t (teacher forcing) and the
-                // composite weight W_ih[:, ctx_vis] . W_key_vis (so that U_vis = feat . (.)^T needs no extra level) in one
-                // launch; then, behind the world features of side 2, the visual keys and their gate images
+            {   // ---- side 1: the embedding part of the decoder gates
                 TRY(prologue(1, sd));
                 GemmBatch g;
-                if (teacher_forced)
-                    g.add(B * T, 4 * H, H, w + ws.S, 4 * H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge, 4 * H, 0.f, w + ws.bsum);
-                g.add(4 * H, F, H, p.dec_w_ih + 2 * H, 3 * H, 1, p.vis_key_w, F, 1, w + ws.w_sk, F);
-                g.overhead();
+                add_ge(g);
                 TRY(g.launch(sd));
-                TRY(order_after(sd, sd2));
-                GemmBatch k;      // projected visual keys (seq2seq_model.py:466-467)
-                k.add(B * M, H, F, w + ws.feat, F, 1, p.vis_key_w, 1, F, w + ws.pkv, H);
-                k.add(B * M, 4 * H, F, w + ws.feat, F, 1, w + ws.w_sk, 1, F, w + ws.uv, 4 * H);
-                k.overhead();     // U image: its algorithmic counterpart, W_ih[:, ctx_vis] . ctx_vis per step, is charged to the decoder kernel
-                TRY(k.launch(sd));
             }
-            return 0;
-        };
-        TRY(order_after(sd, st, sd2));   // fork: whatever produced the inputs / masks on the caller's stream
-        TRY(prologue(0, st));
-        TRY(side_work());
-        {
-            GemmBatch g;
-            // encoder input projections W_ih x + b_ih, both directions (seq2seq_model.py:70)
-            if (!given) {
-                g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih, 1, E, w + ws.gx, (int64_t)D * 4 * He, 0.f, p.enc_b_ih);
-                if (D == 2)
-                    g.add(B * L, 4 * He, E, w + ws.xe, E, 1, p.enc_w_ih_rev, 1, E, w + ws.gx + 4 * He, (int64_t)D * 4 * He,
-                          0.f, p.enc_b_ih_rev);
-            }
-            // composite weights for the textual memories
-            g.add(4 * H, He, H, p.dec_w_ih + H, 3 * H, 1, p.txt_key_w, He, 1, w + ws.w_ck, He);
-            g.overhead();
-            if (cond) { g.add(H, He, H, p.q2k_w + H, 2 * H, 1, p.txt_key_w, He, 1, w + ws.w_2kk, He); g.overhead(); }
-            TRY(g.launch(st));
         }
         // command encoder recurrence (seq2seq_model.py:62-88).  With more than one layer (nn.LSTM(num_layers=n), :44-45)
         // a layer below the last writes its h per direction, [B,L,D*He] times the inter-layer dropout mask: the next
@@ -376,28 +378,31 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
                 TRY(encoder_weight_image(q.w_hh, q.w_hh_rev, He, D, img, st));
                 image = img;
             }
+            // the first layer projects its own input (the embedded command, E floats per token) inside the recurrent
+            // kernel: no launch between the prologue and the recurrence; deeper layers read the GEMM above
+            const EncInput own{w + ws.xe, E, q.w_ih, q.b_ih, q.w_ih_rev, q.b_ih_rev};
+            const EncInput *input = l == 0 ? &own : nullptr;
             if (last) {
                 TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, q.w_hh, q.b_hh, q.w_hh_rev, q.b_hh_rev,
                                          w + ws.enc_out, w + ws.hN, w + ws.enc_gates, w + ws.enc_cells, w + ws.enc_hprev,
-                                         image, st));
+                                         image, st, nullptr, nullptr, input));
             } else {
                 TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, q.w_hh, q.b_hh, q.w_hh_rev, q.b_hh_rev,
                                          nullptr, nullptr, w + ws.deep_gates + l * lay_g, w + ws.deep_cells + l * lay_h,
                                          w + ws.deep_hprev + l * lay_h, image, st, w + ws.deep_y + l * lay_h,
-                                         mk.enc_deep ? mk.enc_deep + l * lay_h : nullptr));
+                                         mk.enc_deep ? mk.enc_deep + l * lay_h : nullptr, input));
             }
         }
-        {   // projected textual keys (:468-469), their images, and the bridge (model.py:195)
+        {
             GemmBatch g;
-            g.add(B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H);
-            g.add(B * L, 4 * H, He, w + ws.enc_out, He, 1, w + ws.w_ck, 1, He, w + ws.ut, 4 * H);
-            g.overhead();     // U images of the textual memories: charged to the decoder kernel as the context terms they replace
-            if (cond) { g.add(B * L, H, He, w + ws.enc_out, He, 1, w + ws.w_2kk, 1, He, w + ws.u2t, H); g.overhead(); }
-            g.add(B, H, He, w + ws.hN, He, 1, p.bridge_w, 1, He, w + ws.hprev, (int64_t)T * H, 0.f, p.bridge_b, 2);
+            add_textual(g);
+            if (merged) { add_visual(g); add_ge(g); }
             TRY(g.launch(st));
         }
     }
-    TRY(order_after(st, sd));          // join: the decoder needs all three branches (side 1 has waited for side 2)
+    if (merged) return 0;
+    TRY(order_after(st, sd));          // join: the decoder needs all three branches
+    TRY(order_after(st, sd2));
     return 0;
 }
 
