@@ -149,7 +149,11 @@ int check_dims(const gscan_dims &d) {
 // least 8 of them while they stay >= 160 rows.  Shorter slices make single products faster in isolation
 // (100x150x9216: 32 -> 21 us from 15 to 58 slices) but the overlapped step slower (0.691 vs 0.683 ms), and the
 // eight-product decoder launch much slower (85 vs 62 us at 160/320-row slices).
-static int pick_split(int K) { return std::max(cdiv(K, 640), std::min(8, cdiv(K, 160))); }
+static int pick_split(int K) {
+    static const int forced = [] { const char *e = getenv("GSCAN_SPLIT"); return e ? atoi(e) : 0; }();
+    if (forced > 0 && K >= 2560) return std::min(forced, cdiv(K, 160));
+    return std::max(cdiv(K, 640), std::min(8, cdiv(K, 160)));
+}
 
 // weight gradient: C[M,N] += A^T . B with the long dimension (rows of the activations) as K, split over
 // workgroups; bias1/bias2 (optional) += column sums of the activation gradient = sum over K of A(m,k)
