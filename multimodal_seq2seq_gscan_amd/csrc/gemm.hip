@@ -447,11 +447,15 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
                   kMaxGroup);
         return;
     }
+    // split_k < 0: accumulate with atomics even if K turns out too short to be split (several products of one launch
+    // adding into the same C)
+    const bool force_atomic = split_k < 0;
+    if (force_atomic) split_k = -split_k;
     if (split_k < 1) split_k = 1;
     int chunk = cdiv(K, split_k);
     chunk = cdiv(chunk, 64) * 64;          // K slices start at multiples of the deepest K round
     split_k = cdiv(K, chunk);
-    if (split_k > 1 && !(beta == 1.f && act == 0 && !bias && !mask)) {
+    if ((split_k > 1 || force_atomic) && !(beta == 1.f && act == 0 && !bias && !mask)) {
         bad_ = true;
         set_error("gemm batch: split-K needs beta=1 and no epilogue (problem %d, beta=%g act=%d)", grp_.count, beta, act);
         return;
@@ -476,7 +480,7 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
     }
     GemmProblem &p = grp_.p[grp_.count++];
     p = GemmProblem{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, gate, chunk,
-                    split_k > 1 ? 1 : 0, asum1, asum2, 0, 0, 0, 0u, 0u, flags, 0};   // tile bookkeeping: at launch
+                    (split_k > 1 || force_atomic) ? 1 : 0, asum1, asum2, 0, 0, 0, 0u, 0u, flags, 0};   // tile bookkeeping: at launch
     tiles_ += cdiv(N, BN) * cdiv(M, 64) * split_k;                            // in 64-row tiles
     last_flops_ = 2.0 * M * N * K;
     flops_ += last_flops_;

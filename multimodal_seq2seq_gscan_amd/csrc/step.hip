@@ -636,8 +636,9 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
             add_grad(b, 4 * He, He, BL, dl, 1, ldd, lhprev + dir * He, (int64_t)D * He, 1, gw_hh, He, gb_ih, gb_hh);
             add_grad(b, 4 * He, Din, BL, dl, 1, ldd, x, Din, 1, gw_ih, Din);
             if (l > 0)
+                // both directions add into the same buffer from one launch: atomics even when K = 4He is too short to split
                 b.add(BL, Din, 4 * He, dl, ldd, 1, dir ? q.w_ih_rev : q.w_ih, Din, 1, w + ws.deep_dy + (l - 1) * lay_h, Din,
-                      1.f, nullptr, 0, nullptr, 2);
+                      1.f, nullptr, 0, nullptr, -2);
         }
         if (l == 0)
             b.add(BL, E, D * 4 * He, ldelta, ldd, 1, w + ws.wih_stack, E, 1, w + ws.dxe, E, 1.f, nullptr, 0, nullptr, 8);

@@ -586,6 +586,10 @@ EDGE_CASES = [
     ("hidden24_encoder72", {"encoder_hidden_size": 72, "decoder_hidden_size": 24, "embedding_dimension": 7}, dict(batch=3), None),
     ("hidden72_encoder128_aux", {"encoder_hidden_size": 128, "decoder_hidden_size": 72, "auxiliary_task": True},
      dict(batch=2), None),
+    # two bidirectional layers at a small hidden size: both directions add their input gradients into one buffer from
+    # one launch with K = 4 He too short to split (they raced before the products were made atomic)
+    ("enc2_bidirectional_hidden8", {"encoder_hidden_size": 8, "num_encoder_layers": 2}, dict(batch=2, max_command=2), None),
+    ("enc3_bidirectional_hidden12", {"encoder_hidden_size": 12, "num_encoder_layers": 3}, dict(batch=3), None),
     ("hidden4", {"encoder_hidden_size": 4, "decoder_hidden_size": 4, "embedding_dimension": 3}, dict(batch=2), None),
     # 8x8 grid at hidden 100: the visual gate images (102 KB per row) do not fit LDS next to the rest and are
     # streamed from L2 by the decoder kernels (round 1 refused this shape)

@@ -26,11 +26,11 @@ rng = random.Random(args.seed)
 TOL = 1e-4
 bad = 0
 for case in range(args.cases):
-    H = rng.choice([20, 32, 40, 48, 64, 80, 96, 100])
-    He = rng.choice([20, 32, 40, 48, 64, 80, 96, 100, 128])
+    H = rng.choice(list(range(4, 101, 4)))              # every compiled decoder size
+    He = rng.choice(list(range(4, 129, 4)))             # every compiled encoder size
     cfg = model_kwargs("demo", cnn_dropout_p=0.0, encoder_dropout_p=0.0, decoder_dropout_p=0.0,
                        decoder_hidden_size=H, encoder_hidden_size=He, embedding_dimension=rng.choice([4, 5, 8, 25]),
-                       cnn_kernel_size=rng.choice([1, 3, 5, 7, 13]), cnn_hidden_num_channels=rng.choice([8, 20, 50]),
+                       cnn_kernel_size=rng.choice([1, 3, 5, 7, 13]), cnn_hidden_num_channels=rng.choice([8, 20, 50, 70]),
                        conditional_attention=rng.random() < 0.6, auxiliary_task=rng.random() < 0.5,
                        encoder_bidirectional=rng.random() < 0.7, num_encoder_layers=rng.choice([1, 1, 2, 3]),
                        input_vocabulary_size=rng.choice([8, 14, 21]), target_vocabulary_size=rng.choice([5, 6, 9]),
@@ -46,6 +46,8 @@ for case in range(args.cases):
         model.load_state_dict(params, strict=False)
         model = model.cuda().eval()
         d = {k: v.cuda() for k, v in batch.items()}
+        if rng.random() < 0.5:
+            d["world"] = d["world"].to(torch.uint8)         # the batcher's form: widened inside the kernels
         logp, aux = model(commands_input=d["commands"], commands_lengths=batch["cmd_lengths"].tolist(),
                           situations_input=d["world"], target_batch=d["targets"],
                           target_lengths=batch["tgt_lengths"].tolist())
