@@ -259,7 +259,8 @@ int gscan_world_encoder_backward(const void *world, int world_is_u8, const float
     ARG(B > 0 && G > 0 && C > 0 && Co > 0 && K3 > 0 && (K3 & 1), "world_encoder_backward: bad dims");
     float *const gw[3] = {grad_w[0], grad_w[1], grad_w[2]};
     float *const gb[3] = {grad_b[0], grad_b[1], grad_b[2]};
-    return world_conv_backward(world, world_is_u8, dfeat, B, G, C, Co, K3, list_scratch, gw, gb, (hipStream_t)stream);
+    if (int rc = world_conv_lists(world, world_is_u8, B, G, C, list_scratch, (hipStream_t)stream)) return rc;
+    return world_conv_backward(dfeat, B, G, C, Co, K3, list_scratch, gw, gb, (hipStream_t)stream);
 }
 
 int gscan_encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths,

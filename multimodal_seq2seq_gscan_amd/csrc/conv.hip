@@ -329,22 +329,25 @@ size_t world_conv_backward_scratch_floats(int B, int G, int C) {
     return 2 * (size_t)C * kConvSegments * seg + (size_t)C * kConvSegments + 64;
 }
 
-int world_conv_backward(const void *world, int world_is_u8, const float *dfeat, int B, int G, int C, int Co, int K3,
-                        float *scratch, float *const (&gw)[3], float *const (&gb)[3], hipStream_t stream) {
-    TRY_RC(conv_check(B, G, C, Co, K3));
-    GSCAN_CHECK(B < 65536, "world encoder: more than 65535 examples per call (B=%d)", B);
+static ConvArgs conv_backward_args(int B, int G, int C, int Co, int K3, float *scratch) {
     ConvArgs a{};
-    a.B = B; a.G = G; a.C = C; a.Co = Co; a.K3 = K3; a.dfeat = dfeat;
-    for (int i = 0; i < 3; ++i) { a.gw[i] = gw[i]; a.gb[i] = gb[i]; }
+    a.B = B; a.G = G; a.C = C; a.Co = Co; a.K3 = K3;
     a.slice = cdiv(B, kConvSegments);
     a.nw_blocks = C;
     const size_t seg = (size_t)a.slice * G * G;
     a.seg_keys = reinterpret_cast<uint32_t *>(scratch);
     a.seg_vals = scratch + (size_t)C * kConvSegments * seg;
     a.seg_count = reinterpret_cast<int *>(scratch + 2 * (size_t)C * kConvSegments * seg);
-    const int npairs = (26 + K3 * K3) * cdiv(Co, 64);
-    const dim3 lists(C, kConvSegments), grid(C + cdiv((int64_t)B * G * G, 64), cdiv(npairs, kConvWaves / kConvSegments));
-    ProbeScope probe(P_CONV_BWD, stream, 0.0, conv_algorithmic_flops(B, G, C, Co, K3));
+    return a;
+}
+
+// Pass 1 of the backward: the per-(channel, batch quarter) lists of non-zeros.  It needs the world only, so the step
+// launches it long before the gradient wrt the features exists.
+int world_conv_lists(const void *world, int world_is_u8, int B, int G, int C, float *scratch, hipStream_t stream) {
+    GSCAN_CHECK(B > 0 && B < 65536 && G > 0 && G <= 255 && C > 0 && C <= 255 && world && scratch,
+                "world encoder lists: unsupported arguments (B=%d G=%d C=%d)", B, G, C);
+    const ConvArgs a = conv_backward_args(B, G, C, 1, 1, scratch);
+    const dim3 lists(C, kConvSegments);
     if (world_is_u8)
         hipLaunchKernelGGL(world_channel_lists_kernel<uint8_t>, lists, dim3(kConvThreads), 0, stream, a,
                            static_cast<const uint8_t *>(world));
@@ -352,6 +355,20 @@ int world_conv_backward(const void *world, int world_is_u8, const float *dfeat, 
         hipLaunchKernelGGL(world_channel_lists_kernel<float>, lists, dim3(kConvThreads), 0, stream, a,
                            static_cast<const float *>(world));
     GSCAN_LAUNCHED("world_channel_lists_kernel");
+    return 0;
+}
+
+// Pass 2: kernel and bias gradients from the lists of world_conv_lists and d(features).
+int world_conv_backward(const float *dfeat, int B, int G, int C, int Co, int K3, float *scratch,
+                        float *const (&gw)[3], float *const (&gb)[3], hipStream_t stream) {
+    TRY_RC(conv_check(B, G, C, Co, K3));
+    GSCAN_CHECK(B < 65536, "world encoder: more than 65535 examples per call (B=%d)", B);
+    ConvArgs a = conv_backward_args(B, G, C, Co, K3, scratch);
+    a.dfeat = dfeat;
+    for (int i = 0; i < 3; ++i) { a.gw[i] = gw[i]; a.gb[i] = gb[i]; }
+    const int npairs = (26 + K3 * K3) * cdiv(Co, 64);
+    const dim3 grid(C + cdiv((int64_t)B * G * G, 64), cdiv(npairs, kConvWaves / kConvSegments));
+    ProbeScope probe(P_CONV_BWD, stream, 0.0, conv_algorithmic_flops(B, G, C, Co, K3));
     hipLaunchKernelGGL(world_conv_bwd_kernel<0>, grid, dim3(kConvThreads), 0, stream, a);
     GSCAN_LAUNCHED("world_conv_bwd_kernel");
     return 0;

@@ -35,58 +35,66 @@ int embed_rows(const int64_t *tok, const float *table, int vocab, const float *m
 // ------------------------------------------------------------------------------------------
 // dtable[v, :] += sum over rows with tok[row] == v, v != pad of g[row, :] * mask[row, :]
 // (the padding row of nn.Embedding(padding_idx=...) never receives gradient).
-// Vocabularies are tiny (6..21 entries), so each workgroup sums its 64 rows into a private
-// [vocab, D] table in LDS (ds_add_f32; consecutive lanes take consecutive columns of a row, so a wave's
-// lanes hit different addresses) and flushes the table with one global atomic per touched entry.
+// Vocabularies are tiny (6..21 entries) and thousands of rows carry the same token, so atomics on a shared table —
+// global or LDS — serialise (round 1: 18 us for 5 120 x 100).  A thread owns ONE column and a row slot: 256 threads
+// = (256 / DP) row slots x DP columns, DP = the next power of two >= D; it walks its rows with its own [vocab] sums in
+// LDS (priv[v][thread]: nobody else touches them, plain read-modify-write), the slots of a column are added at the
+// end and one global atomic per touched (v, column) leaves the workgroup.
 // ------------------------------------------------------------------------------------------
-constexpr int kEmbedRows = 64;
-__global__ void embed_grad_kernel(const int64_t *__restrict__ tok, const float *__restrict__ g, int64_t ldg,
-                                  const float *__restrict__ mask, int rows, int D, int vocab, int pad,
-                                  float *__restrict__ dtable) {
+constexpr int kEmbedRows = 32;
+constexpr int kEmbedThreads = 256;
+__global__ __launch_bounds__(kEmbedThreads) void embed_grad_kernel(const int64_t *__restrict__ tok, const float *__restrict__ g, int64_t ldg,
+                                  const float *__restrict__ mask, int rows, int D, int DP, int v0, int vocab, int pad,
+                                  float *__restrict__ dtable) {   // tokens v0 .. v0 + vocab - 1
     TraceScope trace_scope(TK_EMBED_GRAD);
-    extern __shared__ float table[];
-    const int n = vocab * D;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) table[i] = 0.f;
-    __syncthreads();
+    extern __shared__ float priv[];                       // [vocab][kEmbedThreads]
+    const int tid = threadIdx.x, d = tid & (DP - 1), slot = tid / DP, slots = kEmbedThreads / DP;
+    for (int v = 0; v < vocab; ++v) priv[v * kEmbedThreads + tid] = 0.f;
     const int r0 = blockIdx.x * kEmbedRows, r1 = min(rows, r0 + kEmbedRows);
-    const int nel = (r1 - r0) * D;
-    // a thread takes (row, column) elements; four elements' loads (token -> gradient, mask) are in flight at once
-    for (int i0 = threadIdx.x; i0 < nel; i0 += 4 * blockDim.x) {
-        float x[4];
-        int at[4];
+    if (d < D) {
+        // eight rows per pass: token, gradient and mask loads are all unconditional (a row past the end repeats the
+        // last one with weight zero), so one pass costs one memory latency, not a chain of them
+        constexpr int U = 8;
+        for (int r = r0 + slot; r < r1; r += U * slots) {
+            float x[U], m[U];
+            int64_t t[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = i0 + u * blockDim.x;
-            at[u] = -1;
-            x[u] = 0.f;
-            if (idx < nel) {
-                const int rr = idx / D, d = idx - rr * D, r = r0 + rr;
-                const int64_t t = tok[r];
-                if (t >= 0 && t < vocab && t != pad) {
-                    at[u] = (int)t * D + d;
-                    x[u] = g[(int64_t)r * ldg + d];
-                    if (mask) x[u] *= mask[(int64_t)r * D + d];
-                }
+            for (int u = 0; u < U; ++u) {
+                const int rr = min(r + u * slots, r1 - 1);
+                t[u] = tok[rr];
+                x[u] = g[(int64_t)rr * ldg + d];
+                m[u] = mask ? mask[(int64_t)rr * D + d] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t tv = t[u] - v0;
+                const bool live = r + u * slots < r1 && tv >= 0 && tv < vocab && t[u] != pad;
+                if (live) priv[(int)tv * kEmbedThreads + tid] += x[u] * m[u];
             }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (at[u] >= 0) atomicAdd(&table[at[u]], x[u]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float x = table[i];
-        if (x != 0.f) atomicAdd(&dtable[i], x);
+    for (int i = tid; i < vocab * D; i += kEmbedThreads) {
+        const int v = i / D, c = i - v * D;
+        float sum = 0.f;
+        for (int s = 0; s < slots; ++s) sum += priv[v * kEmbedThreads + s * DP + c];
+        if (sum != 0.f) atomicAdd(&dtable[(int64_t)v0 * D + i], sum);
     }
 }
 
 int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mask, int rows, int D, int vocab,
                int pad, float *dtable, hipStream_t stream) {
-    const size_t lds = (size_t)vocab * D * sizeof(float);
-    GSCAN_CHECK(lds <= 64 * 1024, "embed_grad: vocabulary table of %d x %d floats does not fit in LDS", vocab, D);
-    hipLaunchKernelGGL(embed_grad_kernel, dim3(cdiv(rows, kEmbedRows)), dim3(256), lds, stream, tok, g, ldg, mask,
-                       rows, D, vocab, pad, dtable);
-    GSCAN_LAUNCHED("embed_grad_kernel");
+    GSCAN_CHECK(D >= 1 && D <= kEmbedThreads, "embed_grad: embedding dimension %d is not supported (1..%d)", D, kEmbedThreads);
+    int DP = 1;
+    while (DP < D) DP <<= 1;
+    constexpr int kChunk = 64;                             // vocabulary entries per launch: 64 KB of per-thread sums
+    for (int v0 = 0; v0 < vocab; v0 += kChunk) {
+        const int n = std::min(kChunk, vocab - v0);
+        hipLaunchKernelGGL(embed_grad_kernel, dim3(cdiv(rows, kEmbedRows)), dim3(kEmbedThreads),
+                           (size_t)n * kEmbedThreads * sizeof(float), stream, tok, g, ldg, mask, rows, D, DP, v0, n, pad,
+                           dtable);
+        GSCAN_LAUNCHED("embed_grad_kernel");
+    }
     return 0;
 }
 

@@ -179,8 +179,9 @@ int conv_weight_image(const float *const (&w)[3], int C, int Co, int K3, float *
 int world_conv_forward(const void *world, int world_is_u8, const float *img, const float *const (&b)[3],
                        const float *mask, int B, int G, int C, int Co, int K3, float *feat, hipStream_t stream);
 size_t world_conv_backward_scratch_floats(int B, int G, int C);
-int world_conv_backward(const void *world, int world_is_u8, const float *dfeat, int B, int G, int C, int Co, int K3,
-                        float *scratch, float *const (&gw)[3], float *const (&gb)[3], hipStream_t stream);
+int world_conv_lists(const void *world, int world_is_u8, int B, int G, int C, float *scratch, hipStream_t stream);
+int world_conv_backward(const float *dfeat, int B, int G, int C, int Co, int K3, float *scratch,
+                        float *const (&gw)[3], float *const (&gb)[3], hipStream_t stream);
 int trace_set_conv(unsigned long long *buf);
 
 // loss.hip
