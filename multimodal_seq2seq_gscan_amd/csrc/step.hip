@@ -550,34 +550,40 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     a.w_image = w + ws.dec_w_bwd;
     a.stamps = probe_stamps_enabled() ? w + ws.stamps + 16 : nullptr;
     TRY(decoder_run(true, B, H, cond, a, st));
-    TRY(order_after(sd, st));          // the leaves start only now: the recurrence owns every CU while it runs
-
-    {   // leaves: head weights (the permuted W_o2h gradient is scattered back below) and the decoder parameter
-        // gradients (dense products over the B*T saved rows)
-        GemmBatch b;
-        add_grad(b, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H);
-        add_grad(b, H, 4 * H, BT, w + ws.dpreo, 1, H, S, 4 * H, 1, w + ws.dwo_perm, 4 * H);
-        add_grad(b, 4 * H, 3 * H, BT, delta, 1, 5 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
-        add_grad(b, 4 * H, H, BT, delta, 1, 5 * H, hprev, H, 1, g.dec_w_hh, H, g.dec_b_ih, g.dec_b_hh);
-        add_grad(b, H, H, BT, w + ws.dqt, 1, H, hprev, H, 1, g.txt_query_w, H);
-        if (cond) {
-            add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, hprev, H, 1, g.q2k_w, 2 * H, g.q2k_b);
-            add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H);
-            add_grad(b, H, H, BT, w + ws.dqv, 1, H, w + ws.q2, H, 1, g.vis_query_w, H);
-        } else {
-            add_grad(b, H, H, BT, w + ws.dqv, 1, H, hprev, H, 1, g.vis_query_w, H);
+    // where the decoder's weight-gradient leaves fork off the chain (GSCAN_LEAVES_FORK, A/B): 0 behind the recurrence,
+    // 1 behind the dS += product, 2 behind keys_backward (one fork event in the whole backward pass)
+    static const int leaves_fork = [] { const char *e = getenv("GSCAN_LEAVES_FORK"); return e ? atoi(e) : 0; }();
+    auto decoder_leaves = [&]() -> int {
+        {   // leaves: head weights (the permuted W_o2h gradient is scattered back below) and the decoder parameter
+            // gradients (dense products over the B*T saved rows)
+            GemmBatch b;
+            add_grad(b, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H);
+            add_grad(b, H, 4 * H, BT, w + ws.dpreo, 1, H, S, 4 * H, 1, w + ws.dwo_perm, 4 * H);
+            add_grad(b, 4 * H, 3 * H, BT, delta, 1, 5 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
+            add_grad(b, 4 * H, H, BT, delta, 1, 5 * H, hprev, H, 1, g.dec_w_hh, H, g.dec_b_ih, g.dec_b_hh);
+            add_grad(b, H, H, BT, w + ws.dqt, 1, H, hprev, H, 1, g.txt_query_w, H);
+            if (cond) {
+                add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, hprev, H, 1, g.q2k_w, 2 * H, g.q2k_b);
+                add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H);
+                add_grad(b, H, H, BT, w + ws.dqv, 1, H, w + ws.q2, H, 1, g.vis_query_w, H);
+            } else {
+                add_grad(b, H, H, BT, w + ws.dqv, 1, H, hprev, H, 1, g.vis_query_w, H);
+            }
+            // gradient wrt the embedded target token (the e columns of dS): only the embedding table consumes it, so
+            // this third of the LSTM-input back-propagation is a leaf too
+            b.add(BT, H, 4 * H, delta, 5 * H, 1, w + ws.wcat5, 3 * H, 1, dS, 4 * H, 1.f);
+            TRY(b.launch(sd));
+            TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, sd));
+            TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd));
         }
-        // gradient wrt the embedded target token (the e columns of dS): only the embedding table consumes it, so
-        // this third of the LSTM-input back-propagation is a leaf too
-        b.add(BT, H, 4 * H, delta, 5 * H, 1, w + ws.wcat5, 3 * H, 1, dS, 4 * H, 1.f);
-        TRY(b.launch(sd));
-        TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, sd));
-        TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd));
-    }
+        return 0;
+    };
+    if (leaves_fork == 0) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
     // chain: gradient wrt [ctx_text | ctx_vis] through the LSTM input and the conditional query
     // (one product: [delta | dzq] . [W_ih[:, ctx] ; (W_q2k[:, ctx_text] | 0)], K = 5H when conditional)
     TRY(gemm_f32(BT, 2 * H, cond ? 5 * H : 4 * H, 1.f, delta, 5 * H, 1, w + ws.wcat5 + H, 3 * H, 1, 1.f, dS + H, 4 * H,
                  nullptr, 0, nullptr, 1, st));
+    if (leaves_fork == 1) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
     {   // chain: value path of both attentions (dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]), then through the
         // key layers and the bridge to the encoder outputs / final state / conv features — one launch, row per WG
         KeysBackwardArgs k{};
@@ -590,6 +596,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         TRY(keys_backward(B, H, k, st));
     }
     TRY(order_after(sd, st, sd2));     // one event releases both leaf streams
+    if (leaves_fork == 2) TRY(decoder_leaves());
     {   // leaves: key and bridge weights
         GemmBatch b;
         add_grad(b, H, He, BL, w + ws.dpk_t, 1, H, w + ws.enc_out, He, 1, g.txt_key_w, He);

@@ -94,6 +94,45 @@ def test_shard_batch_covers_every_row_once():
         assert torch.equal(torch.cat([p["targets"] for p in parts]), batch["targets"])
 
 
+def test_shard_batch_is_balanced_and_refuses_fewer_rows_than_ranks():
+    """Shards differ by at most one row; a global batch with fewer rows than ranks raises on EVERY rank (all ranks see
+    the same B) instead of leaving some ranks without rows while the others wait in the step's collective — the
+    short trailing batch of an epoch (gSCAN_dataset.py:195-196) is dropped by train_on_dataset in that case."""
+    from multimodal_seq2seq_gscan_amd.train import shard_batch
+    batch = {"commands": torch.arange(11).view(11, 1), "targets": torch.arange(11).view(11, 1)}
+    for world in (2, 3, 4, 8, 11):
+        sizes = [shard_batch(batch, r, world)["commands"].shape[0] for r in range(world)]
+        assert sum(sizes) == 11 and max(sizes) - min(sizes) <= 1 and min(sizes) >= 1, (world, sizes)
+        assert torch.equal(torch.cat([shard_batch(batch, r, world)["targets"] for r in range(world)]), batch["targets"])
+    for rank in range(12):
+        with pytest.raises(ValueError, match="cannot be sharded"):
+            shard_batch(batch, rank, 12)
+
+
+def test_epoch_with_a_trailing_batch_smaller_than_the_world_is_trimmed(tmp_path):
+    """An epoch of 13 examples at batch size 4 ends in a batch of ONE row; with 2 ranks that batch is dropped on both
+    (the loop's `continue`), every other batch is split 2 + 2 and all 12 rows are trained on exactly once."""
+    import numpy as np
+    from multimodal_seq2seq_gscan_amd.dataset import GroundedScanDataset
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, write_dataset_file
+    from multimodal_seq2seq_gscan_amd.train import shard_batch
+    path = str(tmp_path / "dataset.txt")
+    write_dataset_file(path, {"train": 13}, Shape(batch=1, max_command=6, max_target=6), seed=1)
+    data = GroundedScanDataset(path, str(tmp_path), k=0, split="train", generate_vocabulary=True)
+    data.read_dataset()
+    world = 2
+    seen = [[], []]
+    steps = 0
+    for batch in data.get_data_iterator(batch_size=4, device=torch.device("cpu")):
+        rows = {"commands": batch[0], "targets": batch[5]}
+        if rows["commands"].shape[0] < world:       # what train_on_dataset does before shard_batch
+            continue
+        steps += 1
+        for rank in range(world):
+            seen[rank].append(shard_batch(rows, rank, world)["commands"].shape[0])
+    assert steps == 3 and seen == [[2, 2, 2], [2, 2, 2]]
+
+
 def _worker_single_exchange(rank: int, world: int, port: int, out_dir: str):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
