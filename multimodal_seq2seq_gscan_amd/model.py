@@ -361,10 +361,10 @@ class Model(nn.Module):
         h = self._hyper
         shapes = ((B, M, 3 * h["Co"]), (B, L, h["E"]), (B, T, h["H"]))
         sizes = [s[0] * s[1] * s[2] for s in shapes]
-        key = tuple(sizes)
-        if self._mask_buffer is None or self._mask_key != key:
+        # one buffer, grown when a larger batch shape arrives (never shrunk or replaced on a mere change of shape)
+        if self._mask_buffer is None or self._mask_buffer.numel() < sum(sizes) or self._mask_buffer.device != device:
             self._mask_buffer = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-            self._mask_key = key
+        self._mask_key = tuple(sizes)
         buf = self._mask_buffer
         _lib.check(lib.gscan_dropout_masks(buf.data_ptr(), sizes[0], sizes[1], sizes[2], self.dropout_p[0],
                                            self.dropout_p[1], self.dropout_p[2], self._dropout_seed,
