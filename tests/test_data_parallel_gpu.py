@@ -80,6 +80,12 @@ def test_two_ranks_on_one_device_match_the_single_process_step(tmp_path, case):
     _compare(ranks, _single_process(case))
 
 
+def test_four_ranks_on_one_device(tmp_path):
+    """Four ranks (7 rows -> shards of 1, 2, 2, 2), the two-collective auxiliary form: the same global gradient."""
+    ranks = _launch(4, "gloo", "demo_aux", tmp_path)
+    _compare(ranks, _single_process("demo_aux"))
+
+
 @pytest.mark.parametrize("case", ["demo", "demo_aux"])
 def test_collectives_on_a_one_rank_rccl_communicator(tmp_path, case):
     """backend "nccl" IS RCCL on ROCm: the step's all-reduces are launched by RCCL on its own stream between the
