@@ -1,231 +1,200 @@
 // Backward of the two attention memories once the decoder's reverse recurrence has produced the per-step
-// gradients, ONE WORKGROUP PER BATCH ROW, all products on the matrix cores:
+// gradients, ONE WORKGROUP PER (BATCH ROW, TILE OF 16 MEMORIES), all products on the matrix cores:
 //   value path  dPK[m,:] += sum_t alpha[t,m] * dctx[t,:]            (context = alpha . PK, seq2seq_model.py:138-139)
 //   key layers  d enc_out = dPK_text . W_key_text                   (seq2seq_model.py:468-469)
 //               d feat    = (dPK_vis . W_key_vis) * dropout mask, zero where ReLU was inactive
 //                                                                    (seq2seq_model.py:466-467, cnn_model.py:33-35)
-//   bridge      d h_N     = d h0 . W_bridge                          (model.py:195)
-// A row's memories are small (L + G*G <= 128 keys of H floats): its dPK stays in LDS between the two stages, so the
-// chain "value path -> key layers" is one launch instead of a batched reduction plus a grouped GEMM with an HBM
-// round trip in between.  The totals dPK_text / dPK_vis are also written out: the key-layer weight gradients
-// are dense products over them (leaves of the step's schedule).
+//   bridge      d h_N     = d h0 . W_bridge                          (model.py:195; one extra workgroup per row)
+// A tile's dPK (16 memories x H floats) stays in LDS between the two stages, so the chain "value path -> key
+// layers" is one launch instead of a batched reduction plus a grouped GEMM with an HBM round trip in between.
+// The totals dPK_text / dPK_vis are also written out: the key-layer weight gradients are dense products over
+// them (leaves of the step's schedule).
+// Why tiles and not whole rows: this launch sits on the step's critical chain while the decoder's leaf products
+// (1500+ GEMM workgroups of 4 waves x 128 VGPRs) run on a side stream.  A 512-thread, 168-VGPR, 61 KB workgroup
+// only fits a CU once three of those have drained from it, and the dispatcher hands every freed slot to the
+// other queue first: the row-per-workgroup version of this kernel waited ~30 us for placement (round-2 device
+// timelines).  A 256-thread workgroup under 128 VGPRs has the footprint of a GEMM workgroup and interleaves with
+// them; it also lifts the 64-memory limit of the row version.
 #include "step.h"
 
 namespace gscan {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kKbThreads = 512, kKbWaves = kKbThreads / 64, kKbSteps = 32, kKbMaxTiles = 8;
-static_assert(kKbThreads == 16 * kKbSteps, "staging maps 16 lanes to a step");
+constexpr int kKbThreads = 256, kKbWaves = kKbThreads / 64, kKbSteps = 32, kKbMaxTiles = 2;
 
-struct KeysLds { int dpk, al, dc, dh, total; };
-__host__ __device__ inline KeysLds keys_lds(int H, int L, int M) {
-    const int HS = (H % 8 == 4) ? H : H + 4, MT = (M + 15) / 16 + (L + 15) / 16;
+struct KeysLds { int dpk, al, dc, total; };
+__host__ __device__ inline KeysLds keys_lds(int H) {
+    const int HS = (H % 8 == 4) ? H : H + 4;
     KeysLds o;
     int p = 0;
-    o.dpk = p; p += MT * 16 * HS;
-    o.al = p;  p += kKbSteps * MT * 16;
-    o.dc = p;  p += kKbSteps * 2 * H;
-    o.dh = p;  p += (H + 3) / 4 * 4;
+    o.dpk = p; p += 16 * HS;
+    o.al = p;  p += kKbSteps * 16;
+    o.dc = p;  p += kKbSteps * H;
     o.total = p;
     return o;
 }
 
 template <int H>
-__global__ __launch_bounds__(kKbThreads) void keys_backward_kernel(KeysBackwardArgs a) {
+__global__ __launch_bounds__(kKbThreads, 4) void keys_backward_kernel(KeysBackwardArgs a) {
     TraceScope trace_scope(TK_KEYS_BWD);
     constexpr int HS = (H % 8 == 4) ? H : H + 4;      // dPK row stride: the 16 rows of an A fragment hit distinct banks
-    constexpr int NTH = (H + 15) / 16, KS = H / 4;
-    static_assert(NTH <= kKbMaxTiles && H % 4 == 0, "hidden size not supported");
+    constexpr int NTH = (H + 15) / 16, KS = H / 4, Q = H / 4;
+    static_assert(NTH <= kKbMaxTiles * kKbWaves && H % 4 == 0, "hidden size not supported");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int T = a.T, L = a.L, M = a.M;
-    const int MTV = (M + 15) / 16, MTT = (L + 15) / 16, MT = MTV + MTT, AS = MT * 16;
-    const KeysLds o = keys_lds(H, L, M);
-    float *dpk_s = sm + o.dpk, *al_s = sm + o.al, *dc_s = sm + o.dc, *dh_s = sm + o.dh;
+    const int MTV = (M + 15) / 16, MTT = (L + 15) / 16, MT = MTV + MTT;
+    const int mt = blockIdx.y;
 
-    // ---- stage 1: dPK = (score path, from the decoder kernel) + alpha^T . dctx, tiles of 16 memories x 16 features.
-    //      Memory tiles: the first MTV cover the grid cells, the rest the command tokens (both zero-padded to 16).
-    const int ntiles = MT * NTH;
+    if (mt == MT) {
+        // ---- bridge: d h_N[e] = sum_k d h0[k] * W_bridge[k][e]
+        float *dh_s = sm;
+        if (tid < H) dh_s[tid] = a.dh0[(int64_t)b * H + tid];
+        __syncthreads();
+        for (int e = tid; e < a.He; e += kKbThreads) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 5
+            for (int k = 0; k < H; k += 4) {
+                s0 = fmaf(dh_s[k], a.w_b[(int64_t)k * a.He + e], s0);
+                s1 = fmaf(dh_s[k + 1], a.w_b[(int64_t)(k + 1) * a.He + e], s1);
+                s2 = fmaf(dh_s[k + 2], a.w_b[(int64_t)(k + 2) * a.He + e], s2);
+                s3 = fmaf(dh_s[k + 3], a.w_b[(int64_t)(k + 3) * a.He + e], s3);
+            }
+            a.dhN[(int64_t)b * a.He + e] = (s0 + s1) + (s2 + s3);
+        }
+        return;
+    }
+
+    const KeysLds o = keys_lds(H);
+    float *dpk_s = sm + o.dpk, *al_s = sm + o.al, *dc_s = sm + o.dc;
+    const bool vis = mt < MTV;
+    const int mx = vis ? M : L, mbase = 16 * (vis ? mt : mt - MTV);
+    float *dpk_g = (vis ? a.dpk_v : a.dpk_t) + (int64_t)b * mx * H;
+    const float *alpha = vis ? a.alpha_s : a.alpha_c;
+    const int dcol = vis ? 2 * H : H;                 // d ctx_text | d ctx_vis inside a dS row
+
+    // ---- stage 1: dPK = (score path, from the decoder kernel) + alpha^T . dctx, tiles of 16 memories x 16 features
     f32x4 acc[kKbMaxTiles];
 #pragma unroll
     for (int i = 0; i < kKbMaxTiles; ++i) {
-        const int tile = wave + kKbWaves * i;
+        const int nt = wave + kKbWaves * i, k = 16 * nt + fr;
         acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (tile < ntiles) {
-            const int mt = tile / NTH, nt = tile - mt * NTH, k = 16 * nt + fr;
-            const bool vis = mt < MTV;
-            const int mx = vis ? M : L, m0 = 16 * (vis ? mt : mt - MTV) + 4 * fg;
-            const float *src = (vis ? a.dpk_v : a.dpk_t) + (int64_t)b * mx * H;
+        if (nt < NTH && k < H) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (m0 + r < mx && k < H) acc[i][r] = src[(m0 + r) * H + k];
+            for (int r = 0; r < 4; ++r) {
+                const int m = mbase + 4 * fg + r;
+                if (m < mx) acc[i][r] = dpk_g[m * H + k];
+            }
         }
     }
-    if (tid < H) dh_s[tid] = a.dh0[(int64_t)b * H + tid];
     for (int t0 = 0; t0 < T; t0 += kKbSteps) {
         const int n = min(kKbSteps, T - t0);
         const int64_t bt0 = (int64_t)b * T + t0;
-        {   // thread = (step t, 16 lanes across the row): no divisions, every load of a thread in flight at once
-            const int t = tid >> 4, q = tid & 15;
-            const bool live = t < n;
-            float av[kKbMaxTiles];
+        {   // every load of a thread in flight at once
+            constexpr int NA = kKbSteps * 16 / kKbThreads, ND = (kKbSteps * Q + kKbThreads - 1) / kKbThreads;
+            float av[NA];
+            float4 dv[ND];
 #pragma unroll
-            for (int i = 0; i < kKbMaxTiles; ++i) {                         // alpha, [step][padded memories]
-                const int c = q + 16 * i;
-                av[i] = 0.f;
-                if (live && i < MT) {
-                    if (i < MTV) { if (c < M) av[i] = a.alpha_s[(bt0 + t) * M + c]; }
-                    else if (c - MTV * 16 < L) av[i] = a.alpha_c[(bt0 + t) * L + c - MTV * 16];
-                }
+            for (int i = 0; i < NA; ++i) {
+                const int idx = tid + kKbThreads * i, t = idx >> 4, q = idx & 15;
+                av[i] = (t < n && mbase + q < mx) ? alpha[(bt0 + t) * mx + mbase + q] : 0.f;
             }
-            constexpr int NQ = (2 * H / 4 + 15) / 16;                       // [step][dctx_text | dctx_vis], 16-byte loads
-            float4 dv[NQ];
-            const float4 *src4 = reinterpret_cast<const float4 *>(a.ds + (bt0 + (live ? t : 0)) * 4 * H + H);
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int c4 = q + 16 * i;
+            for (int i = 0; i < ND; ++i) {
+                const int idx = tid + kKbThreads * i, t = idx / Q, c4 = idx - t * Q;
                 dv[i] = float4{0.f, 0.f, 0.f, 0.f};
-                if (live && c4 < 2 * H / 4) dv[i] = src4[c4];
+                if (t < n) dv[i] = *reinterpret_cast<const float4 *>(a.ds + (bt0 + t) * 4 * H + dcol + 4 * c4);
             }
 #pragma unroll
-            for (int i = 0; i < kKbMaxTiles; ++i)
-                if (i < MT) al_s[t * AS + q + 16 * i] = av[i];
+            for (int i = 0; i < NA; ++i) al_s[tid + kKbThreads * i] = av[i];
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int c4 = q + 16 * i;
-                if (c4 < 2 * H / 4) *reinterpret_cast<float4 *>(dc_s + t * 2 * H + 4 * c4) = dv[i];
+            for (int i = 0; i < ND; ++i) {
+                const int idx = tid + kKbThreads * i;
+                if (idx < kKbSteps * Q) *reinterpret_cast<float4 *>(dc_s + 4 * idx) = dv[i];
             }
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < kKbMaxTiles; ++i) {
-            const int tile = wave + kKbWaves * i;
-            if (tile < ntiles) {
-                const int mt = tile / NTH, nt = tile - mt * NTH;
-                const float *ap = al_s + fg * AS + 16 * mt + fr;                               // A(m, t) = alpha[t][m]
-                const float *bp = dc_s + fg * 2 * H + (mt < MTV ? H : 0) + min(16 * nt + fr, H - 1);   // B(t, k)
+            const int nt = wave + kKbWaves * i;
+            if (nt < NTH) {
+                const float *ap = al_s + fg * 16 + fr;                                  // A(m, t) = alpha[t][m]
+                const float *bp = dc_s + fg * H + min(16 * nt + fr, H - 1);             // B(t, k)
 #pragma unroll
                 for (int s = 0; s < kKbSteps / 4; ++s)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * AS], bp[4 * s * 2 * H], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * 16], bp[4 * s * H], acc[i], 0, 0, 0);
             }
         }
         __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < kKbMaxTiles; ++i) {
-        const int tile = wave + kKbWaves * i;
-        if (tile < ntiles) {
-            const int mt = tile / NTH, nt = tile - mt * NTH, k = 16 * nt + fr;
-            const bool vis = mt < MTV;
-            const int mx = vis ? M : L, m0 = 16 * (vis ? mt : mt - MTV) + 4 * fg;
-            float *dst = (vis ? a.dpk_v : a.dpk_t) + (int64_t)b * mx * H;
+        const int nt = wave + kKbWaves * i, k = 16 * nt + fr;
+        if (nt < NTH && k < H) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (k < H) {
-                    dpk_s[(16 * mt + 4 * fg + r) * HS + k] = acc[i][r];       // padded memories: exact zeros
-                    if (m0 + r < mx) dst[(m0 + r) * H + k] = acc[i][r];
-                }
+                const int m = mbase + 4 * fg + r;
+                dpk_s[(4 * fg + r) * HS + k] = acc[i][r];                               // padded memories: exact zeros
+                if (m < mx) dpk_g[m * H + k] = acc[i][r];
             }
         }
     }
     __syncthreads();
 
-    // ---- stage 2: through the key layers.  A job = one 16-column tile of d feat (F columns, MTV memory tiles) or
-    //      of d enc_out (He columns, MTT memory tiles); the job's B fragments (H/4 steps) are read once.
-    //      Latency, not arithmetic, bounds this stage (a wave runs two or three jobs back to back and each starts
-    //      with loads): the NEXT job's B fragments and the current job's ReLU gates / dropout masks are requested
-    //      before the current job's MFMAs, so every load has a whole job to arrive.
-    const int NTF = (a.F + 15) / 16, NTE = (a.He + 15) / 16, njobs = NTF + NTE;
-    auto load_b = [&](int job, float (&bw)[KS]) {
-        const bool vis = job < NTF;
-        const int nt = vis ? job : job - NTF, ncols = vis ? a.F : a.He, col = 16 * nt + fr;
-        const float *wsrc = vis ? a.w_kv : a.w_kt;
+    // ---- stage 2: through the key layer.  A job = one 16-column tile of d feat (F columns) or of d enc_out (He
+    //      columns).  Each job starts with its loads (B fragments, ReLU gates, dropout masks); the four workgroups
+    //      a CU holds cover each other's latency, so there is no software pipeline here (a double-buffered B
+    //      fragment pushed the kernel past 128 VGPRs, and with it out of the footprint the header describes).
+    const int ncols = vis ? a.F : a.He, njobs = (ncols + 15) / 16;
+    const float *wsrc = vis ? a.w_kv : a.w_kt;
+    for (int job = wave; job < njobs; job += kKbWaves) {
+        const int col = 16 * job + fr;
+        const bool col_ok = col < ncols;
+        float bw[KS], gate[4], mk[4];
+        {
+            const float *wp = wsrc + (int64_t)fg * ncols + (col_ok ? col : 0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) bw[s] = (job < njobs && col < ncols) ? wsrc[(int64_t)(4 * s + fg) * ncols + col] : 0.f;
-    };
-    auto run_job = [&](int job, const float (&bw)[KS]) {
-        const bool vis = job < NTF;
-        const int nt = vis ? job : job - NTF, ncols = vis ? a.F : a.He, col = 16 * nt + fr;
-        const int mt_lo = vis ? 0 : MTV, nmt = vis ? MTV : MTT, mx = vis ? M : L;
-        constexpr int kMaxMt = 4;                           // 64 memories per attention at most
-        float gate[kMaxMt][4], mk[kMaxMt][4];
+            for (int s = 0; s < KS; ++s) { bw[s] = *wp; wp += 4 * ncols; }
+        }
 #pragma unroll
-        for (int i = 0; i < kMaxMt; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = 16 * i + 4 * fg + r;
-                gate[i][r] = 1.f; mk[i][r] = 1.f;
-                if (vis && i < nmt && m < mx && col < ncols) {
-                    const int64_t at = ((int64_t)b * mx + m) * ncols + col;
-                    gate[i][r] = a.feat[at];
-                    if (a.mask) mk[i][r] = a.mask[at];
-                }
-            }
-#pragma unroll
-        for (int i = 0; i < kMaxMt; ++i) {
-            if (i >= nmt) continue;
-            f32x4 c = {0.f, 0.f, 0.f, 0.f};
-            const float *ap = dpk_s + (16 * (mt_lo + i) + fr) * HS + fg;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], bw[s], c, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = 16 * i + 4 * fg + r;
-                if (m < mx && col < ncols) {
-                    const int64_t at = ((int64_t)b * mx + m) * ncols + col;
-                    // feat = relu(conv) * mask  =>  d conv = (feat != 0) ? d feat * mask : 0
-                    if (vis) a.dfeat[at] = (gate[i][r] == 0.f) ? 0.f : c[r] * mk[i][r];
-                    else a.denc[at] = c[r];
-                }
+        for (int r = 0; r < 4; ++r) {
+            const int m = mbase + 4 * fg + r;
+            gate[r] = 1.f; mk[r] = 1.f;
+            if (vis && m < mx && col_ok) {
+                const int64_t at = ((int64_t)b * mx + m) * ncols + col;
+                gate[r] = a.feat[at];
+                if (a.mask) mk[r] = a.mask[at];
             }
         }
-    };
-    {
-        float bw0[KS], bw1[KS];
-        load_b(wave, bw0);
-        for (int job = wave; job < njobs; job += 2 * kKbWaves) {
-            load_b(job + kKbWaves, bw1);
-            run_job(job, bw0);
-            if (job + kKbWaves >= njobs) break;
-            load_b(job + 2 * kKbWaves, bw0);
-            run_job(job + kKbWaves, bw1);
-        }
-    }
-    // ---- bridge: d h_N[e] = sum_k d h0[k] * W_bridge[k][e]
-    if (tid < a.He) {
-        float wv[H];
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        const float *ap = dpk_s + fr * HS + fg;
 #pragma unroll
-        for (int k = 0; k < H; ++k) wv[k] = a.w_b[(int64_t)k * a.He + tid];   // all loads in flight
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int s = 0; s < KS; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], col_ok ? bw[s] : 0.f, c, 0, 0, 0);
 #pragma unroll
-        for (int k = 0; k < H; k += 4) {
-            s0 = fmaf(dh_s[k], wv[k], s0);
-            s1 = fmaf(dh_s[k + 1], wv[k + 1], s1);
-            s2 = fmaf(dh_s[k + 2], wv[k + 2], s2);
-            s3 = fmaf(dh_s[k + 3], wv[k + 3], s3);
+        for (int r = 0; r < 4; ++r) {
+            const int m = mbase + 4 * fg + r;
+            if (m < mx && col_ok) {
+                const int64_t at = ((int64_t)b * mx + m) * ncols + col;
+                // feat = relu(conv) * mask  =>  d conv = (feat != 0) ? d feat * mask : 0
+                if (vis) a.dfeat[at] = (gate[r] == 0.f) ? 0.f : c[r] * mk[r];
+                else a.denc[at] = c[r];
+            }
         }
-        a.dhN[(int64_t)b * a.He + tid] = (s0 + s1) + (s2 + s3);
     }
 }
 
 template <int H>
 static int launch_keys_backward(int B, const KeysBackwardArgs &a, hipStream_t stream) {
-    const size_t bytes = (size_t)keys_lds(H, a.L, a.M).total * sizeof(float);
-    GSCAN_CHECK(bytes <= 160 * 1024, "keys backward: %zu bytes of LDS needed (L=%d cells=%d)", bytes, a.L, a.M);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GSCAN_HIP(hipFuncSetAttribute((const void *)keys_backward_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((keys_backward_kernel<H>), dim3(B), dim3(kKbThreads), bytes, stream, a);
+    const size_t bytes = (size_t)keys_lds(H).total * sizeof(float);
+    const int tiles = (a.M + 15) / 16 + (a.L + 15) / 16;
+    hipLaunchKernelGGL((keys_backward_kernel<H>), dim3(B, tiles + 1), dim3(kKbThreads), bytes, stream, a);
     GSCAN_LAUNCHED("keys_backward_kernel");
     return 0;
 }
 
 int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream) {
-    GSCAN_CHECK(B > 0 && a.T > 0 && a.L > 0 && a.M > 0 && a.L <= 64 && a.M <= 64 && a.He > 0 && a.F > 0 && a.He <= 512,
+    GSCAN_CHECK(B > 0 && a.T > 0 && a.L > 0 && a.M > 0 && a.He > 0 && a.F > 0,
                 "keys backward: bad dims B=%d T=%d L=%d cells=%d He=%d F=%d", B, a.T, a.L, a.M, a.He, a.F);
     // algorithmic flops: the data-gradient halves of the key layers and of the bridge (SURVEY.md 8d counts backward as
     // 2 x forward MACs: half of it data gradients), 2 * B * (L He H + M F H + He H); the value-path sums

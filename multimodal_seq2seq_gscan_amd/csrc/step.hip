@@ -149,8 +149,10 @@ int check_dims(const gscan_dims &d) {
 // least 8 of them while they stay >= 160 rows.  Shorter slices make single products faster in isolation
 // (100x150x9216: 32 -> 21 us from 15 to 58 slices) but the overlapped step slower (0.691 vs 0.683 ms), and the
 // eight-product decoder launch much slower (85 vs 62 us at 160/320-row slices).
+static thread_local int g_split_override = 0;      // set around one launch's add_grad calls (experiments)
 static int pick_split(int K) {
     static const int forced = [] { const char *e = getenv("GSCAN_SPLIT"); return e ? atoi(e) : 0; }();
+    if (g_split_override > 0 && K >= 2560) return std::min(g_split_override, cdiv(K, 160));
     if (forced > 0 && K >= 2560) return std::min(forced, cdiv(K, 160));
     return std::max(cdiv(K, 640), std::min(8, cdiv(K, 160)));
 }
@@ -557,6 +559,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         {   // leaves: head weights (the permuted W_o2h gradient is scattered back below) and the decoder parameter
             // gradients (dense products over the B*T saved rows)
             GemmBatch b;
+            static const int dec_split = [] { const char *e = getenv("GSCAN_SPLIT_DEC"); return e ? atoi(e) : 0; }();
+            g_split_override = dec_split;
             add_grad(b, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H);
             add_grad(b, H, 4 * H, BT, w + ws.dpreo, 1, H, S, 4 * H, 1, w + ws.dwo_perm, 4 * H);
             add_grad(b, 4 * H, 3 * H, BT, delta, 1, 5 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
@@ -571,6 +575,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
             }
             // gradient wrt the embedded target token (the e columns of dS): only the embedding table consumes it, so
             // this third of the LSTM-input back-propagation is a leaf too
+            g_split_override = 0;
             b.add(BT, H, 4 * H, delta, 5 * H, 1, w + ws.wcat5, 3 * H, 1, dS, 4 * H, 1.f);
             TRY(b.launch(sd));
             TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, sd));
@@ -607,8 +612,10 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     {   // leaf: convolution kernel and bias gradients from the non-zeros of the world and d(features) (conv.hip)
         float *const gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
         float *const gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
-        // (measured: building the lists earlier, right behind the recurrence, moves this leaf next to the encoder's
-        // weight-gradient launch on the chain and costs 25 us: 0.547 -> 0.572 ms per step)
+        // (measured twice: building the lists earlier does not pay.  Right behind the recurrence on this stream: 0.547
+        // -> 0.572 ms.  As passenger workgroups of the forward pass's world-encoder launch: that launch 10.6 -> 15.2 us,
+        // and the 17 us this leaf starts earlier are lost again because it then overlaps the encoder's weight-gradient
+        // launch, which stretches 19 -> 41 us: this stretch of the step is throughput-bound, 0.541 vs 0.538 ms.)
         TRY(world_conv_lists(bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world, bt.world_u8 != nullptr, B, d.G,
                              C, w + ws.conv_lists, sd2));
         TRY(world_conv_backward(w + ws.dfeat, B, d.G, C, Co, d.K3, w + ws.conv_lists, gw, gb, sd2));
