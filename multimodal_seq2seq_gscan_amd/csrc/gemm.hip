@@ -15,175 +15,10 @@
 // the other LDS buffer after them (one barrier per round), and the long-K weight-gradient
 // products are split into K slices with float-atomic accumulation into the zeroed gradient.
 // Tile geometry and LDS images are described next to the kernel below.
-#include "step.h"
+#include "gemm_panel.h"
 
 namespace gscan {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int TNW = 2;           // MFMA tiles per wave along N; along M it is the kernel's template parameter TMW
-constexpr int BN = 2 * 16 * TNW;
-// Depth of a K round (template parameter BK of the kernel): 32; 64 is compiled for experiments (see launch()).
-template <int BK> struct TileK { static constexpr int LDK = BK + 4; };      // k-contiguous image [row][LDK]: 16-byte rows, b128 fragment reads 2-way at worst
-constexpr int LDR_B = BN + 4;    // row-contiguous image [k][LDR]: b64 reads of 2 adjacent columns, conflict-free
-template <int BK> constexpr int b_floats() { return (BN * (BK + 4) > BK * LDR_B) ? BN * (BK + 4) : BK * LDR_B; }
-// Workgroup tile = (32 TMW) x 64 x 32.  TMW = 2 (64 rows) is the throughput shape; TMW = 1 (32 rows) doubles the
-// number of workgroups of a launch whose 64-row tiling would leave CUs with one or two resident workgroups and
-// nothing to hide a K round's load latency behind (most launches of the training step).
-template <int TMW, int BK = 32> struct TileM {
-    static constexpr int BM = 2 * 16 * TMW;
-    static constexpr int LDR_A = BM + 4;   // row-contiguous image [k][LDR]
-    static constexpr int A_FLOATS = (BM * (BK + 4) > BK * LDR_A) ? BM * (BK + 4) : BK * LDR_A;
-};
-
-// Independent products are launched together as one grid ("grouped GEMM"): the step issues ~45 small
-// products, each of which alone cannot fill 256 CUs and costs a launch; workgroup -> (problem, tile, k-slice)
-// is a scan over at most kMaxGroup prefix sums held in kernel arguments.
-//
-// Tile geometry.  Workgroup (32 TMW) x 64 x 32, 4 waves as 2 x 2, each wave (16 TMW) x 32 = TMW x 2 MFMA tiles
-// of 16 x 16 (many small tiles: these products are latency-bound, occupancy hides more than a bigger tile saves).
-// Within a 32-deep tile the MFMA k index of lane group g (= lane >> 4) at step s (0..7) is k = 8 g + s, so a lane
-// of a k-contiguous operand reads its 8 values with two ds_read_b128.  A row-contiguous operand interleaves its
-// MFMA tiles instead (row = 2 i + tile for A, col = 2 i + tile for B), so one ds_read_b64 per k feeds both
-// of a wave's tiles.  Either way a wave issues ~1 LDS read per 4-8 MFMAs instead of 1 per MFMA.
-// Global loads are 16-byte whenever the operand's pointer, strides and extent allow, else 8- or 4-byte.
-
-
-// How one operand's [ROWS x 32] panels move global -> registers -> LDS.  A thread's loads of one K round form an
-// arithmetic progression (same k / stepping rows for a k-contiguous operand, same rows / stepping k for a
-// row-contiguous one), so everything about them is computed ONCE: the K loop pays one compare and one add per
-// load, no multiplies, no 64-bit arithmetic (measured before this: issuing a round's loads cost as many cycles
-// as its MFMAs).  vw = floats per load (4 / 2 / 1: what the operand's alignment allows).
-// KCT / VWT: layout known at compile time (1 / 0 = k-contiguous or not, 4 / 2 / 1 floats per load) or -1 / 0 = read
-// from the problem at run time.  With compile-time layouts the K loop is straight-line code and the compiler's
-// s_waitcnt insertion counts outstanding loads exactly; with run-time branches around the loads it falls back to
-// vmcnt(0) at the joins, which serialises a round's A and B loads.
-template <int ROWS, int BK, int KCT = -1, int VWT = 0>
-struct PanelIter {
-    static_assert(BK % 32 == 0, "a K round is one or more 32-deep halves (fragment maps of the kernel)");
-    static constexpr int LDK = BK + 4;
-    static constexpr int N = ROWS * BK / 256;     // floats per thread per K round
-    const float *src;
-    uint32_t off;       // element offset of load 0 of the current round
-    uint32_t istep;     // offset step between a thread's loads of one round
-    uint32_t kinc;      // offset step per K round
-    int klim;           // k-contiguous: every load reads while k0 < klim; row-contiguous: load i while k0 + kp*i < klim
-    int nlive;          // k-contiguous: loads i < nlive touch rows inside the matrix
-    int kp;             // row-contiguous: k rows between a thread's loads
-    int vw_rt;
-    bool kc_rt;
-    __device__ __forceinline__ bool is_kc() const { return KCT >= 0 ? (KCT != 0) : kc_rt; }
-    __device__ __forceinline__ int width() const { return VWT > 0 ? VWT : vw_rt; }
-
-    __device__ __forceinline__ void init(const float *base, int64_t s_row, int64_t s_k, int nrows, int row0, int vw_,
-                                         int kbeg, int kend, int tid) {
-        src = base; vw_rt = vw_; kc_rt = (s_k == 1);
-        const int vw = width();
-        const uint32_t sr = (uint32_t)s_row, sk = (uint32_t)s_k;
-        if (is_kc()) {
-            const int ch = BK / vw, rp = 256 / ch;                 // chunks per row, rows per pass
-            const int r = row0 + tid / ch, kk = vw * (tid % ch);
-            off = (uint32_t)r * sr + (uint32_t)(kbeg + kk);
-            istep = (uint32_t)rp * sr;
-            kinc = BK;
-            klim = kend - kk;
-            nlive = r < nrows ? (nrows - r + rp - 1) / rp : 0;
-            kp = 0;
-        } else {
-            const int rq = ROWS / vw;                              // loads per k row
-            const int r = row0 + vw * (tid % rq), kk = tid / rq;
-            kp = 256 / rq;
-            off = (uint32_t)(kbeg + kk) * sk + (uint32_t)r * sr;
-            istep = (uint32_t)kp * sk;
-            kinc = (uint32_t)BK * sk;
-            klim = r < nrows ? kend - kk : INT_MIN;
-            nlive = N;
-        }
-    }
-
-    // Loads are UNCONDITIONAL (a dead load reads element 0 of the operand instead) and their registers are not
-    // written before them; dead values are zeroed when they are consumed (store()).  The obvious form — zero the
-    // registers, then load under a lane mask — makes the compiler put s_waitcnt vmcnt(0) in front of every load
-    // (write-after-write on the registers of the previous round's load, counted conservatively across the
-    // branches), which serialised the A and B panel loads of a round and exposed a full load latency per round.
-    template <int VW>
-    __device__ __forceinline__ uint32_t load_vw(float (&v)[N], int k0) const {
-        constexpr int NL = N / VW;
-        uint32_t mask = 0;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const bool live = is_kc() ? (i < nlive && k0 < klim) : (k0 + kp * i < klim);
-            mask |= (live ? 1u : 0u) << i;
-            const float *ptr = src + (live ? off + (uint32_t)i * istep : 0u);
-            if constexpr (VW == 4) {
-                const float4 x = *reinterpret_cast<const float4 *>(ptr);
-                v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
-            } else if constexpr (VW == 2) {
-                const float2 x = *reinterpret_cast<const float2 *>(ptr);
-                v[2 * i] = x.x; v[2 * i + 1] = x.y;
-            } else {
-                v[i] = *ptr;
-            }
-        }
-        return mask;
-    }
-    // loads of the round starting at k0 (returns the mask of live loads), then step to the next round
-    __device__ __forceinline__ uint32_t load(float (&v)[N], int k0) {
-        uint32_t mask;
-        const int vw = width();
-        if (vw == 4) mask = load_vw<4>(v, k0);
-        else if (vw == 2) mask = load_vw<2>(v, k0);
-        else mask = load_vw<1>(v, k0);
-        off += kinc;
-        return mask;
-    }
-
-    // registers -> LDS image: k-contiguous [row][LDK], row-contiguous [k][LDR]
-    template <int LDR>
-    __device__ __forceinline__ void store(float *lds, const float (&v)[N], uint32_t mask, int tid) const {
-        auto val = [&](int load, int e) { return ((mask >> load) & 1u) ? v[e] : 0.f; };
-        const int vw = width();
-        if (is_kc()) {
-            const int ch = BK / vw, rp = 256 / ch;
-            float *dst = lds + (tid / ch) * LDK + vw * (tid % ch);
-            if (vw == 4) {
-#pragma unroll
-                for (int i = 0; i < N / 4; ++i)
-                    *reinterpret_cast<float4 *>(dst + i * rp * LDK) =
-                        float4{val(i, 4 * i), val(i, 4 * i + 1), val(i, 4 * i + 2), val(i, 4 * i + 3)};
-            } else if (vw == 2) {
-#pragma unroll
-                for (int i = 0; i < N / 2; ++i)
-                    *reinterpret_cast<float2 *>(dst + i * rp * LDK) = float2{val(i, 2 * i), val(i, 2 * i + 1)};
-            } else {
-#pragma unroll
-                for (int i = 0; i < N; ++i) dst[i * rp * LDK] = val(i, i);
-            }
-        } else {
-            const int rq = ROWS / vw;
-            float *dst = lds + (tid / rq) * LDR + vw * (tid % rq);
-            if (vw == 4) {
-#pragma unroll
-                for (int i = 0; i < N / 4; ++i)
-                    *reinterpret_cast<float4 *>(dst + i * kp * LDR) =
-                        float4{val(i, 4 * i), val(i, 4 * i + 1), val(i, 4 * i + 2), val(i, 4 * i + 3)};
-            } else if (vw == 2) {
-#pragma unroll
-                for (int i = 0; i < N / 2; ++i)
-                    *reinterpret_cast<float2 *>(dst + i * kp * LDR) = float2{val(i, 2 * i), val(i, 2 * i + 1)};
-            } else {
-#pragma unroll
-                for (int i = 0; i < N; ++i) dst[i * kp * LDR] = val(i, i);
-            }
-        }
-    }
-};
-
-#ifdef GSCAN_GEMM_STAMPS   // experiment build: cycle stamps of one workgroup's life, in the tail of the trace buffer
-#define GST(i) { const long long n_ = clock64(); gst_acc[i] += (unsigned)(n_ - gst_prev); gst_prev = n_; }
-#else
-#define GST(i)
-#endif
 
 template <int TMW, int BK, int KCA, int KCB, int VWA, int VWB>
 __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float (&lds_a)[2][TileM<TMW, BK>::A_FLOATS],
@@ -339,6 +174,8 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
     }
     const uint32_t ldc = (uint32_t)g.ldc;
     const float alpha = g.alpha;
+    gfloat *gc = as_global(g.c);
+    const gfloat *gbias = as_global(g.bias), *ggate = as_global(g.gate), *gmask = as_global(g.mask);
 #pragma unroll
     for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -354,20 +191,20 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
             } else if (g.beta == 0.f && !g.bias && g.act == 0 && !g.mask) {
 #pragma unroll
                 for (int j = 0; j < TNW; ++j)
-                    if (cok[j]) g.c[roff + coff[j]] = alpha * acc[i][j][r];
+                    if (cok[j]) gc[roff + coff[j]] = alpha * acc[i][j][r];
             } else {
 #pragma unroll
                 for (int j = 0; j < TNW; ++j) {
                     if (!cok[j]) continue;
                     const uint32_t at = roff + coff[j];
                     float v = alpha * acc[i][j][r];
-                    if (g.beta != 0.f) v += g.beta * g.c[at];
-                    if (g.bias) v += g.bias[coff[j]];
+                    if (g.beta != 0.f) v += g.beta * gc[at];
+                    if (gbias) v += gbias[coff[j]];
                     if (g.act == 1) v = fmaxf(v, 0.f);
                     else if (g.act == 2) v = tanhf_(v);
-                    else if (g.act == 3 && g.gate[at] == 0.f) v = 0.f;        // ReLU backward
-                    if (g.mask) v *= g.mask[at];
-                    g.c[at] = v;
+                    else if (g.act == 3 && ggate[at] == 0.f) v = 0.f;        // ReLU backward
+                    if (gmask) v *= gmask[at];
+                    gc[at] = v;
                 }
             }
         }
@@ -480,7 +317,7 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
     }
     GemmProblem &p = grp_.p[grp_.count++];
     p = GemmProblem{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, gate, chunk,
-                    (split_k > 1 || force_atomic) ? 1 : 0, asum1, asum2, 0, 0, 0, 0u, 0u, flags, 0};   // tile bookkeeping: at launch
+                    (split_k > 1 || force_atomic) ? 1 : 0, asum1, asum2, 0, 0, 0, 0u, 0u, flags, 0, 0};   // tile bookkeeping: at launch
     tiles_ += cdiv(N, BN) * cdiv(M, 64) * split_k;                            // in 64-row tiles
     last_flops_ = 2.0 * M * N * K;
     flops_ += last_flops_;
@@ -492,6 +329,7 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
 // 40 us; conv 256x5400x576: 36 vs 44 us; dW_ih 400x300x5120 split 8: 44 vs 48 us), 64-row tiles win once a launch
 // has thousands of workgroups (4096^3: 78 vs 72 TFLOP/s).  GSCAN_GEMM_TMW=1|2 forces a shape, for experiments.
 constexpr int kWideTileMinGroups = 2048;
+constexpr int kWideMinRows = 1024, kWideMinTiles = 1024;     // when a launch takes the 128-row tiles of gemm_wide.hip
 
 int GemmBatch::launch(hipStream_t stream) {
     if (bad_) return 1;
@@ -500,12 +338,33 @@ int GemmBatch::launch(hipStream_t stream) {
     const int tmw = forced == 1 || forced == 2 ? forced : (tiles_ < kWideTileMinGroups ? 1 : 2);
     static const int xcd = [] { const char *e = getenv("GSCAN_GEMM_XCD"); return e ? atoi(e) : 1; }();   // on by default
     static const int order = [] { const char *e = getenv("GSCAN_GEMM_ORDER"); return e ? atoi(e) : 1; }();
+    // Wide tiles (gemm_wide.hip, 128 x 16 nf): launches made of tall products with at least kWideMinTiles of them (four
+    // per CU).  GSCAN_GEMM_WIDE=0 never, 2 whenever the layouts allow (tests, experiments).  Measured (tools/gemm_shapes.py,
+    // profiles/r02_gemm_shapes_wide.txt): 4096^3 runs at 106 TFLOP/s on wide tiles against 94 on 64 x 64, but the
+    // training step's own tall products at batch 256 (9216 x 400 x 150: 360 wide tiles) do not gain: with one or two
+    // workgroups per CU and 4-5 K rounds each, start-up, epilogue and the uneven 1.4 workgroups per CU cost what the
+    // larger tile saves (26.6 vs 25.3 us), so no launch of the benchmark step qualifies.
+    static const int wide_mode = [] { const char *e = getenv("GSCAN_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+    bool wide = wide_mode != 0 && !(forced == 1 || forced == 2);
+    int wide_tiles = 0;
+    for (int i = 0; wide && i < grp_.count; ++i) {
+        const GemmProblem &p = grp_.p[i];
+        int tn, nf;
+        gemm_wide_columns(p.N, &tn, &nf);
+        wide_tiles += tn * cdiv(p.M, 128) * cdiv(p.K, p.k_chunk);
+        wide = gemm_wide_supports(p) && (wide_mode == 2 || p.M >= kWideMinRows);
+    }
+    if (wide && wide_mode != 2 && wide_tiles < kWideMinTiles) wide = false;
     int total = 0;
     for (int i = 0; i < kMaxGroup; ++i) grp_.tile_begin[i] = INT_MAX;
     for (int i = 0; i < grp_.count; ++i) {
         GemmProblem &p = grp_.p[i];
         p.tiles_n = cdiv(p.N, BN);
         p.tiles_mn = p.tiles_n * cdiv(p.M, 32 * tmw);
+        if (wide) {
+            gemm_wide_columns(p.N, &p.tiles_n, &p.nf);
+            p.tiles_mn = p.tiles_n * cdiv(p.M, 128);
+        }
         p.nsplit = cdiv(p.K, p.k_chunk);
         if (order && p.nsplit == 1 && p.N > p.M) p.flags |= 16;
         p.tiles_m = p.tiles_mn / p.tiles_n;
@@ -525,6 +384,7 @@ int GemmBatch::launch(hipStream_t stream) {
     const int *t = grp_.tile_begin;
 #define TB t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]
     ProbeScope probe(P_GEMM, stream, flops_, alg_flops_);
+    if (wide) return gemm_wide_launch(grp_, total, stream);
     // 64-deep K rounds (GSCAN_GEMM_BK=64, experiments): isolated long-K split products gain 10-20 % (a round's
     // load latency is paid half as often), but the overlapped training step loses 3 % to the larger workgroups
     // (52 KB of LDS, +40 VGPRs), so 32 is what every launch uses.

@@ -26,6 +26,7 @@ struct GemmProblem {
                                           // or tiles_m when N tiles run slowest): x / d = umulhi(x, inv) for x * d < 2^32
     int flags;                            // log2(floats per global load) of A | of B << 2 | 16: N tiles run slowest
     int tiles_m;
+    int nf;                               // wide tiles (gemm_wide.hip): 16-column MFMA tiles per workgroup tile (BN = 16 nf)
 };
 // tile_begin / xcd_per lead the kernel arguments as one contiguous header: a workgroup finds its problem with ONE
 // batch of scalar loads and fetches that problem's descriptor with a second one (the scan used to walk the
@@ -148,6 +149,7 @@ int dropout_masks(float *out, const size_t (&n)[3], const float (&p)[3], uint64_
                   const uint64_t *dev_stream_id, hipStream_t stream);
 // in-kernel timeline (common.h): one setter per translation unit with kernels
 int trace_set_gemm(unsigned long long *buf);
+int trace_set_gemm_wide(unsigned long long *buf);
 int trace_set_elementwise(unsigned long long *buf);
 int trace_set_loss(unsigned long long *buf);
 int trace_set_lstm_encoder(unsigned long long *buf);

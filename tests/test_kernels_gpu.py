@@ -69,6 +69,41 @@ def test_gemm_epilogues_and_split_k(lib):
     assert got[:, :5].abs().max().item() == 0 and got[:, 5 + N:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("M,N,K,layout,split", [
+    (32768, 400, 150, "nt", 1),     # 256 x 5 wide tiles, 8-byte loads (rows of 150 floats), nf = 5
+    (32768, 100, 100, "nt", 1),     # too few tiles for the rule alone: rides on the 64-row tiles
+    (65536, 240, 96, "nn", 1),      # 512 x 3 tiles, row-contiguous B, nf = 5
+    (4096, 4096, 70, "tn", 1),      # both operands row-contiguous (weight-gradient layout), ragged K
+    (2048, 1040, 4096, "tn", 8),    # split-K with atomics on wide tiles: 16 x 9 x 8 slices
+])
+def test_gemm_tall_products_take_wide_tiles(lib, M, N, K, layout, split):
+    """Launches with >= 1024 tiles of 128 x (16 nf) go to gemm_wide_kernel (csrc/gemm_wide.hip); same contract."""
+    import gpu_ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    Ad = dev(A) if layout[0] == "n" else dev(A.t().contiguous()).t()
+    Bd = dev(B) if layout[1] == "n" else dev(B.t().contiguous()).t()
+    Cd = torch.zeros(M, N, device="cuda")
+    kw = dict(beta=1.0, split_k=split) if split > 1 else {}
+    gpu_ops.gemm((Ad, 0, Ad.stride(0), Ad.stride(1)), (Bd, 0, Bd.stride(0), Bd.stride(1)), (Cd, 0, N), M, N, K, **kw)
+    ref = (dev(A).double() @ dev(B).double())
+    err = (Cd.double() - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, K ** 0.5), f"{layout} {M}x{N}x{K}: max err {err}"
+
+
+def test_gemm_suite_on_forced_wide_tiles():
+    """The layout / epilogue / split-K tests again in a child process with GSCAN_GEMM_WIDE=2: every product whose
+    operand layouts the wide kernel supports runs on it, whatever its size (bias, activation, mask, beta, row sums,
+    atomics, ragged edges in M, N and K)."""
+    import os, subprocess, sys
+    env = dict(os.environ, GSCAN_GEMM_WIDE="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_gemm_layouts or test_gemm_epilogues_and_split_k", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("B,G,Cc,K3,Co,density,u8", [
     (5, 6, 16, 7, 50, 0.2, False),        # the paper's shape, float32 world
     (37, 6, 16, 13, 50, 0.07, True),      # k = 13 (every cell reaches every cell), uint8 world, two backward slices

@@ -22,6 +22,8 @@ SHAPES = [  # (label, M, N, K, layout, split)
     ("dW_kv s15", 100, 150, 9216, "tn", 15), ("dW_kv s58", 100, 150, 9216, "tn", 58),
     ("dWt", 576, 5400, 256, "tn", 1), ("dW_enc s8", 400, 100, 2560, "tn", 8), ("dW_enc s16", 400, 100, 2560, "tn", 16),
     ("dxe s8", 2560, 25, 800, "nn", 8), ("4096^3", 4096, 4096, 4096, "nt", 1),
+    ("uv K152", 9216, 400, 152, "nt", 1), ("uv K160", 9216, 400, 160, "nt", 1), ("uv K128", 9216, 400, 128, "nt", 1),
+    ("uv N384", 9216, 384, 160, "nt", 1), ("ge K128", 5120, 400, 128, "nt", 1),
 ]
 REPS = 3
 
@@ -42,7 +44,7 @@ def run():
 
 def parse(path):
     import csv
-    rows = [r for r in csv.DictReader(open(path)) if "gemm_group_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "gemm_group_kernel" in r["Kernel_Name"] or "gemm_wide_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     assert len(rows) == REPS * len(SHAPES), (len(rows), len(SHAPES))
     for i, (label, M, N, K, layout, split) in enumerate(SHAPES):
