@@ -168,19 +168,6 @@ __device__ __forceinline__ void attention_scores(const float *v_s, const float *
     }
 }
 
-// global -> LDS copy of n floats (n % 4 == 0, both 16-byte aligned), four 16-byte loads in flight per thread
-__device__ __forceinline__ void stage(float *dst, const float *src, int n, int tid, int nthreads) {
-    const float4 *s4 = reinterpret_cast<const float4 *>(src);
-    float4 *d4 = reinterpret_cast<float4 *>(dst);
-    const int n4 = n >> 2;
-    int i = tid;
-    for (; i + 3 * nthreads < n4; i += 4 * nthreads) {
-        const float4 x0 = s4[i], x1 = s4[i + nthreads], x2 = s4[i + 2 * nthreads], x3 = s4[i + 3 * nthreads];
-        d4[i] = x0; d4[i + nthreads] = x1; d4[i + 2 * nthreads] = x2; d4[i + 3 * nthreads] = x3;
-    }
-    for (; i < n4; i += nthreads) d4[i] = s4[i];
-}
-
 // ------------------------------------------------------------------------------------------
 // geometry shared by the kernels, the weight-image kernel and the host
 // ------------------------------------------------------------------------------------------
@@ -236,6 +223,49 @@ __device__ __forceinline__ void quad_offset(int u_off, int pk_off, int u2_off, i
     else { off = u2_off + (col - 5 * H); stride = H; }
 }
 
+// global -> LDS copy of up to five arrays (each n % 4 == 0 floats, 16-byte aligned on both sides) as ONE index space:
+// a thread's 16-byte loads are issued eight at a time whatever array they fall into, so the row's memories arrive in
+// two or three round trips to L2 instead of one or two per array (five arrays copied one after the other, four loads
+// in flight each: ~9 dependent round trips at the benchmark shape, most of the kernels' 8 us of set-up).  The source
+// pointers are cast to the global address space: picked from a table they would be generic, and FLAT loads count
+// on lgkmcnt too, which ties every LDS store's wait to all outstanding loads.
+struct StageList {       // plain scalars: arrays indexed by a per-lane segment number would live in scratch memory
+    const float *p0, *p1, *p2, *p3, *p4;
+    int d0, d1, d2, d3, d4;     // LDS float offsets
+    int e0, e1, e2, e3, e4;     // cumulative sizes in 16-byte units
+};
+using fvec4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void stage_all(float *smem, const StageList &sl, int tid) {
+    constexpr int U = 8;
+    const int total = sl.e4;
+    for (int base = tid; base < total; base += U * kDecThreads) {
+        fvec4 x[U];
+        int at[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(base + u * kDecThreads, total - 1);            // clamped: the load is unconditional
+            const float *src = i < sl.e0 ? sl.p0 : i < sl.e1 ? sl.p1 : i < sl.e2 ? sl.p2 : i < sl.e3 ? sl.p3 : sl.p4;
+            const int first = i < sl.e0 ? 0 : i < sl.e1 ? sl.e0 : i < sl.e2 ? sl.e1 : i < sl.e3 ? sl.e2 : sl.e3;
+            const int dst = i < sl.e0 ? sl.d0 : i < sl.e1 ? sl.d1 : i < sl.e2 ? sl.d2 : i < sl.e3 ? sl.d3 : sl.d4;
+            x[u] = ((const __attribute__((address_space(1))) fvec4 *)src)[i - first];
+            at[u] = dst + 4 * (i - first);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (base + u * kDecThreads < total) *reinterpret_cast<fvec4 *>(smem + at[u]) = x[u];
+    }
+}
+__device__ __forceinline__ StageList stage_list(const DecoderArgs &a, const DecoderLds &o, int b, int H, int L, int M,
+                                                bool cond, bool uv_lds) {
+    StageList sl;
+    sl.p0 = a.u_v + (int64_t)b * M * 4 * H; sl.d0 = o.uv;  sl.e0 = uv_lds ? M * H : 0;            // 16-byte units
+    sl.p1 = a.pk_v + (int64_t)b * M * H;    sl.d1 = o.pkv; sl.e1 = sl.e0 + M * H / 4;
+    sl.p2 = a.u_t + (int64_t)b * L * 4 * H; sl.d2 = o.ut;  sl.e2 = sl.e1 + L * H;
+    sl.p3 = a.pk_t + (int64_t)b * L * H;    sl.d3 = o.pkt; sl.e3 = sl.e2 + L * H / 4;
+    sl.p4 = cond ? a.u2_t + (int64_t)b * L * H : sl.p3; sl.d4 = o.u2t; sl.e4 = sl.e3 + (cond ? L * H / 4 : 0);
+    return sl;
+}
+
 // ------------------------------------------------------------------------------------------
 // GREEDY = false: teacher forcing over the T given target tokens, everything backward needs is saved (training /
 // scoring).  GREEDY = true (predict.py:101-112): the row feeds its own argmax back for up to T steps and stops at
@@ -282,15 +312,18 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
 
     // ---- one-time loads: register image of the weights (coalesced), memories -> LDS -----------
     float w[NS][K0];
+    {   // 16-byte loads: a workgroup's request for one image step spans 8 KB (four times as many L2 channels busy as
+        // with dword loads while all 256 workgroups walk the same image at the same time)
+        static_assert(K0 % 4 == 0, "a thread's half-row is a whole number of 16-byte groups");
+        const float4 *img4 = reinterpret_cast<const float4 *>(a.w_image);
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int i = 0; i < K0; ++i) w[s][i] = a.w_image[(s * K0 + i) * kDecThreads + tid];
-    if (uv_lds) stage(Uv, a.u_v + (int64_t)b * M * 4 * H, M * 4 * H, tid, kDecThreads);
-    stage(PKv, a.pk_v + (int64_t)b * M * H, M * H, tid, kDecThreads);
-    stage(Ut, a.u_t + (int64_t)b * L * 4 * H, L * 4 * H, tid, kDecThreads);
-    stage(PKt, a.pk_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
-    if (COND) stage(U2t, a.u2_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
+        for (int q = 0; q < NS * K0 / 4; ++q) {
+            const float4 v = img4[q * kDecThreads + tid];
+            w[(4 * q) / K0][(4 * q) % K0] = v.x; w[(4 * q) / K0][(4 * q) % K0 + 1] = v.y;
+            w[(4 * q) / K0][(4 * q) % K0 + 2] = v.z; w[(4 * q) / K0][(4 * q) % K0 + 3] = v.w;
+        }
+    }
+    stage_all(smem, stage_list(a, o, b, H, L, M, COND, uv_lds), tid);
     if (tid < HP) { h_s[tid] = 0.f; q2_s[tid] = 0.f; }      // zero the padding of the dot inputs
     if (tid < 16) stamp_acc[tid] = 0.f;
     lds_barrier();
@@ -562,8 +595,12 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
               *wh_s = lg_ch + kHeadChunk * V;
         float bw[H];
         if (wave < NT) {
+            const float4 *img4 = reinterpret_cast<const float4 *>(a.head_image);
 #pragma unroll
-            for (int i = 0; i < H; ++i) bw[i] = a.head_image[i * kDecThreads + tid];
+            for (int q = 0; q < H / 4; ++q) {
+                const float4 v = img4[q * kDecThreads + tid];
+                bw[4 * q] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
+            }
         }
         for (int i = tid; i < V * H; i += kDecThreads) wh_s[i] = a.w_h2o[i];
         float nll_acc = 0.f, cnt_acc = 0.f;                  // threads < kHeadChunk (all in wave 0): get_loss terms
@@ -862,15 +899,17 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     GSCAN_STAMP_ONCE(10)
 
     float wt[NS][K0];
+    {
+        static_assert(K0 % 4 == 0, "a thread's half-column is a whole number of 16-byte groups");
+        const float4 *img4 = reinterpret_cast<const float4 *>(a.w_image);
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int i = 0; i < K0; ++i) wt[s][i] = a.w_image[(s * K0 + i) * kDecThreads + tid];
-    if (uv_lds) stage(Uv, a.u_v + (int64_t)b * M * 4 * H, M * 4 * H, tid, kDecThreads);
-    stage(PKv, a.pk_v + (int64_t)b * M * H, M * H, tid, kDecThreads);
-    stage(Ut, a.u_t + (int64_t)b * L * 4 * H, L * 4 * H, tid, kDecThreads);
-    stage(PKt, a.pk_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
-    if (COND) stage(U2t, a.u2_t + (int64_t)b * L * H, L * H, tid, kDecThreads);
+        for (int q = 0; q < NS * K0 / 4; ++q) {
+            const float4 v = img4[q * kDecThreads + tid];
+            wt[(4 * q) / K0][(4 * q) % K0] = v.x; wt[(4 * q) / K0][(4 * q) % K0 + 1] = v.y;
+            wt[(4 * q) / K0][(4 * q) % K0 + 2] = v.z; wt[(4 * q) / K0][(4 * q) % K0 + 3] = v.w;
+        }
+    }
+    stage_all(smem, stage_list(a, o, b, H, L, M, COND, uv_lds), tid);
     for (int i = tid; i < M * H; i += kDecThreads) dPKv[i] = 0.f;
     for (int i = tid; i < L * H; i += kDecThreads) dPKt[i] = 0.f;
     for (int i = tid; i < 7 * HP; i += kDecThreads) vec[i] = 0.f;        // d_s / dqv_s incl. padding

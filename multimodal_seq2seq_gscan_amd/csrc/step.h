@@ -58,10 +58,10 @@ constexpr int kDecPairs = 256;     // lane pairs; a weight row lives in one pair
 struct DecoderGeometry { int rows, slots, k0; int64_t image_floats; };
 DecoderGeometry decoder_geometry(int H, bool cond);
 // Register images of the decoder weights (written once per step, by the prologue kernel):
-//   fwd/bwd image[(slot*K0 + i)*512 + tid] = element i of the half-row that thread tid keeps in slot `slot`
+//   fwd/bwd image[((f/4)*512 + tid)*4 + f%4], f = slot*K0 + i = element i of the half-row that thread tid keeps in slot `slot`
 //     (task r = slot*256 + tid/2, position kk = (tid&1)*K0 + i along the dot); forward: row q of block sg of
 //     [W_hh (4 blocks) | W_query_text | W_q2k[:, :H] or W_query_vis | W_query_vis]; backward: column q of block sg;
-//   head image[i*512 + tid] = MFMA B fragment of the permuted output_to_hidden: wo_perm[16 w + fr][4 i + fg].
+//   head image[((i/4)*512 + tid)*4 + i%4] = MFMA B fragment of the permuted output_to_hidden: wo_perm[16 w + fr][4 i + fg].
 struct DecoderImageArgs {
     const float *w_hh, *w_qt, *w_qv, *w_q2k, *w_o2h;
     float *fwd_image, *bwd_image, *head_image;
@@ -71,8 +71,9 @@ struct DecoderImageArgs {
 // element e of the concatenation [fwd image | bwd image | head image]
 __device__ __forceinline__ void decoder_image_element(const DecoderImageArgs &a, int e) {
     const int H = a.H, total = a.slots * a.k0 * kDecThreads;
+    // every image is stored in 16-byte groups: element i of thread tid sits at ((i / 4) * 512 + tid) * 4 + i % 4
     if (e >= 2 * total) {
-        const int x = e - 2 * total, tid = x % kDecThreads, i = x / kDecThreads;
+        const int x = e - 2 * total, tid = (x >> 2) % kDecThreads, i = 4 * (x / (4 * kDecThreads)) + (x & 3);
         const int n = 16 * (tid >> 6) + (tid & 15), k = 4 * i + ((tid >> 4) & 3);     // wo_perm[n][k], k in S order
         float v = 0.f;
         if (n < H) {
@@ -85,7 +86,7 @@ __device__ __forceinline__ void decoder_image_element(const DecoderImageArgs &a,
     }
     const bool bwd = e >= total;
     const int x = bwd ? e - total : e;
-    const int tid = x % kDecThreads, i = (x / kDecThreads) % a.k0, s = x / (kDecThreads * a.k0);
+    const int tid = (x >> 2) % kDecThreads, f = 4 * (x / (4 * kDecThreads)) + (x & 3), i = f % a.k0, s = f / a.k0;
     const int r = s * kDecPairs + (tid >> 1), kk = (tid & 1) * a.k0 + i;               // kk: position along the dot
     float v = 0.f;
     const int rows = (a.cond ? 7 : 6) * H;
