@@ -216,7 +216,8 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 // Step prologue: everything that only rearranges parameters or gathers embeddings, in ONE launch.
 //   seg 0  bsum[4H]            = dec_b_ih + dec_b_hh
 //   seg 1  wo_perm[H,4H]       = W_o2h with its columns [e|h|ctx_t|ctx_v] reordered to S order [e|ctx_t|ctx_v|h]
-//   seg 2  wih_stack[D*4He,E]  = [W_ih_fwd ; W_ih_rev]   (one GEMM then gives dXe for both directions)
+//   seg 2  wih_stack[D*4He,E]  = [W_ih_fwd ; W_ih_rev]   (one GEMM then gives dXe for both directions), and its
+//          per-direction transpose wih_t[D][E][4He] (lstm_encoder.hip's input projection)
 //   seg 3  dwo_perm[H,4H]      = 0   (gradient scratch of wo_perm, filled by a split-K GEMM in backward)
 //   seg 4  xe[B*L,E]           = dropout(Emb_enc[commands])      seq2seq_model.py:58-59
 //   seg 5  S[:, 0:H]           = dropout(Emb_dec[targets])       seq2seq_model.py:383-384
@@ -245,8 +246,20 @@ __global__ void prologue_kernel(PrologueArgs a) {
             a.wo_perm[i] = a.w_o2h[(int64_t)row * 4 * H + src];
         } else if (idx < a.end[2]) {
             const int64_t i = idx - a.end[1];
-            const int64_t per = (int64_t)4 * a.He * a.E;
-            a.wih_stack[i] = (i < per) ? a.w_ih_f[i] : a.w_ih_r[i - per];
+            const int64_t per = (int64_t)4 * a.He * a.E, nw = (int64_t)a.D * per;
+            // wih_t: the same weights column-major per direction with the bias sum as one more column,
+            // [dir][E + 1][4He]: the A operand of the first encoder layer's own input projection (lstm_encoder.hip;
+            // its B operand carries a row of ones)
+            if (i < nw) {
+                const float v = (i < per) ? a.w_ih_f[i] : a.w_ih_r[i - per];
+                a.wih_stack[i] = v;
+                const int dir = i >= per, r = (int)((i - dir * per) / a.E), e = (int)((i - dir * per) % a.E);
+                a.wih_t[((int64_t)dir * (a.E + 1) + e) * 4 * a.He + r] = v;
+            } else {
+                const int dir = (int)((i - nw) / (4 * a.He)), r = (int)((i - nw) % (4 * a.He));
+                a.wih_t[((int64_t)dir * (a.E + 1) + a.E) * 4 * a.He + r] =
+                    dir ? a.enc_b_ih_r[r] + a.enc_b_hh_r[r] : a.enc_b_ih_f[r] + a.enc_b_hh_f[r];
+            }
         } else if (idx < a.end[3]) {
             a.dwo_perm[idx - a.end[2]] = 0.f;
         } else if (idx < a.end[4]) {

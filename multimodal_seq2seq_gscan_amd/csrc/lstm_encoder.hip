@@ -42,6 +42,12 @@ __device__ __forceinline__ void dots_lds(const float (&w)[R][HE], const float *v
     for (int r = 0; r < R; ++r) out[r] = a0[r] + a1[r];
 }
 
+#ifdef GSCAN_ENC_STAMPS   // experiment build: cycle stamps of workgroup (0,0), in the tail of the trace buffer
+#define EST(i) if (g_trace_buf && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { const long long n_ = clock64(); g_trace_buf[1520 + i] += (unsigned long long)(n_ - est_prev); est_prev = n_; }
+#else
+#define EST(i)
+#endif
+
 template <int HE> struct EncShape {
     static constexpr int R = HE <= 100 ? 2 : 1;                       // weight rows (forward) / columns (backward) per thread
     static constexpr int kThreads = ((4 * HE / R + 63) / 64) * 64;
@@ -58,7 +64,7 @@ template <int HE> struct EncShape {
 //   backward  d_s [len][4He] gate activations  ->  gate pre-activation gradients (in place)
 //             c_s [len][He] cells, o_s [len][He] gradient wrt the summed outputs, part_s [4He] partial dh
 constexpr size_t kEncLdsLimit = 160 * 1024;
-inline size_t encoder_fwd_lds(int L, int HE, int E = 0) { return ((size_t)L * 6 * HE + HE + (size_t)((L + 7) & ~7) * E) * sizeof(float); }
+inline size_t encoder_fwd_lds(int L, int HE, int E = 0) { return ((size_t)L * 6 * HE + HE + (size_t)((L + 15) & ~15) * (E ? E + 1 : 0)) * sizeof(float); }
 inline size_t encoder_bwd_lds(int L, int HE) { return ((size_t)L * 6 * HE + 4 * HE) * sizeof(float); }
 
 // grid (B, D): the two directions of a row run as two workgroups (they only meet in the sums below).
@@ -85,6 +91,9 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
     float *g_s = lds, *c_s = g_s + len * 4 * HE, *h_s = c_s + len * HE, *z_s = h_s + len * HE;
     const bool is_gate = j < NT, is_unit = j < HE;
     const int64_t row0 = (int64_t)b * L;                             // row of (b, t, dir) = (row0 + t) * D + dir
+#ifdef GSCAN_ENC_STAMPS
+    long long est_prev = clock64();
+#endif
 
     if (in.x) {
         // the first layer projects its own input: g_s[t][row] = W_ih[row] . x[b,t] + b_ih[row] + b_hh[row]
@@ -92,37 +101,56 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
         // thread computes the projections of the gate rows it owns, so nothing crosses threads but x — and the
         // launch that used to compute them for the whole batch is off the critical chain of the step.
         const int E = in.E;
-        float *x_s = z_s + HE;                                       // [E][LP] time-contiguous, LP = len rounded up to 8
-        const int LP = (len + 7) & ~7;
-        for (int idx = j; idx < LP * E; idx += nthr) {
+        float *x_s = z_s + HE;                                       // [E][LP] time-contiguous, LP = len rounded up to 16
+        const int LP = (len + 15) & ~15;
+        for (int idx = j; idx < LP * (E + 1); idx += nthr) {         // row E: ones (the bias column of the image)
             const int e = idx / LP, t = idx - e * LP;
-            x_s[idx] = t < len ? in.x[(row0 + t) * E + e] : 0.f;
+            x_s[idx] = t < len ? (e < E ? in.x[(row0 + t) * E + e] : 1.f) : 0.f;
         }
         lds_barrier();
-        if (is_gate) {
-            const float *w_ih = dir ? in.w_ih_r : in.w_ih_f, *b_ih = dir ? in.b_ih_r : in.b_ih_f;
-            const float *b_hh = dir ? b_hh_r : b_hh_f;
+        EST(0)
+        {
+            // [4He rows] x [len steps] x [E]: a tile of 16 gate rows x 16 time steps per wave on the matrix cores, A
+            // fragments from the column-major image of W_ih the prologue writes (a lane group reads 16 consecutive
+            // rows: 64-byte pieces), B fragments = x from LDS.  As per-thread FMAs (a thread per gate row, x broadcast
+            // from LDS) this phase took 12-13 000 of the kernel's 45 000 cycles whichever way its loads were arranged
+            // (tools/encoder_stamps.py): 800 FMAs and 100 broadcast b128 reads per thread, two workgroups per CU.
+            using f32x4 = __attribute__((ext_vector_type(4))) float;
+            const int EK = E + 1;                                    // K of the product: E inputs and the bias column
+            const float *wt = in.w_ih_t + (int64_t)dir * EK * 4 * HE;
+            const int lane = j & 63, wave = j >> 6, fr = lane & 15, fg = lane >> 4;
+            constexpr int NTILE = 4 * HE / 16, SU = 8, NW = EncShape<HE>::kThreads / 64, TPW = (NTILE + NW - 1) / NW;
+            static_assert(HE % 4 == 0, "gate rows come in whole tiles of 16");
+            // every global load of a wave's tiles (A fragments of up to 32 columns) is issued before the first MFMA: a
+            // tile at a time, each tile waited out its own L2 round trip (~1 200 cycles)
+            for (int t0 = 0; t0 < len; t0 += 16) {
+                f32x4 c[TPW];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int gr = j + r * NT;
-                const float *wrow = w_ih + (int64_t)gr * E;
-                const float bias = b_ih[gr] + b_hh[gr];
-                for (int t0 = 0; t0 < len; t0 += 8) {                // eight time steps per pass over the weight row
-                    float acc[8];
+                for (int i = 0; i < TPW; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int s0 = 0; 4 * s0 < EK; s0 += SU) {
+                    float av[TPW][SU], bv[SU];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) acc[u] = bias;
-                    for (int e = 0; e < E; ++e) {
-                        const float wv = wrow[e];
-                        const float4 x0 = *reinterpret_cast<const float4 *>(x_s + e * LP + t0);
-                        const float4 x1 = *reinterpret_cast<const float4 *>(x_s + e * LP + t0 + 4);
-                        acc[0] = fmaf(wv, x0.x, acc[0]); acc[1] = fmaf(wv, x0.y, acc[1]);
-                        acc[2] = fmaf(wv, x0.z, acc[2]); acc[3] = fmaf(wv, x0.w, acc[3]);
-                        acc[4] = fmaf(wv, x1.x, acc[4]); acc[5] = fmaf(wv, x1.y, acc[5]);
-                        acc[6] = fmaf(wv, x1.z, acc[6]); acc[7] = fmaf(wv, x1.w, acc[7]);
+                    for (int u = 0; u < SU; ++u) {
+                        const int k = 4 * (s0 + u) + fg, kc = min(k, EK - 1);
+                        bv[u] = (k < EK) ? x_s[kc * LP + t0 + fr] : 0.f;         // x_s is zero at steps >= len
+#pragma unroll
+                        for (int i = 0; i < TPW; ++i)
+                            av[i][u] = wt[(int64_t)kc * 4 * HE + 16 * min(wave + i * NW, NTILE - 1) + fr];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (t0 + u < len) g_s[(t0 + u) * 4 * HE + gr] = acc[u];
+                    for (int u = 0; u < SU; ++u)
+#pragma unroll
+                        for (int i = 0; i < TPW; ++i)
+                            c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u], bv[u], c[i], 0, 0, 0);
+                }
+                const int t = t0 + fr;                               // C: column = time step, rows 4 fg + r of the tile
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int tile = wave + i * NW;
+                    if (t < len && tile < NTILE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g_s[t * 4 * HE + 16 * tile + 4 * fg + r] = c[i][r];
+                    }
                 }
             }
         }
@@ -136,6 +164,7 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
             *reinterpret_cast<float4 *>(g_s + t * 4 * HE + 4 * q) = float4{x.x + bb.x, x.y + bb.y, x.z + bb.z, x.w + bb.w};
         }
     }
+    EST(1)
     // padded positions: zero saved h_prev (it multiplies delta = 0 in a GEMM later); out stays zero
     for (int idx = j; idx < (L - len) * HE; idx += nthr) {
         const int t = len + idx / HE, k = idx % HE;
@@ -157,6 +186,7 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
     float c = 0.f;
     const float *h_prev = z_s;
     lds_barrier();
+    EST(2)
     for (int s = 0; s < len; ++s) {
         const int t = dir ? (len - 1 - s) : s;
         float *g = g_s + t * 4 * HE;
@@ -180,6 +210,7 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
         h_prev = h_s + t * HE;
         lds_barrier();
     }
+    EST(3)
     // write-back: saved activations for the backward pass, the direction sums (atomics: two addends commute)
     for (int idx = j; idx < len * HE; idx += nthr) {
         const int t = idx / HE, q = idx - t * HE;
@@ -196,6 +227,7 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_ke
         if (hcat) hcat[row * HE + k] = hcat_mask ? h_s[idx] * hcat_mask[row * HE + k] : h_s[idx];
     }
     if (h_final && is_unit && len > 0) atomicAdd(h_final + (int64_t)b * HE + j, h_s[(dir ? 0 : len - 1) * HE + j]);
+    EST(4)
 }
 
 // Backward: thread (seg, q) owns columns q + r*(He/R), r < R, of block seg of W_hh (its R dot products share the
@@ -371,8 +403,8 @@ int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int
     GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm: bad dims B=%d L=%d D=%d", B, L, D);
     EncInput in{};
     if (input) in = *input;
-    GSCAN_CHECK(!in.x || (in.E > 0 && in.w_ih_f && in.b_ih_f && (D == 1 || (in.w_ih_r && in.b_ih_r))),
-                "encoder lstm: input projection requested without its weights");
+    GSCAN_CHECK(!in.x || (in.E > 0 && in.w_ih_t),
+                "encoder lstm: the first layer's own input projection needs the column-major image of [W_ih | b_ih + b_hh]");
     GSCAN_CHECK(in.x || gx, "encoder lstm: neither input projections nor inputs given");
     GSCAN_CHECK(hcat || (out && h_final), "encoder lstm: neither direction sums nor per-direction outputs requested");
     GSCAN_CHECK(D == 1 || (w_hh_r && b_hh_r), "encoder lstm: reverse weights missing");

@@ -116,7 +116,7 @@ int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mas
 struct PrologueArgs {
     const float *b_ih, *b_hh, *w_o2h, *w_ih_f, *w_ih_r, *enc_emb, *dec_emb, *mask_enc, *mask_dec;
     const int64_t *commands, *targets;
-    float *bsum, *wo_perm, *wih_stack, *dwo_perm, *xe, *S, *wcat5, *zero_extra;
+    float *bsum, *wo_perm, *wih_stack, *wih_t, *dwo_perm, *xe, *S, *wcat5, *zero_extra;
     const float *w_ih_dec, *w_q2k;
     int cond;
     int64_t zero_extra_count;
@@ -125,6 +125,7 @@ struct PrologueArgs {
     DecoderImageArgs img;
     // seg 9: register image of the encoder's recurrent weights, [dir][r][k][thread] (lstm_encoder.hip)
     const float *enc_w_hh_f, *enc_w_hh_r;
+    const float *enc_b_ih_f, *enc_b_hh_f, *enc_b_ih_r, *enc_b_hh_r;      // first layer: folded into wih_t (seg 2)
     float *enc_image;
     int enc_rows;                          // weight rows per thread
     // seg 10: [tap][ch][o] image of the three convolution kernels (conv.hip)
@@ -209,7 +210,9 @@ int sequence_metrics(const float *logp, const int64_t *targets, int B, int T, in
 // lstm_encoder.hip
 bool hidden_size_supported(int h);
 // x != NULL: the kernel projects its own input x [B,L,E] through W_ih (+ b_ih) instead of reading gx (first layer)
-struct EncInput { const float *x; int E; const float *w_ih_f, *b_ih_f, *w_ih_r, *b_ih_r; };
+// w_ih_t: the input weights column-major per direction plus the bias sums, [dir][E + 1][4He] (prologue seg 2): what
+// the kernel multiplies by
+struct EncInput { const float *x; int E; const float *w_ih_f, *b_ih_f, *w_ih_r, *b_ih_r; const float *w_ih_t; };
 int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int32_t *lengths, const float *w_hh_f,
                          const float *b_hh_f, const float *w_hh_r, const float *b_hh_r, float *out, float *h_final,
                          float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream,
@@ -309,7 +312,7 @@ struct Workspace {
     int64_t feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, row_stats, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
-        wo_perm, dwo_perm, wih_stack, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, conv_img, conv_lists, wcat5,
+        wo_perm, dwo_perm, wih_stack, wih_t, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, conv_img, conv_lists, wcat5,
         deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image,   // encoder layers below the last
         ge_table, head_wc;        // greedy decoding: [V,4H] tables
     WorkspaceSlot slot[96];

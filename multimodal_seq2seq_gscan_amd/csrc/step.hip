@@ -60,6 +60,7 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(wo_perm, H * 4 * H);
     SLOT(dwo_perm, H * 4 * H);
     SLOT(wih_stack, D * 4 * He * E);
+    SLOT(wih_t, D * 4 * He * (E + 1));
     SLOT(w_sk, 4 * H * F);
     SLOT(w_ck, 4 * H * He);
     SLOT(w_2kk, H * He);
@@ -275,7 +276,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.w_ih_f = p.enc_w_ih; a.w_ih_r = p.enc_w_ih_rev; a.enc_emb = p.enc_emb; a.dec_emb = p.dec_emb;
         a.mask_enc = mk.enc; a.mask_dec = mk.dec; a.commands = bt.commands;
         a.targets = teacher_forced ? bt.targets : nullptr;
-        a.bsum = w + ws.bsum; a.wo_perm = w + ws.wo_perm; a.wih_stack = w + ws.wih_stack;
+        a.bsum = w + ws.bsum; a.wo_perm = w + ws.wo_perm; a.wih_stack = w + ws.wih_stack; a.wih_t = w + ws.wih_t;
         a.dwo_perm = w + ws.dwo_perm; a.xe = w + ws.xe; a.S = w + ws.S;
         a.H = H; a.He = He; a.E = E; a.D = D; a.BL = B * L; a.BT = B * T; a.Vi = d.Vi; a.V = V;
         a.wcat5 = w + ws.wcat5; a.w_ih_dec = p.dec_w_ih; a.w_q2k = p.q2k_w; a.cond = cond ? 1 : 0;
@@ -285,12 +286,13 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.img = DecoderImageArgs{p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, p.out2hid_w, w + ws.dec_w_fwd,
                                  w + ws.dec_w_bwd, w + ws.dec_w_head, H, cond ? 1 : 0, geo.slots, geo.k0};
         a.enc_w_hh_f = p.enc_w_hh; a.enc_w_hh_r = p.enc_w_hh_rev; a.enc_image = w + ws.enc_w_image;
+        a.enc_b_ih_f = p.enc_b_ih; a.enc_b_hh_f = p.enc_b_hh; a.enc_b_ih_r = p.enc_b_ih_rev; a.enc_b_hh_r = p.enc_b_hh_rev;
         a.enc_rows = encoder_rows_per_thread(He);
         a.conv_w[0] = p.conv1_w; a.conv_w[1] = p.conv2_w; a.conv_w[2] = p.conv3_w;
         a.conv_img = w + ws.conv_img; a.cC = C; a.cCo = Co; a.cK3 = d.K3;
         a.w_key_vis = p.vis_key_w; a.w_key_txt = p.txt_key_w; a.F = F;
         a.w_sk = w + ws.w_sk; a.w_ck = w + ws.w_ck; a.w_2kk = w + ws.w_2kk;
-        const int64_t n[14] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * E, (int64_t)H * 4 * H,
+        const int64_t n[14] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * (E + 1), (int64_t)H * 4 * H,
                                given ? 0 : (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
                                a.zero_extra_count, 2 * geo.image_floats + (int64_t)H * kDecThreads,
                                (int64_t)D * 4 * He * He, given ? 0 : conv_image_floats(C, Co, d.K3),
@@ -391,7 +393,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
             }
             // the first layer projects its own input (the embedded command, E floats per token) inside the recurrent
             // kernel: no launch between the prologue and the recurrence; deeper layers read the GEMM above
-            const EncInput own{w + ws.xe, E, q.w_ih, q.b_ih, q.w_ih_rev, q.b_ih_rev};
+            const EncInput own{w + ws.xe, E, q.w_ih, q.b_ih, q.w_ih_rev, q.b_ih_rev, w + ws.wih_t};
             const EncInput *input = l == 0 ? &own : nullptr;
             if (last) {
                 TRY(encoder_lstm_forward(B, L, He, D, w + ws.gx, bt.cmd_lengths, q.w_hh, q.b_hh, q.w_hh_rev, q.b_hh_rev,
