@@ -23,23 +23,24 @@ namespace gscan {
 template <int HE, int R>
 __device__ __forceinline__ void dots_lds(const float (&w)[R][HE], const float *v, float (&out)[R]) {
     static_assert(HE % 4 == 0, "hidden size must be a multiple of 4");
-    float a0[R], a1[R];
+    // packed FMAs (v_pk_fma_f32: two lanes of a register pair per instruction): with two workgroups per CU the
+    // recurrence's step was bound by the issue of these FMAs (2 waves x 200 scalar FMAs x 4 cycles of the ~2 000 per step)
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    f32x2 a01[R], a23[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) a0[r] = a1[r] = 0.f;
+    for (int r = 0; r < R; ++r) { a01[r] = f32x2{0.f, 0.f}; a23[r] = f32x2{0.f, 0.f}; }
     const float4 *v4 = reinterpret_cast<const float4 *>(v);
 #pragma unroll
     for (int i = 0; i < HE / 4; ++i) {
         const float4 x = v4[i];
 #pragma unroll
         for (int r = 0; r < R; ++r) {              // R * 2 independent chains: enough to cover the FMA latency
-            a0[r] = fmaf(w[r][4 * i + 0], x.x, a0[r]);
-            a1[r] = fmaf(w[r][4 * i + 1], x.y, a1[r]);
-            a0[r] = fmaf(w[r][4 * i + 2], x.z, a0[r]);
-            a1[r] = fmaf(w[r][4 * i + 3], x.w, a1[r]);
+            a01[r] += f32x2{w[r][4 * i + 0], w[r][4 * i + 1]} * f32x2{x.x, x.y};
+            a23[r] += f32x2{w[r][4 * i + 2], w[r][4 * i + 3]} * f32x2{x.z, x.w};
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) out[r] = a0[r] + a1[r];
+    for (int r = 0; r < R; ++r) out[r] = (a01[r][0] + a23[r][0]) + (a01[r][1] + a23[r][1]);
 }
 
 #ifdef GSCAN_ENC_STAMPS   // experiment build: cycle stamps of workgroup (0,0), in the tail of the trace buffer

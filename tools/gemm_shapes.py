@@ -24,6 +24,9 @@ SHAPES = [  # (label, M, N, K, layout, split)
     ("dxe s8", 2560, 25, 800, "nn", 8), ("4096^3", 4096, 4096, 4096, "nt", 1),
     ("uv K152", 9216, 400, 152, "nt", 1), ("uv K160", 9216, 400, 160, "nt", 1), ("uv K128", 9216, 400, 128, "nt", 1),
     ("uv N384", 9216, 384, 160, "nt", 1), ("ge K128", 5120, 400, 128, "nt", 1),
+    ("dW_ih s8 @32", 400, 300, 5120, "tn", 8), ("dW_hh s8 @32", 400, 100, 5120, "tn", 8), ("dW_qt s8 @32", 100, 100, 5120, "tn", 8),
+    ("dS+= @32", 5120, 300, 500, "nn", 1), ("uv @32", 9216, 400, 150, "nt", 1), ("ge @32", 5120, 400, 100, "nt", 1),
+    ("de", 5120, 100, 400, "nn", 1), ("de @32", 5120, 100, 400, "nn", 1),
 ]
 REPS = 3
 
@@ -32,8 +35,9 @@ def run():
     import torch
     import gpu_ops
     for label, M, N, K, layout, split in SHAPES:
-        A = torch.randn(M, K, device="cuda") if layout[0] == "n" else torch.randn(K, M, device="cuda").t()
-        B = torch.randn(K, N, device="cuda") if layout[1] == "n" else torch.randn(N, K, device="cuda").t()
+        pad = (lambda n: (n + 31) // 32 * 32) if label.endswith("@32") else (lambda n: n)    # row pitch padded to 128 bytes
+        A = torch.randn(M, pad(K), device="cuda")[:, :K] if layout[0] == "n" else torch.randn(K, pad(M), device="cuda")[:, :M].t()
+        B = torch.randn(K, pad(N), device="cuda")[:, :N] if layout[1] == "n" else torch.randn(N, pad(K), device="cuda")[:, :K].t()
         Cm = torch.zeros(M, N, device="cuda")
         args = ((A, 0, A.stride(0), A.stride(1)), (B, 0, B.stride(0), B.stride(1)), (Cm, 0, N), M, N, K)
         kw = dict(beta=1.0, split_k=split) if split > 1 else {}
