@@ -47,8 +47,13 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
 
     PanelIter<BM, BK, KCA, VWA> pa;
     PanelIter<BN, BK, KCB, VWB> pb;
+#ifdef GSCAN_GEMM_SAMEPANEL   // timing experiment (wrong results): every workgroup reads tile (0, 0)'s panels: L1 / L2 hits only
+    pa.init(g.a, g.sam, g.sak, g.M, 0, 1 << (g.flags & 3), kbeg, kend, tid);
+    pb.init(g.b, g.sbn, g.sbk, g.N, 0, 1 << ((g.flags >> 2) & 3), kbeg, kend, tid);
+#else
     pa.init(g.a, g.sam, g.sak, g.M, m0, 1 << (g.flags & 3), kbeg, kend, tid);
     pb.init(g.b, g.sbn, g.sbk, g.N, n0, 1 << ((g.flags >> 2) & 3), kbeg, kend, tid);
+#endif
 
     f32x4 acc[TMW][TNW];
 #pragma unroll
