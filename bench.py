@@ -3,6 +3,7 @@
 batches, one process per GPU.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus N ...        (no launcher: starts N fresh rank processes itself, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -205,6 +206,61 @@ def batcher_leg(args, cfg: dict, n_params: int) -> dict:
                     "resident = the last full batch of the run repeated from HBM"}
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh processes of this same command with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's JSON line, fail if any rank fails.  The parent
+    never touches the device (torch.cuda.device_count() does not initialise it); the children are ordinary rank
+    processes, exactly what torch.distributed.run would have started."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if args.backend == "nccl" and not args.dry_launch:
+        visible = torch.cuda.device_count()
+        if n > visible:
+            print(f"bench.py: --gpus {n} but only {visible} HIP device(s) are visible: one rank per GPU (RCCL refuses "
+                  f"two ranks on one device)", file=sys.stderr, flush=True)
+            return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=120))
+        except subprocess.TimeoutExpired:      # a rank that outlives rank 0 by two minutes is stuck in a collective
+            p.kill()
+            codes.append(p.wait())
+    for line in out.decode(errors="replace").splitlines():
+        # ONE JSON line is the contract; anything else a library wrote to rank 0's stdout (gloo's connection notes) is
+        # passed on to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr, flush=True)
+        return next(c for c in codes if c) or 1
+    return 0
+
+
+def dry_launch(args, world: int, rank: int) -> None:
+    """--dry-launch: the rank plumbing only (rendezvous, a barrier, one all-reduce), no model and no device: what the
+    CPU test of the self-launcher runs with --backend gloo."""
+    dist.init_process_group(backend=args.backend)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "backend": args.backend, "rank_sum": float(t.item())}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,19 +279,38 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--graph", action="store_true",
                     help="replay captured HIP graphs instead of launching eagerly (pays off once the host is the limiter)")
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="distinct resident batches the steps cycle through (1 = the same batch every step)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = rehearsal "
+                         "(gradients staged through the host, ranks may share a device)")
+    ap.add_argument("--dry-launch", action="store_true", help="N > 1: exercise the rank plumbing only (no device)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become one.  Nothing above this line has touched the device.
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
+                         f"--nproc-per-node {args.gpus}, or without a launcher at all")
+    if args.dry_launch:
+        return dry_launch(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the HIP device (the product path has no CPU fallback)")
+    if args.backend == "gloo":
+        local %= torch.cuda.device_count()                # rehearsal: ranks may share a device
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group(backend="nccl")          # RCCL over xGMI
+        # "nccl" IS RCCL on ROCm.  The process group carries the rendezvous, the barriers and the max-over-ranks of the
+        # timings; the gradient all-reduce itself runs through the library's own communicator on the step's stream
+        # (train.RcclCommunicator), created from this group.
+        dist.init_process_group(backend=args.backend, **({"device_id": torch.device("cuda", local)}
+                                                         if args.backend == "nccl" else {}))
 
     from multimodal_seq2seq_gscan_amd import _lib
     from multimodal_seq2seq_gscan_amd.config import model_kwargs
@@ -251,8 +326,19 @@ def main():
                   max_command=args.command_length, max_target=args.target_length, ragged=args.ragged)
     torch.manual_seed(42)                                 # identical initialisation on every rank (train.py:27)
     model = Model(**cfg).cuda()
-    batch = {k: v.cuda() for k, v in make_batch(shape, seed=1234 + rank).items()}   # resident in HBM
-    batch["cmd_lengths"] = batch["cmd_lengths"].to(torch.int32)
+    # --rotate K distinct batches, all resident in HBM before the timed region; the steps cycle through them
+    batches = []
+    for k in range(max(1, args.rotate)):
+        b = {key: v.cuda() for key, v in make_batch(shape, seed=1234 + rank + 1000 * k).items()}
+        b["cmd_lengths"] = b["cmd_lengths"].to(torch.int32)
+        batches.append(b)
+    batch = batches[0]
+    taken = [0]
+
+    def next_batch():
+        taken[0] += 1
+        return batches[taken[0] % len(batches)]
+
     step = TrainStep(model, learning_rate=1e-3, graph=args.graph)
 
     def fence():
@@ -262,14 +348,15 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(batch)
+        step(next_batch())
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step(batch)
+        out = step(next_batch())
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tdev = "cpu" if args.backend == "gloo" else "cuda"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -280,23 +367,23 @@ def main():
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step(batch)
+            step(next_batch())
         fence()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=tdev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         windows.append(1e3 * float(t.item()) / args.steps)
 
     # second pass over the same K steps, launched eagerly, with HIP-event probes around each kernel family
     # (events cannot be read back from inside a captured graph)
-    probe_step = TrainStep(model, learning_rate=1e-3, graph=False)
+    probe_step = TrainStep(model, learning_rate=1e-3, graph=False) if args.graph else step
     for _ in range(3):
-        probe_step(batch)
+        probe_step(next_batch())
     torch.cuda.synchronize()
     lib.gscan_probe_reset()
     lib.gscan_probe_enable(1)
     for _ in range(args.steps):
-        probe_step(batch)
+        probe_step(next_batch())
     torch.cuda.synchronize()
     lib.gscan_probe_enable(0)
     families = {}
@@ -319,8 +406,22 @@ def main():
     if rank == 0:
         B, L, T = args.batch, args.command_length, args.target_length
         ex_per_s = world * B * args.steps / elapsed
-        dominant = max(families, key=lambda k: families[k]["ms_per_step"])
+        # The roofline block prices the GEMM family (the conv + LSTM + projection products north_star's MFMA target
+        # names).  So that the line cannot flatter: `families_ranked` lists EVERY family by time per step with its
+        # own algorithmic TFLOP/s and fraction of the same peak, the two persistent decoder kernels summed as one
+        # family (together they are the largest consumer).
+        dominant = "gemm" if "gemm" in families else max(families, key=lambda k: families[k]["ms_per_step"])
         d = families[dominant]
+        merged = dict(families)
+        if "decoder_forward" in merged and "decoder_backward" in merged:
+            f, b = merged.pop("decoder_forward"), merged.pop("decoder_backward")
+            ms = f["ms_per_step"] + b["ms_per_step"]
+            alg = f["tflops"] * f["ms_per_step"] + b["tflops"] * b["ms_per_step"]      # TFLOP/s x ms = GFLOP per step
+            merged["decoder_pair"] = {"ms_per_step": ms, "launches_per_step": f["launches_per_step"] + b["launches_per_step"],
+                                      "tflops": alg / ms if ms > 0 else 0.0}
+        ranked = [{"family": k, "ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": round(v["launches_per_step"], 2),
+                   "algorithmic_tflops": round(v["tflops"], 3), "frac_of_fp32_peak": round(v["tflops"] / PEAK_FP32_TFLOPS, 4)}
+                  for k, v in sorted(merged.items(), key=lambda kv: -kv[1]["ms_per_step"])]
         mflop = algorithmic_mflop_per_example(cfg, grid, L, T)
         traffic, traffic_source = pmc_traffic(dominant, args.workload if not args.auxiliary and T == 20 else "other")
         windows_sorted = sorted(windows)
@@ -340,7 +441,11 @@ def main():
                                    f"dropout {cfg['encoder_dropout_p']}/{cfg['decoder_dropout_p']}/{cfg['cnn_dropout_p']}, "
                                    f"conditional attention{', auxiliary head' if args.auxiliary else ''}, Adam+LR step included",
                        "global_batch": world * B, "parallelism": f"dp{world}", "parameters": model.flat_parameters.numel(),
-                       "launch": "hipGraph replay (3 graphs per step)" if args.graph else "eager, 19 launches per step (forward on the caller's stream, backward on 3 streams)"},
+                       "launch": "hipGraph replay (3 graphs per step)" if args.graph else "eager (forward on the caller's stream, backward on 3 streams)",
+                       "resident_batches": len(batches),
+                       "gradient_exchange": (None if world == 1 else
+                                             "gscan_allreduce_f32: RCCL on the step's stream" if step.exchange.comm is not None
+                                             else f"torch.distributed {args.backend}")},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(d["tflops"], 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_FP32_TFLOPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": round(d["avg_us"], 2),
@@ -350,6 +455,7 @@ def main():
                                  "U-image products not counted; per-launch list in DESIGN.md 5) / their HIP-event time; fp32 "
                                  "matrix peak = fp32 vector peak on gfx950; traffic = HBM-side bytes per launch from the "
                                  "rocprofv3 PMC passes named in traffic_source, null when that profile is stale"},
+            "families_ranked": ranked,
             "kernel_families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in families.items()},
             "step_algorithmic_tflops": round(ex_per_s * mflop / 1e6, 3),
             "final_loss": round(loss, 4),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 7
+#define GSCAN_ABI_VERSION 8
 #define GSCAN_MAX_ENC_LAYERS 4
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
@@ -246,6 +246,22 @@ int gscan_dropout_masks(float *out, size_t n_cnn, size_t n_enc, size_t n_dec, fl
 
 /* Counter-based (Philox-4x32-10) scaled dropout mask: out[i] = keep ? 1/(1-p) : 0. */
 int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, void *stream);
+
+/* ---- data-parallel gradient exchange (NOT in the reference, which is single-process: seq2seq/train.py:24,65;
+ * SURVEY.md 8(b) `flat_allreduce`, 8(e)).  One RCCL communicator per process (one process per GPU); the all-reduce
+ * is enqueued on the CALLER'S stream, between gscan_backward_nll and gscan_adam_step_mean, so the step needs no
+ * hop to a communication stream.  RCCL is resolved at run time from the librccl.so.1 the process already holds
+ * (PyTorch-ROCm's); these four calls fail with a message when there is none, nothing else in the library needs it.
+ *   rank 0:     gscan_comm_unique_id(id)  -> ship the GSCAN_COMM_ID_BYTES bytes to every rank (any side channel:
+ *                                            the torch.distributed store, MPI, a file)
+ *   every rank: hipSetDevice(local GPU); gscan_comm_init(&comm, nranks, rank, id)   (collective: blocks until all join)
+ *   every step: gscan_allreduce_f32(comm, flat_gradients, n, stream)               (in place, sum)
+ *   at exit:    gscan_comm_destroy(comm)                                                                            */
+#define GSCAN_COMM_ID_BYTES 128
+int gscan_comm_unique_id(void *id_host);
+int gscan_comm_init(void **comm, int nranks, int rank, const void *id_host);
+int gscan_allreduce_f32(void *comm, float *buf, size_t n, void *stream);
+int gscan_comm_destroy(void *comm);
 
 /* Per-kernel-family timing for roofline reports: when enabled, every launch of a family
  * ("decoder_forward", "decoder_backward", "encoder_forward", "encoder_backward", "gemm", "conv_forward",

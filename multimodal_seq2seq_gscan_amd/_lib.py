@@ -11,8 +11,9 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # GSCAN_HIP_LIB: development override, used by tools/variants.py to time experimental builds side by side
 LIB_PATH = os.environ.get("GSCAN_HIP_LIB") or os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_ENC_LAYERS = 4
+COMM_ID_BYTES = 128
 
 _f32p = C.POINTER(C.c_float)
 _i64p = C.POINTER(C.c_int64)
@@ -101,6 +102,10 @@ PROTOTYPES = {
     "gscan_adam_scalars": (None, [_f, _f, _f, _f, _f, _i64, _vp]),
     "gscan_trace_set": (_i, [_vp]),
     "gscan_dropout_masks": (_i, [_vp, _sz, _sz, _sz, _f, _f, _f, _u64, _u64, _vp, _vp]),
+    "gscan_comm_unique_id": (_i, [_vp]),
+    "gscan_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),
+    "gscan_allreduce_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "gscan_comm_destroy": (_i, [_vp]),
     "gscan_probe_enable": (_i, [_i]),
     "gscan_probe_reset": (_i, []),
     "gscan_probe_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),

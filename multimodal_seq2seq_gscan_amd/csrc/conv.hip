@@ -27,7 +27,7 @@
 // kernel taps of one input channel, a wave per (tap, batch quarter), a lane per output channel: one Co-float row of
 // dfeat per hit, the four quarter sums added in LDS, and the tap's gradients leave as plain adds into the reference's
 // [Co, C, k, k] layout — no atomics, fixed summation order.  Extra workgroups add the bias gradients (column sums of
-// dfeat).
+// dfeat over 64-row chunks, ONE float atomic per chunk and column: the only sums of this file whose order varies).
 #include "step.h"
 
 namespace gscan {

@@ -291,6 +291,12 @@ struct KeysBackwardArgs {
 };
 int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream);
 
+// comm.hip: RCCL all-reduce on the caller's stream (run-time binding)
+int comm_unique_id(void *id_host);
+int comm_init(void **comm, int nranks, int rank, const void *id_host);
+int comm_allreduce_f32(void *comm, float *buf, size_t n, hipStream_t stream);
+int comm_destroy(void *comm);
+
 // probe.hip
 enum ProbeId { P_DECODER_FWD = 0, P_DECODER_BWD, P_ENCODER_FWD, P_ENCODER_BWD, P_GEMM, P_CONV_FWD, P_CONV_BWD, P_KEYS_BWD, P_COUNT };
 struct ProbeScope {

@@ -238,10 +238,20 @@ class GroundedScanDataset:
             for lo in range(0, len(order), window):
                 part = order[lo:lo + window]
                 order[lo:lo + window] = part[np.argsort(self._target_lengths[part], kind="stable")]
-            # the batches of a window in random order (otherwise lengths would rise steadily inside every window)
-            nb = (len(order) + batch_size - 1) // batch_size
-            perm = np.random.permutation(nb)
-            order = np.concatenate([order[b * batch_size:(b + 1) * batch_size] for b in perm])
+            # the batches of a window in random order (otherwise lengths would rise steadily inside every window).
+            # Only the FULL batches are permuted: _index_batches cuts at multiples of batch_size, so a short batch
+            # anywhere but at the end would make every later batch straddle two length-sorted ones (about half of the
+            # padding saved is lost again when N % batch_size != 0).  The short remainder — a random sample of the
+            # last window's rows, so that no length is excluded from the full batches systematically — stays the
+            # epoch's last batch, as in the reference (gSCAN_dataset.py:195-196).
+            full, rest = divmod(len(order), batch_size)
+            if rest:
+                last = np.arange(full * batch_size - (full * batch_size) % window, len(order))   # rows of the last window
+                keep = np.sort(np.random.permutation(len(last))[:len(last) - rest])              # stay sorted by length
+                drop = np.setdiff1d(np.arange(len(last)), keep)
+                order = np.concatenate([order[:last[0]], order[last[keep]], order[last[drop]]])
+            perm = np.random.permutation(full)
+            order = np.concatenate([order[b * batch_size:(b + 1) * batch_size] for b in perm] + [order[full * batch_size:]])
         self._order = order
 
     def _index_batches(self, batch_size: int, shard: Tuple[int, int]):
@@ -251,11 +261,13 @@ class GroundedScanDataset:
             yield self._order[lo:lo + batch_size]
 
     def batches(self, batch_size: int, device: Optional[torch.device] = None, shard: Tuple[int, int] = (0, 1),
-                stager: Optional["BatchStager"] = None) -> Iterator[Dict[str, torch.Tensor]]:
+                stager: Optional["BatchStager"] = None, row_shard: Tuple[int, int] = (0, 1)
+                ) -> Iterator[Dict[str, torch.Tensor]]:
         """Device batches for TrainStep / greedy_decode: commands, targets, target_positions, agent_positions (int64),
         cmd_lengths, tgt_lengths (int32), world (UINT8 [B,G,G,C]) — views of one device slab that arrived in one
         asynchronous copy, a batch ahead of the consumer; plus `index` (host int64: the examples' positions in the
-        split).  A batch's tensors stay valid until the iterator is advanced twice more."""
+        split).  row_shard = (rank, world): only this rank's rows of every batch.  A batch's tensors stay valid until the iterator is advanced ONCE more (the device slab is handed back
+        to the copy stream at the next delivery; keep a batch longer and it races with the copy three batches on: clone it)."""
         if device is None:
             device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         if device.type != "cuda":
@@ -265,7 +277,15 @@ class GroundedScanDataset:
         if own:
             stager = BatchStager(device, self.slab_bytes(batch_size))
         pending = None
+        rank, world = row_shard
         for idx in self._index_batches(batch_size, shard):
+            if world > 1:
+                # data-parallel training: this rank gathers and copies ONLY its rows of the global batch (rows
+                # [floor(r B / W), floor((r+1) B / W)), as train.shard_batch cuts them); a trailing batch with fewer
+                # rows than ranks is dropped on every rank
+                if len(idx) < world:
+                    continue
+                idx = idx[rank * len(idx) // world:(rank + 1) * len(idx) // world]
             staged = stager.stage(self, idx)          # host gather + asynchronous copy of the NEXT batch ...
             if pending is not None:
                 yield stager.deliver(pending)         # ... while the consumer works on this one

@@ -258,6 +258,7 @@ class Model(nn.Module):
         self._host_masks = None
         self._dropout_seed = int(kwargs.get("seed", 42))
         self._dropout_calls = 0
+        self._dropout_rank = 0
         self._mask_buffer = None
         self._mask_buffer_deep = None
         self._dummy_aux = None
@@ -349,6 +350,18 @@ class Model(nn.Module):
         drawing them on the device (SURVEY.md §7 hard part 3)."""
         self._host_masks = (cnn, enc, dec, enc_deep)
 
+    def set_dropout_rank(self, rank: int) -> None:
+        """Data parallelism: rank r draws from its own Philox streams, so row i of every shard does not get the mask
+        row i of every other shard gets (streams keyed by (seed, rank, step))."""
+        if not 0 <= int(rank) < (1 << 16):
+            raise ValueError(f"dropout rank {rank} out of range")
+        self._dropout_rank = int(rank)
+
+    def _philox_stream(self, deep: bool = False) -> int:
+        """64-bit Philox stream id of the next mask draw: [rank (16 bits) | 0 = step masks, 1 = inter-layer masks
+        (4 bits) | draw counter (40 bits)]; the seed is the Philox key."""
+        return (self._dropout_rank << 44) | (int(deep) << 40) | (self._dropout_calls & ((1 << 40) - 1))
+
     def _draw_masks(self, B: int, L: int, T: int, M: int, device) -> Tuple[Optional[torch.Tensor], ...]:
         if self._host_masks is not None:
             masks, self._host_masks = self._host_masks, None
@@ -368,8 +381,9 @@ class Model(nn.Module):
         buf = self._mask_buffer
         _lib.check(lib.gscan_dropout_masks(buf.data_ptr(), sizes[0], sizes[1], sizes[2], self.dropout_p[0],
                                            self.dropout_p[1], self.dropout_p[2], self._dropout_seed,
-                                           self._dropout_calls, _lib.ptr(self._mask_stream_id),
+                                           self._philox_stream(), _lib.ptr(self._mask_stream_id),
                                            torch.cuda.current_stream().cuda_stream), "gscan_dropout_masks")
+        deep_stream = self._philox_stream(deep=True)
         self._dropout_calls += 1
         out, off = [], 0
         for shape, n, p in zip(shapes, sizes, self.dropout_p):
@@ -386,7 +400,7 @@ class Model(nn.Module):
             if self._mask_buffer_deep is None or self._mask_buffer_deep.numel() != n:
                 self._mask_buffer_deep = torch.empty(n, dtype=torch.float32, device=device)
             _lib.check(lib.gscan_dropout_mask(self._mask_buffer_deep.data_ptr(), n, self.dropout_p[1],
-                                              self._dropout_seed, (1 << 40) + self._dropout_calls,
+                                              self._dropout_seed, deep_stream,
                                               torch.cuda.current_stream().cuda_stream), "gscan_dropout_mask")
             out.append(self._mask_buffer_deep.view(shape))
         return tuple(out)
@@ -491,7 +505,7 @@ class Model(nn.Module):
         lengths = _as_int32_lengths(commands_lengths, device)
         B, L = commands_input.shape
         if self._mask_stream_id is not None:      # a TrainStep owns the device-side Philox stream id: keep it moving
-            self._mask_stream_id.fill_(self._dropout_calls)
+            self._mask_stream_id.fill_(self._philox_stream())
         masks = self._draw_masks(B, L, target_batch.shape[1], situations_input.shape[1] ** 2, device)
         if torch.is_grad_enabled():
             logp, aux = _NetworkFunction.apply(self._anchor, self, commands_input, lengths, situations_input,

@@ -14,6 +14,8 @@ from typing import Iterator, List, Tuple
 
 import torch
 
+from ._lib import GscanError
+
 logger = logging.getLogger(__name__)
 
 
@@ -34,8 +36,15 @@ def greedy_decode(model, commands: torch.Tensor, cmd_lengths, world: torch.Tenso
     python lists `tokens` (the trailing <EOS> still included, as the loop produces it), `alpha_text`, `alpha_vis`
     and the summed visual attention [B, G*G]."""
     B = commands.shape[0]
-    tokens, steps, alpha_text, alpha_vis, att_sum = model.greedy_decode(commands, cmd_lengths, world, sos_idx, eos_idx,
-                                                                        max_decoding_steps)
+    try:
+        tokens, steps, alpha_text, alpha_vis, att_sum = model.greedy_decode(commands, cmd_lengths, world, sos_idx,
+                                                                            eos_idx, max_decoding_steps)
+    except GscanError as e:
+        # The one-launch decoder keeps the composite head [V,4H] and a [V,V] table in LDS on top of the row's memories
+        # and takes vocabularies up to 64 entries: a configuration the training kernels accept can exceed that.  The
+        # same decoding then runs token by token through the HIP step kernel (the reference's own call sequence).
+        logger.warning("one-launch greedy decoding not available for these dimensions (%s): decoding stepwise", e)
+        return greedy_decode_stepwise(model, commands, cmd_lengths, world, sos_idx, eos_idx, max_decoding_steps)
     lengths = list(cmd_lengths) if not isinstance(cmd_lengths, torch.Tensor) else cmd_lengths.tolist()
     tok, n_steps, at, av = tokens.cpu(), steps.cpu().tolist(), alpha_text.cpu(), alpha_vis.cpu()
     rows = {"tokens": [], "alpha_text": [], "alpha_vis": [], "att_sum": att_sum}

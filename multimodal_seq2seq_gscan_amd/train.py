@@ -127,13 +127,54 @@ class FlatAdam:
         self.lr_steps = 0
 
 
+class RcclCommunicator:
+    """One RCCL communicator of this process, driven through the C ABI (`gscan_comm_*`, `gscan_allreduce_f32`): the
+    all-reduce is enqueued on the CALLER'S stream, right behind the backward kernels and in front of the optimiser —
+    torch.distributed runs its collectives on a stream of its own, two event hops (~50 us) per step.  The 128-byte
+    unique id travels from rank 0 to the others through the process group that is already up (any backend);
+    `torch.cuda.set_device(local_rank)` must have happened before."""
+
+    def __init__(self, process_group=None):
+        lib = _lib.load()
+        self.rank = dist.get_rank(process_group)
+        self.world_size = dist.get_world_size(process_group)
+        uid = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        if self.rank == 0:
+            _lib.check(lib.gscan_comm_unique_id(C.addressof(uid)), "gscan_comm_unique_id")
+        box = [bytes(uid.raw)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                                   group=process_group)
+        uid = C.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
+        self._handle = C.c_void_p()
+        _lib.check(lib.gscan_comm_init(C.byref(self._handle), self.world_size, self.rank, C.addressof(uid)),
+                   "gscan_comm_init")
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place sum over the ranks, on the current stream."""
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("RcclCommunicator.all_reduce takes a contiguous float32 device tensor")
+        _lib.check(_lib.load().gscan_allreduce_f32(self._handle, t.data_ptr(), t.numel(),
+                                                   torch.cuda.current_stream().cuda_stream), "gscan_allreduce_f32")
+        return t
+
+    def close(self) -> None:
+        if self._handle:
+            torch.cuda.synchronize()
+            _lib.check(_lib.load().gscan_comm_destroy(self._handle), "gscan_comm_destroy")
+            self._handle = C.c_void_p()
+
+
 class GradientExchange:
     """The data-parallel exchange of one step.  Without the auxiliary loss: ONE all-reduce of
     [gradients of the local SUM loss | sum NLL, tokens, ., rows] (`mean_from_sums`).  With it (two different
     divisors): a 4-float statistics all-reduce before backward (`seeds`), one flat gradient all-reduce after it.
-    With a single process all of them are no-ops."""
+    With a single process all of them are no-ops.
 
-    def __init__(self, process_group=None, always_collective: bool = False):
+    Transport of float32 device buffers when the process group's backend is "nccl" (= RCCL): the library's own
+    communicator on the caller's stream (`RcclCommunicator`).  `native=False`, or a failure to create that
+    communicator (logged), leaves them to torch.distributed — RCCL as well, through its communication stream."""
+
+    def __init__(self, process_group=None, always_collective: bool = False, native: Optional[bool] = None):
         self.group = process_group
         active = dist.is_available() and dist.is_initialized()
         self.world_size = dist.get_world_size(process_group) if active else 1
@@ -144,6 +185,15 @@ class GradientExchange:
         # gloo has no device collectives: device buffers are staged through host memory (two processes sharing one
         # GPU in the tests; RCCL refuses two ranks on one device).  "nccl" = RCCL reduces in place over xGMI.
         self.host_staged = self.collective and dist.get_backend(process_group) == "gloo"
+        self.comm: Optional[RcclCommunicator] = None
+        if native is None:
+            native = os.environ.get("GSCAN_NATIVE_ALLREDUCE", "1") != "0"
+        if self.collective and not self.host_staged and native and torch.cuda.is_available():
+            try:
+                self.comm = RcclCommunicator(process_group)
+            except (_lib.GscanError, RuntimeError) as e:      # every rank fails or none: init is a collective
+                logger.warning("RCCL communicator on the caller's stream unavailable (%s): gradients go through "
+                               "torch.distributed's RCCL stream instead", e)
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         if not self.collective:
@@ -152,6 +202,8 @@ class GradientExchange:
             host = t.detach().cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(host)
+        elif self.comm is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+            self.comm.all_reduce(t)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
@@ -192,11 +244,14 @@ class TrainStep:
                  adam_beta_2: float = 0.999, lr_decay: float = 0.9, lr_decay_steps: float = 20000.0,
                  weight_target_loss: float = 0.3, process_group=None, graph: bool = False,
                  fused_loss: Optional[bool] = None, single_exchange: Optional[bool] = None,
-                 always_collective: bool = False, on_gradients=None, **_):
+                 always_collective: bool = False, on_gradients=None,
+                 native_allreduce: Optional[bool] = None, **_):
         self.model = model
         self.optimizer = FlatAdam(model, learning_rate, adam_beta_1, adam_beta_2, lr_decay, lr_decay_steps)
         self.weight_target_loss = float(weight_target_loss)
-        self.exchange = GradientExchange(process_group, always_collective)
+        self.exchange = GradientExchange(process_group, always_collective, native_allreduce)
+        # every rank draws its own dropout masks (Philox streams keyed by seed, rank and step)
+        model.set_dropout_rank(self.exchange.rank)
         self.graph = bool(graph)
         # on_gradients(flat mean-loss gradient of the global batch): called between the exchange and the optimiser
         # (which clears the buffer); diagnostics and tests only — it costs a device pass in the one-collective form
@@ -266,7 +321,7 @@ class TrainStep:
             self.optimizer.advance()
             return
         self.optimizer.stage_scalars()
-        self._host_stream_id[0] = self.model._dropout_calls
+        self._host_stream_id[0] = self.model._philox_stream()
         self.model._mask_stream_id.copy_(self._host_stream_id, non_blocking=True)
         self.model._dropout_calls += 1
 
@@ -461,18 +516,17 @@ def train_on_dataset(data_path: str, data_directory: str, generate_vocabularies:
     vocab = dev_set.target_vocabulary
     # one ring of pinned / device slabs for the whole run: a batch is gathered into a slab, crosses PCIe in one
     # asynchronous copy a batch ahead of the step, and stays uint8 (the kernels widen the world in registers)
-    stager = BatchStager(model.flat_parameters.device, training_set.slab_bytes(training_batch_size))
+    stager = BatchStager(model.flat_parameters.device,
+                         training_set.slab_bytes(-(-training_batch_size // max(1, world_size))))
     keys = ("commands", "cmd_lengths", "world", "targets", "tgt_lengths", "target_positions")
     while training_iteration < max_training_iterations:          # train.py:88
         training_set.shuffle_data(bucket_batches=length_bucket_batches, batch_size=training_batch_size)
-        for staged in training_set.batches(training_batch_size, stager=stager):
+        # under data parallelism every rank stages only ITS rows of each global batch (1/W of the host gather and of
+        # the PCIe traffic); the epoch's short trailing batch (gSCAN_dataset.py:195-196) is dropped by every rank when
+        # it holds fewer rows than there are ranks.  NOTE: a shard is padded to ITS longest rows, which changes
+        # nothing in the loss (padding is inert) and saves decoder steps on ranks with short rows.
+        for staged in training_set.batches(training_batch_size, stager=stager, row_shard=(rank, world_size)):
             batch = {key: staged[key] for key in keys}
-            if world_size > 1:
-                # the epoch's short trailing batch (gSCAN_dataset.py:195-196) may hold fewer rows than there are
-                # ranks: every rank sees the same batch, so every rank drops it
-                if batch["commands"].shape[0] < world_size:
-                    continue
-                batch = shard_batch(batch, rank, world_size)
             out = step(batch)
             if training_iteration % print_every == 0 and rank == 0:
                 accuracy, exact_match = model.get_metrics(out["logp"], batch["targets"])

@@ -72,8 +72,12 @@ def main():
     grad, losses, params, tokens, step = run(model, batches, shard=(rank, world), always_collective=(world == 1))
     assert step.exchange.collective and step.exchange.host_staged == (backend == "gloo")
     assert step.single_exchange == (not cfg["auxiliary_task"]) and not step.fused_loss
-    torch.save({"grad": grad, "losses": losses, "params": params, "tokens": tokens,
+    native = step.exchange.comm is not None
+    assert native == (backend == "nccl" and os.environ.get("GSCAN_NATIVE_ALLREDUCE", "1") != "0")
+    torch.save({"grad": grad, "losses": losses, "params": params, "tokens": tokens, "native": native,
                 "rows": [int(b["commands"].shape[0]) for b in batches]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    if native:
+        step.exchange.comm.close()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,5 +1,8 @@
 """Checkpoint-interop fixture, produced by the REFERENCE (authoring container only; the reference is imported,
 never copied):  python tests/golden/make_golden_checkpoint.py  ->  tests/golden/demo_reference_checkpoint.pth.tar
+                python tests/golden/make_golden_checkpoint.py --logp-only  ->  demo_reference_checkpoint_logp.npz
+                (the REFERENCE loads the committed checkpoint with its own Model.load_model and scores one seeded
+                batch: log-probabilities + loss, the known answer for `load_model` -> `Model.forward` on the device)
 
 A checkpoint written by the reference's own Model.save_checkpoint after two Adam steps at the README demo
 dimensions (model.py:246-261), plus — checked here, at generation time — the reverse direction: a checkpoint
@@ -73,5 +76,31 @@ def main():
     shutil.rmtree(tmp)
 
 
+def logp_fixture():
+    """model.py:228-235 then :206-219 in the reference: what a forward pass must give after loading the checkpoint."""
+    import numpy as np
+    torch.set_num_threads(4)
+    tmp = tempfile.mkdtemp()
+    cfg = model_kwargs("demo", output_directory=tmp, cnn_hidden_num_channels=4, cnn_kernel_size=3)
+    ref = ReferenceModel(**cfg)
+    ref.load_model(os.path.join(HERE, "demo_reference_checkpoint.pth.tar"))
+    ref.eval()
+    shape = Shape(batch=5, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=7, max_target=10, ragged=True)
+    b = make_batch(shape, 777)
+    with torch.no_grad():
+        logp, _ = ref(commands_input=b["commands"], commands_lengths=b["cmd_lengths"].tolist(),
+                      situations_input=b["world"], target_batch=b["targets"], target_lengths=b["tgt_lengths"].tolist())
+        loss = ref.get_loss(logp, b["targets"])
+    out = os.path.join(HERE, "demo_reference_checkpoint_logp.npz")
+    np.savez_compressed(out, logp=logp.numpy(), loss=np.float32(loss.item()), iteration=np.int64(ref.trained_iterations),
+                        **{k: v.numpy() for k, v in b.items()})
+    print("wrote", out, os.path.getsize(out), "bytes; loss", float(loss))
+    shutil.rmtree(tmp)
+
+
 if __name__ == "__main__":
-    main()
+    if "--logp-only" in sys.argv:
+        logp_fixture()
+    else:
+        main()
+        logp_fixture()

@@ -88,7 +88,90 @@ def test_four_ranks_on_one_device(tmp_path):
 
 @pytest.mark.parametrize("case", ["demo", "demo_aux"])
 def test_collectives_on_a_one_rank_rccl_communicator(tmp_path, case):
-    """backend "nccl" IS RCCL on ROCm: the step's all-reduces are launched by RCCL on its own stream between the
-    library's launches (identity on one rank, but the stream hand-over is the production one)."""
+    """backend "nccl" IS RCCL on ROCm.  The step's float32 all-reduces go through the library's own communicator
+    (`gscan_comm_init` from the process group, `gscan_allreduce_f32` on the step's stream: the worker asserts it was
+    created and used); identity on one rank, but the launch sequence is the production one."""
     ranks = _launch(1, "nccl", case, tmp_path)
+    assert ranks[0]["native"] is True
     _compare(ranks, _single_process(case))
+
+
+def test_collectives_through_torch_distributed_rccl(tmp_path):
+    """The fallback transport: torch.distributed's RCCL stream (GSCAN_NATIVE_ALLREDUCE=0)."""
+    os.environ["GSCAN_NATIVE_ALLREDUCE"] = "0"
+    try:
+        ranks = _launch(1, "nccl", "demo", tmp_path)
+    finally:
+        del os.environ["GSCAN_NATIVE_ALLREDUCE"]
+    assert ranks[0]["native"] is False
+    _compare(ranks, _single_process("demo"))
+
+
+def test_c_abi_communicator_without_torch_distributed():
+    """gscan_comm_unique_id / gscan_comm_init / gscan_allreduce_f32 / gscan_comm_destroy by themselves (what a
+    maintainer of the reference would bind): a one-rank communicator, a sum on the current stream and on a side
+    stream, ordered with the kernels around it."""
+    import ctypes as C
+    from multimodal_seq2seq_gscan_amd import _lib
+    lib = _lib.load()
+    uid = C.create_string_buffer(_lib.COMM_ID_BYTES)
+    _lib.check(lib.gscan_comm_unique_id(C.addressof(uid)), "unique_id")
+    assert any(uid.raw)
+    comm = C.c_void_p()
+    _lib.check(lib.gscan_comm_init(C.byref(comm), 1, 0, C.addressof(uid)), "comm_init")
+    x = torch.arange(440_279, dtype=torch.float32, device="cuda")
+    want = (x * 2 + 1).cpu()
+    x.mul_(2)
+    _lib.check(lib.gscan_allreduce_f32(comm, x.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream), "allreduce")
+    x.add_(1)
+    assert torch.equal(x.cpu(), want)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _lib.check(lib.gscan_allreduce_f32(comm, x.data_ptr(), x.numel(), side.cuda_stream), "allreduce")
+    side.synchronize()
+    assert torch.equal(x.cpu(), want)
+    assert lib.gscan_allreduce_f32(None, x.data_ptr(), 4, None) != 0 and b"NULL" in lib.gscan_last_error()
+    torch.cuda.synchronize()
+    _lib.check(lib.gscan_comm_destroy(comm), "comm_destroy")
+
+
+def test_dropout_streams_differ_by_rank_and_repeat_per_rank():
+    """Philox streams keyed by (seed, rank, step).  Two ranks must not draw the same masks for their
+    local rows; one rank must draw the same masks again from the same (seed, rank, step)."""
+    from multimodal_seq2seq_gscan_amd.config import model_kwargs
+    from multimodal_seq2seq_gscan_amd.model import Model
+
+    def draws(rank, steps=2):
+        torch.manual_seed(0)
+        m = Model(**model_kwargs("compositional")).cuda().train()
+        m.set_dropout_rank(rank)
+        out = []
+        for _ in range(steps):
+            out.append([x.clone() for x in m._draw_masks(8, 10, 20, 36, torch.device("cuda"))])
+        return out
+    r0, r0_again, r1 = draws(0), draws(0), draws(1)
+    for step in range(2):
+        for a, b, c in zip(r0[step], r0_again[step], r1[step]):
+            assert torch.equal(a, b)                               # reproducible per rank
+            assert (a != c).float().mean().item() > 0.05           # p = 0.1 .. 0.3: independent draws differ often
+    for a, b in zip(r0[0], r0[1]):
+        assert not torch.equal(a, b)                               # and every step draws afresh
+    with pytest.raises(ValueError):
+        Model(**model_kwargs("demo")).set_dropout_rank(1 << 16)
+
+
+def test_bench_self_launch_two_ranks_share_the_device():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the ranks before touching the device.
+    Rehearsed here with --backend gloo (two ranks on the box's one GPU; RCCL needs a device per rank)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
+                        "--warmup", "2", "--windows", "0", "--cpu-seconds", "0", "--batch", "32"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["value"] > 0
+    assert out["config"]["gradient_exchange"] == "torch.distributed gloo"

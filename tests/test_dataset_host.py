@@ -169,6 +169,37 @@ def test_length_buckets_permute_the_split_and_cut_padding(tmp_path):
     assert live <= bucketed < plain and (bucketed - live) < 0.5 * (plain - live)
 
 
+def test_length_buckets_with_a_short_trailing_batch(tmp_path):
+    """N % batch_size != 0: the short batch stays the LAST batch of the epoch (gSCAN_dataset.py:195-196) and every
+    full batch is cut on a boundary of a length-sorted batch — the padding saved does not depend on N dividing evenly
+    (a short batch shuffled into the middle made every later batch straddle two sorted ones)."""
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, write_dataset_file
+    path = str(tmp_path / "dataset.txt")
+    write_dataset_file(path, {"train": 413}, Shape(batch=1, max_target=30), seed=5)
+    data = GroundedScanDataset(path, str(tmp_path), k=0, split="train", generate_vocabulary=True)
+    data.read_dataset()
+    lengths = data._target_lengths
+
+    def spans():      # (rows, longest, shortest) per batch
+        return [(len(b[6]), int(b[6].max()), int(b[6].min())) for b in data.get_data_iterator(batch_size=20, device=torch.device("cpu"))]
+
+    np.random.seed(1)
+    data.shuffle_data()
+    plain = sum(n * hi for n, hi, _ in spans())
+    saved = []
+    for trial in range(4):
+        data.shuffle_data(bucket_batches=5, batch_size=20)
+        assert sorted(data._order.tolist()) == list(range(413))
+        got = spans()
+        assert [n for n, _, _ in got] == [20] * 20 + [13]                  # the short batch is last
+        saved.append(plain - sum(n * hi for n, hi, _ in got))
+        # a full batch is one fifth of a sorted 100-row window: its length span is a fraction of the split's
+        spread = int(lengths.max() - lengths.min())
+        assert np.mean([hi - lo for _, hi, lo in got[:20]]) < 0.45 * spread
+    live = int(lengths.sum())
+    assert min(saved) > 0.5 * (plain - live)
+
+
 def test_staging_slab_layout():
     from multimodal_seq2seq_gscan_amd.dataset import _Slab
     offsets, total = _Slab.layout(256, 10, 20, 576)

@@ -137,3 +137,13 @@ def test_oracle_greedy_decode_matches_reference_predict_loop():
         assert torch.allclose(torch.stack(row["logits"]), torch.from_numpy(fx["logits"][r, :n]), atol=2e-5)
         assert torch.allclose(torch.stack(row["alpha_text"])[:, :L], torch.from_numpy(fx["alpha_text"][r, :n, :L]), atol=2e-5)
         assert torch.allclose(torch.stack(row["alpha_vis"]), torch.from_numpy(fx["alpha_vis"][r, :n]), atol=2e-5)
+
+
+def test_oracle_scores_the_reference_checkpoint_as_the_reference_does():
+    """The weights of the checkpoint the reference WROTE, scored by the oracle, against the log-probabilities the
+    reference computed after loading that file itself (make_golden_checkpoint.py --logp-only)."""
+    fx = load_fixture("demo_reference_checkpoint_logp.npz")
+    ck = torch.load(os.path.join(GOLDEN, "demo_reference_checkpoint.pth.tar"), map_location="cpu", weights_only=False)
+    loss, _, logp = oracle.loss_and_grads(dict(ck["state_dict"]), fixture_batch(fx), conditional=True, auxiliary=False)
+    assert abs(loss.item() - float(fx["loss"])) < TOL
+    assert (logp - torch.from_numpy(fx["logp"])).abs().max().item() < TOL

@@ -716,3 +716,39 @@ def test_staged_batcher_delivers_the_packed_rows_while_the_step_runs(tmp_path):
     for d, h in zip(on_device, on_host):
         assert d[3].dtype == torch.float32 and torch.equal(d[3].cpu(), h[3]) and torch.equal(d[0].cpu(), h[0])
         assert torch.equal(d[5].cpu(), h[5]) and torch.equal(d[8].cpu(), h[8]) and (d[1] == h[1]).all()
+
+
+def test_reference_checkpoint_scores_the_same_on_the_device(tmp_path):
+    """§8 f4 on the device (model.py:228-235 then :206-219): `load_model` of the checkpoint the REFERENCE wrote, then
+    `Model.forward` / `get_loss` on the HIP path, against the log-probabilities the reference itself computed after
+    loading the same file (tests/golden/make_golden_checkpoint.py --logp-only)."""
+    from multimodal_seq2seq_gscan_amd.model import Model
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fx = load_fixture("demo_reference_checkpoint_logp.npz")
+    cfg = model_kwargs("demo", output_directory=str(tmp_path), cnn_hidden_num_channels=4, cnn_kernel_size=3)
+    torch.manual_seed(123)                                    # different initial weights: everything must come from the file
+    model = Model(**cfg).cuda()
+    model.load_model(os.path.join(golden, "demo_reference_checkpoint.pth.tar"))
+    assert model.trained_iterations == int(fx["iteration"]) == 2
+    model.eval()
+    batch = fixture_batch(fx)
+    d = {k: v.cuda() for k, v in batch.items()}
+    with torch.no_grad():
+        logp, _ = model(commands_input=d["commands"], commands_lengths=batch["cmd_lengths"].tolist(),
+                        situations_input=d["world"], target_batch=d["targets"],
+                        target_lengths=batch["tgt_lengths"].tolist())
+        loss = model.get_loss(logp, d["targets"])
+    msg, err = report("logp after load_model", logp.cpu(), torch.from_numpy(fx["logp"]))
+    assert err < TOL, msg
+    assert abs(loss.item() - float(fx["loss"])) < TOL
+    # and the other direction on the device: save from here, load into a fresh model, same scores bit for bit
+    path = model.save_checkpoint("again.pth.tar", is_best=False, optimizer_state_dict={"state": {}, "param_groups": []})
+    torch.manual_seed(7)
+    again = Model(**cfg).cuda()
+    again.load_model(path)
+    again.eval()
+    with torch.no_grad():
+        logp2, _ = again(commands_input=d["commands"], commands_lengths=batch["cmd_lengths"].tolist(),
+                         situations_input=d["world"], target_batch=d["targets"],
+                         target_lengths=batch["tgt_lengths"].tolist())
+    assert torch.equal(logp2, logp)
