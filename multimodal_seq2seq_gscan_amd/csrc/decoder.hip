@@ -61,8 +61,9 @@ __device__ __forceinline__ int opaque(int x) {
     return x;
 }
 
-// lane <-> lane^1 exchange on the DPP datapath (quad_perm [1,0,3,2]); both lanes of a pair must be active
-__device__ __forceinline__ float pair_sum(float v) { return v + dpp_move<0xb1, 0xf>(v); }
+// The two lanes of a pair (decoder_pair_of, step.h: lane s and lane 7-s of a group of eight) exchange on the DPP datapath
+// (row_half_mirror); both lanes must be active and both end up with the sum
+__device__ __forceinline__ float pair_sum(float v) { return v + dpp_move<0x141, 0xf>(v); }
 
 // Dot products of register-resident half rows with an LDS vector (K0 % 4 == 0), as packed FMAs
 // (v_pk_fma_f32).  The vector is read in chunks of four float4; the next chunk's reads are issued before the
@@ -183,7 +184,6 @@ DecoderGeometry decoder_geometry(int H, bool cond) {
 struct DecoderLds {
     int uv, pkv, ut, pkt, u2t, dpkv, dpkt, vec, total;
 };
-constexpr int kPartStride = 512;   // columns per m-group slab of partial sums (>= 5H)
 // uv_in_lds = false: the gate images of the visual memories U_vis [M,4H] (the largest resident block: 102 KB for an
 // 8x8 grid at H = 100) stay in global memory and the two phases that read them stream them from L2 every step.
 __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bool cond, bool backward,
@@ -199,7 +199,7 @@ __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bo
     o.dpkv = p; p += backward ? M * H : 0;
     o.dpkt = p; p += backward ? L * H : 0;
     o.vec = p;
-    p += (backward ? 7 * HP + 15 * H : 2 * HP + 14 * H + 4 * kPartStride) + 256;
+    p += (backward ? 7 * HP + 19 * H : 2 * HP + 6 * H) + 256;
     // scratch of the fused output head, overlaid on the memories (forward: after the loop; backward: before staging)
     const int head = backward ? kHeadChunk * (V + H + 4) + V * H + 32 : kHeadChunk * (5 * H + 4 + V) + V * H;
     o.total = p > head ? p : head;
@@ -266,6 +266,60 @@ __device__ __forceinline__ StageList stage_list(const DecoderArgs &a, const Deco
     return sl;
 }
 
+// Role of thread tid in the column-sum phases.  A group of eight lanes 8g..8g+7 holds the gate rows of two hidden
+// units: its lower quad (lanes 8g+j) unit g, its upper quad (lanes 8g+4+j) unit 64+g, lane j of a quad = gate j
+// (i, f, g, o).  The dot phase pairs lane s with lane 7-s of the same eight (DPP row_half_mirror) and the weight
+// image gives pair (g, j) the W_hh row of (unit g, gate j) in slot 0 and of (unit 64+g, gate 3-j) in slot 1 — so
+// after the pair sum every lane already holds the W_hh.h term of ITS (unit, gate): slot 0 in the lower quad, slot
+// 1 in the upper one (decoder_image_element, step.h).
+struct GateLane { int unit, gate; bool valid, upper; };
+template <int H>
+__device__ __forceinline__ GateLane gate_lane(int tid) {
+    GateLane r;
+    r.upper = (tid >> 2) & 1;
+    r.gate = tid & 3;
+    r.unit = (r.upper ? 64 : 0) + (tid >> 3);
+    r.valid = r.unit < H;
+    return r;
+}
+
+// quad (four adjacent lanes) butterfly sum: every lane of the quad ends up with the total
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_move<0xb1, 0xf>(v);        // quad_perm [1,0,3,2]
+    v += dpp_move<0x4e, 0xf>(v);        // quad_perm [2,3,0,1]
+    return v;
+}
+template <int I>
+__device__ __forceinline__ float quad_bcast(float v) { return dpp_move<I * 0x55, 0xf>(v); }   // lane I of the quad
+
+// sum_m alpha_m * X[m][4c .. 4c+3] for ONE column quad c of a row-memory image X, by the four lanes of a quad: lane j
+// takes the memories m = j, j+4, ... (16-byte LDS reads, three in flight), the quad adds up on the DPP datapath and
+// lane j returns column 4c + j.  alpha_m lives in lane m of `alpha` (every wave holds the whole distribution) and is
+// fetched with ds_bpermute, so the loop runs the same number of rounds in every lane; threads without a column quad
+// pass stride = 0 and ignore the result.  n is uniform in the workgroup.
+template <bool GLOBAL = false>
+__device__ __forceinline__ float quad_column_sum(const float *base, int stride, int n, int j, float alpha) {
+    constexpr int U = 3;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < n; i0 += 4 * U) {
+        f32x4 x[U];
+        float am[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = i0 + 4 * u + j, mc = min(m, n - 1);
+            if (GLOBAL) x[u] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(
+                               (const __attribute__((address_space(1))) float *)base + (int64_t)mc * stride);
+            else x[u] = *reinterpret_cast<const f32x4 *>(base + mc * stride);
+            const float al = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mc, __float_as_int(alpha)));
+            am[u] = m < n ? al : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += am[u] * x[u];
+    }
+    const float s0 = quad_sum(acc[0]), s1 = quad_sum(acc[1]), s2 = quad_sum(acc[2]), s3 = quad_sum(acc[3]);
+    return j == 0 ? s0 : j == 1 ? s1 : j == 2 ? s2 : s3;
+}
+
 // ------------------------------------------------------------------------------------------
 // GREEDY = false: teacher forcing over the T given target tokens, everything backward needs is saved (training /
 // scoring).  GREEDY = true (predict.py:101-112): the row feeds its own argmax back for up to T steps and stops at
@@ -273,31 +327,39 @@ __device__ __forceinline__ StageList stage_list(const DecoderArgs &a, const Deco
 // W_h2o . W_o2h ([V, 4H], in LDS) applied every step, nothing is saved but tokens and attention rows.
 // UVL = false: the visual gate images are streamed from L2 (decoder_lds); compiled for the hidden sizes whose 8x8-grid
 // memories overflow LDS only.
+//
+// One step = six phases, a workgroup barrier behind each:
+//   A  every product with h_{t-1}: W_hh h (stays in the owning lanes' registers), W_query_text h -> LDS,
+//      W_q2k[:, :H] h (or W_query_vis h) -> LDS
+//   B  textual scores v . tanh(q + PK_m), a wave per memory
+//   C  softmax (in every wave's registers), then column sums over the command: the gate images U_t (kept in the
+//      registers of the lane that owns the gate), the textual context, and the conditional query tanh(. + U2_t)
+//   D  visual query from the conditional query (conditional attention only)
+//   E  visual scores
+//   F  softmax, column sums over the grid cells (U_v -> owning lanes; PK_v -> visual context), gate activations —
+//      one gate per lane —, cell update by lane 0 of each quad, h_t -> LDS
+// ------------------------------------------------------------------------------------------
 template <int H, bool COND, bool GREEDY, bool UVL = true>
 __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a) {
     TraceScope trace_scope(TK_DECODER_FWD);
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
                   HP = 2 * K0;
-    constexpr int NQT = (COND ? 6 : 5) * H / 4;   // column quads of the textual images [U_t | PK_t | U2_t]
-    constexpr int NQV = 5 * H / 4;                // column quads of the visual images [U_v | PK_v]
-    static_assert(NQV <= 128 && 5 * H <= kPartStride, "hidden size too large for the m-group split");
+    constexpr int NQ2 = (COND ? 2 : 1) * H / 4;   // column quads of [PK_t | U2_t]
+    static_assert(H <= 128 && 4 * NQ2 <= kDecThreads, "hidden size too large for the quad roles");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = kDecThreads / 64;
-    const int pair = tid >> 1, half = tid & 1;
+    const int pair = decoder_pair_of(tid), half = decoder_half_of(tid);
     const int T = a.T, L = a.L, M = a.M;
     constexpr bool uv_lds = UVL;
     const DecoderLds o = decoder_lds(H, L, M, a.V, COND, false, uv_lds);
-    float *Uv = smem + o.uv, *PKv = smem + o.pkv, *Ut = smem + o.ut, *PKt = smem + o.pkt, *U2t = smem + o.u2t;
+    float *PKv = smem + o.pkv, *PKt = smem + o.pkt;
     float *vec = smem + o.vec;
     float *h_s = vec;                                       // dot input, zero-padded to HP
     float *qt_s = vec + HP, *qv_s = qt_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H;
-    float *gsum_s = vv_s + H;                               // [4H] ge + gh + uc per gate row
-    float *col_s = gsum_s + 4 * H;                          // [6H] textual column sums
-    float *q2_s = col_s + 6 * H;                            // dot input, zero-padded to HP; above col_s so that
-                                                            // q2_s[r - 5H] is a positive offset from &col_s[r]
-    float *part_s = q2_s + HP;                              // [4][kPartStride] visual partial column sums
-    float *sc_s = part_s + 4 * kPartStride, *bq_s = sc_s + 64, *stamp_acc = sc_s + 192;
-    static_assert(H <= 128, "bq_s holds one bias per hidden unit in 128 floats");
+    float *qh_s = vv_s + H;                                 // W_q2k[:, :H] h (conditional)
+    float *ctxt_s = qh_s + H;                               // textual context (greedy head)
+    float *q2_s = ctxt_s + H;                               // dot input, zero-padded to HP
+    float *sc_s = q2_s + HP, *bq_s = sc_s + 64, *stamp_acc = sc_s + 192;
     // greedy decoding only: composite head [V,4H] (S order), embedding part of the logits [V,V], visual context,
     // logits, current token (behind everything else in LDS)
     float *wc_s = smem + o.total, *le_s = wc_s + a.V * 4 * H, *ctxv_s = le_s + a.V * a.V, *logit_s = ctxv_s + H;
@@ -305,10 +367,26 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     long long stamp_prev = a.stamps ? clock64() : 0;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
-    const int mg = (M + 3) / 4;                             // memories per visual m-group
-    int qt_off = o.ut, qt_stride = 0, qv_off = o.uv, qv_stride = 0;   // this thread's column quads (C1 / F1)
-    if (tid < NQT) quad_offset(o.ut, o.pkt, o.u2t, H, tid, qt_off, qt_stride);
-    if ((tid & 127) < NQV) quad_offset(o.uv, o.pkv, o.pkv, H, tid & 127, qv_off, qv_stride);
+    // roles in the column-sum phases
+    const GateLane gl = gate_lane<H>(tid);
+    const int j4 = tid & 3;
+    const float *ut_col = smem + o.ut + (gl.valid ? 4 * gl.unit : 0);           // U_t column quad of this lane's unit
+    const int ut_stride = gl.valid ? 4 * H : 0;
+    // [PK_t | U2_t] column quad (threads 0 .. 4 NQ2 - 1): columns < H -> textual context, the rest -> conditional query
+    const int cq2 = tid >> 2;
+    const bool has2 = cq2 < NQ2;
+    const float *k2_col = smem + (!has2 ? o.pkt : (4 * cq2 < H ? o.pkt + 4 * cq2 : o.u2t + (4 * cq2 - H)));
+    const int k2_stride = has2 ? H : 0;
+    // visual phase: lanes with a unit sum its U_v column quad; the first H/4 quads WITHOUT a unit (upper quads of the
+    // groups 8g, g >= H - 64) sum the PK_v column quads = the visual context
+    const int spare = gl.upper && !gl.valid ? (tid >> 3) - max(0, H - 64) : -1;
+    const bool ctx_role = spare >= 0 && spare < H / 4;
+    const float *uv_col = smem + (gl.valid ? o.uv + 4 * gl.unit : o.pkv + (ctx_role ? 4 * spare : 0));
+    const int uv_stride = gl.valid ? 4 * H : (ctx_role ? H : 0);
+    static_assert(H <= 64 || 4 * (128 - H) >= H, "not enough spare quads for the visual context");
+    // activation of gate j as a * sigmoid(s x) + c: tanh x = 2 sigmoid(2x) - 1 for the cell candidate (gate 2)
+    const float act_s = gl.gate == 2 ? -2.8853900817779268f : -1.4426950408889634f;
+    const float act_a = gl.gate == 2 ? 2.f : 1.f, act_c = gl.gate == 2 ? -1.f : 0.f;
 
     // ---- one-time loads: register image of the weights (coalesced), memories -> LDS -----------
     float w[NS][K0];
@@ -327,7 +405,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     if (tid < HP) { h_s[tid] = 0.f; q2_s[tid] = 0.f; }      // zero the padding of the dot inputs
     if (tid < 16) stamp_acc[tid] = 0.f;
     lds_barrier();
-    float c = 0.f;
+    float c = 0.f;                                          // cell state: lane 0 of the quad of each unit
     if (GREEDY) {
         const int V = a.V;
         for (int i = tid; i < V * 4 * H; i += kDecThreads) wc_s[i] = a.head_wc[i];
@@ -335,11 +413,12 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     }
     if (tid < H) {
         const float h0 = a.hprev[(int64_t)b * (GREEDY ? 1 : T) * H + tid];
-        c = a.c0 ? a.c0[(int64_t)b * H + tid] : h0;         // c0 = h0 unless given (seq2seq_model.py:494-504)
         h_s[tid] = h0;
         vt_s[tid] = a.v_t[tid];
         vv_s[tid] = a.v_v[tid];
     }
+    if (gl.valid && gl.gate == 0)                           // c0 = h0 unless given (seq2seq_model.py:494-504)
+        c = a.c0 ? a.c0[(int64_t)b * H + gl.unit] : a.hprev[(int64_t)b * (GREEDY ? 1 : T) * H + gl.unit];
     if (COND && tid < H) bq_s[tid] = a.b_q2k[tid];
     float att_acc = 0.f;                                    // wave 0, lane m
     lds_barrier();
@@ -363,25 +442,24 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     for (int t = 0; t < T; ++t) {
         GSCAN_STAMP(0)
         const unsigned bt = (unsigned)b * T + t;            // 32-bit offsets: B*T*4H < 2^31 is checked on the host
-        float ge[NS], gh[NS];
-        const unsigned ge_row = GREEDY ? (unsigned)tok_s[0] : bt;     // greedy: row of the [V, 4H] table of the token fed in
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {                      // embedding part of the gates: issued early, used in C2
-            const int r = s * kDecPairs + pair;
-            // unconditional in the slots that hold gate rows: a guarded load makes the compiler drain vmcnt first
-            ge[s] = (s * kDecPairs < 4 * H) ? a.ge[ge_row * 4 * H + min(r, 4 * H - 1)] : 0.f;
-        }
+        // embedding part of this lane's gate (+ both biases): issued first, consumed in phase C.  Unconditional (a
+        // guarded load makes the compiler drain vmcnt first); greedy: row of the [V, 4H] table of the token fed in
+        const unsigned ge_row = GREEDY ? (unsigned)tok_s[0] : bt;
+        const float ge = a.ge[ge_row * 4 * H + (gl.valid ? gl.gate * H + gl.unit : 0)];
 
         // ---- A: everything that multiplies h_{t-1} -------------------------------------------
+        float gh[NS];
         shared_dots<NS, K0>(w, h_s + half * K0, gh);        // rows >= 6H (phase D rows) compute an unused value
+        float ghh = 0.f;                                    // W_hh h of this lane's (unit, gate)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int r = s * kDecPairs + pair;
             const float acc = pair_sum(gh[s]);
-            gh[s] = acc;                                    // gate rows and q2k rows keep it for phase C2
+            if (s * kDecPairs < 4 * H && s < 2) { if (gl.upper == (s == 1)) ghh = acc; }
             if (r >= 4 * H && r < 6 * H && half == 0) {
-                if (r < 5 * H) qt_s[r - 4 * H] = acc;           // saved to global in C2 (see there)
-                else if (!COND) qv_s[r - 5 * H] = acc;
+                if (r < 5 * H) qt_s[r - 4 * H] = acc;
+                else if (COND) qh_s[r - 5 * H] = acc;
+                else qv_s[r - 5 * H] = acc;
             }
         }
         lds_barrier();
@@ -391,8 +469,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         attention_scores<H>(vt_s, qt_s, PKt, len, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(2)
-        // softmax over the command (seq2seq_model.py:136-137) in every wave's registers: lane m holds alpha_m,
-        // consumers fetch it with v_readlane — no LDS round trip, no serial single-wave phase
+        // ---- C: softmax over the command (seq2seq_model.py:136-137) in every wave's registers: lane m holds
+        // alpha_m; then the column sums sum_m alpha_m [U_t | PK_t | U2_t][m, :]
         float alpha;
         {
             const float x = (lane < len) ? sc_s[lane] : -INFINITY;
@@ -400,56 +478,29 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
             const float e = (lane < len) ? __expf(x - mx) : 0.f;
             alpha = e * __builtin_amdgcn_rcpf(wave_sum(e));
         }
-        // ---- C1: textual column sums sum_m alpha_m [U_t | PK_t | U2_t][m, :], one column quad per thread --
-        if (wave < (NQT + 63) / 64) {
-            float4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float *src = smem + qt_off;
-#pragma unroll 4
-            for (int m = 0; m < len; ++m) {
-                const float am = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), m));
-                acc = fma4(am, *reinterpret_cast<const float4 *>(src + m * qt_stride), acc);
-            }
-            if (tid < NQT) *reinterpret_cast<float4 *>(col_s + 4 * tid) = acc;
-        }
-        lds_barrier();
-        GSCAN_STAMP(3)
-        // ---- C2: hand the sums to their owners: gate rows, textual context, conditional query ------
-        // This is the one place where a wave waits for a global load (ge).  vmcnt counts stores too and the wait
-        // is a full drain here, so every store of phases A-C1 is issued after it instead of before: a store then
-        // has most of a step to be acknowledged before the next drain.
-        // all of them are consumed here, BEFORE this phase's stores: a wait behind a store would wait for its
-        // acknowledgement too
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            ge[s] += gh[s];
-            asm volatile("" : "+v"(ge[s]));                  // keeps the additions (and their wait) up here
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int r = s * kDecPairs + pair;
-            if (half == 0) {
-                if (r < 4 * H) {
-                    gsum_s[r] = ge[s] + col_s[r];
-                } else if (r < 5 * H) {
-                    if (!GREEDY) {
-                        a.s[bt * 4 * H + H + (r - 4 * H)] = col_s[r];
-                        a.qt[bt * H + r - 4 * H] = gh[s];
-                    }
-                } else if (r < 6 * H) {
-                    if (COND) {
-                        const float q = tanhf_(gh[s] + col_s[r] + bq_s[r - 5 * H]);   // seq2seq_model.py:394-396
-                        q2_s[r - 5 * H] = q;
-                        if (!GREEDY) a.q2[bt * H + r - 5 * H] = q;
-                    } else if (!GREEDY) {
-                        a.qv[bt * H + r - 5 * H] = gh[s];
-                    }
+        const float uct = quad_column_sum(ut_col, ut_stride, len, j4, alpha);     // this lane's gate, textual part
+        // This is the one place where a wave waits for a global load (ge): vmcnt counts stores too, so every store
+        // of phases A-C is issued behind this wait and has most of a step to be acknowledged before the next one
+        float pre = ge + ghh + uct;
+        asm volatile("" : "+v"(pre));
+        if (wave < (4 * NQ2 + 63) / 64) {
+            const float s2 = quad_column_sum(k2_col, k2_stride, len, j4, alpha);
+            const int col = 4 * cq2 + j4;
+            if (has2) {
+                if (col < H) {
+                    ctxt_s[col] = s2;
+                    if (!GREEDY) { a.s[bt * 4 * H + H + col] = s2; a.qt[bt * H + col] = qt_s[col]; }
+                } else {                                    // conditional query (seq2seq_model.py:394-396)
+                    const float q = tanhf_(s2 + qh_s[col - H] + bq_s[col - H]);
+                    q2_s[col - H] = q;
+                    if (!GREEDY) a.q2[bt * H + col - H] = q;
                 }
             }
         }
         if (wave == 0 && lane < L) a.alpha_c[bt * L + lane] = alpha;
         if (COND) {
             lds_barrier();
-            GSCAN_STAMP(4)
+            GSCAN_STAMP(3)
             // ---- D: visual query from the conditional query ---------------------------------
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -459,6 +510,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
                     if (half == 0) { qv_s[r - 6 * H] = acc; if (!GREEDY) a.qv[bt * H + r - 6 * H] = acc; }
                 }
             }
+        } else if (!GREEDY && tid < H) {
+            a.qv[bt * H + tid] = qv_s[tid];
         }
         lds_barrier();
         GSCAN_STAMP(5)
@@ -467,6 +520,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
         attention_scores<H>(vv_s, qv_s, PKv, M, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(6)
+        // ---- F: softmax, column sums over the cells, gates, cell update (seq2seq_model.py:414) ----
         {
             const float x = (lane < M) ? sc_s[lane] : -INFINITY;
             const float mx = wave_max(x);
@@ -477,58 +531,39 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
                 att_acc += alpha;                              // seq2seq_model.py:479,490
             }
         }
-        // ---- F1: visual column sums over four m-groups of two waves each: thread = (group, column quad) ---
+        float ucv;
+        if (uv_lds) {
+            ucv = quad_column_sum(uv_col, uv_stride, M, j4, alpha);
+        } else {                                               // U_vis streamed from L2 (it did not fit LDS)
+            const float from_l2 = quad_column_sum<true>(a.u_v + (int64_t)b * M * 4 * H + (gl.valid ? 4 * gl.unit : 0),
+                                                        gl.valid ? 4 * H : 0, M, j4, alpha);
+            const float from_lds = quad_column_sum(smem + o.pkv + (ctx_role ? 4 * spare : 0), ctx_role ? H : 0, M, j4, alpha);
+            ucv = gl.valid ? from_l2 : from_lds;
+        }
         {
-            const int grp = wave >> 1, q = tid & 127;          // the m range is wave-uniform
-            const int m_lo = grp * mg, m_hi = min(M, m_lo + mg);
-            float4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (uv_lds || q >= H) {                            // LDS-resident images (always: the PK columns)
-                const float *src = smem + qv_off;
-#pragma unroll 3
-                for (int m = m_lo; m < m_hi; ++m) {
-                    const float am = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), m));
-                    acc = fma4(am, *reinterpret_cast<const float4 *>(src + m * qv_stride), acc);
+            // one gate per lane: i, f, o = sigmoid, g = tanh, as a * sigmoid(s x) + c
+            const float act = fmaf(act_a, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(act_s * (pre + ucv))), act_c);
+            const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
+            if (gl.valid) {
+                if (!GREEDY) a.gates[bt * 4 * H + gl.gate * H + gl.unit] = act;
+                if (gl.gate == 0) {
+                    c = gf * c + gi * gg;
+                    const float h = go * tanhf_(c);
+                    h_s[gl.unit] = h;
+                    if (!GREEDY) {
+                        a.cells[bt * H + gl.unit] = c;
+                        a.s[bt * 4 * H + 3 * H + gl.unit] = h;
+                        if (t + 1 < T) a.hprev[(bt + 1) * H + gl.unit] = h;
+                    }
                 }
-            } else {                                           // U_vis streamed from L2 (it did not fit LDS)
-                const float *src = a.u_v + (int64_t)b * M * 4 * H + 4 * q;
-#pragma unroll 4
-                for (int m = m_lo; m < m_hi; ++m) {
-                    const float am = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), m));
-                    acc = fma4(am, *reinterpret_cast<const float4 *>(src + (int64_t)m * 4 * H), acc);
-                }
+            } else if (ctx_role) {
+                const int col = 4 * spare + j4;
+                if (GREEDY) ctxv_s[col] = ucv;
+                else a.s[bt * 4 * H + 2 * H + col] = ucv;
             }
-            if (q < NQV) *reinterpret_cast<float4 *>(part_s + grp * kPartStride + 4 * q) = acc;
         }
         lds_barrier();
         GSCAN_STAMP(7)
-
-        // ---- H: gates, cell update (seq2seq_model.py:414) and visual context -----------------------
-        if (tid < H) {
-            float g4[4];
-#pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-                const int r = gi * H + tid;
-                const float pre = gsum_s[r] + (part_s[r] + part_s[kPartStride + r]) +
-                                  (part_s[2 * kPartStride + r] + part_s[3 * kPartStride + r]);
-                g4[gi] = (gi == 2) ? tanhf_(pre) : sigmoidf_(pre);
-                if (!GREEDY) a.gates[bt * 4 * H + r] = g4[gi];
-            }
-            c = g4[1] * c + g4[0] * g4[2];
-            const float h = g4[3] * tanhf_(c);
-            h_s[tid] = h;
-            if (!GREEDY) {
-                a.cells[bt * H + tid] = c;
-                a.s[bt * 4 * H + 3 * H + tid] = h;
-                if (t + 1 < T) a.hprev[(bt + 1) * H + tid] = h;
-            }
-        } else if (tid >= 128 && tid < 128 + H) {
-            const int r = 4 * H + (tid - 128);
-            const float cv = (part_s[r] + part_s[kPartStride + r]) + (part_s[2 * kPartStride + r] + part_s[3 * kPartStride + r]);
-            if (GREEDY) ctxv_s[tid - 128] = cv;
-            else a.s[bt * 4 * H + 2 * H + (tid - 128)] = cv;
-        }
-        lds_barrier();
-        GSCAN_STAMP(8)
         if (GREEDY) {
             // output head on [e | ctx_text | ctx_vis | h] (seq2seq_model.py:421-424) as the composite W_h2o . W_o2h,
             // argmax (= argmax of log_softmax, predict.py:106-107; the first of equal maxima), feed back, stop at <EOS>
@@ -537,7 +572,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
                 const float *wrow = wc_s + v * 4 * H;
                 float p = 0.f;
                 for (int k = lane; k < H; k += 64)
-                    p += wrow[H + k] * col_s[4 * H + k] + wrow[2 * H + k] * ctxv_s[k] + wrow[3 * H + k] * h_s[k];
+                    p += wrow[H + k] * ctxt_s[k] + wrow[2 * H + k] * ctxv_s[k] + wrow[3 * H + k] * h_s[k];
                 p = wave_sum(p);
                 if (lane == 0) logit_s[v] = p + le_s[tok * V + v];
             }
@@ -708,12 +743,12 @@ __device__ __forceinline__ void score_backward(float dsm, const float *q_s, cons
 }
 
 // d alpha[m] = delta . U[m] (+ dzq . U2[m]) + dctx(ext) . PK[m] for the memories of one attention, one wave per
-// memory, 16-byte LDS reads.  float4 index idx < H covers the four delta blocks against U, the next H/4 the
+// memory, 16-byte LDS reads.  float4 index idx < H covers the gate deltas of unit idx (dperm_s, unit-major like U), the next H/4 the
 // external context gradient against PK, the last H/4 (conditional, textual only) dzq against U2.  The left-hand
 // vectors do not depend on m: each lane reads its (up to three) float4 of them once.
 // u_global != NULL: the U rows are read from global memory ([n, 4H]) instead of LDS.
 template <int H, int HP, bool WITH_U2>
-__device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s, const float *ext_s, int u_off,
+__device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s, const float *dperm_s, const float *ext_s, int u_off,
                                             int pk_off, int u2_off, int n, const float *add, float *sc_s, int wave,
                                             int nwave, int lane, const float *u_global = nullptr) {
     constexpr int Q = H / 4, NQ = (WITH_U2 ? 6 : 5) * Q, NI = (NQ + 63) / 64;
@@ -726,8 +761,8 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
         x[i] = float4{0.f, 0.f, 0.f, 0.f};
         yoff[i] = u_off;
         ystr[i] = 0;
-        if (idx < 4 * Q) {
-            x[i] = *reinterpret_cast<const float4 *>(d_s + (idx / Q) * HP + 4 * (idx % Q));
+        if (idx < 4 * Q) {              // the U images are unit-major: column quad idx = the four gates of unit idx
+            x[i] = *reinterpret_cast<const float4 *>(dperm_s + 4 * idx);
             yoff[i] = u_off + 4 * idx; ystr[i] = 4 * H;
         } else if (idx < 5 * Q) {
             x[i] = *reinterpret_cast<const float4 *>(ext_s + 4 * (idx - 4 * Q));
@@ -783,7 +818,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
                   HP = 2 * K0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = kDecThreads / 64;
-    const int pair = tid >> 1, half = tid & 1;
+    const int pair = decoder_pair_of(tid), half = decoder_half_of(tid);
     const int T = a.T, L = a.L, M = a.M;
     constexpr bool uv_lds = UVL;
     const DecoderLds o = decoder_lds(H, L, M, a.V, COND, true, uv_lds);
@@ -794,7 +829,8 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     float *dqv_s = vec + 6 * HP;      // [HP]
     float *qt_s = vec + 7 * HP, *q2_s = qt_s + H, *qv_s = q2_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H,
           *exc_s = vv_s + H, *exs_s = exc_s + H, *part_s = exs_s + H;    // part_s: 8H
-    float *sc_s = part_s + 8 * H, *al_s = sc_s + 64, *datt_s = sc_s + 128, *stamp_acc = sc_s + 192;
+    float *dperm_s = part_s + 8 * H;  // [H][4] the gate deltas again, unit-major (the layout of the U images)
+    float *sc_s = dperm_s + 4 * H, *al_s = sc_s + 64, *datt_s = sc_s + 128, *stamp_acc = sc_s + 192;
     long long stamp_prev = a.stamps ? clock64() : 0;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
@@ -991,6 +1027,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             const float d_o = dh * tc * og * (1.f - og);
             dc = dct * fg;
             d_s[tid] = di; d_s[HP + tid] = df; d_s[2 * HP + tid] = dg; d_s[3 * HP + tid] = d_o;
+            *reinterpret_cast<float4 *>(dperm_s + 4 * tid) = float4{di, df, dg, d_o};
             const unsigned dp = bt * 5 * uH + utid;      // rows of [delta (4H) | dzq (H)]
             a.delta[dp] = di; a.delta[dp + uH] = df; a.delta[dp + 2 * uH] = dg; a.delta[dp + 3 * uH] = d_o;
             // dqt of step t+1, kept in LDS by this thread since phase 7 of that step: stores go out right after
@@ -1010,7 +1047,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         GSCAN_STAMP(1)
 
         // ---- 2: d alpha_vis[m] = delta . U_vis[m] + dctx_vis(ext) . PK_vis[m] + d att_sum[m] ---
-        dalpha_rows<H, HP, false>(smem, d_s, exs_s, o.uv, o.pkv, o.pkv, M, datt_s, sc_s, wave, nwave, lane,
+        dalpha_rows<H, HP, false>(smem, d_s, dperm_s, exs_s, o.uv, o.pkv, o.pkv, M, datt_s, sc_s, wave, nwave, lane,
                                   uv_lds ? nullptr : a.u_v + (int64_t)b * M * 4 * H);
         lds_barrier();
         GSCAN_STAMP(2)
@@ -1052,7 +1089,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
         GSCAN_STAMP(5)
 
         // ---- 5: d alpha_text[m] = delta . U_text[m] + dzq . U2_text[m] + dctx_text(ext) . PK_text[m]
-        dalpha_rows<H, HP, COND>(smem, d_s, exc_s, o.ut, o.pkt, o.u2t, len, nullptr, sc_s, wave, nwave, lane);
+        dalpha_rows<H, HP, COND>(smem, d_s, dperm_s, exc_s, o.ut, o.pkt, o.u2t, len, nullptr, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(6)
         // ---- 6: the same for the textual attention -----------------------------------------------

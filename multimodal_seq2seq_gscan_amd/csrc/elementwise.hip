@@ -227,7 +227,8 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 //   seg 8  register images of the decoder's recurrent weights and of the output head (step.h)
 //   seg 9  register image of the encoder's recurrent weights: [dir][r][k][thread] = W_hh_dir[thread + r*NT][k]
 //   seg 10 [tap][ch][o] image of the three convolution kernels (conv.hip)
-//   seg 11-13 composite weights W_ih[:, ctx] . W_key (visual, textual) and W_q2k[:, ctx_text] . W_key_text
+//   seg 11-13 composite weights W_ih[:, ctx] . W_key (visual, textual; rows unit-major: row 4 unit + gate) and
+//          W_q2k[:, ctx_text] . W_key_text
 // ------------------------------------------------------------------------------------------
 
 __global__ void prologue_kernel(PrologueArgs a) {
@@ -307,7 +308,10 @@ __global__ void prologue_kernel(PrologueArgs a) {
             else if (idx < a.end[12]) { i = (int)(idx - a.end[11]); A = a.w_ih_dec; lda = 3 * H; col0 = H; Wk = a.w_key_txt; N = a.He; out = a.w_ck; }
             else { i = (int)(idx - a.end[12]); A = a.w_q2k; lda = 2 * H; col0 = H; Wk = a.w_key_txt; N = a.He; out = a.w_2kk; }
             const int r = i / N, c = i - r * N;
-            const float *arow = A + (int64_t)r * lda + col0;
+            // the gate images U = memory . (W_ih[:, ctx] . W_key)^T come out UNIT-major (column 4 unit + gate): the
+            // decoder's column sums read the four gates of a unit as one 16-byte word
+            const int src = (idx < a.end[12]) ? (r & 3) * H + (r >> 2) : r;
+            const float *arow = A + (int64_t)src * lda + col0;
             const float *wcol = Wk + c;
             float acc0 = 0.f, acc1 = 0.f;
             int h = 0;

@@ -59,9 +59,21 @@ struct DecoderGeometry { int rows, slots, k0; int64_t image_floats; };
 DecoderGeometry decoder_geometry(int H, bool cond);
 // Register images of the decoder weights (written once per step, by the prologue kernel):
 //   fwd/bwd image[((f/4)*512 + tid)*4 + f%4], f = slot*K0 + i = element i of the half-row that thread tid keeps in slot `slot`
-//     (task r = slot*256 + tid/2, position kk = (tid&1)*K0 + i along the dot); forward: row q of block sg of
+//     (task r = slot*256 + decoder_pair_of(tid), position kk = decoder_half_of(tid)*K0 + i along the dot; gate rows
+//     of the forward image unit-major: decoder_gate_row); forward: row q of block sg of
 //     [W_hh (4 blocks) | W_query_text | W_q2k[:, :H] or W_query_vis | W_query_vis]; backward: column q of block sg;
 //   head image[((i/4)*512 + tid)*4 + i%4] = MFMA B fragment of the permuted output_to_hidden: wo_perm[16 w + fr][4 i + fg].
+// Lane pairs of the decoder kernels: lane s and lane 7-s of every group of eight lanes (one DPP row_half_mirror apart)
+// hold the two halves of a weight row.  pair = 4 (tid / 8) + min(s, 7 - s), half = s / 4.
+__host__ __device__ inline int decoder_pair_of(int tid) { const int s = tid & 7; return 4 * (tid >> 3) + (s < 4 ? s : 7 - s); }
+__host__ __device__ inline int decoder_half_of(int tid) { return (tid >> 2) & 1; }
+// Forward image only: the gate rows are handed out UNIT-major so that the four gates of a hidden unit meet in one
+// quad of lanes (decoder.hip, gate_lane): task r < 4H of slot 0 (r < 256) is W_hh row (gate r % 4, unit r / 4); of
+// slot 1 it is (gate 3 - r % 4, unit 64 + (r - 256) / 4) — the upper quad of a group of eight sees its pairs mirrored.
+__host__ __device__ inline int decoder_gate_row(int r, int H) {
+    const int slot = r / kDecPairs, pr = r % kDecPairs, unit = 64 * slot + pr / 4, gate = slot ? 3 - pr % 4 : pr % 4;
+    return gate * H + unit;
+}
 struct DecoderImageArgs {
     const float *w_hh, *w_qt, *w_qv, *w_q2k, *w_o2h;
     float *fwd_image, *bwd_image, *head_image;
@@ -87,13 +99,13 @@ __device__ __forceinline__ void decoder_image_element(const DecoderImageArgs &a,
     const bool bwd = e >= total;
     const int x = bwd ? e - total : e;
     const int tid = (x >> 2) % kDecThreads, f = 4 * (x / (4 * kDecThreads)) + (x & 3), i = f % a.k0, s = f / a.k0;
-    const int r = s * kDecPairs + (tid >> 1), kk = (tid & 1) * a.k0 + i;               // kk: position along the dot
+    const int r = s * kDecPairs + decoder_pair_of(tid), kk = decoder_half_of(tid) * a.k0 + i;   // kk: position along the dot
     float v = 0.f;
     const int rows = (a.cond ? 7 : 6) * H;
     if (r < rows && kk < H) {
         const int sg = r / H, q = r % H;                                               // block, index inside it
         if (!bwd) {          // row q of block sg, element kk
-            if (sg < 4) v = a.w_hh[(int64_t)r * H + kk];
+            if (sg < 4) v = a.w_hh[(int64_t)decoder_gate_row(r, H) * H + kk];
             else if (sg == 4) v = a.w_qt[(int64_t)q * H + kk];
             else if (sg == 5) v = a.cond ? a.w_q2k[(int64_t)q * 2 * H + kk] : a.w_qv[(int64_t)q * H + kk];
             else v = a.w_qv[(int64_t)q * H + kk];
@@ -202,7 +214,11 @@ int sequence_metrics(const float *logp, const int64_t *targets, int B, int T, in
 // Hidden sizes with compiled kernels (the recurrent weights live in registers, so the size is a template parameter):
 // EVERY multiple of 4 — decoder / keys kernels up to 100 (five column quads per unit must fit 128 threads, 7 H^2
 // weights the register file), encoder up to 128.
+#ifdef GSCAN_DEC_HIDDEN_ONLY      // development builds (assembly inspection): one decoder hidden size only
+#define GSCAN_DEC_HIDDEN_SIZES(X) X(GSCAN_DEC_HIDDEN_ONLY)
+#else
 #define GSCAN_DEC_HIDDEN_SIZES(X) X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64) X(68) X(72) X(76) X(80) X(84) X(88) X(92) X(96) X(100)
+#endif
 #define GSCAN_DEC_HIDDEN_LIST "multiples of 4 from 4 to 100"
 #define GSCAN_ENC_HIDDEN_SIZES(X) X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64) X(68) X(72) X(76) X(80) X(84) X(88) X(92) X(96) X(100) X(104) X(108) X(112) X(116) X(120) X(124) X(128)
 #define GSCAN_ENC_HIDDEN_LIST "multiples of 4 from 4 to 128"
