@@ -52,9 +52,9 @@ def source_hash() -> str:
 
 
 def pmc_traffic(kernel_family: str, workload: str):
-    """(bytes per launch or None, provenance string)."""
+    """(bytes per launch of the GEMM family or None, provenance string, {kernel: bytes per launch} of every profiled kernel)."""
     if kernel_family != "gemm" or not os.path.exists(PMC_TRAFFIC):
-        return None, "no PMC profile for this kernel family"
+        return None, "no PMC profile for this kernel family", {}
     try:
         with open(PMC_TRAFFIC) as f:
             prof = json.load(f)
@@ -62,12 +62,13 @@ def pmc_traffic(kernel_family: str, workload: str):
             print(f"bench.py: WARNING: {PMC_TRAFFIC} was collected on other kernel sources "
                   f"({prof.get('source_sha')} != {source_hash()}): roofline.traffic is null; rerun tools/gpu_round.sh",
                   file=sys.stderr, flush=True)
-            return None, "stale PMC profile (kernel sources changed since it was collected)"
+            return None, "stale PMC profile (kernel sources changed since it was collected)", {}
         if prof.get("workload", "compositional") != workload:
-            return None, f"PMC profile is of workload {prof.get('workload')}"
-        return round(float(prof["traffic_bytes_per_launch"])), f"profiles/pmc_traffic_latest.json ({prof.get('tag', '?')})"
+            return None, f"PMC profile is of workload {prof.get('workload')}", {}
+        return round(float(prof["traffic_bytes_per_launch"])), f"profiles/pmc_traffic_latest.json ({prof.get('tag', '?')})", \
+            {k: round(float(v["traffic_bytes_per_launch"])) for k, v in prof.get("kernels", {}).items()}
     except (OSError, ValueError, KeyError) as e:
-        return None, f"unreadable PMC profile: {e}"
+        return None, f"unreadable PMC profile: {e}", {}
 
 
 def algorithmic_mflop_per_example(cfg: dict, G: int, L: int, T: int) -> float:
@@ -423,7 +424,7 @@ def main():
                    "algorithmic_tflops": round(v["tflops"], 3), "frac_of_fp32_peak": round(v["tflops"] / PEAK_FP32_TFLOPS, 4)}
                   for k, v in sorted(merged.items(), key=lambda kv: -kv[1]["ms_per_step"])]
         mflop = algorithmic_mflop_per_example(cfg, grid, L, T)
-        traffic, traffic_source = pmc_traffic(dominant, args.workload if not args.auxiliary and T == 20 else "other")
+        traffic, traffic_source, traffic_all = pmc_traffic(dominant, args.workload if not args.auxiliary and T == 20 else "other")
         windows_sorted = sorted(windows)
         label = {"compositional": "S4 GECA-like (auxiliary head)" if args.auxiliary else "S1 compositional",
                  "target_length": "S3 target_length", "demo": "S0 demo"}[args.workload]
@@ -448,7 +449,7 @@ def main():
                                              else f"torch.distributed {args.backend}")},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(d["tflops"], 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_FP32_TFLOPS, 4),
-                         "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": round(d["avg_us"], 2),
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_by_kernel": traffic_all, "avg_launch_us": round(d["avg_us"], 2),
                          "algorithmic_gflop_per_launch": round(d["algorithmic_gflop_per_launch"], 4),
                          "executed_over_algorithmic": round(d["executed_tflops"] / d["tflops"], 3) if d["tflops"] > 0 else None,
                          "note": "achieved = ALGORITHMIC flops of the family's launches (SURVEY.md 8d: composite-weight and "

@@ -19,7 +19,7 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_w" -o run -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$out/pmc_w.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_m" -o run -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$out/pmc_m.log" 2>&1
 python tools/pmc_mfma.py "$(find $out/pmc_m -name '*counter_collection.csv' | head -1)" > "$out/pmc_mfma.json"
-python tools/pmc_traffic.py "$(find $out/pmc_f -name '*counter_collection.csv' | head -1)" "$(find $out/pmc_w -name '*counter_collection.csv' | head -1)" gemm_group_kernel "$tag" > "$out/pmc_traffic.json"
+python tools/pmc_traffic.py "$(find $out/pmc_f -name '*counter_collection.csv' | head -1)" "$(find $out/pmc_w -name '*counter_collection.csv' | head -1)" gemm_group_kernel,decoder_fwd_kernel,decoder_bwd_kernel,keys_backward_kernel "$tag" > "$out/pmc_traffic.json"
 cat "$out/pmc_traffic.json"
 cp "$(find $out/prof -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
 head -12 "$out/kernel_stats.csv"
