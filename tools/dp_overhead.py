@@ -17,9 +17,9 @@ dist.init_process_group("nccl", rank=0, world_size=1)
 for aux in (False, True):
     cfg = model_kwargs("compositional", auxiliary_task=aux)
     batch = {k: v.cuda() for k, v in make_batch(Shape(batch=256), 1).items()}
-    for collective in (False, True):
+    for collective, native in ((False, None), (True, False), (True, True)):
         torch.manual_seed(0)
-        step = TrainStep(Model(**cfg).cuda(), always_collective=collective)
+        step = TrainStep(Model(**cfg).cuda(), always_collective=collective, native_allreduce=native)
         for _ in range(20):
             step(batch)
         torch.cuda.synchronize()
@@ -27,6 +27,8 @@ for aux in (False, True):
         for _ in range(100):
             step(batch)
         torch.cuda.synchronize()
-        print(f"auxiliary={aux} collectives={'RCCL (1 rank)' if collective else 'none'}: "
+        how = "none" if not collective else ("gscan_allreduce_f32 on the step's stream (1 rank)" if step.exchange.comm is not None
+                                              else "torch.distributed RCCL stream (1 rank)")
+        print(f"auxiliary={aux} collectives={how}: "
               f"{1e3 * (time.perf_counter() - t0) / 100:.4f} ms/step", flush=True)
 dist.destroy_process_group()
