@@ -1136,7 +1136,9 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     }
     for (int i = tid; i < M * H; i += kDecThreads) a.dpk_v[(int64_t)b * M * H + i] = dPKv[i];
     for (int i = tid; i < L * H; i += kDecThreads) a.dpk_t[(int64_t)b * L * H + i] = (i / H < len) ? dPKt[i] : 0.f;
-    // energy-vector gradients: every wave holds partial sums for features (lane, lane+64)
+    // energy-vector gradients of this ROW (every wave holds partial sums for features (lane, lane+64)); the rows are
+    // added up by a leaf launch (energy_grad_sum).  256 workgroups adding into the same 2H addresses with atomics kept
+    // this kernel's last writes — and the whole critical chain behind it — waiting ~9 us (profiles/r03_c_*).
     lds_barrier();
     if (lane < H) part_s[wave * H + lane] = dvv_acc.x;
     if (lane + 64 < H) part_s[wave * H + lane + 64] = dvv_acc.y;
@@ -1144,7 +1146,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     if (tid < H) {
         float x = 0.f;
         for (int cch = 0; cch < kDecThreads / 64; ++cch) x += part_s[cch * H + tid];
-        atomicAdd(&a.dv_v[tid], x);
+        a.dv_v[(int64_t)b * H + tid] = x;
     }
     lds_barrier();
     if (lane < H) part_s[wave * H + lane] = dvt_acc.x;
@@ -1153,7 +1155,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     if (tid < H) {
         float x = 0.f;
         for (int cch = 0; cch < kDecThreads / 64; ++cch) x += part_s[cch * H + tid];
-        atomicAdd(&a.dv_t[tid], x);
+        a.dv_t[(int64_t)b * H + tid] = x;
     }
     if (a.stamps && blockIdx.x == 0 && tid < 10) a.stamps[tid] = stamp_acc[tid];
     GSCAN_STAMP_ONCE(12)

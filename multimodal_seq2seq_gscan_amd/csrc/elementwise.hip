@@ -337,11 +337,43 @@ int step_prologue(const PrologueArgs &args, hipStream_t stream) {
     return 0;
 }
 
-// g_w_o2h[row, original column] += dwo_perm[row, S-order column]
-__global__ void unpermute_add_kernel(const float *__restrict__ dwo_perm, float *__restrict__ g_w_o2h, int H) {
+// g_w_o2h[row, original column] += dwo_perm[row, S-order column]; and, in the workgroups behind those, the energy-vector
+// gradients: g_v[k] += sum over the batch rows of the decoder kernel's per-row sums (fixed order, one thread per column)
+__global__ void unpermute_add_kernel(const float *__restrict__ dwo_perm, float *__restrict__ g_w_o2h, int H, int nperm_blocks,
+                                     const float *__restrict__ dv_t_rows, const float *__restrict__ dv_v_rows, int B,
+                                     float *__restrict__ g_v_t, float *__restrict__ g_v_v) {
     TraceScope trace_scope(TK_UNPERMUTE);
+    if ((int)blockIdx.x >= nperm_blocks) {
+        // a workgroup takes 32 columns of [dv_text | dv_vis]; a thread = (column, one of 8 slices of the batch rows): up to
+        // 32 rows per pass, all loads of a pass in flight, then the 8 slice sums are added in a fixed order
+        __shared__ float part[8][32];
+        const int c = threadIdx.x & 31, slice = threadIdx.x >> 5, k = (blockIdx.x - nperm_blocks) * 32 + c;
+        const bool live = k < 2 * H;
+        const float *src = (k < H ? dv_t_rows : dv_v_rows) + (live ? (k < H ? k : k - H) : 0);
+        const int per = (B + 7) / 8, r0 = slice * per, r1 = min(B, r0 + per);
+        float acc = 0.f;
+        for (int base = r0; base < r1; base += 32) {
+            float x[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) x[u] = (live && base + u < r1) ? src[(int64_t)(base + u) * H] : 0.f;
+#pragma unroll
+            for (int u = 16; u > 0; u >>= 1)
+#pragma unroll
+                for (int v = 0; v < u; ++v) x[v] += x[v + u];
+            acc += x[0];
+        }
+        part[slice][c] = acc;
+        __syncthreads();
+        if (slice == 0 && live) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum += part[q][c];
+            (k < H ? g_v_t : g_v_v)[k < H ? k : k - H] += sum;
+        }
+        return;
+    }
     const int n = H * 4 * H;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nperm_blocks * blockDim.x) {
         const int row = i / (4 * H), col = i % (4 * H);
         const int seg = col / H, k = col % H;
         const int dst = (seg == 0 ? 0 : seg == 1 ? 2 * H : seg == 2 ? 3 * H : H) + k;
@@ -349,8 +381,11 @@ __global__ void unpermute_add_kernel(const float *__restrict__ dwo_perm, float *
     }
 }
 
-int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream) {
-    hipLaunchKernelGGL(unpermute_add_kernel, dim3(cdiv(H * 4 * H, 256)), dim3(256), 0, stream, dwo_perm, g_w_o2h, H);
+int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream, const float *dv_t_rows,
+                  const float *dv_v_rows, int B, float *g_v_t, float *g_v_v) {
+    const int nperm = cdiv(H * 4 * H, 256), nsum = dv_t_rows ? cdiv(2 * H, 32) : 0;
+    hipLaunchKernelGGL(unpermute_add_kernel, dim3(nperm + nsum), dim3(256), 0, stream, dwo_perm, g_w_o2h, H, nperm, dv_t_rows,
+                       dv_v_rows, B, g_v_t, g_v_v);
     GSCAN_LAUNCHED("unpermute_add_kernel");
     return 0;
 }

@@ -152,7 +152,8 @@ struct PrologueArgs {
     int F;
 };
 int step_prologue(const PrologueArgs &args, hipStream_t stream);
-int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream);
+int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream, const float *dv_t_rows = nullptr,
+                  const float *dv_v_rows = nullptr, int B = 0, float *g_v_t = nullptr, float *g_v_v = nullptr);
 int adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
               float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
               const float *dev_scalars, int zero_grad, hipStream_t stream);   // zero_grad bit 1: grad_scale divides
@@ -280,7 +281,7 @@ struct DecoderArgs {
     float *stats_out, *seeds_out;      // [4] batch sums, [3] = [1/tokens, w/rows, loss]; written by workgroup 0
     float *delta, *dqt, *dqv;          // [B,T,5H] = [gate deltas (4H) | dzq (H)], [B,T,H], [B,T,H]
     float *dpk_t, *dpk_v;              // [B,L,H] [B,M,H]  score-path key gradients
-    float *dv_t, *dv_v;                // [H] energy-vector gradients, accumulated with atomics
+    float *dv_t, *dv_v;                // [B,H] energy-vector gradients of every row (summed by unpermute_add's launch)
     float *dh0;                        // [B,H] gradient wrt the bridge pre-activation
     float *stamps;                     // diagnostics: [2][16] per-phase cycle sums of workgroup 0, or NULL
     // greedy decoding (forward kernel, GREEDY instantiation; selected by tokens_out != NULL): T = step limit,

@@ -543,13 +543,24 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     // ---- reverse recurrence (occupies every CU: nothing overlaps it).  Its prologue is the backward of the head
     // (log_softmax, hidden_to_output, output_to_hidden) for the row's T steps; seeds (optional, device) multiply
     // dlogp by seeds[0] and daux by seeds[1]
+    // The convolution gradients' lists of non-zeros depend on the batch alone and their leaf ends the step (it starts
+    // behind keys_backward and runs longest): built here on the second leaf stream, forked BEFORE the reverse
+    // recurrence, they run whenever the chip has room — normally as the recurrence drains — and are long done when
+    // the convolution gradients start.  (Built on the caller's stream, or as passengers of the forward world encoder,
+    // they cost the critical chain what they saved: DESIGN.md 6.)
+    static const int early_lists = [] { const char *e = getenv("GSCAN_EARLY_LISTS"); return e ? atoi(e) : 1; }();
+    if (early_lists) {
+        TRY(order_after(sd2, st));
+        TRY(world_conv_lists(bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world, bt.world_u8 != nullptr, B, d.G,
+                             C, w + ws.conv_lists, sd2));
+    }
     const bool use_aux = d.auxiliary && daux;
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.dlogp = dlogp; a.daux = use_aux ? daux : nullptr; a.seeds = seeds;
     if (nll) { a.nll_mode = nll->sum ? 2 : 1; a.w_aux = nll->w_aux; a.stats_out = nll->stats_out; a.seeds_out = nll->seeds_out; }
     a.dlogits = w + ws.dlogits; a.dpreo = w + ws.dpreo; a.ds = dS;
     a.delta = w + ws.delta; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
-    a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = g.txt_energy_w; a.dv_v = g.vis_energy_w;
+    a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = w + ws.dv_t; a.dv_v = w + ws.dv_v;
     a.dh0 = w + ws.dh0;
     a.w_image = w + ws.dec_w_bwd;
     a.stamps = probe_stamps_enabled() ? w + ws.stamps + 16 : nullptr;
@@ -580,7 +591,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
             g_split_override = 0;
             b.add(BT, H, 4 * H, delta, 5 * H, 1, w + ws.wcat5, 3 * H, 1, dS, 4 * H, 1.f);
             TRY(b.launch(sd));
-            TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, sd));
+            TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, sd, w + ws.dv_t, w + ws.dv_v, B, g.txt_energy_w, g.vis_energy_w));
             TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd));
         }
         return 0;
@@ -618,8 +629,9 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         // -> 0.572 ms.  As passenger workgroups of the forward pass's world-encoder launch: that launch 10.6 -> 15.2 us,
         // and the 17 us this leaf starts earlier are lost again because it then overlaps the encoder's weight-gradient
         // launch, which stretches 19 -> 41 us: this stretch of the step is throughput-bound, 0.541 vs 0.538 ms.)
-        TRY(world_conv_lists(bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world, bt.world_u8 != nullptr, B, d.G,
-                             C, w + ws.conv_lists, sd2));
+        if (!early_lists)
+            TRY(world_conv_lists(bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world, bt.world_u8 != nullptr, B,
+                                 d.G, C, w + ws.conv_lists, sd2));
         TRY(world_conv_backward(w + ws.dfeat, B, d.G, C, Co, d.K3, w + ws.conv_lists, gw, gb, sd2));
     }
     // ---- command encoder BPTT (chain), last layer first.  Per layer: the reverse recurrence, then ONE launch on the

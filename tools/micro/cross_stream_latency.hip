@@ -1,8 +1,10 @@
 // Microbenchmark: how long after a kernel on stream A ends does a dependent kernel on stream B start, by mechanism:
 //   (1) hipEventRecord / hipStreamWaitEvent   (2) hipStreamWriteValue32 / hipStreamWaitValue32 on signal memory
-//   (3) same stream (in-order launch), for reference.
+//   (3) same stream (in-order launch), for reference.   (10, 11) hipExtLaunchKernelGGL(..., stopEvent): the kernel's own
+//   completion signal is the event, no marker packet behind it
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/cross_stream_latency.hip -o gpurun_out/micro/xs && gpurun_out/micro/xs
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <algorithm>
 #include <vector>
@@ -49,7 +51,9 @@ int main() {
     float4 *big; float *bg;
     const size_t n4 = (32u << 20) / 16;
     CK(hipMalloc(&big, n4 * 16)); CK(hipMalloc(&bg, 4));
-    for (int mode = 1; mode <= 9; ++mode) {
+    hipEvent_t evt;
+    CK(hipEventCreateWithFlags(&evt, hipEventDisableSystemFence));      // stop events may need timing enabled
+    for (int mode = 1; mode <= 11; ++mode) {
         std::vector<double> lat;
         for (int r = 0; r < reps; ++r) {
             CK(hipMemset(stamps, 0, 16));
@@ -68,6 +72,13 @@ int main() {
                 hipLaunchKernelGGL(producer, dim3(1), dim3(64), 0, a, stamps, spin);
                 e = hipStreamWriteValue32(a, flag, (uint32_t)(r + 1), 0);
                 if (e != hipSuccess) { printf("hipStreamWriteValue32: %s\n", hipGetErrorString(e)); break; }
+            } else if (mode == 10 || mode == 11) {
+                hipEvent_t e = mode == 10 ? ev : evt;
+                if (mode == 10) hipExtLaunchKernelGGL(producer, dim3(1), dim3(64), 0, a, nullptr, e, 0, stamps, spin);
+                else hipExtLaunchKernelGGL(heavy_producer, dim3(2048), dim3(256), 0, a, nullptr, e, 0, stamps, big, n4, 1);
+                hipError_t rc = hipStreamWaitEvent(b, e, 0);
+                if (rc != hipSuccess) { printf("wait on a stop event: %s\n", hipGetErrorString(rc)); break; }
+                hipLaunchKernelGGL(consumer, dim3(1), dim3(64), 0, b, stamps);
             } else if (mode == 3) {
                 hipLaunchKernelGGL(producer, dim3(1), dim3(64), 0, a, stamps, spin);
                 hipLaunchKernelGGL(consumer, dim3(1), dim3(64), 0, a, stamps);
@@ -99,7 +110,8 @@ int main() {
         std::sort(lat.begin(), lat.end());
         const char *names[] = {"", "event record -> stream wait event", "write value -> wait value (armed early)", "same stream",
                                "heavy producer, same stream", "heavy producer, event", "heavy producer, wait value",
-                               "heavy + background, same stream", "heavy + background, event", "heavy + background, wait value"};
+                               "heavy + background, same stream", "heavy + background, event", "heavy + background, wait value",
+                               "stop event of the kernel (no-timing event)", "heavy producer, stop event (timing event)"};
         printf("%-42s median %6.1f us  min %6.1f  max %6.1f\n", names[mode], lat[lat.size() / 2], lat.front(), lat.back());
     }
     return 0;
