@@ -44,6 +44,7 @@ class FlatAdam:
         self.lr, self.betas, self.eps = float(learning_rate), (float(adam_beta_1), float(adam_beta_2)), float(eps)
         self.lr_decay, self.lr_decay_steps = float(lr_decay), float(lr_decay_steps)
         self.steps_taken = 0          # Adam's `step` (bias corrections); restored from a checkpoint
+        self._resume_lr = None        # the rate of the first optimizer.step() after load_state_dict (see _lr_of_this_step)
         self.lr_steps = 0             # LambdaLR's counter; NOT restored on resume, as in the reference (train.py:68-84:
                                       # the scheduler is built before optimizer.load_state_dict and is not checkpointed,
                                       # so a resumed run starts again from the initial learning rate)
@@ -63,7 +64,12 @@ class FlatAdam:
         self.lr_steps += 1
 
     def _lr_of_this_step(self) -> float:
-        """The learning rate optimizer.step() number `lr_steps` runs with: the scheduler has stepped lr_steps-1 times."""
+        """The learning rate optimizer.step() number `lr_steps` runs with: the scheduler has stepped lr_steps-1 times.
+        The FIRST step after a resume runs with the checkpoint's own rate: the reference's optimizer.load_state_dict
+        overwrites param_groups[0]['lr'] behind the freshly built scheduler (train.py:68-84), whose next step() then
+        puts the schedule back on its restarted curve."""
+        if self._resume_lr is not None and self.lr_steps == 1:
+            return self._resume_lr
         return self.lr * self.lr_decay ** ((self.lr_steps - 1) / self.lr_decay_steps)
 
     def stage_scalars(self) -> None:
@@ -125,6 +131,8 @@ class FlatAdam:
             self.exp_avg_sq[off:off + n].copy_(sd["state"][i]["exp_avg_sq"].reshape(-1))
             self.steps_taken = int(sd["state"][i]["step"])
         self.lr_steps = 0
+        groups = sd.get("param_groups") or [{}]
+        self._resume_lr = float(groups[0]["lr"]) if "lr" in groups[0] else None
 
 
 class RcclCommunicator:

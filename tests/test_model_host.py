@@ -117,6 +117,15 @@ def test_reference_checkpoint_loads_and_round_trips(tmp_path):
     opt.load_state_dict(opt_state)
     assert opt.steps_taken == 2
     assert opt.lr_steps == 0 and opt.current_lr() == 1e-3      # the scheduler restarts on resume (train.py:68-84)
+    # ... but the FIRST optimizer.step() after the resume runs with the rate the checkpoint carries (the reference's
+    # optimizer.load_state_dict overwrites the group's lr behind the new scheduler), the second is back on the curve
+    saved_lr = ref["optimizer_state_dict"]["param_groups"][0]["lr"]
+    probe = FlatAdam(model, 1e-3)
+    probe.load_state_dict(opt_state)
+    probe.advance()
+    assert probe._lr_of_this_step() == saved_lr and saved_lr < 1e-3
+    probe.advance()
+    assert abs(probe._lr_of_this_step() - 1e-3 * 0.9 ** (1 / 20000.0)) < 1e-12
     names = [n for n, _ in model.named_parameters()]
     for i, n in enumerate(names):
         off, cnt = model._offsets[n]
