@@ -309,7 +309,7 @@ __device__ __forceinline__ float quad_column_sum(const float *base, int stride, 
             const int m = i0 + 4 * u + j, mc = min(m, n - 1);
             if (GLOBAL) x[u] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(
                                (const __attribute__((address_space(1))) float *)base + (int64_t)mc * stride);
-            else x[u] = *reinterpret_cast<const f32x4 *>(base + mc * stride);
+            else x[u] = *reinterpret_cast<const f32x4 *>(base + __mul24(mc, stride));   // 24-bit multiply: full rate (v_mul_lo_u32 is quarter rate)
             const float al = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mc, __float_as_int(alpha)));
             am[u] = m < n ? al : 0.f;
         }

@@ -752,3 +752,37 @@ def test_reference_checkpoint_scores_the_same_on_the_device(tmp_path):
                          situations_input=d["world"], target_batch=d["targets"],
                          target_lengths=batch["tgt_lengths"].tolist())
     assert torch.equal(logp2, logp)
+
+
+def test_batches_staged_per_rank_are_the_shards_of_the_global_batches(tmp_path):
+    """Data parallelism stages only a rank's OWN rows of every global batch (`batches(row_shard=(rank, world))`): the
+    rows must be exactly what train.shard_batch cuts from the full batch, the ranks together cover every batch once,
+    and a trailing batch with fewer rows than ranks is dropped by every rank."""
+    from multimodal_seq2seq_gscan_amd.dataset import GroundedScanDataset
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, write_dataset_file
+    from multimodal_seq2seq_gscan_amd.train import shard_batch
+    path = str(tmp_path / "dataset.txt")
+    write_dataset_file(path, {"train": 66}, Shape(batch=1, max_command=8, max_target=12), seed=13)   # 4 x 16 + 2
+    data = GroundedScanDataset(path, str(tmp_path), k=0, split="train", generate_vocabulary=True)
+    data.read_dataset()
+    np.random.seed(5)
+    data.shuffle_data()
+    world = 3
+    full = [{k: v.clone() for k, v in b.items() if k != "index"} | {"index": b["index"].copy()} for b in data.batches(16)]
+    assert [len(b["index"]) for b in full] == [16, 16, 16, 16, 2]
+    per_rank = [[{k: (v.clone() if torch.is_tensor(v) else v.copy()) for k, v in b.items()}
+                 for b in data.batches(16, row_shard=(r, world))] for r in range(world)]
+    assert all(len(p) == 4 for p in per_rank)                       # the 2-row batch is dropped on every rank
+    for i in range(4):
+        rows = np.concatenate([per_rank[r][i]["index"] for r in range(world)])
+        assert np.array_equal(rows, full[i]["index"])
+        for r in range(world):
+            lo, hi = r * 16 // world, (r + 1) * 16 // world
+            mine = per_rank[r][i]
+            want = shard_batch({k: v for k, v in full[i].items() if k != "index"}, r, world)
+            L, T = mine["commands"].shape[1], mine["targets"].shape[1]          # a shard is padded to ITS longest rows
+            assert mine["commands"].shape[0] == hi - lo
+            assert torch.equal(mine["commands"], want["commands"][:, :L]) and (want["commands"][:, L:] == 0).all()
+            assert torch.equal(mine["targets"], want["targets"][:, :T]) and (want["targets"][:, T:] == 0).all()
+            assert torch.equal(mine["world"], want["world"]) and torch.equal(mine["cmd_lengths"], want["cmd_lengths"])
+            assert torch.equal(mine["target_positions"], want["target_positions"])
