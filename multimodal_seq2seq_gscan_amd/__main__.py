@@ -67,9 +67,12 @@ def _init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    # GSCAN_DIST_BACKEND=gloo: rehearsal of the rank plumbing with the ranks sharing devices (gradients staged through the
+    # host; RCCL wants a device per rank)
+    backend = os.environ.get("GSCAN_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()) if backend == "gloo" else local)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group(backend="nccl")     # RCCL on ROCm
+        dist.init_process_group(backend=backend)    # "nccl" is RCCL on ROCm
     return rank, world
 
 

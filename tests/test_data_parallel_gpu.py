@@ -175,3 +175,33 @@ def test_bench_self_launch_two_ranks_share_the_device():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["value"] > 0
     assert out["config"]["gradient_exchange"] == "torch.distributed gloo"
+
+
+def test_command_line_training_on_a_dataset_file_with_two_ranks(tmp_path):
+    """`python -m seq2seq --mode=train` under two rank processes (what torch.distributed.run starts), on a generated
+    dataset FILE: every rank reads the file, stages only its own rows of each global batch, the step's collectives
+    run (gloo here: two ranks on the box's one device), evaluation is sharded over the ranks, rank 0 checkpoints."""
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, write_dataset_file
+    data_dir = tmp_path / "data"
+    data_dir.mkdir()
+    write_dataset_file(str(data_dir / "dataset.txt"), {"train": 70, "dev": 12}, Shape(batch=1, max_command=8, max_target=10), seed=21)
+    out = tmp_path / "out"
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GSCAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen(
+            [sys.executable, "-m", "seq2seq", "--mode", "train", "--data_directory", str(data_dir), "--output_directory", str(out),
+             "--generate_vocabularies", "--training_batch_size", "16", "--max_training_iterations", "12", "--print_every", "4",
+             "--evaluate_every", "6", "--max_decoding_steps", "10", "--embedding_dimension", "5", "--encoder_hidden_size", "20",
+             "--decoder_hidden_size", "20", "--seed", "2"],
+            env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=420)[0] for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r}:\n{logs[r][-3000:]}"
+    assert "Iteration 00000012" in logs[0] and "Evaluation Accuracy" in logs[0]
+    assert "Iteration" not in logs[1].replace("trained_iterations", "")          # only rank 0 logs progress
+    # (a checkpoint is written only when the dev exact match improves, train.py:141-149: not after 12 iterations)
+    assert os.path.exists(data_dir / "training_input_vocab.txt") and os.path.exists(data_dir / "training_target_vocab.txt")
+    assert logs[0].count("Evaluation Accuracy") == 2 and "Finished training." in logs[0] and "Finished training." in logs[1]
