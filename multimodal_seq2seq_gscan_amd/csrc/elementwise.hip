@@ -313,14 +313,24 @@ __global__ void prologue_kernel(PrologueArgs a) {
             const int src = (idx < a.end[12]) ? (r & 3) * H + (r >> 2) : r;
             const float *arow = A + (int64_t)src * lda + col0;
             const float *wcol = Wk + c;
+            // twenty products fetched per pass (forty loads in flight): at eight the 100-deep dot was thirteen dependent
+            // round trips to L2 and the longest chain of the whole launch
             float acc0 = 0.f, acc1 = 0.f;
             int h = 0;
-            for (; h + 7 < H; h += 8) {
-                float x[8], y[8];
+            constexpr int U = 20;
+            for (; h + U - 1 < H; h += U) {
+                float x[U], y[U];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { x[u] = arow[h + u]; y[u] = wcol[(int64_t)(h + u) * N]; }
+                for (int u = 0; u < U; ++u) { x[u] = arow[h + u]; y[u] = wcol[(int64_t)(h + u) * N]; }
 #pragma unroll
-                for (int u = 0; u < 8; u += 2) { acc0 = fmaf(x[u], y[u], acc0); acc1 = fmaf(x[u + 1], y[u + 1], acc1); }
+                for (int u = 0; u < U; u += 2) { acc0 = fmaf(x[u], y[u], acc0); acc1 = fmaf(x[u + 1], y[u + 1], acc1); }
+            }
+            for (; h + 3 < H; h += 4) {
+                float x[4], y[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { x[u] = arow[h + u]; y[u] = wcol[(int64_t)(h + u) * N]; }
+                acc0 = fmaf(x[0], y[0], acc0); acc1 = fmaf(x[1], y[1], acc1);
+                acc0 = fmaf(x[2], y[2], acc0); acc1 = fmaf(x[3], y[3], acc1);
             }
             for (; h < H; ++h) acc0 = fmaf(arow[h], wcol[(int64_t)h * N], acc0);
             out[i] = acc0 + acc1;
@@ -331,7 +341,10 @@ __global__ void prologue_kernel(PrologueArgs a) {
 int step_prologue(const PrologueArgs &args, hipStream_t stream) {
     const int64_t total = args.end[13];
     if (total == 0) return 0;
-    hipLaunchKernelGGL(prologue_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, stream,
+    // two passes per thread at most at the benchmark shape (the kernel is chains of dependent loads, not bandwidth;
+    // 2048 / 4096 / 8192 / 16384 workgroups: 0.521 / 0.517 / 0.523 / 0.524 ms per step)
+    static const int cap = [] { const char *e = getenv("GSCAN_PROLOGUE_BLOCKS"); return e ? atoi(e) : 4096; }();
+    hipLaunchKernelGGL(prologue_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), cap)), dim3(256), 0, stream,
                        args);
     GSCAN_LAUNCHED("prologue_kernel");
     return 0;
