@@ -215,35 +215,54 @@ __global__ __launch_bounds__(kConvThreads) void world_channel_lists_kernel(ConvA
 // segments; wave (tap, segment) walks that segment's list of channel ch in chunks of 64 (a lane per non-zero tests it
 // against the tap), consumes the hits 16 row loads at a time with a lane per output channel, and the four segment
 // sums of a tap are added in LDS in a fixed order: the workgroup OWNS the tap's Co gradients, which leave as plain adds.
+#ifndef GSCAN_CONV_BWD_HITS
+#define GSCAN_CONV_BWD_HITS 16
+#endif
+constexpr int kBwdHits = GSCAN_CONV_BWD_HITS;     // row gathers a wave keeps in flight
 template <int DUMMY>
 __global__ __launch_bounds__(kConvThreads) void world_conv_bwd_kernel(ConvArgs a) {
     TraceScope trace_scope(TK_CONV_BWD);
     __shared__ float partial[kConvWaves][64];
     const int G = a.G, C = a.C, Co = a.Co, M = G * G, F = 3 * Co;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // 1-D grid: nw_blocks weight workgroups (channel = id % C, tap group = id / C), then the bias chunks
     if ((int)blockIdx.x >= a.nw_blocks) {
-        if (blockIdx.y != 0) return;
         // bias gradients: db_i[o] += sum over rows of dfeat[row, f] for a chunk of 64 rows of the [B*G*G, F] view
         const int chunk = blockIdx.x - a.nw_blocks, rows = a.B * M;
         const int r0 = chunk * 64, r1 = min(rows, r0 + 64);
-        for (int f = threadIdx.x; f < F; f += kConvThreads) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int r = r0;
-            for (; r + 3 < r1; r += 4) {
-                s0 += a.dfeat[(int64_t)r * F + f];
-                s1 += a.dfeat[(int64_t)(r + 1) * F + f];
-                s2 += a.dfeat[(int64_t)(r + 2) * F + f];
-                s3 += a.dfeat[(int64_t)(r + 3) * F + f];
+        // thread = (column, one of kSl slices of the chunk's rows): sixteen loads in flight per pass (four per pass made
+        // the 64 rows sixteen dependent round trips to L2 — the longest chain of the whole launch), slices added in LDS
+        constexpr int kSl = 2;
+        __shared__ float bsl[kSl][kConvThreads / kSl];
+        const int f = threadIdx.x % (kConvThreads / kSl), sl = threadIdx.x / (kConvThreads / kSl);
+        const int per = (r1 - r0 + kSl - 1) / kSl, q0 = r0 + sl * per, q1 = min(r1, q0 + per);
+        float acc = 0.f;
+        if (f < F) {
+            for (int r = q0; r < q1; r += 16) {
+                float x[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) x[u] = (r + u < q1) ? a.dfeat[(int64_t)(r + u) * F + f] : 0.f;
+#pragma unroll
+                for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+                    for (int u = 0; u < w; ++u) x[u] += x[u + w];
+                acc += x[0];
             }
-            for (; r < r1; ++r) s0 += a.dfeat[(int64_t)r * F + f];
-            atomicAdd(&a.gb[f / Co][f % Co], (s0 + s1) + (s2 + s3));
+        }
+        bsl[sl][f] = acc;
+        __syncthreads();
+        if (sl == 0 && f < F) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < kSl; ++q) s += bsl[q][f];
+            atomicAdd(&a.gb[f / Co][f % Co], s);
         }
         return;
     }
     constexpr int kTapsPerGroup = kConvWaves / kConvSegments;
-    const int ch = blockIdx.x, sg = wave % kConvSegments;
+    const int ch = blockIdx.x % C, by = blockIdx.x / C, sg = wave % kConvSegments;
     const int ochunks = (Co + 63) >> 6, npairs = (26 + a.K3 * a.K3) * ochunks;
-    const int pair = blockIdx.y * kTapsPerGroup + wave / kConvSegments;
+    const int pair = by * kTapsPerGroup + wave / kConvSegments;
     const bool owns = pair < npairs;
     const int tg = owns ? pair / ochunks : 0, oc = owns ? pair - tg * ochunks : 0;
     const int o = oc * 64 + lane, oo = min(o, Co - 1);
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(kConvThreads) void world_conv_bwd_kernel(ConvArgs a
             const int qr = (int)(key & 255u) - (kw - h), qc = (int)((key >> 8) & 255u) - (kh - h), b = (int)(key >> 16);
             const bool hit = live && (unsigned)qr < (unsigned)G && (unsigned)qc < (unsigned)G;
             const int row = (b * M + qr * G + qc) * F + conv * Co;
-            acc += consume_hits<16>(__ballot(hit), row, v, a.dfeat, oo);
+            acc += consume_hits<kBwdHits>(__ballot(hit), row, v, a.dfeat, oo);
         }
     }
     partial[wave][lane] = acc;
@@ -367,7 +386,8 @@ int world_conv_backward(const float *dfeat, int B, int G, int C, int Co, int K3,
     a.dfeat = dfeat;
     for (int i = 0; i < 3; ++i) { a.gw[i] = gw[i]; a.gb[i] = gb[i]; }
     const int npairs = (26 + K3 * K3) * cdiv(Co, 64);
-    const dim3 grid(C + cdiv((int64_t)B * G * G, 64), cdiv(npairs, kConvWaves / kConvSegments));
+    a.nw_blocks = C * cdiv(npairs, kConvWaves / kConvSegments);
+    const dim3 grid(a.nw_blocks + cdiv((int64_t)B * G * G, 64));
     ProbeScope probe(P_CONV_BWD, stream, 0.0, conv_algorithmic_flops(B, G, C, Co, K3));
     hipLaunchKernelGGL(world_conv_bwd_kernel<0>, grid, dim3(kConvThreads), 0, stream, a);
     GSCAN_LAUNCHED("world_conv_bwd_kernel");
