@@ -154,6 +154,10 @@ __device__ __forceinline__ float consume_hits(unsigned long long hits, int row, 
     return acc[0];
 }
 
+#ifndef GSCAN_CONV_FWD_HITS
+#define GSCAN_CONV_FWD_HITS 8
+#endif
+constexpr int kFwdHits = GSCAN_CONV_FWD_HITS;     // weight-row gathers a wave keeps in flight
 template <typename T>
 __global__ __launch_bounds__(kConvThreads) void world_conv_fwd_kernel(ConvArgs a, const T *__restrict__ world) {
     TraceScope trace_scope(TK_CONV_FWD);
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(kConvThreads) void world_conv_fwd_kernel(ConvArgs a
             const int kw = (int)(key & 255u) - qr + h, kh = (int)((key >> 8) & 255u) - qc + h, ch = (int)(key >> 16);
             const bool hit = live && (unsigned)kw < (unsigned)k && (unsigned)kh < (unsigned)k;
             const int row = ((tap0 + kh * k + kw) * C + ch) * CoP;
-            acc += consume_hits<8>(__ballot(hit), row, v, a.img, oo);
+            acc += consume_hits<kFwdHits>(__ballot(hit), row, v, a.img, oo);
         }
         if (o < Co) {
             const int f = conv * Co + o;
