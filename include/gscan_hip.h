@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 8
+#define GSCAN_ABI_VERSION 9
 #define GSCAN_MAX_ENC_LAYERS 4
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
@@ -198,6 +198,16 @@ int gscan_adam_step_zero_grad(float *param, float *grad, float *exp_avg, float *
 int gscan_adam_step_mean(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr,
                          float beta1, float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step,
                          const float *count, void *stream);
+
+/* optimizer.step() + optimizer.zero_grad() (train.py:111-113) AND the three dropout masks of the NEXT training step
+ * (gscan_dropout_masks: contiguous cnn | enc | dec, Philox stream `stream_id`) in ONE launch: the masks depend on
+ * nothing but a counter, so a training loop that knows the next batch's shape saves a launch at the head of every step.
+ * count != NULL: gradients of a sum loss, divided by count[0] (gscan_adam_step_mean); NULL: gscan_adam_step_zero_grad.
+ * The mask buffer may be the one the step that just finished used (its backward pass is complete on this stream). */
+int gscan_adam_step_masks(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                          float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *count,
+                          float *mask_out, size_t n_cnn, size_t n_enc, size_t n_dec, float p_cnn, float p_enc, float p_dec,
+                          uint64_t seed, uint64_t stream_id, void *stream);
 
 /* ---- the same loop body for a captured (hipGraph) step: everything that changes from step to step is read from
  * device memory, so one captured sequence can be replayed unchanged ---- */

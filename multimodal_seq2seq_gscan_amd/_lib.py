@@ -11,7 +11,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # GSCAN_HIP_LIB: development override, used by tools/variants.py to time experimental builds side by side
 LIB_PATH = os.environ.get("GSCAN_HIP_LIB") or os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_ENC_LAYERS = 4
 COMM_ID_BYTES = 128
 
@@ -98,6 +98,8 @@ PROTOTYPES = {
     "gscan_adam_step_mean": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i64, _vp, _vp]),
     "gscan_backward_seeded": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp,
                                    _vp, _vp, C.POINTER(Params), _vp]),
+    "gscan_adam_step_masks": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i64, _vp, _vp, _sz, _sz, _sz, _f, _f, _f,
+                                   _u64, _u64, _vp]),
     "gscan_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _vp, _i, _vp]),
     "gscan_adam_scalars": (None, [_f, _f, _f, _f, _f, _i64, _vp]),
     "gscan_trace_set": (_i, [_vp]),

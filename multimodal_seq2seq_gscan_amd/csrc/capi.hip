@@ -218,6 +218,17 @@ int gscan_adam_step_mean(float *param, float *grad, float *exp_avg, float *exp_a
                      count, nullptr, 1 | 2, (hipStream_t)stream);
 }
 
+int gscan_adam_step_masks(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                          float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *count,
+                          float *mask_out, size_t n_cnn, size_t n_enc, size_t n_dec, float p_cnn, float p_enc, float p_dec,
+                          uint64_t seed, uint64_t stream_id, void *stream) {
+    ARG(param && grad && exp_avg && exp_avg_sq && n > 0, "adam_step_masks: bad argument");
+    const size_t nm[3] = {n_cnn, n_enc, n_dec};
+    const float pm[3] = {p_cnn, p_enc, p_dec};
+    return adam_step_masks(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, lr_decay, lr_decay_steps, step, count,
+                           count ? (1 | 2) : 1, mask_out, nm, pm, seed, stream_id, (hipStream_t)stream);
+}
+
 int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, void *stream) {
     ARG(out || n == 0, "dropout_mask: NULL output");
     return dropout_mask(out, n, p, seed, stream_id, (hipStream_t)stream);

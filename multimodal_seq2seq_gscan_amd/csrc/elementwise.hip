@@ -206,6 +206,77 @@ int dropout_masks(float *out, const size_t (&n)[3], const float (&p)[3], uint64_
     return 0;
 }
 
+// optimizer.step() + zero_grad() AND the dropout masks of the NEXT step in one launch (the masks depend on nothing but
+// a counter): the first adam_blocks workgroups are the optimiser, the rest the Philox generator — one launch and one
+// kernel boundary fewer at the head of every training step.  The backward pass that read the previous masks has
+// finished when this kernel runs (same stream), so the new masks go into the same buffer.
+__global__ void adam_masks_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                  float *__restrict__ v, size_t n, float step_size, float beta1, float beta2, float eps,
+                                  float inv_sqrt_bc2, const float *__restrict__ grad_scale, int zero_grad, int adam_blocks,
+                                  float *__restrict__ mask_out, MaskSegments seg, uint64_t seed, uint64_t stream_id) {
+    TraceScope trace_scope(TK_ADAM);
+    if ((int)blockIdx.x < adam_blocks) {
+        const float gs = grad_scale ? ((zero_grad & 2) ? 1.f / grad_scale[0] : grad_scale[0]) : 1.f;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)adam_blocks * blockDim.x) {
+            const float gi = g[i] * gs;
+            if (zero_grad & 1) g[i] = 0.f;
+            const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+            const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+            m[i] = mi;
+            v[i] = vi;
+            const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+            p[i] -= step_size * (mi / denom);
+        }
+        return;
+    }
+    const size_t nm = seg.end[2], nquad = (nm + 3) / 4, blocks = gridDim.x - adam_blocks;
+    for (size_t q = (size_t)(blockIdx.x - adam_blocks) * blockDim.x + threadIdx.x; q < nquad; q += blocks * blockDim.x) {
+        uint32_t c0 = (uint32_t)q, c1 = (uint32_t)(q >> 32), c2 = (uint32_t)stream_id, c3 = (uint32_t)(stream_id >> 32);
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c0, c1, c2, c3, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const uint32_t rnd[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = q * 4 + j;
+            if (i < nm) {
+                const float pp = i < seg.end[0] ? seg.p[0] : (i < seg.end[1] ? seg.p[1] : seg.p[2]);
+                const float u = (float)(rnd[j] >> 8) * (1.0f / 16777216.0f);   // [0,1)
+                mask_out[i] = (u >= pp) ? 1.0f / (1.0f - pp) : 0.f;
+            }
+        }
+    }
+}
+
+int adam_step_masks(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                    float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
+                    int zero_grad, float *mask_out, const size_t (&nm)[3], const float (&pm)[3], uint64_t seed,
+                    uint64_t stream_id, hipStream_t stream) {
+    GSCAN_CHECK(step >= 1, "adam: step is 1-based (got %lld)", (long long)step);
+    float step_size = 0.f, inv_sqrt_bc2 = 0.f;
+    adam_scalars(lr, beta1, beta2, lr_decay, lr_decay_steps, step, &step_size, &inv_sqrt_bc2);
+    MaskSegments seg;
+    size_t acc = 0;
+    for (int i = 0; i < 3; ++i) {
+        GSCAN_CHECK(pm[i] >= 0.f && pm[i] < 1.f, "dropout: p=%g out of [0,1)", pm[i]);
+        acc += nm[i];
+        seg.end[i] = acc;
+        seg.p[i] = pm[i];
+    }
+    GSCAN_CHECK(acc == 0 || mask_out, "adam_step_masks: NULL mask buffer");
+    const int adam_blocks = (int)std::min<size_t>(cdiv(n, 256), 2048);
+    const int mask_blocks = acc ? (int)std::min<size_t>(cdiv((acc + 3) / 4, 256), 2048) : 0;
+    hipLaunchKernelGGL(adam_masks_kernel, dim3(adam_blocks + mask_blocks), dim3(256), 0, stream, param, grad, exp_avg,
+                       exp_avg_sq, n, step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale, zero_grad, adam_blocks, mask_out,
+                       seg, seed, stream_id);
+    GSCAN_LAUNCHED("adam_masks_kernel");
+    return 0;
+}
+
 int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream) {
     const size_t ns[3] = {n, 0, 0};
     const float ps[3] = {p, 0.f, 0.f};

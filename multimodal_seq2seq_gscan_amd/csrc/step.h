@@ -157,6 +157,10 @@ int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stre
 int adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
               float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
               const float *dev_scalars, int zero_grad, hipStream_t stream);   // zero_grad bit 1: grad_scale divides
+int adam_step_masks(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                    float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
+                    int zero_grad, float *mask_out, const size_t (&nm)[3], const float (&pm)[3], uint64_t seed,
+                    uint64_t stream_id, hipStream_t stream);
 void adam_scalars(float lr, float beta1, float beta2, float lr_decay, float lr_decay_steps, int64_t step,
                   float *step_size, float *inv_sqrt_bc2);
 int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream);

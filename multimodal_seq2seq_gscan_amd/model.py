@@ -260,6 +260,7 @@ class Model(nn.Module):
         self._dropout_calls = 0
         self._dropout_rank = 0
         self._mask_buffer = None
+        self._predrawn = None            # (sizes, Philox stream id, device) of masks the optimiser launch drew ahead
         self._mask_buffer_deep = None
         self._dummy_aux = None
         self._mask_key = None
@@ -377,12 +378,19 @@ class Model(nn.Module):
         # one buffer, grown when a larger batch shape arrives (never shrunk or replaced on a mere change of shape)
         if self._mask_buffer is None or self._mask_buffer.numel() < sum(sizes) or self._mask_buffer.device != device:
             self._mask_buffer = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+            self._predrawn = None
         self._mask_key = tuple(sizes)
         buf = self._mask_buffer
-        _lib.check(lib.gscan_dropout_masks(buf.data_ptr(), sizes[0], sizes[1], sizes[2], self.dropout_p[0],
-                                           self.dropout_p[1], self.dropout_p[2], self._dropout_seed,
-                                           self._philox_stream(), _lib.ptr(self._mask_stream_id),
-                                           torch.cuda.current_stream().cuda_stream), "gscan_dropout_masks")
+        # drawn already, in the optimiser launch of the previous step (TrainStep, gscan_adam_step_masks), for exactly
+        # this shape and this position of the Philox counter?  Then there is nothing to launch.
+        if self._predrawn == (tuple(sizes), self._philox_stream(), device):
+            self._predrawn = None
+        else:
+            self._predrawn = None
+            _lib.check(lib.gscan_dropout_masks(buf.data_ptr(), sizes[0], sizes[1], sizes[2], self.dropout_p[0],
+                                               self.dropout_p[1], self.dropout_p[2], self._dropout_seed,
+                                               self._philox_stream(), _lib.ptr(self._mask_stream_id),
+                                               torch.cuda.current_stream().cuda_stream), "gscan_dropout_masks")
         deep_stream = self._philox_stream(deep=True)
         self._dropout_calls += 1
         out, off = [], 0

@@ -80,6 +80,27 @@ class FlatAdam:
                                self.steps_taken, self._host_scalars.data_ptr())
         self._dev_scalars.copy_(self._host_scalars, non_blocking=True)
 
+    def launch_with_next_masks(self, count: Optional[torch.Tensor]) -> bool:
+        """Adam + zero_grad (divided by `count` when given) AND the dropout masks of the next step in one launch
+        (`gscan_adam_step_masks`), for a next batch of the shape the model saw last: the masks depend on a counter
+        only, so the launch at the head of the next step disappears.  Returns False (nothing launched) when there
+        are no device-drawn masks to draw ahead (eval / p = 0 / host masks / graph replay / deeper encoders)."""
+        m = self.model
+        if (m._mask_key is None or m._mask_buffer is None or m._host_masks is not None or not m.training
+                or max(m.dropout_p) <= 0.0 or m._mask_stream_id is not None or m._hyper["NL"] > 1):
+            return False
+        lib = _lib.load()
+        sizes = m._mask_key
+        _lib.check(lib.gscan_adam_step_masks(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(),
+                                             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                             m.flat_parameters.numel(), self._lr_of_this_step(), self.betas[0], self.betas[1],
+                                             self.eps, 1.0, 1.0, self.steps_taken, _lib.ptr(count), m._mask_buffer.data_ptr(),
+                                             sizes[0], sizes[1], sizes[2], m.dropout_p[0], m.dropout_p[1], m.dropout_p[2],
+                                             m._dropout_seed, m._philox_stream(), torch.cuda.current_stream().cuda_stream),
+                   "gscan_adam_step_masks")
+        m._predrawn = (tuple(sizes), m._philox_stream(), m._mask_buffer.device)
+        return True
+
     def launch_mean(self, count: torch.Tensor) -> None:
         """Adam + zero_grad on gradients of a SUM loss: divided by the device scalar `count` (global token count)."""
         lib = _lib.load()
@@ -356,7 +377,8 @@ class TrainStep:
             _, count, loss = self.exchange.mean_from_sums(store)
             if self.on_gradients is not None:
                 self.on_gradients(model.flat_gradients / count)
-            self.optimizer.launch_mean(count)
+            if not self.optimizer.launch_with_next_masks(count):
+                self.optimizer.launch_mean(count)
             model.update_state(is_best=False)
             return {"loss": loss, "tokens": count[0], "logp": fw["logp"], "aux": fw["aux"]}
         self.exchange.all_reduce(self.stats)
@@ -364,7 +386,8 @@ class TrainStep:
         self.exchange.all_reduce(model.flat_gradients)
         if self.on_gradients is not None:
             self.on_gradients(model.flat_gradients)
-        self.optimizer.launch(zero_grad=True, device_scalars=False)
+        if not self.optimizer.launch_with_next_masks(None):
+            self.optimizer.launch(zero_grad=True, device_scalars=False)
         return self._result(fw)
 
     def _replay(self, batch) -> Dict[str, torch.Tensor]:
