@@ -77,6 +77,10 @@ __device__ __forceinline__ int compact_nonzeros(int n, uint32_t *keys, float *va
     const int per = (((n + kConvWaves - 1) / kConvWaves) + 63) / 64 * 64;
     const int lo = wave * per, hi = min(n, lo + per);
     int cnt = 0;
+    const bool single = per <= 64 * U;                      // a wave's whole range in one pass (uniform in the workgroup)
+    float first[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) first[u] = 0.f;
     for (int base = lo; base < hi; base += 64 * U) {
         float v[U];
 #pragma unroll
@@ -86,6 +90,10 @@ __device__ __forceinline__ int compact_nonzeros(int n, uint32_t *keys, float *va
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) cnt += __popcll(__ballot(v[u] != 0.f));
+        if (single) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) first[u] = v[u];
+        }
     }
     if (lane == 0) wave_counts[wave] = cnt;
     __syncthreads();
@@ -98,10 +106,15 @@ __device__ __forceinline__ int compact_nonzeros(int n, uint32_t *keys, float *va
     }
     for (int base = lo; base < hi; base += 64 * U) {
         float v[U];
+        if (single) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = base + u * 64 + lane;
-            v[u] = e < hi ? get(e) : 0.f;
+            for (int u = 0; u < U; ++u) v[u] = first[u];    // pass 1's loads, kept across the barrier: no second round trip
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * 64 + lane;
+                v[u] = e < hi ? get(e) : 0.f;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
