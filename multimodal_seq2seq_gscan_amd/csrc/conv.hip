@@ -29,6 +29,9 @@
 // [Co, C, k, k] layout — no atomics, fixed summation order.  Extra workgroups add the bias gradients (column sums of
 // dfeat over 64-row chunks, ONE float atomic per chunk and column: the only sums of this file whose order varies).
 #include "step.h"
+#include "prologue.h"
+#include <atomic>
+#include <chrono>
 
 namespace gscan {
 
@@ -171,22 +174,35 @@ __device__ __forceinline__ float consume_hits(unsigned long long hits, int row, 
 #define GSCAN_CONV_FWD_HITS 8
 #endif
 constexpr int kFwdHits = GSCAN_CONV_FWD_HITS;     // weight-row gathers a wave keeps in flight
+// The forward pass of one workgroup: example b, share y of ny of its (output cell, convolution) pairs.  flags != NULL
+// (the launch that also runs the step prologue, below): the weight image is being written by other workgroups of the
+// SAME launch; the workgroup compacts its non-zeros first — that needs the world only — and then waits until every
+// image workgroup has published `epoch` in its flag.
 template <typename T>
-__global__ __launch_bounds__(kConvThreads) void world_conv_fwd_kernel(ConvArgs a, const T *__restrict__ world) {
-    TraceScope trace_scope(TK_CONV_FWD);
+__device__ __forceinline__ void world_conv_fwd_body(const ConvArgs &a, const T *__restrict__ world, int b, int y, int ny,
+                                                    const uint32_t *flags, int nflags, uint32_t epoch) {
     extern __shared__ uint32_t conv_lds[];
     const int G = a.G, C = a.C, Co = a.Co, M = G * G, F = 3 * Co, MC = M * C;
     uint32_t *keys = conv_lds;
     float *vals = reinterpret_cast<float *>(conv_lds + MC);
     int *wave_counts = reinterpret_cast<int *>(conv_lds + 2 * MC);
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const T *x = world + (int64_t)b * MC;
     const int count = compact_nonzeros(
         MC, keys, vals, wave_counts, [&](int e) { return (float)x[e]; },
         [&](int e) { const int p = e / C, ch = e - p * C, pr = p / G; return (uint32_t)(pr | ((p - pr * G) << 8) | (ch << 16)); });
-    // an example's (output cell, convolution) pairs are dealt to gridDim.y workgroups x 8 waves
+    if (flags) {
+        // thread i polls image workgroup i's flag (agent-scope loads: they are served past this XCD's L2).  The image
+        // itself is then read with ordinary loads: no L2 can hold a line of it from before this launch (caches are
+        // invalidated when a launch starts) and nothing reads it before this point.
+        if ((int)threadIdx.x < nflags)
+            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+    }
+    // an example's (output cell, convolution) pairs are dealt to ny workgroups x 8 waves
     const int ochunks = (Co + 63) >> 6, npairs = M * 3 * ochunks, CoP = conv_row_floats(Co);
-    for (int pair = blockIdx.y * kConvWaves + wave; pair < npairs; pair += gridDim.y * kConvWaves) {
+    for (int pair = y * kConvWaves + wave; pair < npairs; pair += ny * kConvWaves) {
         const int q = pair / (3 * ochunks), rem = pair - q * 3 * ochunks, conv = rem / ochunks, oc = rem - conv * ochunks;
         const int o = oc * 64 + lane, oo = min(o, Co - 1);
         const int k = conv_ksize(conv, a.K3), h = k >> 1, tap0 = conv_tap0(conv, a.K3);
@@ -210,6 +226,66 @@ __global__ __launch_bounds__(kConvThreads) void world_conv_fwd_kernel(ConvArgs a
             a.feat[at] = val;
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kConvThreads) void world_conv_fwd_kernel(ConvArgs a, const T *__restrict__ world) {
+    TraceScope trace_scope(TK_CONV_FWD);
+    world_conv_fwd_body(a, world, blockIdx.x, blockIdx.y, gridDim.y, nullptr, 0, 0u);
+}
+
+// The step prologue and the world encoder in ONE launch (step.hip's default prelude).  The two have nothing in common
+// but one dependency — the encoder reads the [tap][ch][o] image of the convolution weights that the prologue writes —
+// and as two launches they cost the chain a kernel boundary (6-7 us: the release of the prologue's 8 MB of dirty lines,
+// the dispatch ramp) plus the time either one leaves most of the chip idle (both are chains of L2 round trips).
+// Workgroup roles by block index (dispatch is in index order on every XCD, so a role can wait on roles IN FRONT of it):
+//   [0, n_img)            the weight image, kImageElems elements per workgroup, written THROUGH (agent-scope stores: a
+//                         plain store would sit dirty in the writer's L2, and the release that pushes it out is a
+//                         write-back of that whole L2 — tools/micro/flag_wait.hip: 57 us against 10); when the
+//                         stores are acknowledged the workgroup publishes the launch's epoch in its flag
+//   [n_img, n_img+n_pro)  every other prologue segment, grid-stride over its index space
+//   the rest              the world encoder's workgroups (example b, share y): they wait for the flags behind their
+//                         own compaction pass (world_conv_fwd_body)
+// The epoch is a process-wide counter seeded from the clock: flags need no reset, whatever the workspace held before.
+constexpr int kImageElems = 4 * kConvThreads;
+struct FusedPrologueArgs { int n_img, n_pro, n_conv, n_examples, ny, order; uint32_t *flags; uint32_t epoch; };
+template <typename T>
+__global__ __launch_bounds__(kConvThreads, 8) void prologue_world_kernel(PrologueArgs pa, ConvArgs a, FusedPrologueArgs f,
+                                                                         const T *__restrict__ world) {
+    TraceScope trace_scope(TK_PROLOGUE);
+    const int blk = blockIdx.x;
+    if (blk < f.n_img) {
+        const int total = (26 + a.K3 * a.K3) * a.C * conv_row_floats(a.Co);
+#pragma unroll
+        for (int j = 0; j < kImageElems / kConvThreads; ++j) {
+            const int i = blk * kImageElems + j * kConvThreads + (int)threadIdx.x;
+            if (i < total)
+                __hip_atomic_store(pa.conv_img + i, conv_image_element(pa.conv_w[0], pa.conv_w[1], pa.conv_w[2], a.C, a.Co, a.K3, i),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this thread's written-through stores have landed
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(f.flags + blk, f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // order of the two bulk roles behind the image workgroups: 0 prologue first, 1 world encoder first, 2 interleaved
+    // in proportion (workgroup j of n is the world encoder's when the scaled count j n_conv / n steps up)
+    const int j = blk - f.n_img, n = f.n_pro + f.n_conv;
+    int cb, pb;
+    bool is_conv;
+    if (f.order == 0) { is_conv = j >= f.n_pro; cb = j - f.n_pro; pb = j; }
+    else if (f.order == 1) { is_conv = j < f.n_conv; cb = j; pb = j - f.n_conv; }
+    else {
+        const int c0 = (int)(((int64_t)j * f.n_conv) / n), c1 = (int)(((int64_t)(j + 1) * f.n_conv) / n);
+        is_conv = c1 > c0; cb = c0; pb = j - c0;
+    }
+    if (!is_conv) {
+        const int64_t total = pa.end[13];
+        for (int64_t idx = (int64_t)pb * kConvThreads + threadIdx.x; idx < total; idx += (int64_t)f.n_pro * kConvThreads)
+            prologue_element<8>(pa, idx);
+        return;
+    }
+    world_conv_fwd_body(a, world, cb % f.n_examples, cb / f.n_examples, f.ny, f.flags, f.n_img, f.epoch);
 }
 
 // Backward, pass 1: the non-zeros of input channel ch among the examples of batch segment s, compacted in scan
@@ -357,6 +433,55 @@ int world_conv_forward(const void *world, int world_is_u8, const float *img, con
         hipLaunchKernelGGL(world_conv_fwd_kernel<float>, grid, dim3(kConvThreads), lds, stream, a,
                            static_cast<const float *>(world));
     GSCAN_LAUNCHED("world_conv_fwd_kernel");
+    return 0;
+}
+
+// Prologue + world encoder as one launch (prologue_world_kernel).  `pa` carries every prologue segment but the
+// convolution image (its segment must be empty: the image workgroups of this launch write it); flags = kFusedMaxFlags
+// words of the workspace.  Returns -1 (nothing launched) when the shape does not fit the fused form.
+int prologue_world_forward(const PrologueArgs &pa, const void *world, int world_is_u8, const float *const (&b)[3],
+                           const float *mask, int B, int G, int C, int Co, int K3, float *feat, uint32_t *flags,
+                           hipStream_t stream) {
+    TRY_RC(conv_check(B, G, C, Co, K3));
+    const size_t lds = (size_t)G * G * C * 8 + 4 * kConvWaves;
+    const int n_img = cdiv(conv_image_floats(C, Co, K3), kImageElems);
+    if (lds > 128 * 1024 || n_img > kFusedMaxFlags || pa.end[10] != pa.end[9]) return -1;
+    ConvArgs a{};
+    a.B = B; a.G = G; a.C = C; a.Co = Co; a.K3 = K3; a.img = pa.conv_img; a.mask = mask; a.feat = feat;
+    for (int i = 0; i < 3; ++i) a.b[i] = b[i];
+    static bool attr_set = false;
+    if (!attr_set) {
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_world_kernel<float>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_world_kernel<uint8_t>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    // a value no earlier launch of this process used and, seeded from the clock, none a previous process is likely to
+    // have left in the same memory
+    static std::atomic<uint32_t> epoch{(uint32_t)std::chrono::steady_clock::now().time_since_epoch().count() | 1u};
+    // Both roles want the chip's wave slots to themselves (the world encoder's 4 B workgroups ARE 32 waves per CU at the
+    // benchmark batch), so they overlap little; what the one launch saves is the boundary.  Measured on the step
+    // (profiles/r03_e_fused_prologue_ab.txt): prologue first, 1024 workgroups (one generation, three passes per thread)
+    // 0.5017 ms; 2048: 0.5051; 4096: 0.5057; world encoder first 0.507-0.511; interleaved 0.509-0.521; two launches 0.5092
+    static const int pro_cap = [] { const char *e = getenv("GSCAN_PROLOGUE_BLOCKS"); return e ? atoi(e) : 1024; }();
+    FusedPrologueArgs f{};
+    f.n_img = n_img;
+    f.n_pro = (int)std::min<int64_t>(cdiv(pa.end[13], kConvThreads), pro_cap);
+    f.n_examples = B; f.ny = 4; f.n_conv = B * f.ny;
+    static const int order = [] { const char *e = getenv("GSCAN_FUSED_ORDER"); return e ? atoi(e) : 0; }();
+    f.order = order;
+    f.flags = flags;
+    f.epoch = epoch.fetch_add(2u);
+    ProbeScope probe(P_CONV_FWD, stream, 0.0, conv_algorithmic_flops(B, G, C, Co, K3));
+    const dim3 grid(f.n_img + f.n_pro + B * f.ny);
+    if (world_is_u8)
+        hipLaunchKernelGGL(prologue_world_kernel<uint8_t>, grid, dim3(kConvThreads), lds, stream, pa, a, f,
+                           static_cast<const uint8_t *>(world));
+    else
+        hipLaunchKernelGGL(prologue_world_kernel<float>, grid, dim3(kConvThreads), lds, stream, pa, a, f,
+                           static_cast<const float *>(world));
+    GSCAN_LAUNCHED("prologue_world_kernel");
     return 0;
 }
 

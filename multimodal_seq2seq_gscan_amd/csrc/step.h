@@ -199,6 +199,11 @@ __device__ __forceinline__ float conv_image_element(const float *w1, const float
 int conv_weight_image(const float *const (&w)[3], int C, int Co, int K3, float *img, hipStream_t stream);
 int world_conv_forward(const void *world, int world_is_u8, const float *img, const float *const (&b)[3],
                        const float *mask, int B, int G, int C, int Co, int K3, float *feat, hipStream_t stream);
+// the step prologue and the world encoder in one launch (conv.hip); -1: the shape does not fit, nothing was launched
+constexpr int kFusedMaxFlags = 512;
+int prologue_world_forward(const PrologueArgs &pa, const void *world, int world_is_u8, const float *const (&b)[3],
+                           const float *mask, int B, int G, int C, int Co, int K3, float *feat, uint32_t *flags,
+                           hipStream_t stream);
 size_t world_conv_backward_scratch_floats(int B, int G, int C);
 int world_conv_lists(const void *world, int world_is_u8, int B, int G, int C, float *scratch, hipStream_t stream);
 int world_conv_backward(const float *dfeat, int B, int G, int C, int Co, int K3, float *scratch,
@@ -339,7 +344,7 @@ struct Workspace {
     int64_t feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, row_stats, dlogits, dpreo,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
-        wo_perm, dwo_perm, wih_stack, wih_t, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, conv_img, conv_lists, wcat5,
+        wo_perm, dwo_perm, wih_stack, wih_t, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, conv_img, conv_flags, conv_lists, wcat5,
         deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image,   // encoder layers below the last
         ge_table, head_wc;        // greedy decoding: [V,4H] tables
     WorkspaceSlot slot[96];

@@ -41,6 +41,7 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     };
 #define SLOT(field, count) ws->field = take(#field, (count))
     SLOT(conv_img, conv_image_floats(d.C, d.Co, d.K3));
+    SLOT(conv_flags, kFusedMaxFlags);                // 32-bit flags of the prologue + world encoder launch (conv.hip)
     SLOT(conv_lists, (int64_t)world_conv_backward_scratch_floats(d.B, d.G, d.C));
     SLOT(feat, B * M * F);
     SLOT(pkv, B * M * H);
@@ -270,7 +271,9 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     // behind the prologue (+20..30 us: the event latency lands on the critical path), host issue order (no effect).
     hipStream_t sd2 = g_side.single ? st : g_side.stream2;
     // one prologue launch with the segments of `which` (0: caller's stream, 1: side 1, 2: side 2); the others stay empty
-    auto prologue = [&](int which, hipStream_t stream) -> int {
+    // fuse_world: the world encoder runs in the same launch (conv.hip, prologue_world_kernel), whose image workgroups
+    // take the convolution weight image off the prologue's index space; returns -1 if that launch does not fit the shape
+    auto prologue = [&](int which, hipStream_t stream, bool fuse_world = false) -> int {
         PrologueArgs a{};
         a.b_ih = p.dec_b_ih; a.b_hh = p.dec_b_hh; a.w_o2h = p.out2hid_w;
         a.w_ih_f = p.enc_w_ih; a.w_ih_r = p.enc_w_ih_rev; a.enc_emb = p.enc_emb; a.dec_emb = p.dec_emb;
@@ -295,7 +298,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         const int64_t n[14] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * (E + 1), (int64_t)H * 4 * H,
                                given ? 0 : (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
                                a.zero_extra_count, 2 * geo.image_floats + (int64_t)H * kDecThreads,
-                               (int64_t)D * 4 * He * He, given ? 0 : conv_image_floats(C, Co, d.K3),
+                               (int64_t)D * 4 * He * He, (given || fuse_world) ? 0 : conv_image_floats(C, Co, d.K3),
                                (int64_t)4 * H * F, (int64_t)4 * H * He, cond ? (int64_t)H * He : 0};
         int64_t acc = 0;
         for (int i = 0; i < 14; ++i) {
@@ -303,6 +306,12 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
             const int owner = (i == 0 || i == 5) ? 1 : ((i == 10 || i == 11) ? 2 : 0);
             acc += (owner == which || which == 3) ? n[i] : 0;   // which 3: every segment in one launch
             a.end[i] = acc;
+        }
+        if (fuse_world) {
+            const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
+            return prologue_world_forward(a, bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world,
+                                          bt.world_u8 != nullptr, cb, mk.cnn, B, d.G, C, Co, d.K3, w + ws.feat,
+                                          reinterpret_cast<uint32_t *>(w + ws.conv_flags), stream);
         }
         return step_prologue(a, stream);
     };
@@ -343,8 +352,19 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     const bool merged = fwd_streams == 1 || g_side.single;
     {
         if (merged) {
-            TRY(prologue(3, st));
-            TRY(world_encoder(st));
+            // the prologue and the world encoder as ONE launch (GSCAN_FUSED_PROLOGUE=0: two launches, for A/B runs)
+            static const int fused = [] { const char *e = getenv("GSCAN_FUSED_PROLOGUE"); return e ? atoi(e) : 1; }();
+            int rc = -1;
+            // not while the stream is being captured into a graph: a replay would repeat the launch's epoch argument,
+            // and the flags of the previous replay would already hold it
+            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+            GSCAN_HIP(hipStreamIsCapturing(st, &capturing));
+            if (fused && !given && capturing == hipStreamCaptureStatusNone) rc = prologue(3, st, true);
+            if (rc > 0) return rc;
+            if (rc < 0) {
+                TRY(prologue(3, st));
+                TRY(world_encoder(st));
+            }
         } else {
             TRY(order_after(sd, st, sd2));   // fork: whatever produced the inputs / masks on the caller's stream
             TRY(prologue(0, st));
