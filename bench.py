@@ -202,7 +202,7 @@ def batcher_leg(args, cfg: dict, n_params: int) -> dict:
             "examples_per_s": round(rows / el, 1), "ms_per_step": round(1e3 * el / n, 4), "steps": n,
             "resident_examples_per_s": round(rows / el_res, 1), "fraction_of_resident": round(el_res / el, 3)}
     return {"examples": data.num_examples, "file_write_s": round(t_write, 1), "file_read_s": round(t_read, 1),
-            "h2d_bytes_per_batch": data.slab_bytes(B), "parameters": model.flat_parameters.numel(), **results,
+            "h2d_bytes_per_batch": data.slab_bytes(B), "parameters": model.parameter_count, **results,
             "note": "ragged lengths from the file (every batch padded to ITS longest rows, gSCAN_dataset.py:200-220); "
                     "resident = the last full batch of the run repeated from HBM"}
 
@@ -403,7 +403,7 @@ def main():
 
     batcher = None
     if args.with_batcher and rank == 0 and world == 1:
-        batcher = batcher_leg(args, cfg, model.flat_parameters.numel())
+        batcher = batcher_leg(args, cfg, model.parameter_count)
     if rank == 0:
         B, L, T = args.batch, args.command_length, args.target_length
         ex_per_s = world * B * args.steps / elapsed
@@ -441,7 +441,7 @@ def main():
                                    f"{'ragged' if args.ragged else 'dense'}, "
                                    f"dropout {cfg['encoder_dropout_p']}/{cfg['decoder_dropout_p']}/{cfg['cnn_dropout_p']}, "
                                    f"conditional attention{', auxiliary head' if args.auxiliary else ''}, Adam+LR step included",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "parameters": model.flat_parameters.numel(),
+                       "global_batch": world * B, "parallelism": f"dp{world}", "parameters": model.parameter_count,
                        "launch": "hipGraph replay (3 graphs per step)" if args.graph else "eager (forward on the caller's stream, backward on 3 streams)",
                        "resident_batches": len(batches),
                        "gradient_exchange": (None if world == 1 else

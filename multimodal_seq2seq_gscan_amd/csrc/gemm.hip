@@ -334,13 +334,14 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
 // 40 us; conv 256x5400x576: 36 vs 44 us; dW_ih 400x300x5120 split 8: 44 vs 48 us), 64-row tiles win once a launch
 // has thousands of workgroups (4096^3: 78 vs 72 TFLOP/s).  GSCAN_GEMM_TMW=1|2 forces a shape, for experiments.
 constexpr int kWideTileMinGroups = 2048;
+constexpr int kShortKMinTiles = 512;                         // 64 x 64 tiles of a launch before it takes gemm_shortk.hip
 constexpr int kWideMinRows = 1024, kWideMinTiles = 1024;     // when a launch takes the 128-row tiles of gemm_wide.hip
 
 int GemmBatch::launch(hipStream_t stream) {
     if (bad_) return 1;
     if (grp_.count == 0) return 0;
     static const int forced = [] { const char *e = getenv("GSCAN_GEMM_TMW"); return e ? atoi(e) : 0; }();
-    const int tmw = forced == 1 || forced == 2 ? forced : (tiles_ < kWideTileMinGroups ? 1 : 2);
+    int tmw = forced == 1 || forced == 2 ? forced : (tiles_ < kWideTileMinGroups ? 1 : 2);
     static const int xcd = [] { const char *e = getenv("GSCAN_GEMM_XCD"); return e ? atoi(e) : 1; }();   // on by default
     static const int order = [] { const char *e = getenv("GSCAN_GEMM_ORDER"); return e ? atoi(e) : 1; }();
     // Wide tiles (gemm_wide.hip, 128 x 16 nf): launches made of tall products with at least kWideMinTiles of them (four
@@ -360,6 +361,16 @@ int GemmBatch::launch(hipStream_t stream) {
         wide = gemm_wide_supports(p) && (wide_mode == 2 || p.M >= kWideMinRows);
     }
     if (wide && wide_mode != 2 && wide_tiles < kWideMinTiles) wide = false;
+    // Single-shot tiles (gemm_shortk.hip, 64 x 64 x K): launches whose every product has its whole K extent (<= 152) in
+    // LDS at once.  OFF by default: on the step's forward launch (2 304 tiles, K = 100 / 150) it is SLOWER than the
+    // round-based kernel, 50 us against 37 — 78 KB of LDS per workgroup leave a CU two workgroups, too few to cover one
+    // another's load phase (profiles/r03_f_gemm_shortk_ab.txt).  GSCAN_GEMM_SHORTK=1 by the tile-count rule, 2 whenever
+    // the layouts allow (tests, experiments).
+    static const int shortk_mode = [] { const char *e = getenv("GSCAN_GEMM_SHORTK"); return e ? atoi(e) : 0; }();
+    bool shortk = shortk_mode != 0 && !wide && !(forced == 1 || forced == 2);
+    for (int i = 0; shortk && i < grp_.count; ++i) shortk = gemm_shortk_supports(grp_.p[i]);
+    if (shortk && shortk_mode != 2 && tiles_ < kShortKMinTiles) shortk = false;
+    if (shortk) tmw = 2;
     int total = 0;
     for (int i = 0; i < kMaxGroup; ++i) grp_.tile_begin[i] = INT_MAX;
     for (int i = 0; i < grp_.count; ++i) {
@@ -390,6 +401,7 @@ int GemmBatch::launch(hipStream_t stream) {
 #define TB t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]
     ProbeScope probe(P_GEMM, stream, flops_, alg_flops_);
     if (wide) return gemm_wide_launch(grp_, total, stream);
+    if (shortk) return gemm_shortk_launch(grp_, total, stream);
     // 64-deep K rounds (GSCAN_GEMM_BK=64, experiments): isolated long-K split products gain 10-20 % (a round's
     // load latency is paid half as often), but the overlapped training step loses 3 % to the larger workgroups
     // (52 KB of LDS, +40 VGPRs), so 32 is what every launch uses.

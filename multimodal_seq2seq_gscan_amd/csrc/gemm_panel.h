@@ -208,6 +208,10 @@ struct PanelIter {
 #define GST(i)
 #endif
 
+// gemm_shortk.hip
+bool gemm_shortk_supports(const GemmProblem &p);
+int gemm_shortk_launch(const GemmGroup &grp, int total, hipStream_t stream);
+
 // gemm_wide.hip
 bool gemm_wide_supports(const GemmProblem &p);
 void gemm_wide_columns(int N, int *tiles_n, int *nf);

@@ -278,8 +278,13 @@ class Model(nn.Module):
         params = self._named_unique()
         some = next(iter(params.values()))
         device = some.device
-        total = sum(p.numel() for p in params.values())
-        flat = torch.empty(total, dtype=torch.float32, device=device)
+        # Every parameter starts on a 16-byte boundary of the buffer (up to three zero floats of padding in front of it:
+        # the embedding tables have odd sizes and would leave every matrix behind them on a 4-byte boundary, where the
+        # GEMM kernels fall back to one-float loads).  The padding takes part in the optimiser and the all-reduce as
+        # zeros with zero gradients and stays zero.
+        align = 4
+        total = sum((p.numel() + align - 1) // align * align for p in params.values())
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
         # four extra floats behind the gradients: the loss statistics of a data-parallel step travel in the same
         # all-reduce as the gradients (train.TrainStep)
         self._grad_store = torch.zeros(total + 4, dtype=torch.float32, device=device)
@@ -292,7 +297,7 @@ class Model(nn.Module):
             p.data = flat[off:off + n].view(p.shape)
             p.grad = None
             self._offsets[name] = (off, n)
-            off += n
+            off += (n + align - 1) // align * align
         self._flat, self._flat_grad = flat, grad
         self._workspace = None
         self._anchor = torch.zeros((), dtype=torch.float32, device=device, requires_grad=True)
@@ -320,8 +325,13 @@ class Model(nn.Module):
 
     @property
     def flat_parameters(self) -> torch.Tensor:
-        """All parameters as one fp32 vector (named_parameters() order)."""
+        """All parameters as one fp32 vector (named_parameters() order, each on a 16-byte boundary: `_offsets`)."""
         return self._flat
+
+    @property
+    def parameter_count(self) -> int:
+        """Number of parameters (the flat buffer is a few floats longer: alignment padding)."""
+        return sum(n for _, n in self._offsets.values())
 
     @property
     def flat_gradients(self) -> torch.Tensor:

@@ -104,6 +104,43 @@ def test_gemm_suite_on_forced_wide_tiles():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("M,N,K,lda,ldb,epilogue", [
+    (9216, 400, 150, 150, 150, False),   # the visual gate images: contiguous rows of 150 floats (8-byte loads), ragged N tiles
+    (5120, 400, 100, 400, 300, True),    # embedding part of the gates: column slices of wider buffers, bias
+    (8200, 100, 152, 152, 160, True),    # the longest K the single-shot tiles hold, ragged M, tanh + mask
+    (6000, 70, 37, 40, 37, False),       # odd K: 4-byte loads are refused by the rule, the launch falls back to gemm.hip
+    (40000, 64, 96, 96, 96, False),      # K a whole number of 32-deep chunks: no tail steps
+])
+def test_gemm_short_k_products(lib, M, N, K, lda, ldb, epilogue):
+    """Tall k-contiguous products with K <= 152: the shapes gemm_shortk_kernel (csrc/gemm_shortk.hip: whole-K panels in
+    LDS, one barrier) takes when it is enabled — test_gemm_suite_on_forced_single_shot_tiles runs them on it; here they
+    run on whatever the default rule picks.  Same contract either way."""
+    import gpu_ops
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    Abig, Bbig = torch.randn(M, lda, generator=g), torch.randn(N, ldb, generator=g)
+    A, B = Abig[:, :K], Bbig[:, :K]
+    bias, mask = torch.randn(N, generator=g), (torch.rand(M, N, generator=g) > 0.3).float() * 1.25
+    Cd = torch.zeros(M, N, device="cuda")
+    kw = dict(bias=dev(bias), act=2, mask=dev(mask)) if epilogue else {}
+    gpu_ops.gemm((dev(Abig), 0, lda, 1), (dev(Bbig), 0, 1, ldb), (Cd, 0, N), M, N, K, **kw)
+    ref = A.double() @ B.double().t()
+    if epilogue:
+        ref = torch.tanh(ref + bias.double()) * mask.double()
+    err = (Cd.cpu().double() - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, K ** 0.5), f"{M}x{N}x{K}: max err {err}"
+
+
+def test_gemm_suite_on_forced_single_shot_tiles():
+    """The layout / epilogue tests again in a child process with GSCAN_GEMM_SHORTK=2: every product the single-shot
+    kernel supports runs on it, whatever its size (ragged edges in M, N and K, column-sliced operands, epilogues)."""
+    import os, subprocess, sys
+    env = dict(os.environ, GSCAN_GEMM_SHORTK="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_gemm_layouts or test_gemm_epilogues_and_split_k or test_gemm_short_k", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("B,G,Cc,K3,Co,density,u8", [
     (5, 6, 16, 7, 50, 0.2, False),        # the paper's shape, float32 world
     (37, 6, 16, 13, 50, 0.07, True),      # k = 13 (every cell reaches every cell), uint8 world, two backward slices

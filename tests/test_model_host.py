@@ -37,11 +37,18 @@ def test_seeded_init_matches_reference(workload, init_fixture):
 def test_parameters_are_views_of_one_buffer():
     model = Model(**model_kwargs("demo"))
     flat = model.flat_parameters
-    assert flat.numel() == PARAMETER_TOTALS["demo"]
+    assert model.parameter_count == PARAMETER_TOTALS["demo"]
     off = 0
-    for _, p in model.named_parameters():
-        assert p.data_ptr() == flat.data_ptr() + 4 * off
+    for name, p in model.named_parameters():       # in order, each on the next 16-byte boundary, zeros in between
+        off = (off + 3) // 4 * 4
+        assert model._offsets[name] == (off, p.numel())
+        assert p.data_ptr() == flat.data_ptr() + 4 * off and p.data_ptr() % 16 == 0
         off += p.numel()
+    assert flat.numel() == (off + 3) // 4 * 4
+    covered = torch.zeros_like(flat, dtype=torch.bool)
+    for o, n in model._offsets.values():
+        covered[o:o + n] = True
+    assert bool((flat[~covered] == 0).all())
     model.attach_gradients(zero=True)
     for _, p in model.named_parameters():
         assert p.grad is not None and p.grad.shape == p.shape
@@ -50,7 +57,7 @@ def test_parameters_are_views_of_one_buffer():
     opt = torch.optim.SGD(model.parameters(), lr=0.5)
     before = flat.clone()
     opt.step()                                   # a stock optimizer updates the flat buffer through the views
-    assert torch.allclose(flat, before - 1.0)
+    assert torch.allclose(flat[covered], before[covered] - 1.0) and bool((flat[~covered] == 0).all())
     opt.zero_grad()                              # set_to_none: views are re-attached (zeroed) on demand
     model.attach_gradients(zero=False)
     assert all(p.grad is not None and bool((p.grad == 0).all()) for p in model.parameters())
