@@ -31,50 +31,88 @@ bool gemm_shortk_supports(const GemmProblem &p) {
            p.asum1 == nullptr;
 }
 
-// NL = loads per thread and operand (64 rows x KC chunks over 256 threads)
-template <int VW, int NL>
-__device__ __forceinline__ void shortk_tile(const GemmProblem &g, int local) {
-    using vec = __attribute__((ext_vector_type(VW))) float;
-    float *lds_a = shortk_lds, *lds_b = shortk_lds + SK_BM * SK_LDK;
-    const int rem = local;                                           // no K split: the tile index inside the problem
-    const bool n_major = (g.flags & 16) != 0;
-    const int inner = g.inv_in ? (int)__umulhi((uint32_t)rem, g.inv_in) : rem;
-    const int by = n_major ? rem - inner * (int)g.tiles_m : inner, bx = n_major ? inner : rem - inner * g.tiles_n;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = by * SK_BM, n0 = bx * BN;
-    const int K = g.K, n32 = K >> 5, tail = ((K & 31) + 3) >> 2, kz = 32 * n32 + 4 * tail;
-    const int KC = kz / VW;                                          // chunks per row (kz is a multiple of 4)
-    const uint32_t inv_kc = 0xFFFFFFFFu / (uint32_t)KC + 1u;         // i / KC = umulhi(i, inv_kc) for i * KC < 2^32
+// What a workgroup keeps of a tile between issuing its loads and finishing its epilogue (all wave-uniform).
+struct ShortKTile {
+    float *c; const float *bias, *mask, *gate;
+    uint32_t ldc;
+    float alpha, beta;
+    int M, N, K, act, m0, n0;
+};
+constexpr int SK_NL = 20;                   // 8-byte loads per thread and operand: 64 rows x 80 chunks over 256 threads
+using sk_vec = __attribute__((ext_vector_type(2))) float;
 
-    // ---- all loads of both panels, then the LDS stores ------------------------------------------------------------
-    vec xa[NL], xb[NL];
+// (row, k) of load j of thread tid in a panel of KC two-float chunks per row
+__device__ __forceinline__ void sk_where(int tid, int j, int KC, uint32_t inv_kc, int &row, int &k) {
+    const uint32_t i = (uint32_t)(tid + SK_THREADS * j);
+    row = (int)__umulhi(i, inv_kc);
+    k = 2 * ((int)i - row * KC);
+}
+
+// Tile u of the launch: its problem, its place in it (XCD-aware order as in gemm.hip), and ALL loads of its two panels
+// issued into xa / xb.  Returns false for a padding slot of the XCD order (nothing issued).
+__device__ __forceinline__ bool sk_fetch(const int (&tb)[kMaxGroup], const GemmGroup &grp, int u, ShortKTile &t,
+                                         sk_vec (&xa)[SK_NL], sk_vec (&xb)[SK_NL]) {
+    int pi = 0, first = tb[0];
+#pragma unroll
+    for (int i = 1; i < kMaxGroup; ++i)
+        if (u >= tb[i]) { pi = i; first = tb[i]; }
+    const int per = grp.xcd_per[pi];
+    const GemmProblem &g = grp.p[pi];
+    int local = u - first;
+    const int tiles_mn = g.tiles_mn;
+    if (per > 0) {
+        const int x = local & 7, j = local >> 3;
+        local = x * per + j;
+        if (j >= per || local >= tiles_mn) return false;
+    }
+    const int flags = g.flags, tiles_m = g.tiles_m, tiles_n = g.tiles_n;
+    const uint32_t inv_in = g.inv_in;
+    const bool n_major = (flags & 16) != 0;
+    const int inner = inv_in ? (int)__umulhi((uint32_t)local, inv_in) : local;
+    const int by = n_major ? local - inner * tiles_m : inner, bx = n_major ? inner : local - inner * tiles_n;
+    t.c = g.c; t.bias = g.bias; t.mask = g.mask; t.gate = g.gate; t.ldc = (uint32_t)g.ldc;
+    t.alpha = g.alpha; t.beta = g.beta; t.M = g.M; t.N = g.N; t.K = g.K; t.act = g.act;
+    t.m0 = by * SK_BM; t.n0 = bx * BN;
+    const int K = t.K, kz = ((K >> 5) << 5) + ((((K & 31) + 3) >> 2) << 2), KC = kz >> 1;
+    const uint32_t inv_kc = 0xFFFFFFFFu / (uint32_t)KC + 1u;
     const gfloat *ga = as_global(g.a), *gb = as_global(g.b);
     const uint32_t sam = (uint32_t)g.sam, sbn = (uint32_t)g.sbn;
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-        const uint32_t i = (uint32_t)(tid + SK_THREADS * j);
-        const int row = (int)__umulhi(i, inv_kc), k = VW * ((int)i - row * KC);
-        const bool la = row < SK_BM && m0 + row < g.M && k < K, lb = row < BN && n0 + row < g.N && k < K;
-        xa[j] = *reinterpret_cast<const GSCAN_GLOBAL vec *>(ga + (la ? (uint32_t)(m0 + row) * sam + (uint32_t)k : 0u));
-        xb[j] = *reinterpret_cast<const GSCAN_GLOBAL vec *>(gb + (lb ? (uint32_t)(n0 + row) * sbn + (uint32_t)k : 0u));
+    for (int j = 0; j < SK_NL; ++j) {                 // unconditional: a dead load reads element 0 of the operand
+        int row, k;
+        sk_where(tid, j, KC, inv_kc, row, k);
+        const bool la = row < SK_BM && t.m0 + row < t.M && k < K, lb = row < BN && t.n0 + row < t.N && k < K;
+        xa[j] = *reinterpret_cast<const GSCAN_GLOBAL sk_vec *>(ga + (la ? (uint32_t)(t.m0 + row) * sam + (uint32_t)k : 0u));
+        xb[j] = *reinterpret_cast<const GSCAN_GLOBAL sk_vec *>(gb + (lb ? (uint32_t)(t.n0 + row) * sbn + (uint32_t)k : 0u));
     }
+    return true;
+}
+
+// registers -> LDS images [row][SK_LDK]; dead elements (tile edges, k >= K up to the zero-filled extent) become zeros
+__device__ __forceinline__ void sk_stage(const ShortKTile &t, const sk_vec (&xa)[SK_NL], const sk_vec (&xb)[SK_NL]) {
+    float *lds_a = shortk_lds, *lds_b = shortk_lds + SK_BM * SK_LDK;
+    const int K = t.K, kz = ((K >> 5) << 5) + ((((K & 31) + 3) >> 2) << 2), KC = kz >> 1;
+    const uint32_t inv_kc = 0xFFFFFFFFu / (uint32_t)KC + 1u;
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-        const uint32_t i = (uint32_t)(tid + SK_THREADS * j);
-        const int row = (int)__umulhi(i, inv_kc), k = VW * ((int)i - row * KC);
-        const bool la = row < SK_BM && m0 + row < g.M && k < K, lb = row < BN && n0 + row < g.N && k < K;
-        if (row < SK_BM) {                                           // dead elements (tile edges, k >= K) are stored as zeros
-            vec za = xa[j], zb = xb[j];
-#pragma unroll
-            for (int e = 0; e < VW; ++e) { za[e] = la ? za[e] : 0.f; zb[e] = lb ? zb[e] : 0.f; }
-            *reinterpret_cast<vec *>(lds_a + row * SK_LDK + k) = za;
-            *reinterpret_cast<vec *>(lds_b + row * SK_LDK + k) = zb;
+    for (int j = 0; j < SK_NL; ++j) {
+        int row, k;
+        sk_where(tid, j, KC, inv_kc, row, k);
+        if (row < SK_BM) {
+            const bool la = t.m0 + row < t.M && k < K, lb = t.n0 + row < t.N && k < K;
+            *reinterpret_cast<sk_vec *>(lds_a + row * SK_LDK + k) = la ? xa[j] : sk_vec{0.f, 0.f};
+            *reinterpret_cast<sk_vec *>(lds_b + row * SK_LDK + k) = lb ? xb[j] : sk_vec{0.f, 0.f};
         }
     }
-    __syncthreads();
+}
 
-    // ---- MFMAs: full 32-deep chunks with the next chunk's fragments in flight, then the 4-deep tail steps -----------
-    f32x4 acc[2][2];
+// MFMAs of the staged tile (full 32-deep chunks with the next chunk's fragments in flight, then the 4-deep tail steps)
+// and its epilogue (gemm.hip's, natural tiles on both sides)
+__device__ __forceinline__ void sk_multiply(const ShortKTile &t, f32x4 (&acc)[2][2]) {
+    const float *lds_a = shortk_lds, *lds_b = shortk_lds + SK_BM * SK_LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int K = t.K, n32 = K >> 5, tail = ((K & 31) + 3) >> 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -84,11 +122,11 @@ __device__ __forceinline__ void shortk_tile(const GemmProblem &g, int local) {
     float4 af[2][2][2], bf[2][2][2];                                 // [buffer][tile][half]
     auto read_chunk = [&](int c, int buf) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float4 *qa = reinterpret_cast<const float4 *>(fa + 16 * t * SK_LDK + 32 * c + 8 * fg);
-            const float4 *qb = reinterpret_cast<const float4 *>(fb + 16 * t * SK_LDK + 32 * c + 8 * fg);
-            af[buf][t][0] = qa[0]; af[buf][t][1] = qa[1];
-            bf[buf][t][0] = qb[0]; bf[buf][t][1] = qb[1];
+        for (int q = 0; q < 2; ++q) {
+            const float4 *qa = reinterpret_cast<const float4 *>(fa + 16 * q * SK_LDK + 32 * c + 8 * fg);
+            const float4 *qb = reinterpret_cast<const float4 *>(fb + 16 * q * SK_LDK + 32 * c + 8 * fg);
+            af[buf][q][0] = qa[0]; af[buf][q][1] = qa[1];
+            bf[buf][q][0] = qb[0]; bf[buf][q][1] = qb[1];
         }
     };
     auto mma_chunk = [&](int buf) {
@@ -118,32 +156,36 @@ __device__ __forceinline__ void shortk_tile(const GemmProblem &g, int local) {
         const int k = 32 * n32 + 4 * s + fg;
         float a[2], b[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { a[t] = fa[16 * t * SK_LDK + k]; b[t] = fb[16 * t * SK_LDK + k]; }
+        for (int q = 0; q < 2; ++q) { a[q] = fa[16 * q * SK_LDK + k]; b[q] = fb[16 * q * SK_LDK + k]; }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+}
 
-    // ---- epilogue (gemm.hip's, natural tiles on both sides): C fragment column = lane & 15, row = (lane >> 4) * 4 + reg
+__device__ __forceinline__ void sk_epilogue(const ShortKTile &t, const f32x4 (&acc)[2][2]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    // C fragment: column = lane & 15, row = (lane >> 4) * 4 + reg
     int coff[2];
     bool cok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        coff[j] = n0 + wn * 32 + 16 * j + fr;
-        cok[j] = coff[j] < g.N;
+        coff[j] = t.n0 + wn * 32 + 16 * j + fr;
+        cok[j] = coff[j] < t.N;
     }
-    const uint32_t ldc = (uint32_t)g.ldc;
-    const float alpha = g.alpha;
-    gfloat *gc = as_global(g.c);
-    const gfloat *gbias = as_global(g.bias), *ggate = as_global(g.gate), *gmask = as_global(g.mask);
-    const bool plain = g.beta == 0.f && !g.bias && g.act == 0 && !g.mask;
+    const uint32_t ldc = t.ldc;
+    const float alpha = t.alpha;
+    gfloat *gc = as_global(t.c);
+    const gfloat *gbias = as_global(t.bias), *ggate = as_global(t.gate), *gmask = as_global(t.mask);
+    const bool plain = t.beta == 0.f && !t.bias && t.act == 0 && !t.mask;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * 32 + 16 * i + fg * 4 + r;
-            if (row >= g.M) continue;
+            const int row = t.m0 + wm * 32 + 16 * i + fg * 4 + r;
+            if (row >= t.M) continue;
             const uint32_t roff = (uint32_t)row * ldc;
             if (plain) {
 #pragma unroll
@@ -155,11 +197,11 @@ __device__ __forceinline__ void shortk_tile(const GemmProblem &g, int local) {
                     if (!cok[j]) continue;
                     const uint32_t at = roff + coff[j];
                     float v = alpha * acc[i][j][r];
-                    if (g.beta != 0.f) v += g.beta * gc[at];
+                    if (t.beta != 0.f) v += t.beta * gc[at];
                     if (gbias) v += gbias[coff[j]];
-                    if (g.act == 1) v = fmaxf(v, 0.f);
-                    else if (g.act == 2) v = tanhf_(v);
-                    else if (g.act == 3 && ggate[at] == 0.f) v = 0.f;
+                    if (t.act == 1) v = fmaxf(v, 0.f);
+                    else if (t.act == 2) v = tanhf_(v);
+                    else if (t.act == 3 && ggate[at] == 0.f) v = 0.f;
                     if (gmask) v *= gmask[at];
                     gc[at] = v;
                 }
@@ -167,37 +209,48 @@ __device__ __forceinline__ void shortk_tile(const GemmProblem &g, int local) {
         }
 }
 
+// PERSISTENT: the launch has at most two workgroups per CU, each walks tiles u = block, block + grid, ...  The loads of
+// a workgroup's NEXT tile are issued (into 80 staging registers) before the MFMAs of its current one, so a tile's load
+// latency hides behind a tile's multiplication instead of one of the two resident workgroups' turns.
 __global__ __launch_bounds__(SK_THREADS) void gemm_shortk_kernel(int tb0, int tb1, int tb2, int tb3, int tb4, int tb5, int tb6,
-                                                                 int tb7, int tb8, int tb9, int tb10, int tb11, GemmGroup grp) {
+                                                                 int tb7, int tb8, int tb9, int tb10, int tb11, GemmGroup grp,
+                                                                 int total) {
     const int tb[kMaxGroup] = {tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7, tb8, tb9, tb10, tb11};
     static_assert(kMaxGroup == 12, "the preloaded header is twelve scalars");
     TraceScope trace_scope(TK_GEMM);
-    int pi = 0, first = tb[0];
-#pragma unroll
-    for (int i = 1; i < kMaxGroup; ++i)
-        if ((int)blockIdx.x >= tb[i]) { pi = i; first = tb[i]; }
-    asm volatile("" : "+s"(pi), "+s"(first));
-    int per = grp.xcd_per[pi];
-    GemmProblem g = grp.p[pi];
-    asm volatile("" : "+s"(g.M), "+s"(g.N), "+s"(g.K), "+s"(g.alpha), "+s"(g.beta), "+s"(g.a), "+s"(g.sam), "+s"(g.b),
-                      "+s"(g.sbn), "+s"(g.c), "+s"(g.ldc), "+s"(per));
-    asm volatile("" : "+s"(g.bias), "+s"(g.act), "+s"(g.mask), "+s"(g.gate), "+s"(g.tiles_n), "+s"(g.tiles_mn), "+s"(g.flags),
-                      "+s"(g.inv_in), "+s"(g.tiles_m));
-    int local = blockIdx.x - first;
-    if (per > 0) {                                   // XCD-aware order, as in gemm.hip
-        const int x = local & 7, j = local >> 3;
-        local = x * per + j;
-        if (j >= per || local >= g.tiles_mn) return;
+    sk_vec xa[SK_NL], xb[SK_NL];
+    ShortKTile cur, nxt;
+    int u = blockIdx.x;
+#ifdef GSCAN_GEMM_STAMPS
+    unsigned gst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long gst_prev = clock64();
+#endif
+    bool have = u < total && sk_fetch(tb, grp, u, nxt, xa, xb);
+    GST(0)                                            // first tile's descriptor and loads issued
+    while (u < total) {
+        cur = nxt;
+        const bool cur_ok = have;
+        if (cur_ok) sk_stage(cur, xa, xb);
+        GST(1)                                        // wait for the panels + LDS stores
+        // barriers that order LDS traffic only: __syncthreads() would also drain vmcnt, i.e. wait for the previous
+        // tile's epilogue stores to be acknowledged and for the loads just issued for the next one
+        lds_barrier();
+        GST(2)
+        u += gridDim.x;
+        have = u < total && sk_fetch(tb, grp, u, nxt, xa, xb);
+        GST(3)                                        // next tile's descriptor and loads issued
+        f32x4 acc[2][2];
+        if (cur_ok) sk_multiply(cur, acc);
+        GST(4)                                        // fragment reads + MFMAs
+        lds_barrier();                                // every wave is done with the LDS images
+        GST(5)
+        if (cur_ok) sk_epilogue(cur, acc);
+        GST(6)
     }
-    const int vw = 1 << min(g.flags & 3, (g.flags >> 2) & 3);       // 2 or 4 floats per load
-    const int kz = ((g.K >> 5) << 5) + ((((g.K & 31) + 3) >> 2) << 2);
-    if (vw == 4) {
-        if (kz <= 112) shortk_tile<4, 7>(g, local);                // 64 x 28 chunks
-        else shortk_tile<4, 10>(g, local);                         // 64 x 40
-    } else {
-        if (kz <= 104) shortk_tile<2, 13>(g, local);               // 64 x 52
-        else shortk_tile<2, 20>(g, local);                         // 64 x 80
-    }
+#ifdef GSCAN_GEMM_STAMPS
+    if (g_trace_buf && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) g_trace_buf[1500 + i] += gst_acc[i];
+#endif
 }
 
 int gemm_shortk_launch(const GemmGroup &grp, int total, hipStream_t stream) {
@@ -208,8 +261,9 @@ int gemm_shortk_launch(const GemmGroup &grp, int total, hipStream_t stream) {
         attr_set = true;
     }
     const int *t = grp.tile_begin;
-    hipLaunchKernelGGL(gemm_shortk_kernel, dim3(total), dim3(SK_THREADS), kShortKLdsBytes, stream, t[0], t[1], t[2], t[3], t[4],
-                       t[5], t[6], t[7], t[8], t[9], t[10], t[11], grp);
+    static const int cap = [] { const char *e = getenv("GSCAN_SHORTK_WGS"); return e ? atoi(e) : 512; }();   // two per CU
+    hipLaunchKernelGGL(gemm_shortk_kernel, dim3(std::min(total, cap)), dim3(SK_THREADS), kShortKLdsBytes, stream, t[0], t[1],
+                       t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], grp, total);
     GSCAN_LAUNCHED("gemm_shortk_kernel");
     return 0;
 }
