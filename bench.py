@@ -420,6 +420,8 @@ def main():
             alg = f["tflops"] * f["ms_per_step"] + b["tflops"] * b["ms_per_step"]      # TFLOP/s x ms = GFLOP per step
             merged["decoder_pair"] = {"ms_per_step": ms, "launches_per_step": f["launches_per_step"] + b["launches_per_step"],
                                       "tflops": alg / ms if ms > 0 else 0.0}
+        elif "decoder_forward" in merged:      # both recurrences in one launch (gscan_train_step_nll), recorded as forward
+            merged["decoder_pair"] = merged.pop("decoder_forward")
         ranked = [{"family": k, "ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": round(v["launches_per_step"], 2),
                    "algorithmic_tflops": round(v["tflops"], 3), "frac_of_fp32_peak": round(v["tflops"] / PEAK_FP32_TFLOPS, 4)}
                   for k, v in sorted(merged.items(), key=lambda kv: -kv[1]["ms_per_step"])]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 9
+#define GSCAN_ABI_VERSION 10
 #define GSCAN_MAX_ENC_LAYERS 4
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
@@ -240,6 +240,15 @@ int gscan_backward_seeded(const gscan_dims *dims, const gscan_params *params, co
 int gscan_backward_nll(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
                        const gscan_masks *masks, void *workspace, float weight_target_loss, int sum_reduction,
                        float *stats, float *seeds, const gscan_params *grads, void *stream);
+
+/* One training iteration's forward pass, loss and backward pass (seq2seq/train.py:96-110: model(...), get_loss,
+ * loss.backward()) as ONE call: what gscan_forward followed by gscan_backward_nll compute.  Arguments as in those two
+ * calls; `logp` / `aux_logp` receive the forward pass's outputs.  With GSCAN_FUSED_DECODER=1 in the environment the
+ * decoder's forward and reverse recurrences run as one launch (a row's workgroup runs both on the same CU) where the
+ * row's memories fit LDS in both directions: an experiment, slower than two launches on MI355X. */
+int gscan_train_step_nll(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                         const gscan_masks *masks, void *workspace, float *logp, float *aux_logp, float weight_target_loss,
+                         int sum_reduction, float *stats, float *seeds, const gscan_params *grads, void *stream);
 
 /* Adam with the step-dependent scalars [lr_t / (1 - beta1^t), 1 / sqrt(1 - beta2^t)] read from device memory
  * (gscan_adam_scalars computes them on the host); zero_grad != 0 also clears the gradient buffer

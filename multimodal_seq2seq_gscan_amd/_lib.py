@@ -11,7 +11,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # GSCAN_HIP_LIB: development override, used by tools/variants.py to time experimental builds side by side
 LIB_PATH = os.environ.get("GSCAN_HIP_LIB") or os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_ENC_LAYERS = 4
 COMM_ID_BYTES = 128
 
@@ -95,6 +95,8 @@ PROTOTYPES = {
                                  _vp, _vp]),
     "gscan_backward_nll": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _f, _i,
                                 _vp, _vp, C.POINTER(Params), _vp]),
+    "gscan_train_step_nll": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp, _vp, _f,
+                                  _i, _vp, _vp, C.POINTER(Params), _vp]),
     "gscan_adam_step_mean": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i64, _vp, _vp]),
     "gscan_backward_seeded": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp,
                                    _vp, _vp, C.POINTER(Params), _vp]),

@@ -85,6 +85,19 @@ int gscan_backward_nll(const gscan_dims *dims, const gscan_params *params, const
                          &nll, *grads, (hipStream_t)stream);
 }
 
+int gscan_train_step_nll(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
+                         const gscan_masks *masks, void *workspace, float *logp, float *aux_logp, float weight_target_loss,
+                         int sum_reduction, float *stats, float *seeds, const gscan_params *grads, void *stream) {
+    ARG(dims && params && batch && workspace && grads && stats && seeds && logp, "train_step_nll: NULL argument");
+    ARG(batch->commands && batch->cmd_lengths && (batch->world || batch->world_u8) && batch->targets,
+        "train_step_nll: NULL batch array");
+    ARG(!dims->auxiliary || batch->target_positions, "train_step_nll: auxiliary task set but target_positions is NULL");
+    gscan_masks none{nullptr, nullptr, nullptr};
+    const NllSeed nll{weight_target_loss, sum_reduction != 0, stats, seeds};
+    return step_train_nll(*dims, *params, *batch, masks ? *masks : none, (float *)workspace, logp, aux_logp, nll, *grads,
+                          (hipStream_t)stream);
+}
+
 int gscan_encode(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
                  const gscan_masks *masks, void *workspace, void *stream) {
     ARG(dims && params && batch && workspace, "encode: NULL argument");

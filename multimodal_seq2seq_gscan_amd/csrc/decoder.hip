@@ -340,8 +340,7 @@ __device__ __forceinline__ float quad_column_sum(const float *base, int stride, 
 //      one gate per lane —, cell update by lane 0 of each quad, h_t -> LDS
 // ------------------------------------------------------------------------------------------
 template <int H, bool COND, bool GREEDY, bool UVL = true>
-__global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a) {
-    TraceScope trace_scope(TK_DECODER_FWD);
+__device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
                   HP = 2 * K0;
     constexpr int NQ2 = (COND ? 2 : 1) * H / 4;   // column quads of [PK_t | U2_t]
@@ -713,6 +712,12 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     GSCAN_STAMP_ONCE(11)
 }
 
+template <int H, bool COND, bool GREEDY, bool UVL = true>
+__global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a) {
+    TraceScope trace_scope(TK_DECODER_FWD);
+    decoder_fwd_body<H, COND, GREEDY, UVL>(a);
+}
+
 // Backward of s_m = v . tanh(q + PK_m) for one attention.  Lane m of `dsm` holds d s_m.  Wave w owns the memories
 // w, w+nwave, ...; a lane owns features (lane, lane+64):  dPK[m][k] += ds_m v_k (1 - th^2)  (accumulated over the
 // T steps in LDS), the same term summed over this wave's memories goes to part_s[wave][k] (-> d q_k after the
@@ -812,8 +817,7 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
 // which is again a dense GEMM).
 // ------------------------------------------------------------------------------------------
 template <int H, bool COND, bool UVL = true>
-__global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a) {
-    TraceScope trace_scope(TK_DECODER_BWD);
+__device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
                   HP = 2 * K0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -858,6 +862,17 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             // the loss is mean-over-live-tokens NLL (+ w * mean-over-rows auxiliary NLL): every workgroup sums the
             // per-row partials of the forward pass in the same fixed order and seeds its row with 1/tokens, w/rows
             float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+            if (a.fused) {
+                // one launch with the forward pass: the other rows' partials do not exist yet.  The seed needs the
+                // number of live targets only, counted here from the targets themselves (the same rule as the forward
+                // epilogue: position t is scored against token t + 1, the last position against literal 0)
+                const int n = a.B * T;
+                for (int i = tid; i < n; i += kDecThreads) {
+                    const int t = i % T;
+                    const int64_t tgt = (t + 1 < T) ? a.targets[i + 1] : (int64_t)0;
+                    p1 += (tgt != a.pad_tgt && tgt >= 0 && tgt < V) ? 1.f : 0.f;
+                }
+            } else
             for (int r = tid; r < a.B; r += kDecThreads) {
                 const float4 x = *reinterpret_cast<const float4 *>(a.row_stats + 4 * r);
                 p0 += x.x; p1 += x.y; p2 += x.z;
@@ -870,7 +885,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
             for (int i = 0; i < kDecThreads / 64; ++i) { p0 += red[3 * i]; p1 += red[3 * i + 1]; p2 += red[3 * i + 2]; }
             sc = (a.nll_mode == 2) ? 1.f : 1.f / p1;
             aux_scale = a.aux_saved ? ((a.nll_mode == 2) ? a.w_aux : a.w_aux / (float)a.B) : 0.f;
-            if (b == 0 && tid == 0) {
+            if (b == 0 && tid == 0 && !a.fused) {
                 a.stats_out[0] = p0; a.stats_out[1] = p1; a.stats_out[2] = p2; a.stats_out[3] = (float)a.B;
                 a.seeds_out[0] = sc; a.seeds_out[1] = aux_scale;
                 a.seeds_out[2] = p0 * sc + p2 * aux_scale;
@@ -1161,6 +1176,40 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     GSCAN_STAMP_ONCE(12)
 }
 
+template <int H, bool COND, bool UVL = true>
+__global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a) {
+    TraceScope trace_scope(TK_DECODER_BWD);
+    decoder_bwd_body<H, COND, UVL>(a);
+}
+
+// Teacher-forced forward recurrence and the reverse recurrence of a training step in ONE launch: a row's workgroup runs
+// its forward pass (output head and loss partials included) and then, on the same CU, its backward pass.  Rows never
+// interact in either direction: the only cross-row quantity of the backward pass is the number of live target tokens
+// (the seed 1 / tokens of the mean loss), which depends on the targets alone and is counted by every workgroup
+// (DecoderArgs::fused); the batch's loss VALUE, which needs every row's forward pass, is added up by a leaf launch
+// behind this one (unpermute_add's extra workgroup).  Saves the kernel boundary between the two recurrences (~7 us: the
+// release of 28 MB of saved activations, the dispatch of 256 maximal workgroups); what the backward pass reads was
+// written by the same CU.
+template <int H, bool COND>
+__global__ __launch_bounds__(kDecThreads) void decoder_fwdbwd_kernel(DecoderArgs af, DecoderArgs ab) {
+    TraceScope trace_scope(TK_DECODER_FWD);
+    decoder_fwd_body<H, COND, false, true>(af);
+    __syncthreads();                      // this row's saved activations have landed (vmcnt) before any thread reads them
+    // The backward pass's arguments are read from the kernel-argument segment HERE, through a pointer the compiler
+    // cannot see through: taken from `ab` directly, their scalar loads are hoisted to the top of the kernel and sixty
+    // more SGPRs stay live (spilled, reloaded in every phase) across the forward pass's time loop.
+    static_assert(sizeof(DecoderArgs) % 8 == 0, "the second argument starts right behind the first");
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) char *ka =
+        (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const DecoderArgs b2 = *reinterpret_cast<const __attribute__((address_space(4))) DecoderArgs *>(ka + sizeof(DecoderArgs));
+    decoder_bwd_body<H, COND, true>(b2);
+#else
+    (void)ab;
+#endif
+}
+
 // Register images of the decoder weights are written once per step by the step prologue kernel
 // (decoder_image_element in step.h; layout described there).
 
@@ -1215,6 +1264,48 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
     return launch(decoder_fwd_kernel<H, COND, false, true>, "decoder_fwd_kernel");
 }
 
+
+// The fused launch needs both layouts with every memory in LDS (no U_vis streaming): callers fall back to two launches
+// when this says no.
+bool decoder_fused_supported(int H, int L, int M, int V, bool cond) {
+    const size_t f = (size_t)decoder_lds(H, L, M, V, cond, false, true).total * sizeof(float);
+    const size_t b = (size_t)decoder_lds(H, L, M, V, cond, true, true).total * sizeof(float);
+    return decoder_hidden_supported(H) && f <= kLdsLimit && b <= kLdsLimit;
+}
+
+template <int H, bool COND>
+static int launch_decoder_fused(int B, const DecoderArgs &af, const DecoderArgs &ab, hipStream_t stream) {
+    const size_t f = (size_t)decoder_lds(H, af.L, af.M, af.V, COND, false, true).total * sizeof(float);
+    const size_t b = (size_t)decoder_lds(H, ab.L, ab.M, ab.V, COND, true, true).total * sizeof(float);
+    const size_t bytes = f > b ? f : b;
+    GSCAN_CHECK(bytes <= kLdsLimit, "fused decoder: %zu bytes of LDS per row", bytes);
+    GSCAN_CHECK(af.w_image && ab.w_image, "decoder: weight image missing");
+    const double macs = (double)H * H + 2.0 * af.L * H + (COND ? 2.0 * H * H : 0.0) + (double)H * H +
+                        2.0 * af.M * H + 4.0 * H * 3.0 * H + 4.0 * H * H + (double)H * af.V;
+    // both recurrences in one launch: recorded as the forward family with the flops of both
+    ProbeScope probe(P_DECODER_FWD, stream, 4.0 * macs * B * af.T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fwdbwd_kernel<H, COND>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((decoder_fwdbwd_kernel<H, COND>), dim3(B), dim3(kDecThreads), bytes, stream, af, ab);
+    GSCAN_LAUNCHED("decoder_fwdbwd_kernel");
+    return 0;
+}
+
+int decoder_run_fused(int B, int H, bool cond, const DecoderArgs &af, const DecoderArgs &ab, hipStream_t stream) {
+    GSCAN_CHECK(B > 0 && af.T > 0 && af.L > 0 && af.M > 0 && af.L <= 64 && af.M <= 64, "decoder: bad dims B=%d T=%d L=%d M=%d",
+                B, af.T, af.L, af.M);
+    switch (H) {
+#define X(n) case n: return cond ? launch_decoder_fused<n, true>(B, af, ab, stream) : launch_decoder_fused<n, false>(B, af, ab, stream);
+        GSCAN_DEC_HIDDEN_SIZES(X)
+#undef X
+        default: break;
+    }
+    GSCAN_CHECK(false, "decoder_hidden_size %d has no compiled kernel (supported: " GSCAN_DEC_HIDDEN_LIST ")", H);
+}
 
 bool decoder_hidden_supported(int h) {
 #define X(n) if (h == n) return true;

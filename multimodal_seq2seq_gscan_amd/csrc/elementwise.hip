@@ -327,8 +327,32 @@ int step_prologue(const PrologueArgs &args, hipStream_t stream) {
 // gradients: g_v[k] += sum over the batch rows of the decoder kernel's per-row sums (fixed order, one thread per column)
 __global__ void unpermute_add_kernel(const float *__restrict__ dwo_perm, float *__restrict__ g_w_o2h, int H, int nperm_blocks,
                                      const float *__restrict__ dv_t_rows, const float *__restrict__ dv_v_rows, int B,
-                                     float *__restrict__ g_v_t, float *__restrict__ g_v_v) {
+                                     float *__restrict__ g_v_t, float *__restrict__ g_v_v, int nsum_blocks, LossStatsArgs ls) {
     TraceScope trace_scope(TK_UNPERMUTE);
+    if ((int)blockIdx.x >= nperm_blocks + nsum_blocks) {
+        // the batch's loss statistics from the forward pass's per-row partials [sum NLL, live tokens, aux NLL, 1], in a
+        // fixed order: what the reverse kernel's workgroup 0 writes when it runs as a launch of its own (decoder.hip)
+        __shared__ float red[3 * 4];
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+        for (int r = tid; r < ls.B; r += blockDim.x) {
+            const float4 x = *reinterpret_cast<const float4 *>(ls.row_stats + 4 * r);
+            p0 += x.x; p1 += x.y; p2 += x.z;
+        }
+        p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+        if (lane == 0) { red[3 * wave] = p0; red[3 * wave + 1] = p1; red[3 * wave + 2] = p2; }
+        __syncthreads();
+        if (tid == 0) {
+            p0 = p1 = p2 = 0.f;
+            for (int i = 0; i < (int)blockDim.x / 64; ++i) { p0 += red[3 * i]; p1 += red[3 * i + 1]; p2 += red[3 * i + 2]; }
+            const float sc = (ls.nll_mode == 2) ? 1.f : 1.f / p1;
+            const float aux_scale = ls.has_aux ? ((ls.nll_mode == 2) ? ls.w_aux : ls.w_aux / (float)ls.B) : 0.f;
+            ls.stats_out[0] = p0; ls.stats_out[1] = p1; ls.stats_out[2] = p2; ls.stats_out[3] = (float)ls.B;
+            ls.seeds_out[0] = sc; ls.seeds_out[1] = aux_scale;
+            ls.seeds_out[2] = p0 * sc + p2 * aux_scale;
+        }
+        return;
+    }
     if ((int)blockIdx.x >= nperm_blocks) {
         // a workgroup takes 32 columns of [dv_text | dv_vis]; a thread = (column, one of 8 slices of the batch rows): up to
         // 32 rows per pass, all loads of a pass in flight, then the 8 slice sums are added in a fixed order
@@ -368,10 +392,12 @@ __global__ void unpermute_add_kernel(const float *__restrict__ dwo_perm, float *
 }
 
 int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream, const float *dv_t_rows,
-                  const float *dv_v_rows, int B, float *g_v_t, float *g_v_v) {
+                  const float *dv_v_rows, int B, float *g_v_t, float *g_v_v, const LossStatsArgs *loss_stats) {
     const int nperm = cdiv(H * 4 * H, 256), nsum = dv_t_rows ? cdiv(2 * H, 32) : 0;
-    hipLaunchKernelGGL(unpermute_add_kernel, dim3(nperm + nsum), dim3(256), 0, stream, dwo_perm, g_w_o2h, H, nperm, dv_t_rows,
-                       dv_v_rows, B, g_v_t, g_v_v);
+    LossStatsArgs ls{};
+    if (loss_stats) ls = *loss_stats;
+    hipLaunchKernelGGL(unpermute_add_kernel, dim3(nperm + nsum + (loss_stats ? 1 : 0)), dim3(256), 0, stream, dwo_perm, g_w_o2h,
+                       H, nperm, dv_t_rows, dv_v_rows, B, g_v_t, g_v_v, nsum, ls);
     GSCAN_LAUNCHED("unpermute_add_kernel");
     return 0;
 }

@@ -152,8 +152,12 @@ struct PrologueArgs {
     int F;
 };
 int step_prologue(const PrologueArgs &args, hipStream_t stream);
+// loss_stats (optional): one more workgroup adds up the forward pass's per-row loss partials (the fused decoder launch
+// cannot: decoder.hip, decoder_fwdbwd_kernel)
+struct LossStatsArgs { const float *row_stats; int B, nll_mode, has_aux; float w_aux; float *stats_out, *seeds_out; };
 int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream, const float *dv_t_rows = nullptr,
-                  const float *dv_v_rows = nullptr, int B = 0, float *g_v_t = nullptr, float *g_v_v = nullptr);
+                  const float *dv_v_rows = nullptr, int B = 0, float *g_v_t = nullptr, float *g_v_v = nullptr,
+                  const LossStatsArgs *loss_stats = nullptr);
 int adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
               float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
               const float *dev_scalars, int zero_grad, hipStream_t stream);   // zero_grad bit 1: grad_scale divides
@@ -285,6 +289,8 @@ struct DecoderArgs {
     const int64_t *targets, *positions;   // [B,T]; [B] or NULL
     int pad_tgt, B;
     float *row_stats;                  // [B,4] = [sum NLL, live tokens, aux NLL, 1] of the row, or NULL
+    int fused;                         // backward in the forward pass's launch (decoder_run_fused): the seed's token count
+                                       // comes from the targets, stats_out / seeds_out are left to the leaf launch
     int nll_mode;                      // backward: seed from row_stats / targets instead of dlogp / daux / seeds
                                        // (1: mean loss as the reference's, 2: sum loss for the data-parallel step)
     float w_aux;                       // weight of the auxiliary loss (train.py:105-107)
@@ -305,6 +311,8 @@ struct DecoderArgs {
 bool decoder_hidden_supported(int h);
 size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward);
 int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
+bool decoder_fused_supported(int H, int L, int M, int V, bool cond);
+int decoder_run_fused(int B, int H, bool cond, const DecoderArgs &forward, const DecoderArgs &backward, hipStream_t stream);
 
 // attention_grad.hip: value path of both attentions + key layers + bridge, one workgroup per batch row
 struct KeysBackwardArgs {
@@ -369,6 +377,9 @@ int step_greedy(const gscan_dims &d, int max_steps, const gscan_params &p, const
                 hipStream_t st);
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                   const float *dlogp, const float *daux, const float *seeds, const NllSeed *nll, const gscan_params &g,
-                  hipStream_t st);
+                  hipStream_t st, const DecoderArgs *fused_forward = nullptr);
+// forward + training loss + backward as one sequence (the decoder's two recurrences in one launch where the shape allows)
+int step_train_nll(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
+                   float *logp, float *aux_logp, const NllSeed &nll, const gscan_params &g, hipStream_t st);
 
 }  // namespace gscan

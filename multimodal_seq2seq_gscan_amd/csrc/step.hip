@@ -468,6 +468,35 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     return 0;
 }
 
+// One training step's forward pass, loss and backward pass (train.py:96-110) as one call: the prelude, the decoder's two
+// recurrences, the rest of the backward pass.  GSCAN_FUSED_DECODER=1 runs the two recurrences as ONE launch
+// (decoder_fwdbwd_kernel; shapes whose backward layout needs the visual gate images streamed from L2 keep two).  That
+// launch is correct (the whole GPU suite passes on it) and OFF by default: it removes the 7 us boundary between the
+// recurrences, but the kernel takes 243 us against 106.5 + 124.5 for the two (rocprofv3; 103 spilled SGPRs against
+// 49 / 42, seven spilled VGPRs: one register allocation for two loops that each fill the file) and the step 0.501
+// against 0.490 ms (profiles/r03_h_fused_decoder_ab.txt).
+int step_train_nll(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
+                   float *logp, float *aux_logp, const NllSeed &nll, const gscan_params &g, hipStream_t st) {
+    TRY(check_dims(d));
+    static const int fused = [] { const char *e = getenv("GSCAN_FUSED_DECODER"); return e ? atoi(e) : 0; }();
+    const bool cond = d.conditional != 0;
+    if (!fused || !decoder_fused_supported(d.H, d.L, d.G * d.G, d.V, cond)) {
+        TRY(step_forward(d, p, bt, mk, w, logp, aux_logp, st));
+        return step_backward(d, p, bt, mk, w, nullptr, nullptr, nullptr, &nll, g, st);
+    }
+    Workspace ws;
+    TRY(workspace_layout(d, &ws));
+    GSCAN_CHECK(logp != nullptr, "forward: logp is NULL");
+    GSCAN_CHECK(!d.auxiliary || aux_logp, "forward: auxiliary task set but aux_logp is NULL");
+    TRY(encode_branches(d, p, bt, mk, w, ws, true, st));
+    DecoderArgs a = decoder_args(d, p, bt, w, ws);
+    a.w_image = w + ws.dec_w_fwd;
+    a.logp_out = logp;
+    a.aux_out = d.auxiliary ? aux_logp : nullptr;
+    a.stamps = probe_stamps_enabled() ? w + ws.stamps : nullptr;
+    return step_backward(d, p, bt, mk, w, nullptr, nullptr, nullptr, &nll, g, st, &a);
+}
+
 // --------------------------------------------------------------------------------------
 // greedy decoding (predict.py:82-115): encode once, then one decoder step per call with the caller's token
 // --------------------------------------------------------------------------------------
@@ -548,7 +577,7 @@ int step_greedy(const gscan_dims &d, int max_steps, const gscan_params &p, const
 // --------------------------------------------------------------------------------------
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                   const float *dlogp, const float *daux, const float *seeds, const NllSeed *nll, const gscan_params &g,
-                  hipStream_t st) {
+                  hipStream_t st, const DecoderArgs *fused_forward) {
     TRY(check_dims(d));
     Workspace ws;
     TRY(workspace_layout(d, &ws));
@@ -557,6 +586,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     const int BT = B * T, BL = B * L, BM_ = B * M;
     const bool cond = d.conditional != 0;
     GSCAN_CHECK(dlogp || nll, "backward: dlogp is NULL");
+    GSCAN_CHECK(!fused_forward || nll, "backward: the fused decoder launch seeds itself from the training loss");
     TRY(side_init());
     hipStream_t sd = g_side.single ? st : g_side.stream, sd2 = g_side.single ? st : g_side.stream2;
     float *S = w + ws.S, *dS = w + ws.dS;
@@ -586,7 +616,17 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     a.dh0 = w + ws.dh0;
     a.w_image = w + ws.dec_w_bwd;
     a.stamps = probe_stamps_enabled() ? w + ws.stamps + 16 : nullptr;
-    TRY(decoder_run(true, B, H, cond, a, st));
+    if (fused_forward) {           // both recurrences in one launch (step_train_nll)
+        a.fused = 1;
+        TRY(decoder_run_fused(B, H, cond, *fused_forward, a, st));
+    } else {
+        TRY(decoder_run(true, B, H, cond, a, st));
+    }
+    // the fused launch leaves the batch's loss statistics to the leaf launch behind the decoder's weight gradients
+    LossStatsArgs loss_stats{};
+    if (fused_forward)
+        loss_stats = LossStatsArgs{w + ws.row_stats, B, nll->sum ? 2 : 1, d.auxiliary ? 1 : 0, nll->w_aux, nll->stats_out,
+                                   nll->seeds_out};
     // where the decoder's weight-gradient leaves fork off the chain (GSCAN_LEAVES_FORK, A/B): 0 behind the recurrence,
     // 1 behind the dS += product, 2 behind keys_backward (one fork event in the whole backward pass)
     static const int leaves_fork = [] { const char *e = getenv("GSCAN_LEAVES_FORK"); return e ? atoi(e) : 0; }();
@@ -613,7 +653,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
             g_split_override = 0;
             b.add(BT, H, 4 * H, delta, 5 * H, 1, w + ws.wcat5, 3 * H, 1, dS, 4 * H, 1.f);
             TRY(b.launch(sd));
-            TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, sd, w + ws.dv_t, w + ws.dv_v, B, g.txt_energy_w, g.vis_energy_w));
+            TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, sd, w + ws.dv_t, w + ws.dv_v, B, g.txt_energy_w, g.vis_energy_w,
+                              fused_forward ? &loss_stats : nullptr));
             TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd));
         }
         return 0;
@@ -711,6 +752,9 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         const int Din = l == 0 ? E : D * He;
         const float *x = l == 0 ? w + ws.xe : w + ws.deep_y + (l - 1) * lay_h;
         GemmBatch b;
+        // this launch ends the step on an otherwise idle chip: its split is its own knob (GSCAN_SPLIT_ENC)
+        static const int enc_split = [] { const char *e = getenv("GSCAN_SPLIT_ENC"); return e ? atoi(e) : 0; }();
+        g_split_override = enc_split;
         for (int dir = 0; dir < D; ++dir) {
             const float *dl = ldelta + dir * 4 * He;
             float *gw_ih = dir ? gq.w_ih_rev : gq.w_ih, *gw_hh = dir ? gq.w_hh_rev : gq.w_hh;
@@ -724,6 +768,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         }
         if (l == 0)
             b.add(BL, E, D * 4 * He, ldelta, ldd, 1, w + ws.wih_stack, E, 1, w + ws.dxe, E, 1.f, nullptr, 0, nullptr, 8);
+        g_split_override = 0;
         if (last && text_leaves_on_chain) {      // the command's key layer and the bridge: their inputs were made on this stream
             add_grad(b, H, He, BL, w + ws.dpk_t, 1, H, w + ws.enc_out, He, 1, g.txt_key_w, He);
             add_grad(b, H, He, B, w + ws.dh0, 1, H, w + ws.hN, He, 1, g.bridge_w, He, g.bridge_b);

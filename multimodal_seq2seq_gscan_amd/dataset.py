@@ -346,8 +346,10 @@ class BatchStager:
     stage(): gathers the rows of a batch from the packed arrays straight into the next pinned slab (numpy writes
     into the pinned memory: no intermediate tensors, no per-array pin_memory() allocations) and enqueues ONE
     host-to-device copy of the used part of the slab on the copy stream.  deliver(): makes the consumer's stream
-    wait for that copy and returns views of the device slab.  A device slab is reused `depth` batches later, after
-    the copy stream has waited for the event the consumer's stream recorded when it moved on."""
+    wait for that copy and returns views of the device slab.  A device slab is reused `depth` batches later: the copy
+    that overwrites it waits for an event recorded on the consumer's stream at THAT moment, i.e. for everything the
+    consumer has enqueued by then — a batch's views stay valid until the iterator has been advanced `depth - 1` times
+    more, whatever the consumer launched on them in between."""
 
     def __init__(self, device: torch.device, slab_bytes: int, depth: int = 3):
         self.device, self.depth, self.slab_bytes = device, depth, slab_bytes
@@ -413,8 +415,11 @@ class BatchStager:
         host["tgt_lengths"][:] = tgt_len
         np.take(data._grids, idx, axis=0, out=host["world"], mode="clip")
         copy = self.copy_stream
-        if self.released[slot] is not None:
-            copy.wait_event(self.released[slot])       # the consumer is done with this device slab
+        if self.count > self.depth:                    # the slab held a batch before: everything the consumer has
+            if self.released[slot] is None:            # enqueued so far (all of it older than this copy) goes first
+                self.released[slot] = torch.cuda.Event()
+            self.released[slot].record(torch.cuda.current_stream(self.device))
+            copy.wait_event(self.released[slot])
         with torch.cuda.stream(copy):
             dev_used.copy_(host_used, non_blocking=True)
         self.copied[slot].record(copy)
@@ -423,10 +428,6 @@ class BatchStager:
     def deliver(self, staged: tuple) -> Dict[str, torch.Tensor]:
         slot, dev, idx = staged
         current = torch.cuda.current_stream(self.device)
-        if self._last is not None:                    # everything the consumer launched on the previous batch
-            if self.released[self._last] is None:
-                self.released[self._last] = torch.cuda.Event()
-            self.released[self._last].record(current)
         self._last = slot
         current.wait_event(self.copied[slot])
         return dict(dev, index=idx)

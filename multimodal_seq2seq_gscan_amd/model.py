@@ -436,7 +436,7 @@ class Model(nn.Module):
             raise RuntimeError("Model.forward runs on the HIP device only: move the model and the batch to "
                                "'cuda' (there is no CPU fallback in this package)")
 
-    def _launch_forward(self, commands, lengths, world, targets, masks, positions=None):
+    def _launch_forward(self, commands, lengths, world, targets, masks, positions=None, train_nll=None):
         lib = _lib.load()
         self._require_device(commands, world, targets)
         B, L = commands.shape
@@ -461,9 +461,17 @@ class Model(nn.Module):
         mstruct = _lib.Masks(*[_lib.ptr(m) for m in masks])
         logp = torch.empty(B, T, self._hyper["V"], dtype=torch.float32, device=commands.device)
         aux = torch.empty(B, G * G, dtype=torch.float32, device=commands.device) if self.auxiliary_task else None
-        _lib.check(lib.gscan_forward(C.byref(dims), C.byref(self._param_struct), C.byref(batch), C.byref(mstruct),
-                                     self._workspace.data_ptr(), logp.data_ptr(), _lib.ptr(aux),
-                                     torch.cuda.current_stream().cuda_stream), "gscan_forward")
+        if train_nll is None:
+            _lib.check(lib.gscan_forward(C.byref(dims), C.byref(self._param_struct), C.byref(batch), C.byref(mstruct),
+                                         self._workspace.data_ptr(), logp.data_ptr(), _lib.ptr(aux),
+                                         torch.cuda.current_stream().cuda_stream), "gscan_forward")
+        else:       # forward + training loss + backward in one call (train.TrainStep)
+            weight_target_loss, sum_reduction, stats, seeds = train_nll
+            _lib.check(lib.gscan_train_step_nll(C.byref(dims), C.byref(self._param_struct), C.byref(batch), C.byref(mstruct),
+                                                self._workspace.data_ptr(), logp.data_ptr(), _lib.ptr(aux),
+                                                float(weight_target_loss), int(sum_reduction), stats.data_ptr(),
+                                                seeds.data_ptr(), C.byref(self._grad_struct),
+                                                torch.cuda.current_stream().cuda_stream), "gscan_train_step_nll")
         self._generation += 1
         call = dict(dims=dims, batch=batch, masks=mstruct, generation=self._generation,
                     keep=(commands, lengths, world, targets, masks, positions))

@@ -299,6 +299,9 @@ class TrainStep:
         self.single_exchange = bool(single_exchange)
         if self.single_exchange:
             self.fused_loss = False
+        # eager steps whose backward pass seeds itself (fused_loss, or the one-collective data-parallel form) make ONE
+        # library call per iteration (gscan_train_step_nll; GSCAN_ONE_CALL=0: gscan_forward + gscan_backward_nll)
+        self.one_call = (not self.graph) and os.environ.get("GSCAN_ONE_CALL", "1") != "0"
         device = model.flat_parameters.device
         self.stats = torch.zeros(4, dtype=torch.float32, device=device)
         self.seeds = torch.zeros(3, dtype=torch.float32, device=device)
@@ -311,7 +314,7 @@ class TrainStep:
             self._host_stream_id = torch.zeros(1, dtype=torch.int64).pin_memory()
 
     # ---- the three launch sections of a step ------------------------------------------------
-    def _section_forward(self, batch) -> dict:
+    def _section_forward(self, batch, train_nll=None) -> dict:
         lib = _lib.load()
         model = self.model
         stream = torch.cuda.current_stream().cuda_stream
@@ -320,6 +323,10 @@ class TrainStep:
         T = targets.shape[1]
         masks = model._draw_masks(B, L, T, world.shape[1] ** 2, commands.device)
         pos = batch["target_positions"] if model.auxiliary_task else None
+        if train_nll is not None:      # forward, loss and backward in ONE library call (gscan_train_step_nll)
+            logp, aux, call = model._launch_forward(commands, batch["cmd_lengths"], world, targets, masks, pos,
+                                                    train_nll=train_nll)
+            return {"logp": logp, "aux": aux, "call": call}
         logp, aux, call = model._launch_forward(commands, batch["cmd_lengths"], world, targets, masks, pos)
         if self.fused_loss or self.single_exchange:
             return {"logp": logp, "aux": aux, "call": call}
@@ -370,10 +377,13 @@ class TrainStep:
         if self.graph:
             return self._replay(batch)
         self._host_prologue()
-        fw = self._section_forward(batch)
         if self.single_exchange:
             store = model._grad_store
-            model._launch_backward_nll(fw["call"], self.weight_target_loss, store[-4:], self.seeds, sum_reduction=True)
+            if self.one_call:
+                fw = self._section_forward(batch, train_nll=(self.weight_target_loss, True, store[-4:], self.seeds))
+            else:
+                fw = self._section_forward(batch)
+                model._launch_backward_nll(fw["call"], self.weight_target_loss, store[-4:], self.seeds, sum_reduction=True)
             _, count, loss = self.exchange.mean_from_sums(store)
             if self.on_gradients is not None:
                 self.on_gradients(model.flat_gradients / count)
@@ -381,8 +391,12 @@ class TrainStep:
                 self.optimizer.launch_mean(count)
             model.update_state(is_best=False)
             return {"loss": loss, "tokens": count[0], "logp": fw["logp"], "aux": fw["aux"]}
-        self.exchange.all_reduce(self.stats)
-        self._section_backward(fw)
+        if self.fused_loss and self.one_call:      # one process, eager: forward + loss + backward in one library call
+            fw = self._section_forward(batch, train_nll=(self.weight_target_loss, False, self.stats, self.seeds))
+        else:
+            fw = self._section_forward(batch)
+            self.exchange.all_reduce(self.stats)
+            self._section_backward(fw)
         self.exchange.all_reduce(model.flat_gradients)
         if self.on_gradients is not None:
             self.on_gradients(model.flat_gradients)
