@@ -336,6 +336,66 @@ def test_fused_loss_backward_matches_two_phase_path(auxiliary):
     assert torch.allclose(g0, g1, atol=1e-6, rtol=1e-4), (g0 - g1).abs().max().item()
 
 
+_ONE_CALL_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2]); sys.path.insert(0, os.path.join(sys.argv[2], "golden"))
+from helpers import fixture_params
+from test_parity_gpu import build_model
+from multimodal_seq2seq_gscan_amd.config import model_kwargs
+from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+from multimodal_seq2seq_gscan_amd.train import TrainStep
+aux, sum_red = sys.argv[3] == "1", sys.argv[4] == "1"
+cfg = model_kwargs("demo", auxiliary_task=aux)
+shape = Shape(batch=6, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=7, max_target=10, ragged=True)
+batch = {k: v.cuda() for k, v in make_batch(shape, 321).items()}
+batch = dict(batch, cmd_lengths=batch["cmd_lengths"].to(torch.int32))
+model = build_model(cfg, fixture_params(cfg, {"seed_weights": 5}))
+model._dropout_seed = 99
+step = TrainStep(model, learning_rate=0.0)
+stats = torch.zeros(4, device="cuda")
+fw = step._section_forward(batch, train_nll=(step.weight_target_loss, sum_red, stats, step.seeds))
+torch.cuda.synchronize()
+torch.save({"seeds": step.seeds.cpu(), "stats": stats.cpu(), "grads": model.flat_gradients.cpu(), "logp": fw["logp"].cpu()}, sys.argv[5])
+"""
+
+
+@pytest.mark.parametrize("auxiliary,sum_reduction", [(False, False), (True, False), (False, True)])
+def test_one_call_train_step_equals_forward_then_backward(tmp_path, auxiliary, sum_reduction):
+    """gscan_train_step_nll (forward + loss + backward in one library call, what TrainStep issues) against
+    gscan_forward followed by gscan_backward_nll — and once more in a child process with GSCAN_FUSED_DECODER=1, where
+    the decoder's forward and reverse recurrences run as ONE launch (the token count behind the seed comes from the
+    targets, the loss statistics from the leaf launch): same log-probabilities, loss, statistics and gradients."""
+    import os, subprocess, sys
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+    from multimodal_seq2seq_gscan_amd.train import TrainStep
+    cfg = model_kwargs("demo", auxiliary_task=auxiliary)
+    shape = Shape(batch=6, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=7, max_target=10, ragged=True)
+    batch = {k: v.cuda() for k, v in make_batch(shape, 321).items()}
+    batch = dict(batch, cmd_lengths=batch["cmd_lengths"].to(torch.int32))
+    model = build_model(cfg, fixture_params(cfg, {"seed_weights": 5}))
+    model._dropout_seed = 99
+    step = TrainStep(model, learning_rate=0.0)
+    stats = torch.zeros(4, device="cuda")
+    fw = step._section_forward(batch)
+    model._launch_backward_nll(fw["call"], step.weight_target_loss, stats, step.seeds, sum_reduction=sum_reduction)
+    torch.cuda.synchronize()
+    ref = {"seeds": step.seeds.cpu().clone(), "stats": stats.cpu().clone(), "grads": model.flat_gradients.cpu().clone(),
+           "logp": fw["logp"].cpu().clone()}
+    here = os.path.dirname(os.path.abspath(__file__))
+    for fused_decoder in ("0", "1"):
+        out = str(tmp_path / f"one_call_{fused_decoder}.pt")
+        env = dict(os.environ, GSCAN_FUSED_DECODER=fused_decoder)
+        r = subprocess.run([sys.executable, "-c", _ONE_CALL_WORKER, os.path.dirname(here), here, str(int(auxiliary)),
+                            str(int(sum_reduction)), out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        got = torch.load(out)
+        assert torch.equal(got["logp"], ref["logp"]), fused_decoder                  # the forward pass is bitwise the same
+        assert torch.allclose(got["seeds"], ref["seeds"], atol=1e-6, rtol=1e-5), (fused_decoder, got["seeds"], ref["seeds"])
+        assert torch.allclose(got["stats"], ref["stats"], atol=1e-4, rtol=1e-5), (fused_decoder, got["stats"], ref["stats"])
+        assert got["stats"][1].item() > 0 and got["grads"].abs().max().item() > 0
+        assert torch.allclose(got["grads"], ref["grads"], atol=1e-6, rtol=1e-4), (fused_decoder, (got["grads"] - ref["grads"]).abs().max())
+
+
 def test_decode_input_steps_match_teacher_forced_forward():
     """encode_input + one decode_input per target token (the greedy-decoding surface, predict.py:82-106) reproduces
     the teacher-forced forward pass: same logits step by step, same attention, same final state."""
