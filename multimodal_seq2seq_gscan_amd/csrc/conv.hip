@@ -327,28 +327,34 @@ __global__ __launch_bounds__(kConvThreads) void world_conv_bwd_kernel(ConvArgs a
         // the 64 rows sixteen dependent round trips to L2 — the longest chain of the whole launch), slices added in LDS
         constexpr int kSl = 2;
         __shared__ float bsl[kSl][kConvThreads / kSl];
-        const int f = threadIdx.x % (kConvThreads / kSl), sl = threadIdx.x / (kConvThreads / kSl);
+        const int fl = threadIdx.x % (kConvThreads / kSl), sl = threadIdx.x / (kConvThreads / kSl);
         const int per = (r1 - r0 + kSl - 1) / kSl, q0 = r0 + sl * per, q1 = min(r1, q0 + per);
-        float acc = 0.f;
-        if (f < F) {
-            for (int r = q0; r < q1; r += 16) {
-                float x[16];
+        // F = 3 Co columns in groups of kConvThreads / kSl (more than one group from Co = 86 on: the first version of this
+        // code summed the first 256 columns only — found by tools/fuzz_parity.py --extremes at Co = 200)
+        for (int f0 = 0; f0 < F; f0 += kConvThreads / kSl) {
+            const int f = f0 + fl;
+            float acc = 0.f;
+            if (f < F) {
+                for (int r = q0; r < q1; r += 16) {
+                    float x[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) x[u] = (r + u < q1) ? a.dfeat[(int64_t)(r + u) * F + f] : 0.f;
+                    for (int u = 0; u < 16; ++u) x[u] = (r + u < q1) ? a.dfeat[(int64_t)(r + u) * F + f] : 0.f;
 #pragma unroll
-                for (int w = 8; w > 0; w >>= 1)
+                    for (int w = 8; w > 0; w >>= 1)
 #pragma unroll
-                    for (int u = 0; u < w; ++u) x[u] += x[u + w];
-                acc += x[0];
+                        for (int u = 0; u < w; ++u) x[u] += x[u + w];
+                    acc += x[0];
+                }
             }
-        }
-        bsl[sl][f] = acc;
-        __syncthreads();
-        if (sl == 0 && f < F) {
-            float s = 0.f;
+            bsl[sl][fl] = acc;
+            __syncthreads();
+            if (sl == 0 && f < F) {
+                float s = 0.f;
 #pragma unroll
-            for (int q = 0; q < kSl; ++q) s += bsl[q][f];
-            atomicAdd(&a.gb[f / Co][f % Co], s);
+                for (int q = 0; q < kSl; ++q) s += bsl[q][fl];
+                atomicAdd(&a.gb[f / Co][f % Co], s);
+            }
+            __syncthreads();
         }
         return;
     }

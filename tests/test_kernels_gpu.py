@@ -147,6 +147,7 @@ def test_gemm_suite_on_forced_single_shot_tiles():
     (3, 4, 15, 7, 50, 1.0, False),        # a DENSE world: the sparse kernels are exact for any input
     (2, 15, 16, 7, 70, 0.05, True),       # the reference's 15 x 15 test grid, Co > 64 (two output-channel chunks)
     (4, 3, 5, 3, 7, 0.5, False),          # tiny everything
+    (3, 6, 16, 7, 100, 0.15, True),       # 3 Co = 300 feature columns: more than one column group of the bias sums
 ])
 def test_world_encoder_forward_and_weight_gradients(lib, B, G, Cc, K3, Co, density, u8):
     """The input-sparse world encoder equals the reference's three conv2d on the transposed image + ReLU + dropout

@@ -16,6 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps-before", type=int, default=30)
 ap.add_argument("--single-stream", action="store_true")
 ap.add_argument("--traced-steps", type=int, default=2, help="trace this many consecutive steps, print the last")
+ap.add_argument("--workload", default="compositional", choices=["compositional", "target_length"],
+                help="target_length = S3: k = 13, T = 120")
 args = ap.parse_args()
 if args.single_stream:
     os.environ["GSCAN_SINGLE_STREAM"] = "1"
@@ -39,9 +41,10 @@ RECORDS = 256
 
 lib = _lib.load()
 torch.manual_seed(0)
-model = Model(**model_kwargs("compositional")).cuda()
+model = Model(**model_kwargs(args.workload)).cuda()
 step = TrainStep(model)
-batch = {k: v.cuda() for k, v in make_batch(Shape(batch=256), 1).items()}
+shape = Shape(batch=256, input_vocab=17, target_vocab=8, max_target=120) if args.workload == "target_length" else Shape(batch=256)
+batch = {k: v.cuda() for k, v in make_batch(shape, 1).items()}
 for _ in range(args.steps_before):
     step(batch)
 torch.cuda.synchronize()
