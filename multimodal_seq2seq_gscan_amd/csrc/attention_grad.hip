@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kKbThreads, 4) void keys_backward_kernel(KeysBackwa
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int T = a.T, L = a.L, M = a.M;
     const int MTV = (M + 15) / 16, MTT = (L + 15) / 16, MT = MTV + MTT;
-    const int mt = blockIdx.y + a.tile0;              // visual tiles, textual tiles, then the bridge workgroup
+    const int mt = blockIdx.y;
 
     if (mt == MT) {
         // ---- bridge: d h_N[e] = sum_k d h0[k] * W_bridge[k][e]
@@ -184,32 +184,26 @@ __global__ __launch_bounds__(kKbThreads, 4) void keys_backward_kernel(KeysBackwa
     }
 }
 
-// which: 3 = everything in one launch; 1 = the command's memories and the bridge only (what the command encoder's
-// reverse recurrence waits for: a fifth of the work); 2 = the grid cells only (leaves: d feat, d PK_vis)
 template <int H>
-static int launch_keys_backward(int B, KeysBackwardArgs a, int which, hipStream_t stream) {
+static int launch_keys_backward(int B, const KeysBackwardArgs &a, hipStream_t stream) {
     const size_t bytes = (size_t)keys_lds(H).total * sizeof(float);
-    const int mtv = (a.M + 15) / 16, mtt = (a.L + 15) / 16;
-    a.tile0 = which == 1 ? mtv : 0;
-    const int ny = which == 1 ? mtt + 1 : (which == 2 ? mtv : mtv + mtt + 1);
-    hipLaunchKernelGGL((keys_backward_kernel<H>), dim3(B, ny), dim3(kKbThreads), bytes, stream, a);
+    const int tiles = (a.M + 15) / 16 + (a.L + 15) / 16;
+    hipLaunchKernelGGL((keys_backward_kernel<H>), dim3(B, tiles + 1), dim3(kKbThreads), bytes, stream, a);
     GSCAN_LAUNCHED("keys_backward_kernel");
     return 0;
 }
 
-int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream, int which) {
-    GSCAN_CHECK(which >= 1 && which <= 3, "keys backward: which = %d", which);
+int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream) {
     GSCAN_CHECK(B > 0 && a.T > 0 && a.L > 0 && a.M > 0 && a.He > 0 && a.F > 0,
                 "keys backward: bad dims B=%d T=%d L=%d cells=%d He=%d F=%d", B, a.T, a.L, a.M, a.He, a.F);
     // algorithmic flops: the data-gradient halves of the key layers and of the bridge (SURVEY.md 8d counts backward as
     // 2 x forward MACs: half of it data gradients), 2 * B * (L He H + M F H + He H); the value-path sums
     // dPK += alpha^T . dctx are the data-gradient halves of the context reductions, 2 * B * T * (L + M) * H
-    const double alg_t = 2.0 * B * ((double)a.L * a.He * H + (double)a.He * H) + 2.0 * B * a.T * (double)a.L * H;
-    const double alg_v = 2.0 * B * (double)a.M * a.F * H + 2.0 * B * a.T * (double)a.M * H;
-    const double alg = (which & 1 ? alg_t : 0.0) + (which & 2 ? alg_v : 0.0);
+    const double alg = 2.0 * B * ((double)a.L * a.He * H + (double)a.M * a.F * H + (double)a.He * H) +
+                       2.0 * B * a.T * (double)(a.L + a.M) * H;
     ProbeScope probe(P_KEYS_BWD, stream, alg, alg);
     switch (H) {
-#define X(n) case n: return launch_keys_backward<n>(B, a, which, stream);
+#define X(n) case n: return launch_keys_backward<n>(B, a, stream);
         GSCAN_DEC_HIDDEN_SIZES(X)
 #undef X
         default: break;

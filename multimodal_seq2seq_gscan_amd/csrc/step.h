@@ -323,9 +323,8 @@ struct KeysBackwardArgs {
     const float *w_kt, *w_kv, *w_b;        // [H,He] [H,F] [H,He]
     const float *feat, *mask;              // [B,M,F]; mask may be NULL
     float *denc, *dhN, *dfeat;             // [B,L,He] [B,He] [B,M,F]
-    int tile0;                             // set by the launcher: first tile index of the launch
 };
-int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream, int which = 3);
+int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream);
 
 // comm.hip: RCCL all-reduce on the caller's stream (run-time binding)
 int comm_unique_id(void *id_host);

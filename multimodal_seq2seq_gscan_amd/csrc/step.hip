@@ -215,10 +215,8 @@ static int side_init() {
     // measured 0.5% faster than lowest priority
     int prio_least = 0, prio_greatest = 0;
     GSCAN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    const char *low = getenv("GSCAN_SIDE_LOW_PRIORITY");        // A/B: leaves at the lowest priority instead
-    const int prio = (low && low[0] == '1') ? prio_least : prio_greatest;
-    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, prio));
-    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream2, hipStreamNonBlocking, prio));
+    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, prio_greatest));
+    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream2, hipStreamNonBlocking, prio_greatest));
     // The events order kernels of ONE device across streams: no system-scope fence (cache write-back / invalidate for
     // the host's benefit) is needed when one completes, and leaving it out takes 6 us off a step (0.5525 -> 0.546 ms,
     // profiles/r02_ab_event_flags.txt).  GSCAN_EVENT_FLAGS=0 restores the default fence.
@@ -659,14 +657,6 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         }
         return 0;
     };
-    // GSCAN_TAIL_SPLIT=1 (experiment): the chain behind the reverse recurrence carries only
-    // what the command encoder's reverse recurrence needs — the ctx_text columns of the dS += product, then the command's
-    // memories and the bridge of keys_backward (a fifth of that kernel) — and the grid-cell halves of both run as leaves
-    // on the second side stream in front of the convolution gradients.  Measured SLOWER (0.4966 against 0.4911 ms per
-    // step, profiles/r03_g_tail_experiments.txt): with every leaf released at once the chain's kernels wait for CUs
-    // (the command's keys 8 -> 42 us, the encoder's reverse recurrence 16 -> 33 us) — this stretch of the step is
-    // bound by the throughput of its kernels, not by the order they are issued in.
-    static const int tail_split = [] { const char *e = getenv("GSCAN_TAIL_SPLIT"); return e ? atoi(e) : 0; }();
     KeysBackwardArgs k{};
     k.T = T; k.L = L; k.M = M; k.He = He; k.F = F;
     k.alpha_c = w + ws.alpha_c; k.alpha_s = w + ws.alpha_s; k.ds = dS;
@@ -677,27 +667,6 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     float *const gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
     float *const gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
     const void *world = bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world;
-    if (tail_split && !g_side.single) {
-        TRY(order_after(sd, st, sd2));     // one event behind the reverse recurrence releases both leaf streams
-        TRY(decoder_leaves());             // side 1
-        // chain: gradient wrt ctx_text through the LSTM input and the conditional query
-        // ([delta | dzq] . [W_ih[:, ctx_text] ; W_q2k[:, ctx_text]], K = 5H when conditional), then the command's keys
-        TRY(gemm_f32(BT, H, cond ? 5 * H : 4 * H, 1.f, delta, 5 * H, 1, w + ws.wcat5 + H, 3 * H, 1, 1.f, dS + H, 4 * H,
-                     nullptr, 0, nullptr, 1, st));
-        TRY(keys_backward(B, H, k, st, 1));
-        // side 2: gradient wrt ctx_vis (the conditional query does not reach it: K = 4H), the grid cells' keys, the
-        // convolution gradients and the visual key layer's weights
-        TRY(gemm_f32(BT, H, 4 * H, 1.f, delta, 5 * H, 1, w + ws.wcat5 + 2 * H, 3 * H, 1, 1.f, dS + 2 * H, 4 * H, nullptr, 0,
-                     nullptr, 1, sd2));
-        TRY(keys_backward(B, H, k, sd2, 2));
-        if (!early_lists) TRY(world_conv_lists(world, bt.world_u8 != nullptr, B, d.G, C, w + ws.conv_lists, sd2));
-        TRY(world_conv_backward(w + ws.dfeat, B, d.G, C, Co, d.K3, w + ws.conv_lists, gw, gb, sd2));
-        {
-            GemmBatch b;
-            add_grad(b, H, F, BM_, w + ws.dpk_v, 1, H, w + ws.feat, F, 1, g.vis_key_w, F);
-            TRY(b.launch(sd2));
-        }
-    } else {
     if (leaves_fork == 0) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
     // chain: gradient wrt [ctx_text | ctx_vis] through the LSTM input and the conditional query
     // (one product: [delta | dzq] . [W_ih[:, ctx] ; (W_q2k[:, ctx_text] | 0)], K = 5H when conditional)
@@ -724,8 +693,6 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         if (!early_lists) TRY(world_conv_lists(world, bt.world_u8 != nullptr, B, d.G, C, w + ws.conv_lists, sd2));
         TRY(world_conv_backward(w + ws.dfeat, B, d.G, C, Co, d.K3, w + ws.conv_lists, gw, gb, sd2));
     }
-    }
-    const bool text_leaves_on_chain = tail_split && !g_side.single;
     // ---- command encoder BPTT (chain), last layer first.  Per layer: the reverse recurrence, then ONE launch on the
     // caller's stream (the leaf streams are still busy with the key / conv gradients and would finish last
     // otherwise) with the layer's weight gradients for both directions and the gradient wrt its input: the embedded
@@ -769,10 +736,6 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         if (l == 0)
             b.add(BL, E, D * 4 * He, ldelta, ldd, 1, w + ws.wih_stack, E, 1, w + ws.dxe, E, 1.f, nullptr, 0, nullptr, 8);
         g_split_override = 0;
-        if (last && text_leaves_on_chain) {      // the command's key layer and the bridge: their inputs were made on this stream
-            add_grad(b, H, He, BL, w + ws.dpk_t, 1, H, w + ws.enc_out, He, 1, g.txt_key_w, He);
-            add_grad(b, H, He, B, w + ws.dh0, 1, H, w + ws.hN, He, 1, g.bridge_w, He, g.bridge_b);
-        }
         TRY(b.launch(st));
     }
     TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));
