@@ -276,6 +276,8 @@ def main():
     ap.add_argument("--with-batcher", action="store_true",
                     help="also time the step fed by the dataset reader / batcher on a generated dataset file (SURVEY 8 f1)")
     ap.add_argument("--batcher-examples", type=int, default=100000)
+    ap.add_argument("--min-warmup-seconds", type=float, default=0.2,
+                    help="untimed warm-up steps go on until this much time has passed (on top of --warmup steps)")
     ap.add_argument("--windows", type=int, default=4, help="extra timed windows of K steps for the spread (0 = none)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--graph", action="store_true",
@@ -348,7 +350,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_warm = time.perf_counter()
     for _ in range(args.warmup):
+        step(next_batch())
+    # untimed warm-up continues until the device has been busy for a fifth of a second: ten steps are 5 ms, not enough
+    # for clocks and allocator pools to settle (the first timed window used to be the slowest of the five)
+    while time.perf_counter() - t_warm < args.min_warmup_seconds:
         step(next_batch())
     fence()
     t0 = time.perf_counter()
@@ -406,6 +413,12 @@ def main():
         batcher = batcher_leg(args, cfg, model.parameter_count)
     if rank == 0:
         B, L, T = args.batch, args.command_length, args.target_length
+        # `value`: the MEDIAN of the timed windows (each is exactly K steps between barrier + synchronize pairs, maximum
+        # over ranks).  One window is 25 ms of wall clock and a single host or device stall of a few milliseconds —
+        # seen twice in some sixty runs of a round: 0.89 ms against 0.49 — would otherwise be the number of the round;
+        # the first window and the spread are reported next to it.
+        first_window_ms = 1e3 * elapsed / args.steps
+        elapsed = 1e-3 * sorted(windows)[len(windows) // 2] * args.steps
         ex_per_s = world * B * args.steps / elapsed
         # The roofline block prices the GEMM family (the conv + LSTM + projection products north_star's MFMA target
         # names).  So that the line cannot flatter: `families_ranked` lists EVERY family by time per step with its
@@ -435,6 +448,8 @@ def main():
             "value": round(ex_per_s, 1), "unit": "examples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_window": "median of the timed windows of K steps each" if len(windows) > 1 else "the one timed window",
+            "ms_per_step_first_window": round(first_window_ms, 4),
             "ms_per_step_windows": {"n": len(windows), "min": round(windows_sorted[0], 4),
                                     "median": round(windows_sorted[len(windows) // 2], 4),
                                     "max": round(windows_sorted[-1], 4)},
