@@ -276,8 +276,8 @@ def main():
     ap.add_argument("--with-batcher", action="store_true",
                     help="also time the step fed by the dataset reader / batcher on a generated dataset file (SURVEY 8 f1)")
     ap.add_argument("--batcher-examples", type=int, default=100000)
-    ap.add_argument("--min-warmup-seconds", type=float, default=0.2,
-                    help="untimed warm-up steps go on until this much time has passed (on top of --warmup steps)")
+    ap.add_argument("--min-warmup-steps", type=int, default=300,
+                    help="untimed warm-up runs at least this many steps (0.15 s at S1), whatever --warmup says")
     ap.add_argument("--windows", type=int, default=4, help="extra timed windows of K steps for the spread (0 = none)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--graph", action="store_true",
@@ -350,12 +350,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    t_warm = time.perf_counter()
-    for _ in range(args.warmup):
-        step(next_batch())
-    # untimed warm-up continues until the device has been busy for a fifth of a second: ten steps are 5 ms, not enough
-    # for clocks and allocator pools to settle (the first timed window used to be the slowest of the five)
-    while time.perf_counter() - t_warm < args.min_warmup_seconds:
+    # untimed warm-up: W steps as asked, and at least --min-warmup-steps (ten steps are 5 ms, not enough for clocks and
+    # allocator pools to settle: the first timed window used to be the slowest of the five).  A COUNT, not a duration:
+    # every rank must run the same number of steps, each has a collective in it.
+    for _ in range(max(args.warmup, args.min_warmup_steps)):
         step(next_batch())
     fence()
     t0 = time.perf_counter()
