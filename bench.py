@@ -447,6 +447,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "value_window": "median of the timed windows of K steps each" if len(windows) > 1 else "the one timed window",
+            "warmup_steps_run": max(args.warmup, args.min_warmup_steps),
             "ms_per_step_first_window": round(first_window_ms, 4),
             "ms_per_step_windows": {"n": len(windows), "min": round(windows_sorted[0], 4),
                                     "median": round(windows_sorted[len(windows) // 2], 4),
