@@ -207,18 +207,53 @@ def batcher_leg(args, cfg: dict, n_params: int) -> dict:
                     "resident = the last full batch of the run repeated from HBM"}
 
 
+def visible_gpu_count(sysfs: str = ""):
+    """GPUs this process tree would see, WITHOUT a HIP / HSA call (torch.cuda.device_count() falls through to
+    hipGetDeviceCount on this build, which initialises the runtime in the launcher parent): the KFD topology lists
+    one node per agent, GPUs are the nodes with simd_count > 0; the *_VISIBLE_DEVICES lists, where set, narrow that.
+    None when the topology cannot be read — then the children report a bad LOCAL_RANK themselves."""
+    # GSCAN_KFD_TOPOLOGY: another directory of the same layout (tests)
+    sysfs = sysfs or os.environ.get("GSCAN_KFD_TOPOLOGY", "/sys/class/kfd/kfd/topology/nodes")
+    try:
+        nodes = sorted(os.listdir(sysfs), key=lambda n: int(n) if n.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    gpus = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(sysfs, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            gpus += 1
+    if gpus == 0:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        listed = os.environ.get(var)
+        if listed is not None:
+            gpus = min(gpus, len([x for x in listed.split(",") if x.strip() != ""]))
+    return gpus
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh processes of this same command with
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's JSON line, fail if any rank fails.  The parent
-    never touches the device (torch.cuda.device_count() does not initialise it); the children are ordinary rank
-    processes, exactly what torch.distributed.run would have started."""
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's JSON line, fail as soon as any rank fails.  The
+    parent makes NO HIP call (the device count comes from sysfs); the children are ordinary rank processes, exactly
+    what torch.distributed.run would have started."""
     import socket
     import subprocess
+    import threading
     n = args.gpus
+    if os.environ.get("GSCAN_FORBID_HIP_IN_PARENT") == "1":     # tests: any torch.cuda call below this line raises
+        def _forbidden(*_a, **_k):
+            raise RuntimeError("torch.cuda touched in the launcher parent")
+        for name in ("device_count", "is_available", "init", "current_device", "set_device"):
+            setattr(torch.cuda, name, _forbidden)
     if args.backend == "nccl" and not args.dry_launch:
-        visible = torch.cuda.device_count()
-        if n > visible:
-            print(f"bench.py: --gpus {n} but only {visible} HIP device(s) are visible: one rank per GPU (RCCL refuses "
+        visible = visible_gpu_count()
+        if visible is not None and n > visible:
+            print(f"bench.py: --gpus {n} but only {visible} GPU(s) are visible: one rank per GPU (RCCL refuses "
                   f"two ranks on one device)", file=sys.stderr, flush=True)
             return 2
     with socket.socket() as sock:
@@ -228,23 +263,45 @@ def launch_ranks(args) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("GSCAN_FORBID_HIP_IN_PARENT", None)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            codes.append(p.wait(timeout=120))
-        except subprocess.TimeoutExpired:      # a rank that outlives rank 0 by two minutes is stuck in a collective
+    # rank 0's stdout is drained by a thread so that the parent can watch EVERY child: the first rank that exits
+    # non-zero ends the run (the others would otherwise sit in a rendezvous or a collective until torch's timeout)
+    captured = []
+    reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    failed = None
+    deadline_after_rank0 = None
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None and p.poll() is not None:
+                codes[i] = p.returncode
+                if p.returncode != 0 and failed is None:
+                    failed = i
+        if failed is not None:
+            break
+        if codes[0] is not None and deadline_after_rank0 is None:
+            deadline_after_rank0 = time.monotonic() + 120     # a rank that outlives rank 0 by two minutes is stuck
+        if deadline_after_rank0 is not None and time.monotonic() > deadline_after_rank0:
+            break
+        time.sleep(0.05)
+    for i, p in enumerate(procs):
+        if codes[i] is None:                                   # exactly the children this parent started
             p.kill()
-            codes.append(p.wait())
+            codes[i] = p.wait()
+            if failed is None:
+                failed = i
+    reader.join(timeout=10)
+    out = captured[0] if captured else b""
     for line in out.decode(errors="replace").splitlines():
         # ONE JSON line is the contract; anything else a library wrote to rank 0's stdout (gloo's connection notes) is
         # passed on to stderr
-        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
-    if any(codes):
-        print(f"bench.py: rank exit codes {codes}", file=sys.stderr, flush=True)
-        return next(c for c in codes if c) or 1
+        print(line, file=sys.stdout if line.startswith("{") and failed is None else sys.stderr, flush=True)
+    if failed is not None or any(codes):
+        print(f"bench.py: rank exit codes {codes} (first failure: rank {failed})", file=sys.stderr, flush=True)
+        return next((c for c in codes if c), 1) or 1
     return 0
 
 
@@ -267,7 +324,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="rows per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="rows per GPU (weak scaling: the global batch grows with N)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling (SURVEY.md 8d's secondary line): a fixed global batch, e.g. 2048, split "
+                         "evenly over the N ranks; the line then says \"scaling\": \"strong\"")
     ap.add_argument("--target-length", type=int, default=20)
     ap.add_argument("--command-length", type=int, default=10)
     ap.add_argument("--workload", default="compositional", choices=["compositional", "target_length", "demo"])
@@ -288,6 +348,9 @@ def main():
                     help="process-group backend for N > 1: nccl = RCCL over xGMI (one rank per GPU); gloo = rehearsal "
                          "(gradients staged through the host, ranks may share a device)")
     ap.add_argument("--dry-launch", action="store_true", help="N > 1: exercise the rank plumbing only (no device)")
+    ap.add_argument("--always-collective", action="store_true",
+                    help="issue the data-parallel collectives even with ONE rank (needs the launcher environment: "
+                         "WORLD_SIZE=1 RANK=0 MASTER_*): the RCCL communicator and its stream hand-over on a single GPU")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -296,6 +359,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.global_batch:
+        if args.global_batch % args.gpus:
+            raise SystemExit(f"--global-batch {args.global_batch} does not divide over --gpus {args.gpus}")
+        args.batch = args.global_batch // args.gpus
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}, or without a launcher at all")
@@ -308,7 +375,7 @@ def main():
     elif local >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.always_collective:
         # "nccl" IS RCCL on ROCm.  The process group carries the rendezvous, the barriers and the max-over-ranks of the
         # timings; the gradient all-reduce itself runs through the library's own communicator on the step's stream
         # (train.RcclCommunicator), created from this group.
@@ -342,7 +409,7 @@ def main():
         taken[0] += 1
         return batches[taken[0] % len(batches)]
 
-    step = TrainStep(model, learning_rate=1e-3, graph=args.graph)
+    step = TrainStep(model, learning_rate=1e-3, graph=args.graph, always_collective=args.always_collective)
 
     def fence():
         torch.cuda.synchronize()
@@ -422,22 +489,46 @@ def main():
         # names).  So that the line cannot flatter: `families_ranked` lists EVERY family by time per step with its
         # own algorithmic TFLOP/s and fraction of the same peak, the two persistent decoder kernels summed as one
         # family (together they are the largest consumer).
-        dominant = "gemm" if "gemm" in families else max(families, key=lambda k: families[k]["ms_per_step"])
-        d = families[dominant]
         merged = dict(families)
         if "decoder_forward" in merged and "decoder_backward" in merged:
             f, b = merged.pop("decoder_forward"), merged.pop("decoder_backward")
             ms = f["ms_per_step"] + b["ms_per_step"]
             alg = f["tflops"] * f["ms_per_step"] + b["tflops"] * b["ms_per_step"]      # TFLOP/s x ms = GFLOP per step
-            merged["decoder_pair"] = {"ms_per_step": ms, "launches_per_step": f["launches_per_step"] + b["launches_per_step"],
-                                      "tflops": alg / ms if ms > 0 else 0.0}
-        elif "decoder_forward" in merged:      # both recurrences in one launch (gscan_train_step_nll), recorded as forward
-            merged["decoder_pair"] = merged.pop("decoder_forward")
+            xalg = f["executed_tflops"] * f["ms_per_step"] + b["executed_tflops"] * b["ms_per_step"]
+            n = f["launches_per_step"] + b["launches_per_step"]
+            merged["decoder_pair"] = {"ms_per_step": ms, "launches_per_step": n, "tflops": alg / ms if ms > 0 else 0.0,
+                                      "executed_tflops": xalg / ms if ms > 0 else 0.0, "avg_us": 1e3 * ms / n,
+                                      "algorithmic_gflop_per_launch": alg / n}
         ranked = [{"family": k, "ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": round(v["launches_per_step"], 2),
                    "algorithmic_tflops": round(v["tflops"], 3), "frac_of_fp32_peak": round(v["tflops"] / PEAK_FP32_TFLOPS, 4)}
                   for k, v in sorted(merged.items(), key=lambda kv: -kv[1]["ms_per_step"])]
         mflop = algorithmic_mflop_per_example(cfg, grid, L, T)
-        traffic, traffic_source, traffic_all = pmc_traffic(dominant, args.workload if not args.auxiliary and T == 20 else "other")
+        # `roofline` = the family with the LARGEST time per step (the decoder's two recurrences count as one family);
+        # `roofline_gemm` = the grouped-GEMM family beside it (the conv + LSTM + projection products north_star's MFMA
+        # target names), whichever of the two is not already in `roofline`.
+        dominant = max(merged, key=lambda k: merged[k]["ms_per_step"])
+        pmc_workload = args.workload if not args.auxiliary and T == 20 else "other"
+        pmc_names = {"gemm": ["gemm"], "decoder_pair": ["decoder_fwd_kernel", "decoder_bwd_kernel"]}
+
+        def roofline_block(name):
+            d = merged[name]
+            traffic, traffic_source, traffic_all = pmc_traffic("gemm", pmc_workload)
+            if name == "decoder_pair":        # bytes per launch of the pair = the mean of its two kernels
+                pair = [traffic_all.get(k) for k in pmc_names["decoder_pair"]]
+                traffic = round(sum(pair) / 2) if all(v is not None for v in pair) else None
+            elif name != "gemm":
+                traffic = traffic_all.get(name)
+            return {"bound": "mfma", "kernel": name, "achieved": round(d["tflops"], 3), "peak": PEAK_FP32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_source, "traffic_by_kernel": traffic_all,
+                    "ms_per_step": round(d["ms_per_step"], 4), "launches_per_step": round(d["launches_per_step"], 2),
+                    "avg_launch_us": round(d["avg_us"], 2),
+                    "algorithmic_gflop_per_launch": round(d["algorithmic_gflop_per_launch"], 4),
+                    "executed_over_algorithmic": round(d["executed_tflops"] / d["tflops"], 3) if d["tflops"] > 0 else None,
+                    "note": "achieved = ALGORITHMIC flops of the family's launches (SURVEY.md 8d; per-family formulas in "
+                            "DESIGN.md 4) / their HIP-event time on the launch streams; fp32 matrix peak = fp32 vector "
+                            "peak on gfx950; traffic = HBM-side bytes per launch from the rocprofv3 PMC passes named in "
+                            "traffic_source, null when that profile is stale"}
         windows_sorted = sorted(windows)
         label = {"compositional": "S4 GECA-like (auxiliary head)" if args.auxiliary else "S1 compositional",
                  "target_length": "S3 target_length", "demo": "S0 demo"}[args.workload]
@@ -445,9 +536,7 @@ def main():
             "metric": "training examples/sec (forward+backward) on compositional_splits, 1/2/4/8 GPUs",
             "value": round(ex_per_s, 1), "unit": "examples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "value_window": "median of the timed windows of K steps each" if len(windows) > 1 else "the one timed window",
-            "warmup_steps_run": max(args.warmup, args.min_warmup_steps),
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "ms_per_step_first_window": round(first_window_ms, 4),
             "ms_per_step_windows": {"n": len(windows), "min": round(windows_sorted[0], 4),
                                     "median": round(windows_sorted[len(windows) // 2], 4),
@@ -460,18 +549,15 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}", "parameters": model.parameter_count,
                        "launch": "hipGraph replay (3 graphs per step)" if args.graph else "eager (forward on the caller's stream, backward on 3 streams)",
                        "resident_batches": len(batches),
-                       "gradient_exchange": (None if world == 1 else
+                       "value_window": "median of the timed windows of K steps each" if len(windows) > 1 else "the one timed window",
+                       "warmup_steps_run": max(args.warmup, args.min_warmup_steps),
+                       "gradient_exchange": (None if not step.exchange.collective else
                                              "gscan_allreduce_f32: RCCL on the step's stream" if step.exchange.comm is not None
-                                             else f"torch.distributed {args.backend}")},
-            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(d["tflops"], 3),
-                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_FP32_TFLOPS, 4),
-                         "traffic": traffic, "traffic_source": traffic_source, "traffic_by_kernel": traffic_all, "avg_launch_us": round(d["avg_us"], 2),
-                         "algorithmic_gflop_per_launch": round(d["algorithmic_gflop_per_launch"], 4),
-                         "executed_over_algorithmic": round(d["executed_tflops"] / d["tflops"], 3) if d["tflops"] > 0 else None,
-                         "note": "achieved = ALGORITHMIC flops of the family's launches (SURVEY.md 8d: composite-weight and "
-                                 "U-image products not counted; per-launch list in DESIGN.md 5) / their HIP-event time; fp32 "
-                                 "matrix peak = fp32 vector peak on gfx950; traffic = HBM-side bytes per launch from the "
-                                 "rocprofv3 PMC passes named in traffic_source, null when that profile is stale"},
+                                             else f"torch.distributed {args.backend}"),
+                       # ranks of the communicator the step's all-reduce runs on, as RCCL itself reports them
+                       "rccl_nranks": step.exchange.comm.nranks if step.exchange.comm is not None else None},
+            "roofline": roofline_block(dominant),
+            "roofline_gemm": roofline_block("gemm") if dominant != "gemm" and "gemm" in merged else None,
             "families_ranked": ranked,
             "kernel_families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in families.items()},
             "step_algorithmic_tflops": round(ex_per_s * mflop / 1e6, 3),
@@ -484,7 +570,8 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    step.close()                       # the library's own RCCL communicator goes before the process group
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

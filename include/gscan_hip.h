@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 10
+#define GSCAN_ABI_VERSION 11
 #define GSCAN_MAX_ENC_LAYERS 4
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
@@ -281,6 +281,8 @@ int gscan_comm_unique_id(void *id_host);
 int gscan_comm_init(void **comm, int nranks, int rank, const void *id_host);
 int gscan_allreduce_f32(void *comm, float *buf, size_t n, void *stream);
 int gscan_comm_destroy(void *comm);
+/* ranks of the communicator as RCCL reports them (ncclCommCount): what bench.py prints as rccl_nranks */
+int gscan_comm_count(void *comm, int *nranks);
 
 /* Per-kernel-family timing for roofline reports: when enabled, every launch of a family
  * ("decoder_forward", "decoder_backward", "encoder_forward", "encoder_backward", "gemm", "conv_forward",
@@ -314,6 +316,14 @@ int gscan_probe_read(const char *name, double *total_ms, double *executed_flops,
 int gscan_gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak,
                    const float *b, int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc,
                    const float *bias, int act, const float *mask, int split_k, void *stream);
+/* The same product as the training step issues it: asum (optional, [M]) += sum_k A(m,k) (the bias gradient that
+ * rides along a weight gradient), and `scratch` (optional, scratch_floats floats of device memory that no other
+ * launch in flight uses) for the partial tiles of a split-K product, which are then added in a FIXED order by a
+ * second launch: bitwise reproducible, where gscan_gemm_f32's float atomics are not (csrc/gemm_mt.hip). */
+int gscan_gemm_f32_scratch(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak,
+                           const float *b, int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc,
+                           const float *bias, int act, const float *mask, int split_k, float *asum,
+                           float *scratch, size_t scratch_floats, void *stream);
 
 /* ConvolutionalNet.forward (seq2seq/cnn_model.py:22-36) on its own: the three same-padded convolutions (kernels
  * 1, 5, K3; kh walks grid columns and kw grid rows because the reference convolves the transposed image), bias,

@@ -11,7 +11,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # GSCAN_HIP_LIB: development override, used by tools/variants.py to time experimental builds side by side
 LIB_PATH = os.environ.get("GSCAN_HIP_LIB") or os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_ENC_LAYERS = 4
 COMM_ID_BYTES = 128
 
@@ -110,11 +110,14 @@ PROTOTYPES = {
     "gscan_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),
     "gscan_allreduce_f32": (_i, [_vp, _vp, _sz, _vp]),
     "gscan_comm_destroy": (_i, [_vp]),
+    "gscan_comm_count": (_i, [_vp, C.POINTER(_i)]),
     "gscan_probe_enable": (_i, [_i]),
     "gscan_probe_reset": (_i, []),
     "gscan_probe_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                               C.POINTER(_i64)]),
     "gscan_gemm_f32": (_i, [_i, _i, _i, _f, _vp, _i64, _i64, _vp, _i64, _i64, _f, _vp, _i64, _vp, _i, _vp, _i, _vp]),
+    "gscan_gemm_f32_scratch": (_i, [_i, _i, _i, _f, _vp, _i64, _i64, _vp, _i64, _i64, _f, _vp, _i64, _vp, _i, _vp, _i, _vp,
+                                    _vp, _sz, _vp]),
     "gscan_world_encoder_forward": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp, _vp,
                                          _vp]),
     "gscan_world_encoder_backward_scratch_floats": (_sz, [_i, _i, _i]),

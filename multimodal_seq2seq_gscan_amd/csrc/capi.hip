@@ -181,7 +181,7 @@ int gscan_trace_set(unsigned long long *device_buffer) {
                                           "-DGSCAN_TRACE: tools/device_timeline.py does)");
 #endif
     GSCAN_HIP(hipDeviceSynchronize());
-    int rc = trace_set_gemm(device_buffer) | trace_set_gemm_wide(device_buffer) | trace_set_gemm_shortk(device_buffer) | trace_set_elementwise(device_buffer) | trace_set_loss(device_buffer) |
+    int rc = trace_set_gemm(device_buffer) | trace_set_gemm_mt(device_buffer) | trace_set_elementwise(device_buffer) | trace_set_loss(device_buffer) |
              trace_set_lstm_encoder(device_buffer) | trace_set_decoder(device_buffer) |
              trace_set_attention_grad(device_buffer) | trace_set_conv(device_buffer);
     GSCAN_CHECK(rc == 0, "trace_set: hipMemcpyToSymbol failed");
@@ -253,6 +253,7 @@ int gscan_allreduce_f32(void *comm, float *buf, size_t n, void *stream) {
     return comm_allreduce_f32(comm, buf, n, (hipStream_t)stream);
 }
 int gscan_comm_destroy(void *comm) { return comm_destroy(comm); }
+int gscan_comm_count(void *comm, int *nranks) { return comm_count(comm, nranks); }
 
 int gscan_probe_enable(int on) { return probe_enable(on); }
 int gscan_probe_reset(void) { return probe_reset(); }
@@ -267,6 +268,14 @@ int gscan_gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam
                    const float *mask, int split_k, void *stream) {
     return gemm_f32(M, N, K, alpha, a, sam, sak, b, sbk, sbn, beta, c, ldc, bias, act, mask, split_k,
                     (hipStream_t)stream);
+}
+
+int gscan_gemm_f32_scratch(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
+                           int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
+                           const float *mask, int split_k, float *asum, float *scratch, size_t scratch_floats,
+                           void *stream) {
+    return gemm_f32_ex(M, N, K, alpha, a, sam, sak, b, sbk, sbn, beta, c, ldc, bias, act, mask, split_k, asum, scratch,
+                       scratch_floats, (hipStream_t)stream);
 }
 
 int gscan_world_encoder_forward(const void *world, int world_is_u8, const float *const conv_w[3],

@@ -22,6 +22,7 @@ using GetUniqueIdFn = int (*)(UniqueId *);
 using CommInitRankFn = int (*)(void **, int, UniqueId, int);
 using AllReduceFn = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
 using CommDestroyFn = int (*)(void *);
+using CommCountFn = int (*)(void *, int *);
 using GetErrorStringFn = const char *(*)(int);
 constexpr int kNcclFloat32 = 7, kNcclSum = 0;                // ncclDataType_t / ncclRedOp_t values of the NCCL 2 API
 
@@ -31,6 +32,7 @@ struct Rccl {
     CommInitRankFn comm_init_rank = nullptr;
     AllReduceFn all_reduce = nullptr;
     CommDestroyFn comm_destroy = nullptr;
+    CommCountFn comm_count = nullptr;
     GetErrorStringFn error_string = nullptr;
     bool tried = false;
 };
@@ -54,6 +56,7 @@ int rccl_load() {
     g_rccl.comm_init_rank = (CommInitRankFn)dlsym(h, "ncclCommInitRank");
     g_rccl.comm_destroy = (CommDestroyFn)dlsym(h, "ncclCommDestroy");
     g_rccl.error_string = (GetErrorStringFn)dlsym(h, "ncclGetErrorString");
+    g_rccl.comm_count = (CommCountFn)dlsym(h, "ncclCommCount");
     AllReduceFn ar = (AllReduceFn)dlsym(h, "ncclAllReduce");
     GSCAN_CHECK(g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.error_string && ar,
                 "comm: the RCCL library lacks one of ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / "
@@ -92,6 +95,14 @@ int comm_allreduce_f32(void *comm, float *buf, size_t n, hipStream_t stream) {
     if (n == 0) return 0;
     TRY_RC(rccl_load());
     GSCAN_RCCL(g_rccl.all_reduce(buf, buf, n, kNcclFloat32, kNcclSum, comm, stream));
+    return 0;
+}
+
+int comm_count(void *comm, int *nranks) {
+    GSCAN_CHECK(comm && nranks, "comm_count: NULL argument");
+    TRY_RC(rccl_load());
+    GSCAN_CHECK(g_rccl.comm_count, "comm_count: the RCCL library has no ncclCommCount");
+    GSCAN_RCCL(g_rccl.comm_count(comm, nranks));
     return 0;
 }
 

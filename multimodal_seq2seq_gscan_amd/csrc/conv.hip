@@ -178,9 +178,27 @@ constexpr int kFwdHits = GSCAN_CONV_FWD_HITS;     // weight-row gathers a wave k
 // (the launch that also runs the step prologue, below): the weight image is being written by other workgroups of the
 // SAME launch; the workgroup compacts its non-zeros first — that needs the world only — and then waits until every
 // image workgroup has published `epoch` in its flag.
+// Chunk `chunk` (kImageElems elements) of the [tap][ch][o] weight image, written THROUGH (agent-scope stores: a plain
+// store would sit dirty in the writer's L2, and the release that pushes it out is a write-back of that whole L2 —
+// tools/micro/flag_wait.hip: 57 us against 10).  All threads of the workgroup take part.
+constexpr int kImageElems = 4 * kConvThreads;
+struct FusedImageArgs { const float *w[3]; float *img; };
+__device__ __forceinline__ void fused_image_chunk(const FusedImageArgs &ia, const ConvArgs &a, int chunk) {
+    const int total = (26 + a.K3 * a.K3) * a.C * conv_row_floats(a.Co);
+#pragma unroll
+    for (int j = 0; j < kImageElems / kConvThreads; ++j) {
+        const int i = chunk * kImageElems + j * kConvThreads + (int)threadIdx.x;
+        if (i < total)
+            __hip_atomic_store(ia.img + i, conv_image_element(ia.w[0], ia.w[1], ia.w[2], a.C, a.Co, a.K3, i),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void world_conv_fwd_body(const ConvArgs &a, const T *__restrict__ world, int b, int y, int ny,
-                                                    const uint32_t *flags, int nflags, uint32_t epoch) {
+                                                    uint32_t *flags, int nflags, uint32_t epoch,
+                                                    const FusedImageArgs &img_args = FusedImageArgs{}, int late_after = 0,
+                                                    bool acquire = false) {
     extern __shared__ uint32_t conv_lds[];
     const int G = a.G, C = a.C, Co = a.Co, M = G * G, F = 3 * Co, MC = M * C;
     uint32_t *keys = conv_lds;
@@ -192,12 +210,44 @@ __device__ __forceinline__ void world_conv_fwd_body(const ConvArgs &a, const T *
         MC, keys, vals, wave_counts, [&](int e) { return (float)x[e]; },
         [&](int e) { const int p = e / C, ch = e - p * C, pr = p / G; return (uint32_t)(pr | ((p - pr * G) << 8) | (ch << 16)); });
     if (flags) {
-        // thread i polls image workgroup i's flag (agent-scope loads: they are served past this XCD's L2).  The image
-        // itself is then read with ordinary loads: no L2 can hold a line of it from before this launch (caches are
-        // invalidated when a launch starts) and nothing reads it before this point.
-        if ((int)threadIdx.x < nflags)
-            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+        // Thread i polls image workgroup i's flag (agent-scope loads: served past this XCD's L2).  The wait is BOUNDED and
+        // needs no dispatch order: a workgroup that has not seen a flag after kFlagPolls polls writes that chunk of
+        // the image ITSELF (the values are a pure function of the parameters: a second writer stores the same
+        // bytes) and publishes the flag, so no resident workgroup ever depends on one that is not running yet.
+        // In dispatch order (image workgroups first, what this chip does) the self-service path never runs; the
+        // count of self-served chunks is kept in the word behind the flags (gscan_fused_prologue_selfserved).
+        bool late = false;
+        if ((int)threadIdx.x < nflags) {
+            int polls = 0;
+            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch &&
+                   polls < late_after) {
                 __builtin_amdgcn_s_sleep(1);
+                ++polls;
+            }
+            late = polls >= late_after;
+        }
+        if (__syncthreads_or(late)) {
+            for (int i = 0; i < nflags; ++i) {
+                const int missing = __syncthreads_or(
+                    threadIdx.x == 0 && __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch);
+                if (!missing) continue;
+                fused_image_chunk(img_args, a, i);
+                __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the written-through stores have landed
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    __hip_atomic_store(flags + i, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd(flags + kFusedMaxFlags, 1u);
+                }
+            }
+        }
+        // The image is read with ordinary loads.  With GSCAN_FUSED_ACQUIRE=1 one lane issues an agent-scope acquire
+        // first (invalidates this CU's L1: cdna_hip_programming.md Guideline 16's consumer form); without it the
+        // reads are fresh because no cache holds a line of the image when they are issued: L1 and L2 are invalidated
+        // at the launch boundary and nothing in this launch reads the image before the flags are up.
+        if (acquire && threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
     }
     // an example's (output cell, convolution) pairs are dealt to ny workgroups x 8 waves
@@ -231,38 +281,38 @@ __device__ __forceinline__ void world_conv_fwd_body(const ConvArgs &a, const T *
 template <typename T>
 __global__ __launch_bounds__(kConvThreads) void world_conv_fwd_kernel(ConvArgs a, const T *__restrict__ world) {
     TraceScope trace_scope(TK_CONV_FWD);
-    world_conv_fwd_body(a, world, blockIdx.x, blockIdx.y, gridDim.y, nullptr, 0, 0u);
+    world_conv_fwd_body<T>(a, world, blockIdx.x, blockIdx.y, gridDim.y, nullptr, 0, 0u);
 }
 
 // The step prologue and the world encoder in ONE launch (step.hip's default prelude).  The two have nothing in common
 // but one dependency — the encoder reads the [tap][ch][o] image of the convolution weights that the prologue writes —
 // and as two launches they cost the chain a kernel boundary (6-7 us: the release of the prologue's 8 MB of dirty lines,
 // the dispatch ramp) plus the time either one leaves most of the chip idle (both are chains of L2 round trips).
-// Workgroup roles by block index (dispatch is in index order on every XCD, so a role can wait on roles IN FRONT of it):
-//   [0, n_img)            the weight image, kImageElems elements per workgroup, written THROUGH (agent-scope stores: a
-//                         plain store would sit dirty in the writer's L2, and the release that pushes it out is a
-//                         write-back of that whole L2 — tools/micro/flag_wait.hip: 57 us against 10); when the
-//                         stores are acknowledged the workgroup publishes the launch's epoch in its flag
+// Workgroup roles by block index (the chip dispatches in index order, which makes the waits short; CORRECTNESS does not
+// depend on it: a waiting workgroup that runs out of patience writes the missing chunk itself, world_conv_fwd_body):
+//   [0, n_img)            the weight image, kImageElems elements per workgroup (fused_image_chunk); when the stores
+//                         are acknowledged the workgroup publishes the launch's epoch in its flag
 //   [n_img, n_img+n_pro)  every other prologue segment, grid-stride over its index space
 //   the rest              the world encoder's workgroups (example b, share y): they wait for the flags behind their
 //                         own compaction pass (world_conv_fwd_body)
 // The epoch is a process-wide counter seeded from the clock: flags need no reset, whatever the workspace held before.
-constexpr int kImageElems = 4 * kConvThreads;
-struct FusedPrologueArgs { int n_img, n_pro, n_conv, n_examples, ny, order; uint32_t *flags; uint32_t epoch; };
+struct FusedPrologueArgs {
+    int n_img, n_pro, n_conv, n_examples, ny, order;
+    uint32_t *flags;            // n_img flags, then (at kFusedMaxFlags) the count of self-served chunks
+    uint32_t epoch;
+    int late_after;             // polls before a waiting workgroup writes a missing chunk itself
+    int acquire;                // agent-scope acquire between the flags and the first read of the image
+    int skip_image;             // test hook: the image workgroups do nothing (every chunk is then self-served)
+};
 template <typename T>
 __global__ __launch_bounds__(kConvThreads, 8) void prologue_world_kernel(PrologueArgs pa, ConvArgs a, FusedPrologueArgs f,
                                                                          const T *__restrict__ world) {
     TraceScope trace_scope(TK_PROLOGUE);
     const int blk = blockIdx.x;
+    const FusedImageArgs ia{{pa.conv_w[0], pa.conv_w[1], pa.conv_w[2]}, pa.conv_img};
     if (blk < f.n_img) {
-        const int total = (26 + a.K3 * a.K3) * a.C * conv_row_floats(a.Co);
-#pragma unroll
-        for (int j = 0; j < kImageElems / kConvThreads; ++j) {
-            const int i = blk * kImageElems + j * kConvThreads + (int)threadIdx.x;
-            if (i < total)
-                __hip_atomic_store(pa.conv_img + i, conv_image_element(pa.conv_w[0], pa.conv_w[1], pa.conv_w[2], a.C, a.Co, a.K3, i),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (f.skip_image) return;
+        fused_image_chunk(ia, a, blk);
         __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this thread's written-through stores have landed
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(f.flags + blk, f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -285,7 +335,8 @@ __global__ __launch_bounds__(kConvThreads, 8) void prologue_world_kernel(Prologu
             prologue_element<8>(pa, idx);
         return;
     }
-    world_conv_fwd_body(a, world, cb % f.n_examples, cb / f.n_examples, f.ny, f.flags, f.n_img, f.epoch);
+    world_conv_fwd_body(a, world, cb % f.n_examples, cb / f.n_examples, f.ny, f.flags, f.n_img, f.epoch, ia, f.late_after,
+                        f.acquire != 0);
 }
 
 // Backward, pass 1: the non-zeros of input channel ch among the examples of batch segment s, compacted in scan
@@ -479,6 +530,11 @@ int prologue_world_forward(const PrologueArgs &pa, const void *world, int world_
     f.order = order;
     f.flags = flags;
     f.epoch = epoch.fetch_add(2u);
+    // ~100 cycles per poll: 2 000 polls are some 80 us, ten times the longest wait seen in dispatch order
+    static const int late_after = [] { const char *e = getenv("GSCAN_FUSED_LATE_AFTER"); return e ? atoi(e) : 2000; }();
+    static const int acquire = [] { const char *e = getenv("GSCAN_FUSED_ACQUIRE"); return e ? atoi(e) : 0; }();
+    static const int skip = [] { const char *e = getenv("GSCAN_FUSED_SKIP_IMAGE"); return e ? atoi(e) : 0; }();
+    f.late_after = late_after; f.acquire = acquire; f.skip_image = skip;
     ProbeScope probe(P_CONV_FWD, stream, 0.0, conv_algorithmic_flops(B, G, C, Co, K3));
     const dim3 grid(f.n_img + f.n_pro + B * f.ny);
     if (world_is_u8)

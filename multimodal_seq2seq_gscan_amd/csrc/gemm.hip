@@ -322,7 +322,8 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
     }
     GemmProblem &p = grp_.p[grp_.count++];
     p = GemmProblem{M, N, K, alpha, beta, a, sam, sak, b, sbk, sbn, c, ldc, bias, act, mask, gate, chunk,
-                    (split_k > 1 || force_atomic) ? 1 : 0, asum1, asum2, 0, 0, 0, 0u, 0u, flags, 0, 0};   // tile bookkeeping: at launch
+                    (split_k > 1 || force_atomic) ? 1 : 0, asum1, asum2, 0, 0, 0, 0u, 0u, flags, 0, 0,   // tile bookkeeping: at launch
+                    nullptr, force_atomic ? 2 : (split_k > 1 ? 1 : 0)};   // 2: shares its C with another product of the launch
     tiles_ += cdiv(N, BN) * cdiv(M, 64) * split_k;                            // in 64-row tiles
     last_flops_ = 2.0 * M * N * K;
     flops_ += last_flops_;
@@ -334,53 +335,138 @@ void GemmBatch::add(int M, int N, int K, const float *a, int64_t sam, int64_t sa
 // 40 us; conv 256x5400x576: 36 vs 44 us; dW_ih 400x300x5120 split 8: 44 vs 48 us), 64-row tiles win once a launch
 // has thousands of workgroups (4096^3: 78 vs 72 TFLOP/s).  GSCAN_GEMM_TMW=1|2 forces a shape, for experiments.
 constexpr int kWideTileMinGroups = 2048;
-constexpr int kShortKMinTiles = 512;                         // 64 x 64 tiles of a launch before it takes gemm_shortk.hip
-constexpr int kWideMinRows = 1024, kWideMinTiles = 1024;     // when a launch takes the 128-row tiles of gemm_wide.hip
+
+// Launch on the 128 x 128 macro tiles of gemm_mt.hip.  Every problem keeps its tiles whole unless the caller allowed a
+// K split (weight gradients: beta = 1, no epilogue); those are cut into slices of R rounds each, ONE R for the whole
+// launch, the largest for which the launch has about kMtTarget workgroups (two per CU) — so that every workgroup of
+// the launch does about the same work and the launch is a whole number of chip generations — but never below
+// kMtMinRounds rounds per slice (a slice pays its first panel's latency and its slab).  With scratch the slices
+// leave partial tiles in slabs that a second launch adds up in slice order; without, they add with float atomics.
+constexpr int kMtTarget = 512, kMtMinRounds = 6;
+int GemmBatch::launch_macro_tiles(hipStream_t stream) {
+    static const int target = [] { const char *e = getenv("GSCAN_MT_TARGET"); return e ? atoi(e) : kMtTarget; }();
+    static const int min_rounds = [] { const char *e = getenv("GSCAN_MT_MINR"); return e ? atoi(e) : kMtMinRounds; }();
+    static const int forced_bm = [] { const char *e = getenv("GSCAN_MT_BM"); return e ? atoi(e) : 0; }();
+    static const int xcd = [] { const char *e = getenv("GSCAN_GEMM_XCD"); return e ? atoi(e) : 1; }();
+    static const int order = [] { const char *e = getenv("GSCAN_GEMM_ORDER"); return e ? atoi(e) : 1; }();
+    const size_t slab = gemm_mt_slab_floats();
+    const size_t slab_cap = scratch_ ? scratch_floats_ / slab : 0;
+    // tiles of `bm` rows; returns the workgroups of the launch at R rounds per slice and the slabs that takes
+    auto plan = [&](int bm, int R, size_t *slabs) {
+        int total = 0;
+        *slabs = 0;
+        for (int i = 0; i < grp_.count; ++i) {
+            const GemmProblem &p = grp_.p[i];
+            int tn, nf;
+            gemm_mt_columns(p.N + (p.asum1 ? 1 : 0), &tn, &nf);
+            const int tiles = tn * cdiv(p.M, bm);
+            const int slices = p.split_ok ? cdiv(cdiv(p.K, 32), R) : 1;
+            total += tiles * slices;
+            if (slices > 1 && p.split_ok == 1) *slabs += (size_t)tiles * slices;
+        }
+        return total;
+    };
+    int max_rounds = 1;
+    for (int i = 0; i < grp_.count; ++i)
+        if (grp_.p[i].split_ok) max_rounds = std::max(max_rounds, cdiv(grp_.p[i].K, 32));
+    auto pick_rounds = [&](int bm, int *total) {
+        int R = max_rounds;
+        size_t slabs = 0;
+        while (R > min_rounds && plan(bm, R, &slabs) < target) {
+            size_t next_slabs;
+            plan(bm, R - 1, &next_slabs);
+            if (scratch_ && next_slabs > slab_cap) break;       // the slabs of a finer split would not fit the scratch
+            --R;
+        }
+        *total = plan(bm, R, &slabs);
+        return R;
+    };
+    // 128-row tiles when they alone give the launch its workgroups, else 64-row tiles (twice the workgroups, 2/3 of
+    // the flop per byte); GSCAN_MT_BM=64|128 forces one (experiments)
+    int total128 = 0, total64 = 0;
+    const int R128 = pick_rounds(128, &total128), R64 = pick_rounds(64, &total64);
+    const int bm = forced_bm == 64 || forced_bm == 128 ? forced_bm : (total128 >= target ? 128 : 64);
+    const int R = bm == 128 ? R128 : R64;
+    size_t slabs = 0;
+    plan(bm, R, &slabs);
+    const bool use_slabs = scratch_ && slabs <= slab_cap;
+    int total = 0, total_units = 0, unit_begin[kMaxGroup];
+    size_t slab_at = 0;
+    for (int i = 0; i < kMaxGroup; ++i) { grp_.tile_begin[i] = INT_MAX; unit_begin[i] = INT_MAX; }
+    for (int i = 0; i < grp_.count; ++i) {
+        GemmProblem &p = grp_.p[i];
+        gemm_mt_columns(p.N + (p.asum1 ? 1 : 0), &p.tiles_n, &p.nf);
+        p.tiles_m = cdiv(p.M, bm);
+        p.tiles_mn = p.tiles_n * p.tiles_m;
+        p.k_chunk = p.split_ok ? 32 * R : cdiv(p.K, 32) * 32;
+        p.nsplit = cdiv(p.K, p.k_chunk);
+        // several products of one launch adding into one C (split_k < 0 at add()): float atomics whatever the slice count
+        p.atomic = p.split_ok == 2 ? 1 : (p.nsplit > 1 ? (use_slabs ? 2 : 1) : 0);
+        unit_begin[i] = total_units;
+        if (p.atomic == 2) {
+            p.slab = scratch_ + slab_at * slab;
+            slab_at += (size_t)p.tiles_mn * p.nsplit;
+            total_units += p.tiles_mn * 64;
+        }
+        if (order && p.nsplit == 1 && p.N > p.M) p.flags |= 16;
+        const uint32_t inner = (p.flags & 16) ? (uint32_t)p.tiles_m : (uint32_t)p.tiles_n;
+        p.inv_mn = p.tiles_mn > 1 ? (uint32_t)((1ull << 32) / (uint32_t)p.tiles_mn) + 1u : 0u;    // 0 stands for d = 1
+        p.inv_in = inner > 1 ? (uint32_t)((1ull << 32) / inner) + 1u : 0u;
+        if (((int64_t)p.tiles_mn * p.nsplit + p.tiles_mn) * p.tiles_mn >= (1ll << 32)) {
+            bad_ = true;
+            set_error("gemm batch: problem %d has too many tiles for the reciprocal index arithmetic", i);
+            return 1;
+        }
+        grp_.tile_begin[i] = total;
+        const int n = p.tiles_mn * p.nsplit;
+        grp_.xcd_per[i] = (xcd && n >= 16) ? cdiv(n, 8) : 0;
+        total += grp_.xcd_per[i] ? 8 * grp_.xcd_per[i] : n;
+    }
+    ProbeScope probe(P_GEMM, stream, flops_, alg_flops_);
+    if (int rc = gemm_mt_launch(grp_, total, bm, stream)) return rc;
+    if (total_units > 0) return gemm_mt_reduce_launch(grp_, unit_begin, total_units, bm, stream);
+    return 0;
+}
+
+// Launches with at least this many 128-row macro tiles take gemm_mt.hip by rule (4096^3: 105 TFLOP/s there against 94
+// on the 64 x 64 tiles below); none of the training step's launches at batch 256 comes near (its largest has 642).
+constexpr int kMacroMinTiles = 1024;
 
 int GemmBatch::launch(hipStream_t stream) {
     if (bad_) return 1;
     if (grp_.count == 0) return 0;
+    // Which kernel.  The training step's launches are SMALL — 0.17 to 1.4 GMAC each, one to four 128 x 128 x 32 rounds
+    // per CU — and what bounds them is how evenly and how early the work reaches all 256 CUs, not bytes per flop: on
+    // the whole step the macro tiles of gemm_mt.hip lose to the 32 x 64 tiles below with every planning parameter
+    // tried (0.515-0.577 ms per step against 0.494: profiles/r04_gemm_macro_tiles_ab.txt), although they win once a
+    // launch has thousands of tiles.  So: macro tiles for large launches by rule, and for every launch in
+    // DETERMINISTIC mode (GSCAN_DETERMINISTIC=1, or GSCAN_GEMM_MT=1), where their split-K partial tiles are added in a
+    // fixed order instead of with float atomics — bitwise reproducible weight gradients for 4 % of step time.
+    // GSCAN_GEMM_MT=0: never.
+    static const int mt_mode = [] {
+        const char *e = getenv("GSCAN_GEMM_MT"), *d = getenv("GSCAN_DETERMINISTIC");
+        return e ? atoi(e) : (d && atoi(d) ? 1 : -1);
+    }();
+    if (mt_mode != 0) {
+        int macro_tiles = 0;
+        for (int i = 0; i < grp_.count; ++i) {
+            int tn, nf;
+            gemm_mt_columns(grp_.p[i].N + (grp_.p[i].asum1 ? 1 : 0), &tn, &nf);
+            macro_tiles += tn * cdiv(grp_.p[i].M, 128);
+        }
+        if (mt_mode > 0 || macro_tiles >= kMacroMinTiles) return launch_macro_tiles(stream);
+    }
     static const int forced = [] { const char *e = getenv("GSCAN_GEMM_TMW"); return e ? atoi(e) : 0; }();
-    int tmw = forced == 1 || forced == 2 ? forced : (tiles_ < kWideTileMinGroups ? 1 : 2);
+    // Launches whose 64-row tiling has fewer workgroups than this use 32-row tiles (see kWideTileMinGroups above)
+    const int tmw = forced == 1 || forced == 2 ? forced : (tiles_ < kWideTileMinGroups ? 1 : 2);
     static const int xcd = [] { const char *e = getenv("GSCAN_GEMM_XCD"); return e ? atoi(e) : 1; }();   // on by default
     static const int order = [] { const char *e = getenv("GSCAN_GEMM_ORDER"); return e ? atoi(e) : 1; }();
-    // Wide tiles (gemm_wide.hip, 128 x 16 nf): launches made of tall products with at least kWideMinTiles of them (four
-    // per CU).  GSCAN_GEMM_WIDE=0 never, 2 whenever the layouts allow (tests, experiments).  Measured (tools/gemm_shapes.py,
-    // profiles/r02_gemm_shapes_wide.txt): 4096^3 runs at 106 TFLOP/s on wide tiles against 94 on 64 x 64, but the
-    // training step's own tall products at batch 256 (9216 x 400 x 150: 360 wide tiles) do not gain: with one or two
-    // workgroups per CU and 4-5 K rounds each, start-up, epilogue and the uneven 1.4 workgroups per CU cost what the
-    // larger tile saves (26.6 vs 25.3 us), so no launch of the benchmark step qualifies.
-    static const int wide_mode = [] { const char *e = getenv("GSCAN_GEMM_WIDE"); return e ? atoi(e) : 1; }();
-    bool wide = wide_mode != 0 && !(forced == 1 || forced == 2);
-    int wide_tiles = 0;
-    for (int i = 0; wide && i < grp_.count; ++i) {
-        const GemmProblem &p = grp_.p[i];
-        int tn, nf;
-        gemm_wide_columns(p.N, &tn, &nf);
-        wide_tiles += tn * cdiv(p.M, 128) * cdiv(p.K, p.k_chunk);
-        wide = gemm_wide_supports(p) && (wide_mode == 2 || p.M >= kWideMinRows);
-    }
-    if (wide && wide_mode != 2 && wide_tiles < kWideMinTiles) wide = false;
-    // Single-shot tiles (gemm_shortk.hip, 64 x 64 x K): launches whose every product has its whole K extent (<= 152) in
-    // LDS at once.  OFF by default: on the step's forward launch (2 304 tiles, K = 100 / 150) it is SLOWER than the
-    // round-based kernel, 50 us against 37 — 78 KB of LDS per workgroup leave a CU two workgroups, too few to cover one
-    // another's load phase (profiles/r03_f_gemm_shortk_ab.txt).  GSCAN_GEMM_SHORTK=1 by the tile-count rule, 2 whenever
-    // the layouts allow (tests, experiments).
-    static const int shortk_mode = [] { const char *e = getenv("GSCAN_GEMM_SHORTK"); return e ? atoi(e) : 0; }();
-    bool shortk = shortk_mode != 0 && !wide && !(forced == 1 || forced == 2);
-    for (int i = 0; shortk && i < grp_.count; ++i) shortk = gemm_shortk_supports(grp_.p[i]);
-    if (shortk && shortk_mode != 2 && tiles_ < kShortKMinTiles) shortk = false;
-    if (shortk) tmw = 2;
     int total = 0;
     for (int i = 0; i < kMaxGroup; ++i) grp_.tile_begin[i] = INT_MAX;
     for (int i = 0; i < grp_.count; ++i) {
         GemmProblem &p = grp_.p[i];
         p.tiles_n = cdiv(p.N, BN);
         p.tiles_mn = p.tiles_n * cdiv(p.M, 32 * tmw);
-        if (wide) {
-            gemm_wide_columns(p.N, &p.tiles_n, &p.nf);
-            p.tiles_mn = p.tiles_n * cdiv(p.M, 128);
-        }
         p.nsplit = cdiv(p.K, p.k_chunk);
         if (order && p.nsplit == 1 && p.N > p.M) p.flags |= 16;
         p.tiles_m = p.tiles_mn / p.tiles_n;
@@ -400,8 +486,6 @@ int GemmBatch::launch(hipStream_t stream) {
     const int *t = grp_.tile_begin;
 #define TB t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]
     ProbeScope probe(P_GEMM, stream, flops_, alg_flops_);
-    if (wide) return gemm_wide_launch(grp_, total, stream);
-    if (shortk) return gemm_shortk_launch(grp_, total, stream);
     // 64-deep K rounds (GSCAN_GEMM_BK=64, experiments): isolated long-K split products gain 10-20 % (a round's
     // load latency is paid half as often), but the overlapped training step loses 3 % to the larger workgroups
     // (52 KB of LDS, +40 VGPRs), so 32 is what every launch uses.
@@ -425,6 +509,20 @@ int gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int6
     GemmBatch batch;
     batch.add(M, N, K, a, sam, sak, b, sbk, sbn, c, ldc, beta, bias, act, mask, split_k, nullptr, nullptr, nullptr,
               alpha);
+    return batch.launch(stream);
+}
+
+// The same product with the two extras the training step uses: asum (optional, [M]) += sum_k A(m,k) (bias gradients),
+// and a scratch for split-K partial tiles, which are then added in a fixed order instead of with atomics.
+int gemm_f32_ex(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
+                int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
+                const float *mask, int split_k, float *asum, float *scratch, size_t scratch_floats, hipStream_t stream) {
+    GSCAN_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem %dx%dx%d", M, N, K);
+    GSCAN_CHECK(a && b && c, "gemm: null operand");
+    GSCAN_CHECK(act >= 0 && act <= 2, "gemm: unknown activation %d", act);
+    GemmBatch batch;
+    batch.scratch(scratch, scratch_floats);
+    batch.add(M, N, K, a, sam, sak, b, sbk, sbn, c, ldc, beta, bias, act, mask, split_k, asum, nullptr, nullptr, alpha);
     return batch.launch(stream);
 }
 

@@ -1,4 +1,4 @@
-// Shared by gemm.hip and gemm_wide.hip: tile constants and the global -> registers -> LDS panel mover.
+// Shared by gemm.hip and gemm_mt.hip: tile constants and the global -> registers -> LDS panel mover.
 #pragma once
 #include "step.h"
 
@@ -208,13 +208,12 @@ struct PanelIter {
 #define GST(i)
 #endif
 
-// gemm_shortk.hip
-bool gemm_shortk_supports(const GemmProblem &p);
-int gemm_shortk_launch(const GemmGroup &grp, int total, hipStream_t stream);
-
-// gemm_wide.hip
-bool gemm_wide_supports(const GemmProblem &p);
-void gemm_wide_columns(int N, int *tiles_n, int *nf);
-int gemm_wide_launch(const GemmGroup &grp, int total, hipStream_t stream);
+// gemm_mt.hip
+bool gemm_mt_supports(const GemmProblem &p);
+void gemm_mt_columns(int NV, int *tiles_n, int *nf);
+size_t gemm_mt_slab_floats();
+int gemm_mt_launch(const GemmGroup &grp, int total, int bm, hipStream_t stream);
+int gemm_mt_reduce_launch(const GemmGroup &grp, const int (&unit_begin)[kMaxGroup], int total_units, int bm,
+                          hipStream_t stream);
 
 }  // namespace gscan

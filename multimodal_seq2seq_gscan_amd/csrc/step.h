@@ -10,6 +10,10 @@ int gemm_f32(int M, int N, int K, float alpha, const float *a, int64_t sam, int6
              int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
              const float *mask, int split_k, hipStream_t stream);
 
+int gemm_f32_ex(int M, int N, int K, float alpha, const float *a, int64_t sam, int64_t sak, const float *b,
+                int64_t sbk, int64_t sbn, float beta, float *c, int64_t ldc, const float *bias, int act,
+                const float *mask, int split_k, float *asum, float *scratch, size_t scratch_floats, hipStream_t stream);
+
 constexpr int kMaxGroup = 12;
 struct GemmProblem {
     int M, N, K;
@@ -26,12 +30,20 @@ struct GemmProblem {
                                           // or tiles_m when N tiles run slowest): x / d = umulhi(x, inv) for x * d < 2^32
     int flags;                            // log2(floats per global load) of A | of B << 2 | 16: N tiles run slowest
     int tiles_m;
-    int nf;                               // wide tiles (gemm_wide.hip): 16-column MFMA tiles per workgroup tile (BN = 16 nf)
+    int nf;                               // wide / macro tiles: 16-column MFMA fragments per workgroup tile (BN = 16 nf)
+    float *slab;                          // macro tiles, atomic == 2: partial tiles [tile][slice][wave][4][4][4][64] (gemm_mt.hip)
+    int split_ok;                         // the caller allowed split-K (beta = 1, no epilogue): launch() chooses the slices;
+                                          // 2: another product of the launch adds into the same C (atomics, never slabs)
 };
 // tile_begin / xcd_per lead the kernel arguments as one contiguous header: a workgroup finds its problem with ONE
 // batch of scalar loads and fetches that problem's descriptor with a second one (the scan used to walk the
 // descriptors: six dependent scalar-load round trips, ~1500 cycles, before the first global load could be issued).
 struct GemmGroup { int count; int tile_begin[kMaxGroup]; int xcd_per[kMaxGroup]; GemmProblem p[kMaxGroup]; };
+
+// gemm_mt.hip: floats of one split-K partial tile (slab); a scratch region holds kGemmSlabs of them (GemmBatch::launch
+// never plans more slices than fit)
+size_t gemm_slab_floats();
+constexpr int kGemmSlabs = 768;
 
 // Builder for one grouped launch of independent products.
 class GemmBatch {
@@ -44,12 +56,19 @@ public:
     // images computed in place of per-step context products that the decoder kernel is charged with): it still
     // counts as executed work.
     void overhead() { alg_flops_ -= last_flops_; last_flops_ = 0.0; }
+    // Scratch for the split-K slabs of the macro-tile kernel (gemm_mt.hip): with it split products are added in a fixed
+    // order (bitwise reproducible); without it they fall back to float atomics.  One region per launch IN FLIGHT:
+    // launches that may overlap on different streams must not share one.
+    void scratch(float *ptr, size_t floats) { scratch_ = ptr; scratch_floats_ = floats; }
     int launch(hipStream_t stream);
 private:
     GemmGroup grp_{};
     int tiles_ = 0;
     double flops_ = 0.0, alg_flops_ = 0.0, last_flops_ = 0.0;
     bool bad_ = false;
+    float *scratch_ = nullptr;
+    size_t scratch_floats_ = 0;
+    int launch_macro_tiles(hipStream_t stream);
 };
 
 // decoder.hip
@@ -172,8 +191,7 @@ int dropout_masks(float *out, const size_t (&n)[3], const float (&p)[3], uint64_
                   const uint64_t *dev_stream_id, hipStream_t stream);
 // in-kernel timeline (common.h): one setter per translation unit with kernels
 int trace_set_gemm(unsigned long long *buf);
-int trace_set_gemm_wide(unsigned long long *buf);
-int trace_set_gemm_shortk(unsigned long long *buf);
+int trace_set_gemm_mt(unsigned long long *buf);
 int trace_set_elementwise(unsigned long long *buf);
 int trace_set_loss(unsigned long long *buf);
 int trace_set_lstm_encoder(unsigned long long *buf);
@@ -331,6 +349,7 @@ int comm_unique_id(void *id_host);
 int comm_init(void **comm, int nranks, int rank, const void *id_host);
 int comm_allreduce_f32(void *comm, float *buf, size_t n, hipStream_t stream);
 int comm_destroy(void *comm);
+int comm_count(void *comm, int *nranks);
 
 // probe.hip
 enum ProbeId { P_DECODER_FWD = 0, P_DECODER_BWD, P_ENCODER_FWD, P_ENCODER_BWD, P_GEMM, P_CONV_FWD, P_CONV_BWD, P_KEYS_BWD, P_COUNT };
@@ -355,7 +374,8 @@ struct Workspace {
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
         wo_perm, dwo_perm, wih_stack, wih_t, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, conv_img, conv_flags, conv_lists, wcat5,
         deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image,   // encoder layers below the last
-        ge_table, head_wc;        // greedy decoding: [V,4H] tables
+        ge_table, head_wc,        // greedy decoding: [V,4H] tables
+        gemm_slabs_side, gemm_slabs_main;
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;

@@ -41,7 +41,7 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     };
 #define SLOT(field, count) ws->field = take(#field, (count))
     SLOT(conv_img, conv_image_floats(d.C, d.Co, d.K3));
-    SLOT(conv_flags, kFusedMaxFlags);                // 32-bit flags of the prologue + world encoder launch (conv.hip)
+    SLOT(conv_flags, kFusedMaxFlags + 64);           // 32-bit flags of the prologue + world encoder launch, then its count of self-served chunks (conv.hip)
     SLOT(conv_lists, (int64_t)world_conv_backward_scratch_floats(d.B, d.G, d.C));
     SLOT(feat, B * M * F);
     SLOT(pkv, B * M * H);
@@ -105,6 +105,10 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(enc_delta, B * L * D * 4 * He);
     SLOT(dfeat, B * M * F);
     SLOT(stamps, 64);
+    // split-K slabs of the macro-tile GEMM (gemm_mt.hip): one region per stream that carries split products (side 1:
+    // decoder leaves, then key leaves; the caller's: the encoder's weight gradients), kGemmSlabs partial tiles each
+    SLOT(gemm_slabs_side, kGemmSlabs * (int64_t)gemm_slab_floats());
+    SLOT(gemm_slabs_main, kGemmSlabs * (int64_t)gemm_slab_floats());
     // encoder layers below the last one (num_encoder_layers > 1): saved activations, outputs (= the next layer's
     // input, [B,L,D*He]) and their gradients per layer; register images of W_hh for layers 1..
     const int64_t deep = enc_layers(d) - 1;
@@ -632,6 +636,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         {   // leaves: head weights (the permuted W_o2h gradient is scattered back below) and the decoder parameter
             // gradients (dense products over the B*T saved rows)
             GemmBatch b;
+            b.scratch(w + ws.gemm_slabs_side, (size_t)kGemmSlabs * gemm_slab_floats());
             static const int dec_split = [] { const char *e = getenv("GSCAN_SPLIT_DEC"); return e ? atoi(e) : 0; }();
             g_split_override = dec_split;
             add_grad(b, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H);
@@ -680,6 +685,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     if (leaves_fork == 2) TRY(decoder_leaves());
     {   // leaves: key and bridge weights
         GemmBatch b;
+        b.scratch(w + ws.gemm_slabs_side, (size_t)kGemmSlabs * gemm_slab_floats());     // same stream as the decoder leaves
         add_grad(b, H, He, BL, w + ws.dpk_t, 1, H, w + ws.enc_out, He, 1, g.txt_key_w, He);
         add_grad(b, H, He, B, w + ws.dh0, 1, H, w + ws.hN, He, 1, g.bridge_w, He, g.bridge_b);
         add_grad(b, H, F, BM_, w + ws.dpk_v, 1, H, w + ws.feat, F, 1, g.vis_key_w, F);
@@ -719,6 +725,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         const int Din = l == 0 ? E : D * He;
         const float *x = l == 0 ? w + ws.xe : w + ws.deep_y + (l - 1) * lay_h;
         GemmBatch b;
+        b.scratch(w + ws.gemm_slabs_main, (size_t)kGemmSlabs * gemm_slab_floats());
         // this launch ends the step on an otherwise idle chip: its split is its own knob (GSCAN_SPLIT_ENC)
         static const int enc_split = [] { const char *e = getenv("GSCAN_SPLIT_ENC"); return e ? atoi(e) : 0; }();
         g_split_override = enc_split;

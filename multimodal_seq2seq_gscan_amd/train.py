@@ -167,16 +167,45 @@ class RcclCommunicator:
         lib = _lib.load()
         self.rank = dist.get_rank(process_group)
         self.world_size = dist.get_world_size(process_group)
+        self._handle = C.c_void_p()
+        # The transport decision is COLLECTIVE: a rank that cannot load RCCL or create the communicator must not leave
+        # the others inside a broadcast or on another transport.  Rank 0 always broadcasts (None when it could not draw
+        # an id); after gscan_comm_init every rank contributes a success flag to a MIN all-reduce over the process
+        # group, and the communicator is kept only if every rank has one.
         uid = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        failure = None
+        box = [None]
         if self.rank == 0:
-            _lib.check(lib.gscan_comm_unique_id(C.addressof(uid)), "gscan_comm_unique_id")
-        box = [bytes(uid.raw)]
+            try:
+                _lib.check(lib.gscan_comm_unique_id(C.addressof(uid)), "gscan_comm_unique_id")
+                box = [bytes(uid.raw)]
+            except _lib.GscanError as e:
+                failure = str(e)
         dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
                                    group=process_group)
-        uid = C.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
-        self._handle = C.c_void_p()
-        _lib.check(lib.gscan_comm_init(C.byref(self._handle), self.world_size, self.rank, C.addressof(uid)),
-                   "gscan_comm_init")
+        if box[0] is None:
+            failure = failure or "rank 0 could not draw an RCCL unique id"
+        else:
+            uid = C.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
+            try:
+                _lib.check(lib.gscan_comm_init(C.byref(self._handle), self.world_size, self.rank, C.addressof(uid)),
+                           "gscan_comm_init")
+            except _lib.GscanError as e:
+                failure = str(e)
+                self._handle = C.c_void_p()
+        ok = torch.tensor([0 if failure else 1], dtype=torch.int32,
+                          device="cuda" if dist.get_backend(process_group) == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)
+        if int(ok.item()) == 0:
+            self.close()
+            raise RuntimeError(failure or "another rank could not create its RCCL communicator")
+
+    @property
+    def nranks(self) -> int:
+        """Ranks of the communicator as RCCL reports them (ncclCommCount), not as the process group does."""
+        n = C.c_int(0)
+        _lib.check(_lib.load().gscan_comm_count(self._handle, C.byref(n)), "gscan_comm_count")
+        return int(n.value)
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         """In-place sum over the ranks, on the current stream."""
@@ -220,9 +249,16 @@ class GradientExchange:
         if self.collective and not self.host_staged and native and torch.cuda.is_available():
             try:
                 self.comm = RcclCommunicator(process_group)
-            except (_lib.GscanError, RuntimeError) as e:      # every rank fails or none: init is a collective
+            except (_lib.GscanError, RuntimeError) as e:      # raised on EVERY rank or on none (collective decision)
                 logger.warning("RCCL communicator on the caller's stream unavailable (%s): gradients go through "
                                "torch.distributed's RCCL stream instead", e)
+
+    def close(self) -> None:
+        """Destroy the library's RCCL communicator (include/gscan_hip.h: gscan_comm_destroy at exit); call before
+        dist.destroy_process_group()."""
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         if not self.collective:
@@ -364,6 +400,11 @@ class TrainStep:
     def _result(self, fw: dict) -> Dict[str, torch.Tensor]:
         self.model.update_state(is_best=False)
         return {"loss": self.seeds[2], "tokens": self.stats[1], "logp": fw["logp"], "aux": fw["aux"]}
+
+    def close(self) -> None:
+        """Release what the step holds outside torch's allocator: the library's RCCL communicator.  Call it before
+        dist.destroy_process_group() / interpreter exit (bench.py and train_on_dataset do)."""
+        self.exchange.close()
 
     # ---- eager and captured execution -----------------------------------------------------------
     def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -608,5 +649,6 @@ def train_on_dataset(data_path: str, data_directory: str, generate_vocabularies:
             training_iteration += 1
             if training_iteration > max_training_iterations:
                 break
+    step.close()                                                 # the library's RCCL communicator, before the process group goes
     logger.info("Finished training.")
     return model

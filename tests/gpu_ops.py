@@ -22,6 +22,18 @@ def gemm(a_view, b_view, c, M, N, K, *, alpha=1.0, beta=0.0, bias=None, act=0, m
     _lib.check(rc, "gscan_gemm_f32")
 
 
+def gemm_scratch(a_view, b_view, c, M, N, K, *, alpha=1.0, beta=0.0, bias=None, act=0, mask=None, split_k=1, asum=None,
+                 scratch=None):
+    """gscan_gemm_f32_scratch: the product as the training step issues it (row sums of A, split-K slabs in `scratch`)."""
+    lib = _lib.load()
+    (a, ao, sam, sak), (b, bo, sbk, sbn), (ct, co, ldc) = a_view, b_view, c
+    rc = lib.gscan_gemm_f32_scratch(M, N, K, alpha, a.data_ptr() + 4 * ao, sam, sak, b.data_ptr() + 4 * bo, sbk, sbn, beta,
+                                    ct.data_ptr() + 4 * co, ldc, _lib.ptr(bias), act,
+                                    None if mask is None else mask.data_ptr() + 4 * co, split_k, _lib.ptr(asum),
+                                    _lib.ptr(scratch), 0 if scratch is None else scratch.numel(), stream())
+    _lib.check(rc, "gscan_gemm_f32_scratch")
+
+
 def matmul(A: torch.Tensor, B: torch.Tensor, **kw) -> torch.Tensor:
     """Plain C = A @ B for 2-D tensors of any strides."""
     M, K = A.shape

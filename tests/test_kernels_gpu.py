@@ -69,15 +69,53 @@ def test_gemm_epilogues_and_split_k(lib):
     assert got[:, :5].abs().max().item() == 0 and got[:, 5 + N:].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("M,N,K,layout,split", [
-    (32768, 400, 150, "nt", 1),     # 256 x 5 wide tiles, 8-byte loads (rows of 150 floats), nf = 5
-    (32768, 100, 100, "nt", 1),     # too few tiles for the rule alone: rides on the 64-row tiles
-    (65536, 240, 96, "nn", 1),      # 512 x 3 tiles, row-contiguous B, nf = 5
-    (4096, 4096, 70, "tn", 1),      # both operands row-contiguous (weight-gradient layout), ragged K
-    (2048, 1040, 4096, "tn", 8),    # split-K with atomics on wide tiles: 16 x 9 x 8 slices
+@pytest.mark.parametrize("M,N,K,layout,split,sums", [
+    (400, 300, 5120, "tn", 8, False),      # dW_ih: 4 x 3 macro tiles, the last ones partly dead
+    (400, 100, 5120, "tn", 8, True),       # dW_hh + bias sums: the ones column is fragment 7's fifth column
+    (100, 100, 2560, "tn", 8, True),
+    (96, 128, 1000, "tn", 4, True),        # N a multiple of 16: the ones column opens a fragment of its own; K tail
+    (100, 150, 9216, "tn", 8, False),      # dW_key_vis: 8-byte loads of the 150-wide feature rows
+    (9, 100, 5120, "tn", 8, False),        # dW_h2o: one fragment of rows
+    (5120, 200, 500, "nn", 1, False),      # dS +=: k-contiguous A, row-contiguous B
+    (9216, 400, 150, "nt", 1, False),      # U_vis: both k-contiguous, 8-byte loads
+    (2560, 25, 800, "nn", 8, False),       # dxe: two fragments of columns
 ])
-def test_gemm_tall_products_take_wide_tiles(lib, M, N, K, layout, split):
-    """Launches with >= 1024 tiles of 128 x (16 nf) go to gemm_wide_kernel (csrc/gemm_wide.hip); same contract."""
+def test_gemm_macro_tiles_with_slabs_are_exact_and_reproducible(lib, M, N, K, layout, split, sums):
+    """gemm_mt.hip through gscan_gemm_f32_scratch: split-K partial tiles go to slabs that a second launch adds in a
+    fixed order — the result equals the reference and is BITWISE the same from run to run (the atomics are not)."""
+    import gpu_ops
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    s0 = torch.randn(M, generator=g)
+    Ad = dev(A) if layout[0] == "n" else dev(A.t().contiguous()).t()
+    Bd = dev(B) if layout[1] == "n" else dev(B.t().contiguous()).t()
+    scratch = torch.full((48 << 20,) if split > 1 else (16,), float("nan"), device="cuda")     # NaN: nothing stale is ever added
+    outs = []
+    for _ in range(3):
+        Cd, sd = dev(C0.clone()), dev(s0.clone())
+        gpu_ops.gemm_scratch((Ad, 0, Ad.stride(0), Ad.stride(1)), (Bd, 0, Bd.stride(0), Bd.stride(1)), (Cd, 0, N), M, N, K,
+                             beta=1.0, split_k=split, asum=sd if sums else None, scratch=scratch if split > 1 else None)
+        outs.append((Cd.cpu(), sd.cpu()))
+    ref = C0.double() + A.double() @ B.double()
+    err = (outs[0][0].double() - ref).abs().max().item()
+    assert err < 3e-4 * max(1.0, K ** 0.5), f"{layout} {M}x{N}x{K}: max err {err}"
+    if sums:
+        rs = s0.double() + A.double().sum(1)
+        assert (outs[0][1].double() - rs).abs().max().item() < 3e-4 * K ** 0.5
+    for c, sv in outs[1:]:
+        assert torch.equal(c, outs[0][0]) and torch.equal(sv, outs[0][1]), "slab reduction is not reproducible"
+
+
+@pytest.mark.parametrize("M,N,K,layout,split", [
+    (32768, 400, 150, "nt", 1),     # 256 x 4 macro tiles, 8-byte loads (rows of 150 floats), seven fragments of columns
+    (32768, 100, 100, "nt", 1),     # too few tiles for the rule: rides on the small tiles
+    (65536, 240, 96, "nn", 1),      # 512 x 2 tiles, row-contiguous B
+    (4096, 4096, 70, "tn", 1),      # both operands row-contiguous (weight-gradient layout), ragged K
+    (2048, 1040, 4096, "tn", 8),    # the rule's launch with split-K and no scratch: atomics on macro tiles
+])
+def test_gemm_large_launches_take_macro_tiles(lib, M, N, K, layout, split):
+    """Launches with >= 1024 macro tiles go to gemm_mt_kernel (csrc/gemm_mt.hip) by rule; same contract."""
     import gpu_ops
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
@@ -92,14 +130,15 @@ def test_gemm_tall_products_take_wide_tiles(lib, M, N, K, layout, split):
     assert err < 2e-4 * max(1.0, K ** 0.5), f"{layout} {M}x{N}x{K}: max err {err}"
 
 
-def test_gemm_suite_on_forced_wide_tiles():
-    """The layout / epilogue / split-K tests again in a child process with GSCAN_GEMM_WIDE=2: every product whose
-    operand layouts the wide kernel supports runs on it, whatever its size (bias, activation, mask, beta, row sums,
-    atomics, ragged edges in M, N and K)."""
+@pytest.mark.parametrize("bm", ["64", "128"])
+def test_gemm_suite_on_forced_macro_tiles(bm):
+    """The layout / epilogue / split-K tests again in a child process in DETERMINISTIC mode (GSCAN_DETERMINISTIC=1:
+    every product on the macro tiles whatever its size or operand layout — bias, activation, mask, beta, atomics
+    without scratch, ragged edges in M, N and K, 4-byte loads), once per tile height."""
     import os, subprocess, sys
-    env = dict(os.environ, GSCAN_GEMM_WIDE="2")
+    env = dict(os.environ, GSCAN_DETERMINISTIC="1", GSCAN_MT_BM=bm)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "test_gemm_layouts or test_gemm_epilogues_and_split_k", "-p", "no:cacheprovider"],
+                        "test_gemm_layouts or test_gemm_epilogues_and_split_k or test_gemm_short_k", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -107,14 +146,14 @@ def test_gemm_suite_on_forced_wide_tiles():
 @pytest.mark.parametrize("M,N,K,lda,ldb,epilogue", [
     (9216, 400, 150, 150, 150, False),   # the visual gate images: contiguous rows of 150 floats (8-byte loads), ragged N tiles
     (5120, 400, 100, 400, 300, True),    # embedding part of the gates: column slices of wider buffers, bias
-    (8200, 100, 152, 152, 160, True),    # the longest K the single-shot tiles hold, ragged M, tanh + mask
-    (6000, 70, 37, 40, 37, False),       # odd K: 4-byte loads are refused by the rule, the launch falls back to gemm.hip
+    (8200, 100, 152, 152, 160, True),    # ragged M, tanh + mask
+    (6000, 70, 37, 40, 37, False),       # odd K: 4-byte loads
     (40000, 64, 96, 96, 96, False),      # K a whole number of 32-deep chunks: no tail steps
 ])
 def test_gemm_short_k_products(lib, M, N, K, lda, ldb, epilogue):
-    """Tall k-contiguous products with K <= 152: the shapes gemm_shortk_kernel (csrc/gemm_shortk.hip: whole-K panels in
-    LDS, one barrier) takes when it is enabled — test_gemm_suite_on_forced_single_shot_tiles runs them on it; here they
-    run on whatever the default rule picks.  Same contract either way."""
+    """Tall k-contiguous products with K <= 152 (the forward launch's shapes: column slices of wider buffers, ragged
+    edges, epilogues) on whatever kernel the default rule picks; test_gemm_suite_on_forced_macro_tiles runs them on
+    the macro tiles.  Same contract either way."""
     import gpu_ops
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     Abig, Bbig = torch.randn(M, lda, generator=g), torch.randn(N, ldb, generator=g)
@@ -128,17 +167,6 @@ def test_gemm_short_k_products(lib, M, N, K, lda, ldb, epilogue):
         ref = torch.tanh(ref + bias.double()) * mask.double()
     err = (Cd.cpu().double() - ref).abs().max().item()
     assert err < 2e-4 * max(1.0, K ** 0.5), f"{M}x{N}x{K}: max err {err}"
-
-
-def test_gemm_suite_on_forced_single_shot_tiles():
-    """The layout / epilogue tests again in a child process with GSCAN_GEMM_SHORTK=2: every product the single-shot
-    kernel supports runs on it, whatever its size (ragged edges in M, N and K, column-sliced operands, epilogues)."""
-    import os, subprocess, sys
-    env = dict(os.environ, GSCAN_GEMM_SHORTK="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "test_gemm_layouts or test_gemm_epilogues_and_split_k or test_gemm_short_k", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("B,G,Cc,K3,Co,density,u8", [

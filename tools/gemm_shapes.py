@@ -41,6 +41,13 @@ def run():
         Cm = torch.zeros(M, N, device="cuda")
         args = ((A, 0, A.stride(0), A.stride(1)), (B, 0, B.stride(0), B.stride(1)), (Cm, 0, N), M, N, K)
         kw = dict(beta=1.0, split_k=split) if split > 1 else {}
+        if os.environ.get("GSCAN_SHAPES_SCRATCH") == "1":      # split-K through slabs (gemm_mt.hip) instead of atomics
+            if "scratch" not in globals():
+                globals()["scratch"] = torch.empty(48 << 20, device="cuda")
+            kw["scratch"] = globals()["scratch"]
+            for _ in range(REPS):
+                gpu_ops.gemm_scratch(*args, **kw)
+            continue
         for _ in range(REPS):
             gpu_ops.gemm(*args, **kw)
         torch.cuda.synchronize()
@@ -48,13 +55,21 @@ def run():
 
 def parse(path):
     import csv
-    rows = [r for r in csv.DictReader(open(path)) if "gemm_group_kernel" in r["Kernel_Name"] or "gemm_wide_kernel" in r["Kernel_Name"]]
-    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    allrows = [r for r in csv.DictReader(open(path)) if any(k in r["Kernel_Name"] for k in ("gemm_group_kernel", "gemm_wide_kernel", "gemm_mt_kernel", "gemm_mt_reduce_kernel"))]
+    allrows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    rows = []          # [main duration, reduce duration, kernel, grid]
+    for r in allrows:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if "gemm_mt_reduce_kernel" in r["Kernel_Name"]:
+            rows[-1][1] += d
+        else:
+            rows.append([d, 0, r["Kernel_Name"].split("(")[0].split("::")[-1][:18], int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1))))])
     assert len(rows) == REPS * len(SHAPES), (len(rows), len(SHAPES))
     for i, (label, M, N, K, layout, split) in enumerate(SHAPES):
-        d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[REPS * i:REPS * (i + 1)])
-        us = d[len(d) // 2] / 1e3
-        print(f"{label:10s} {M:5d}x{N:5d}x{K:5d} {layout} split={split:2d}: {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.1f} TFLOP/s")
+        grp = sorted(rows[REPS * i:REPS * (i + 1)], key=lambda x: x[0] + x[1])
+        main, red, name, wgs = grp[len(grp) // 2]
+        us = (main + red) / 1e3
+        print(f"{label:12s} {M:5d}x{N:5d}x{K:5d} {layout} split={split:2d}: {us:7.1f} us (reduce {red / 1e3:4.1f})  {2.0 * M * N * K / us / 1e6:6.1f} TFLOP/s  {name} x{wgs}")
 
 
 if __name__ == "__main__":

@@ -9,8 +9,13 @@ from multimodal_seq2seq_gscan_amd import _lib
 lib = _lib.load()
 SHAPES = [("conv", 256, 5400, 576, "nn", 1), ("uv", 9216, 400, 150, "nt", 1), ("ge", 5120, 400, 100, "nt", 1),
           ("gx", 2560, 400, 25, "nt", 1), ("dS+=", 5120, 300, 500, "nn", 1), ("dW_ih s8", 400, 300, 5120, "tn", 8),
-          ("dW_qt s8", 100, 100, 5120, "tn", 8), ("4096^3", 4096, 4096, 4096, "nt", 1)]
+          ("dW_qt s8", 100, 100, 5120, "tn", 8), ("4096^3", 4096, 4096, 4096, "nt", 1),
+          ("dW_ih s16", 400, 300, 5120, "tn", 16), ("dW_ih s24", 400, 300, 5120, "tn", 24),
+          ("dW_hh s16", 400, 100, 5120, "tn", 16), ("dW_hh s32", 400, 100, 5120, "tn", 32),
+          ("dW_qt s32", 100, 100, 5120, "tn", 32), ("de", 5120, 100, 400, "nn", 1), ("pkv", 9216, 100, 150, "nt", 1)]
 NAMES = ["setup", "issue first", "first landed", "issue next (sum)", "reads+mfma (sum)", "wait+stage (sum)", "barrier (sum)", "epilogue"]
+if os.environ.get("GSCAN_GEMM_MT", "1") != "0":    # gemm_mt.hip numbers its stamps differently
+    NAMES = ["setup", "issue first", "wait+stage (sum)", "barrier A (sum)", "issue next (sum)", "reads+mfma (sum)", "barrier B (sum)", "epilogue(n/a)"]
 for label, M, N, K, layout, split in SHAPES:
     A = torch.randn(M, K, device="cuda") if layout[0] == "n" else torch.randn(K, M, device="cuda").t()
     B = torch.randn(K, N, device="cuda") if layout[1] == "n" else torch.randn(N, K, device="cuda").t()
