@@ -201,7 +201,7 @@ __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bo
     o.vec = p;
     p += (backward ? 7 * HP + 19 * H : 2 * HP + 6 * H) + 256;
     // scratch of the fused output head, overlaid on the memories (forward: after the loop; backward: before staging)
-    const int head = backward ? kHeadChunk * (V + H + 4) + V * H + 32 : kHeadChunk * (5 * H + 4 + V) + V * H;
+    const int head = backward ? kHeadChunk * V + V * 4 * H + 32 : kHeadChunk * (4 * H + 4 + V) + V * 4 * H;
     o.total = p > head ? p : head;
     return o;
 }
@@ -616,27 +616,20 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
     }
     if (a.stamps && blockIdx.x == 0 && tid < 10) a.stamps[tid] = stamp_acc[tid];
 
-    // ---- output head of the row's T steps (it does not feed back, seq2seq_model.py:421-424):
-    //      preo = S . wo_perm^T  ([T,4H] x [4H,H]) on the matrix cores, logits_t = W_h2o . preo_t,
-    //      logp_t = log_softmax(logits_t) (model.py:203).  Wave w owns output columns 16w..16w+15 and keeps its
-    //      B fragments (H steps of k = 4s + lane/16) in registers; A fragments are single LDS reads of the staged
-    //      S rows (row stride 4H+4: conflict-free across the 16 rows of a tile).
+    // ---- output head of the row's T steps (it does not feed back, seq2seq_model.py:421-424).  The reference applies
+    //      hidden_to_output(output_to_hidden(.)), two bias-free Linears with NOTHING between them: their product
+    //      Wc = W_h2o . W_o2h ([V, 4H], columns in S order; written by the step prologue) IS the head, so
+    //      logits_t = Wc . S_t costs V . 4H multiply-adds per step instead of H . 4H + V . H (11 x fewer at V = 9), and the
+    //      H-wide intermediate is never formed (its weight gradients follow from d Wc = dlogits^T . S, step.hip).
+    //      Four lanes per (t, v) logit, each a quarter of the 4H-deep dot from LDS, added on the DPP datapath; then
+    //      logp_t = log_softmax(logits_t) (model.py:203) and the row's NLL partial sums by thread t.
     __syncthreads();                                         // the row's S is complete and visible to the workgroup
     {
-        constexpr int SS = 4 * H + 4, NT = (H + 15) / 16;
-        const int V = a.V, fr = lane & 15, fg = lane >> 4;
-        float *S_ch = smem, *preo_ch = S_ch + kHeadChunk * SS, *lg_ch = preo_ch + kHeadChunk * H,
-              *wh_s = lg_ch + kHeadChunk * V;
-        float bw[H];
-        if (wave < NT) {
-            const float4 *img4 = reinterpret_cast<const float4 *>(a.head_image);
-#pragma unroll
-            for (int q = 0; q < H / 4; ++q) {
-                const float4 v = img4[q * kDecThreads + tid];
-                bw[4 * q] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
-            }
-        }
-        for (int i = tid; i < V * H; i += kDecThreads) wh_s[i] = a.w_h2o[i];
+        constexpr int SS = 4 * H + 4;
+        const int V = a.V;
+        float *S_ch = smem, *wc_s = S_ch + kHeadChunk * SS, *lg_ch = wc_s + V * 4 * H;
+        for (int i = tid; i < V * H; i += kDecThreads)       // 16-byte units
+            reinterpret_cast<float4 *>(wc_s)[i] = reinterpret_cast<const float4 *>(a.head_wc)[i];
         float nll_acc = 0.f, cnt_acc = 0.f;                  // threads < kHeadChunk (all in wave 0): get_loss terms
         for (int t0 = 0; t0 < T; t0 += kHeadChunk) {
             const int n = min(kHeadChunk, T - t0);
@@ -649,33 +642,16 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
                 }
             }
             lds_barrier();
-            if (wave < NT) {
-                for (int mt = 0; mt < (n + 15) / 16; ++mt) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    const float *ap = S_ch + (16 * mt + fr) * SS + fg;
-#pragma unroll
-                    for (int i = 0; i < H; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * i], bw[i], acc, 0, 0, 0);
-                    const int kk = 16 * wave + fr;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int tt = 16 * mt + 4 * fg + r;
-                        if (tt < n && kk < H) {
-                            preo_ch[tt * H + kk] = acc[r];
-                            a.preo[(bt0 + tt) * H + kk] = acc[r];
-                        }
-                    }
-                }
-            }
-            lds_barrier();
-            for (int idx = tid; idx < n * V; idx += kDecThreads) {
-                const int tt = idx / V, v = idx - tt * V;
-                const float4 *x4 = reinterpret_cast<const float4 *>(preo_ch + tt * H);
-                const float4 *w4 = reinterpret_cast<const float4 *>(wh_s + v * H);
-                float acc = 0.f;
+            for (int q0 = 0; q0 < n * V; q0 += kDecThreads / 4) {
+                const int q = q0 + (tid >> 2), qc = min(q, n * V - 1), tt = qc / V, v = qc - tt * V;
+                const float4 *x4 = reinterpret_cast<const float4 *>(S_ch + tt * SS);
+                const float4 *w4 = reinterpret_cast<const float4 *>(wc_s + v * 4 * H);
+                float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll 5
-                for (int i = 0; i < H / 4; ++i) acc = dot4(w4[i], x4[i], acc);
-                lg_ch[idx] = acc;
-                a.logits[bt0 * V + idx] = acc;
+                for (int i = j4; i + 4 < H; i += 8) { acc0 = dot4(w4[i], x4[i], acc0); acc1 = dot4(w4[i + 4], x4[i + 4], acc1); }
+                if ((H / 4) & 1) { const int i = j4 + 4 * (H / 4 - 1); acc0 = dot4(w4[i], x4[i], acc0); }
+                const float sum = quad_sum(acc0 + acc1);
+                if (j4 == 0 && q < n * V) { lg_ch[q] = sum; a.logits[bt0 * V + q] = sum; }
             }
             lds_barrier();
             if (tid < n) {
@@ -698,6 +674,7 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
                     if (tgt != a.pad_tgt && tgt >= 0 && tgt < V) { nll_acc += lse - row[tgt]; cnt_acc += 1.f; }
                 }
             }
+            lds_barrier();
         }
         if (a.row_stats && wave == 0) {
             nll_acc = wave_sum(nll_acc);
@@ -840,52 +817,33 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     len = max(1, min(len, L));
 
     float aux_scale = (a.seeds && a.daux) ? a.seeds[1] : 1.f;
-    // ---- backward of the output head for the row's T steps (log_softmax, hidden_to_output, output_to_hidden):
-    //      dlogits_t = seed * (dlogp_t - exp(logp_t) sum dlogp_t), dpreo_t = W_h2o^T dlogits_t, and
-    //      dS = dpreo . wo_perm ([T,H] x [H,4H]) on the matrix cores: wave w owns column tiles w, w+8, ... and keeps
-    //      their B fragments in registers.  dlogits / dpreo are kept for the weight gradients; dS is what the loop
-    //      below (and the LSTM-input product after it) starts from.
+    // ---- backward of the output head for the row's T steps: dlogits_t = seed * (dlogp_t - exp(logp_t) sum dlogp_t)
+    //      through log_softmax, then through the composite head Wc = W_h2o . W_o2h ([V, 4H], S order; see the forward
+    //      epilogue): dS_t = Wc^T dlogits_t, V multiply-adds per element.  dlogits is kept for the weight gradients
+    //      (d Wc = dlogits^T . S, a GEMM behind this kernel); dS is what the loop below (and the LSTM-input product
+    //      after it) starts from.
     {
-        constexpr int HS = (H % 8 == 4) ? H : H + 4, NTB = H / 4, RB = (NTB + 7) / 8, KS = H / 4;
-        const int V = a.V, fr = lane & 15, fg = lane >> 4;
-        float *dl_ch = smem, *dp_ch = dl_ch + kHeadChunk * V, *wh_s = dp_ch + kHeadChunk * HS;
-        float bw[RB][KS];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int nt = wave + 8 * r;
-#pragma unroll
-            for (int i = 0; i < KS; ++i) bw[r][i] = (nt < NTB) ? a.wo_perm[(4 * i + fg) * 4 * H + 16 * nt + fr] : 0.f;
-        }
-        for (int i = tid; i < V * H; i += kDecThreads) wh_s[i] = a.w_h2o[i];
+        const int V = a.V;
+        float *dl_ch = smem, *wc_s = dl_ch + kHeadChunk * V, *red = wc_s + V * 4 * H;
+        for (int i = tid; i < V * H; i += kDecThreads)       // 16-byte units
+            reinterpret_cast<float4 *>(wc_s)[i] = reinterpret_cast<const float4 *>(a.head_wc)[i];
         float sc = a.seeds ? a.seeds[0] : 1.f;
         if (a.nll_mode) {
             // the loss is mean-over-live-tokens NLL (+ w * mean-over-rows auxiliary NLL): every workgroup sums the
             // per-row partials of the forward pass in the same fixed order and seeds its row with 1/tokens, w/rows
             float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-            if (a.fused) {
-                // one launch with the forward pass: the other rows' partials do not exist yet.  The seed needs the
-                // number of live targets only, counted here from the targets themselves (the same rule as the forward
-                // epilogue: position t is scored against token t + 1, the last position against literal 0)
-                const int n = a.B * T;
-                for (int i = tid; i < n; i += kDecThreads) {
-                    const int t = i % T;
-                    const int64_t tgt = (t + 1 < T) ? a.targets[i + 1] : (int64_t)0;
-                    p1 += (tgt != a.pad_tgt && tgt >= 0 && tgt < V) ? 1.f : 0.f;
-                }
-            } else
             for (int r = tid; r < a.B; r += kDecThreads) {
                 const float4 x = *reinterpret_cast<const float4 *>(a.row_stats + 4 * r);
                 p0 += x.x; p1 += x.y; p2 += x.z;
             }
             p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
-            float *red = wh_s + V * H;
             if (lane == 0) { red[3 * wave] = p0; red[3 * wave + 1] = p1; red[3 * wave + 2] = p2; }
             lds_barrier();
             p0 = p1 = p2 = 0.f;
             for (int i = 0; i < kDecThreads / 64; ++i) { p0 += red[3 * i]; p1 += red[3 * i + 1]; p2 += red[3 * i + 2]; }
             sc = (a.nll_mode == 2) ? 1.f : 1.f / p1;
             aux_scale = a.aux_saved ? ((a.nll_mode == 2) ? a.w_aux : a.w_aux / (float)a.B) : 0.f;
-            if (b == 0 && tid == 0 && !a.fused) {
+            if (b == 0 && tid == 0) {
                 a.stats_out[0] = p0; a.stats_out[1] = p1; a.stats_out[2] = p2; a.stats_out[3] = (float)a.B;
                 a.seeds_out[0] = sc; a.seeds_out[1] = aux_scale;
                 a.seeds_out[2] = p0 * sc + p2 * aux_scale;
@@ -917,31 +875,12 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
                 }
             }
             lds_barrier();
-            for (int idx = tid; idx < n * H; idx += kDecThreads) {
-                const int tt = idx / H, kk = idx - tt * H;
-                float acc = 0.f;
-                for (int v = 0; v < V; ++v) acc = fmaf(dl_ch[tt * V + v], wh_s[v * H + kk], acc);
-                dp_ch[tt * HS + kk] = acc;
-                a.dpreo[bt0 * H + idx] = acc;
-            }
-            lds_barrier();
-            for (int mt = 0; mt < (n + 15) / 16; ++mt) {
-                const float *ap = dp_ch + (16 * mt + fr) * HS + fg;
-#pragma unroll
-                for (int r = 0; r < RB; ++r) {
-                    const int nt = wave + 8 * r;
-                    if (nt < NTB) {
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int i = 0; i < KS; ++i)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * i], bw[r][i], acc, 0, 0, 0);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int tt = 16 * mt + 4 * fg + i;
-                            if (tt < n) a.ds[(bt0 + tt) * 4 * H + 16 * nt + fr] = acc[i];
-                        }
-                    }
-                }
+            for (int idx = tid; idx < n * H; idx += kDecThreads) {       // one 16-byte piece of dS per thread and pass
+                const int tt = idx / H, c4 = idx - tt * H;
+                float4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int v = 0; v < V; ++v)
+                    acc = fma4(dl_ch[tt * V + v], *reinterpret_cast<const float4 *>(wc_s + v * 4 * H + 4 * c4), acc);
+                *reinterpret_cast<float4 *>(a.ds + (bt0 + tt) * 4 * H + 4 * c4) = acc;
             }
             lds_barrier();
         }
@@ -1182,34 +1121,6 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
     decoder_bwd_body<H, COND, UVL>(a);
 }
 
-// Teacher-forced forward recurrence and the reverse recurrence of a training step in ONE launch: a row's workgroup runs
-// its forward pass (output head and loss partials included) and then, on the same CU, its backward pass.  Rows never
-// interact in either direction: the only cross-row quantity of the backward pass is the number of live target tokens
-// (the seed 1 / tokens of the mean loss), which depends on the targets alone and is counted by every workgroup
-// (DecoderArgs::fused); the batch's loss VALUE, which needs every row's forward pass, is added up by a leaf launch
-// behind this one (unpermute_add's extra workgroup).  Saves the kernel boundary between the two recurrences (~7 us: the
-// release of 28 MB of saved activations, the dispatch of 256 maximal workgroups); what the backward pass reads was
-// written by the same CU.
-template <int H, bool COND>
-__global__ __launch_bounds__(kDecThreads) void decoder_fwdbwd_kernel(DecoderArgs af, DecoderArgs ab) {
-    TraceScope trace_scope(TK_DECODER_FWD);
-    decoder_fwd_body<H, COND, false, true>(af);
-    __syncthreads();                      // this row's saved activations have landed (vmcnt) before any thread reads them
-    // The backward pass's arguments are read from the kernel-argument segment HERE, through a pointer the compiler
-    // cannot see through: taken from `ab` directly, their scalar loads are hoisted to the top of the kernel and sixty
-    // more SGPRs stay live (spilled, reloaded in every phase) across the forward pass's time loop.
-    static_assert(sizeof(DecoderArgs) % 8 == 0, "the second argument starts right behind the first");
-#if defined(__HIP_DEVICE_COMPILE__)
-    const __attribute__((address_space(4))) char *ka =
-        (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    const DecoderArgs b2 = *reinterpret_cast<const __attribute__((address_space(4))) DecoderArgs *>(ka + sizeof(DecoderArgs));
-    decoder_bwd_body<H, COND, true>(b2);
-#else
-    (void)ab;
-#endif
-}
-
 // Register images of the decoder weights are written once per step by the step prologue kernel
 // (decoder_image_element in step.h; layout described there).
 
@@ -1264,48 +1175,6 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
     return launch(decoder_fwd_kernel<H, COND, false, true>, "decoder_fwd_kernel");
 }
 
-
-// The fused launch needs both layouts with every memory in LDS (no U_vis streaming): callers fall back to two launches
-// when this says no.
-bool decoder_fused_supported(int H, int L, int M, int V, bool cond) {
-    const size_t f = (size_t)decoder_lds(H, L, M, V, cond, false, true).total * sizeof(float);
-    const size_t b = (size_t)decoder_lds(H, L, M, V, cond, true, true).total * sizeof(float);
-    return decoder_hidden_supported(H) && f <= kLdsLimit && b <= kLdsLimit;
-}
-
-template <int H, bool COND>
-static int launch_decoder_fused(int B, const DecoderArgs &af, const DecoderArgs &ab, hipStream_t stream) {
-    const size_t f = (size_t)decoder_lds(H, af.L, af.M, af.V, COND, false, true).total * sizeof(float);
-    const size_t b = (size_t)decoder_lds(H, ab.L, ab.M, ab.V, COND, true, true).total * sizeof(float);
-    const size_t bytes = f > b ? f : b;
-    GSCAN_CHECK(bytes <= kLdsLimit, "fused decoder: %zu bytes of LDS per row", bytes);
-    GSCAN_CHECK(af.w_image && ab.w_image, "decoder: weight image missing");
-    const double macs = (double)H * H + 2.0 * af.L * H + (COND ? 2.0 * H * H : 0.0) + (double)H * H +
-                        2.0 * af.M * H + 4.0 * H * 3.0 * H + 4.0 * H * H + (double)H * af.V;
-    // both recurrences in one launch: recorded as the forward family with the flops of both
-    ProbeScope probe(P_DECODER_FWD, stream, 4.0 * macs * B * af.T);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fwdbwd_kernel<H, COND>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((decoder_fwdbwd_kernel<H, COND>), dim3(B), dim3(kDecThreads), bytes, stream, af, ab);
-    GSCAN_LAUNCHED("decoder_fwdbwd_kernel");
-    return 0;
-}
-
-int decoder_run_fused(int B, int H, bool cond, const DecoderArgs &af, const DecoderArgs &ab, hipStream_t stream) {
-    GSCAN_CHECK(B > 0 && af.T > 0 && af.L > 0 && af.M > 0 && af.L <= 64 && af.M <= 64, "decoder: bad dims B=%d T=%d L=%d M=%d",
-                B, af.T, af.L, af.M);
-    switch (H) {
-#define X(n) case n: return cond ? launch_decoder_fused<n, true>(B, af, ab, stream) : launch_decoder_fused<n, false>(B, af, ab, stream);
-        GSCAN_DEC_HIDDEN_SIZES(X)
-#undef X
-        default: break;
-    }
-    GSCAN_CHECK(false, "decoder_hidden_size %d has no compiled kernel (supported: " GSCAN_DEC_HIDDEN_LIST ")", H);
-}
 
 bool decoder_hidden_supported(int h) {
 #define X(n) if (h == n) return true;

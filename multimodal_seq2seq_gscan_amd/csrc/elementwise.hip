@@ -287,16 +287,17 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 // ------------------------------------------------------------------------------------------
 // Step prologue: everything that only rearranges parameters or gathers embeddings, in ONE launch.
 //   seg 0  bsum[4H]            = dec_b_ih + dec_b_hh
-//   seg 1  wo_perm[H,4H]       = W_o2h with its columns [e|h|ctx_t|ctx_v] reordered to S order [e|ctx_t|ctx_v|h]
+//   seg 1  head_wc[V,4H]       = W_h2o . W_o2h, columns reordered from W_o2h's [e|h|ctx_t|ctx_v] to S order [e|ctx_t|ctx_v|h]:
+//                                the output head as one matrix (decoder.hip)
 //   seg 2  wih_stack[D*4He,E]  = [W_ih_fwd ; W_ih_rev]   (one GEMM then gives dXe for both directions), and its
 //          per-direction transpose wih_t[D][E][4He] (lstm_encoder.hip's input projection)
-//   seg 3  dwo_perm[H,4H]      = 0   (gradient scratch of wo_perm, filled by a split-K GEMM in backward)
+//   seg 3  dwc[V,4H]           = 0   (gradient scratch of head_wc, filled by a split-K GEMM in backward)
 //   seg 4  xe[B*L,E]           = dropout(Emb_enc[commands])      seq2seq_model.py:58-59
 //   seg 5  S[:, 0:H]           = dropout(Emb_dec[targets])       seq2seq_model.py:383-384
 //   seg 6  wcat5[5H,3H]        = [W_ih_dec ; (0 | W_q2k[:, H:2H] | 0)]: one product then carries delta AND dzq back to
 //                                [e | ctx_text | ctx_vis]
 //   seg 7  zero_extra          = 0   (accumulation targets: encoder direction sums enc_out / hN, split-K dxe)
-//   seg 8  register images of the decoder's recurrent weights and of the output head (step.h)
+//   seg 8  register images of the decoder's recurrent weights (step.h)
 //   seg 9  register image of the encoder's recurrent weights: [dir][r][k][thread] = W_hh_dir[thread + r*NT][k]
 //   seg 10 [tap][ch][o] image of the three convolution kernels (conv.hip)
 //   seg 11-13 composite weights W_ih[:, ctx] . W_key (visual, textual; rows unit-major: row 4 unit + gate) and
@@ -323,82 +324,78 @@ int step_prologue(const PrologueArgs &args, hipStream_t stream) {
     return 0;
 }
 
-// g_w_o2h[row, original column] += dwo_perm[row, S-order column]; and, in the workgroups behind those, the energy-vector
-// gradients: g_v[k] += sum over the batch rows of the decoder kernel's per-row sums (fixed order, one thread per column)
-__global__ void unpermute_add_kernel(const float *__restrict__ dwo_perm, float *__restrict__ g_w_o2h, int H, int nperm_blocks,
-                                     const float *__restrict__ dv_t_rows, const float *__restrict__ dv_v_rows, int B,
-                                     float *__restrict__ g_v_t, float *__restrict__ g_v_v, int nsum_blocks, LossStatsArgs ls) {
+// The output head's weight gradients from d Wc = dlogits^T . S ([V, 4H], columns in S order [e | ctx_t | ctx_v | h]; the
+// head is applied as the ONE matrix Wc = W_h2o . W_o2h, decoder.hip): by the chain rule through that product
+//   g_w_o2h[j, src(col)] += sum_v W_h2o[v, j] . dWc[v, col]        (a thread per element, V terms)
+//   g_w_h2o[v, j]        += sum_col dWc[v, col] . W_o2h[j, src(col)] (a wave per element, 4H terms)
+// with src(col) W_o2h's own column order [e | h | ctx_t | ctx_v]; and, in the workgroups behind those, the energy-vector
+// gradients: the decoder's reverse kernel leaves per-ROW sums [B, H] for the textual and the visual energy vector,
+// added up over the batch here in a fixed order.
+__device__ __forceinline__ int o2h_column(int col, int H) {          // S-order column -> column of W_o2h
+    const int seg = col / H, k = col - seg * H;
+    return (seg == 0 ? 0 : seg == 1 ? 2 * H : seg == 2 ? 3 * H : H) + k;
+}
+__global__ void head_grad_finish_kernel(const float *__restrict__ dwc, const float *__restrict__ w_h2o,
+                                        const float *__restrict__ w_o2h, float *__restrict__ g_w_o2h,
+                                        float *__restrict__ g_w_h2o, int H, int V, int n_o2h_blocks, int n_h2o_blocks,
+                                        const float *__restrict__ dv_t_rows, const float *__restrict__ dv_v_rows, int B,
+                                        float *__restrict__ g_v_t, float *__restrict__ g_v_v) {
     TraceScope trace_scope(TK_UNPERMUTE);
-    if ((int)blockIdx.x >= nperm_blocks + nsum_blocks) {
-        // the batch's loss statistics from the forward pass's per-row partials [sum NLL, live tokens, aux NLL, 1], in a
-        // fixed order: what the reverse kernel's workgroup 0 writes when it runs as a launch of its own (decoder.hip)
-        __shared__ float red[3 * 4];
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-        for (int r = tid; r < ls.B; r += blockDim.x) {
-            const float4 x = *reinterpret_cast<const float4 *>(ls.row_stats + 4 * r);
-            p0 += x.x; p1 += x.y; p2 += x.z;
-        }
-        p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
-        if (lane == 0) { red[3 * wave] = p0; red[3 * wave + 1] = p1; red[3 * wave + 2] = p2; }
-        __syncthreads();
-        if (tid == 0) {
-            p0 = p1 = p2 = 0.f;
-            for (int i = 0; i < (int)blockDim.x / 64; ++i) { p0 += red[3 * i]; p1 += red[3 * i + 1]; p2 += red[3 * i + 2]; }
-            const float sc = (ls.nll_mode == 2) ? 1.f : 1.f / p1;
-            const float aux_scale = ls.has_aux ? ((ls.nll_mode == 2) ? ls.w_aux : ls.w_aux / (float)ls.B) : 0.f;
-            ls.stats_out[0] = p0; ls.stats_out[1] = p1; ls.stats_out[2] = p2; ls.stats_out[3] = (float)ls.B;
-            ls.seeds_out[0] = sc; ls.seeds_out[1] = aux_scale;
-            ls.seeds_out[2] = p0 * sc + p2 * aux_scale;
+    const int blk = blockIdx.x;
+    if (blk < n_o2h_blocks) {
+        const int n = H * 4 * H;
+        for (int i = blk * blockDim.x + threadIdx.x; i < n; i += n_o2h_blocks * blockDim.x) {
+            const int j = i / (4 * H), col = i - j * 4 * H;
+            float acc = 0.f;
+            for (int v = 0; v < V; ++v) acc = fmaf(w_h2o[v * H + j], dwc[v * 4 * H + col], acc);
+            g_w_o2h[(int64_t)j * 4 * H + o2h_column(col, H)] += acc;
         }
         return;
     }
-    if ((int)blockIdx.x >= nperm_blocks) {
-        // a workgroup takes 32 columns of [dv_text | dv_vis]; a thread = (column, one of 8 slices of the batch rows): up to
-        // 32 rows per pass, all loads of a pass in flight, then the 8 slice sums are added in a fixed order
-        __shared__ float part[8][32];
-        const int c = threadIdx.x & 31, slice = threadIdx.x >> 5, k = (blockIdx.x - nperm_blocks) * 32 + c;
-        const bool live = k < 2 * H;
-        const float *src = (k < H ? dv_t_rows : dv_v_rows) + (live ? (k < H ? k : k - H) : 0);
-        const int per = (B + 7) / 8, r0 = slice * per, r1 = min(B, r0 + per);
+    if (blk < n_o2h_blocks + n_h2o_blocks) {
+        const int out = (blk - n_o2h_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (out >= V * H) return;
+        const int v = out / H, j = out - v * H;
         float acc = 0.f;
-        for (int base = r0; base < r1; base += 32) {
-            float x[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) x[u] = (live && base + u < r1) ? src[(int64_t)(base + u) * H] : 0.f;
-#pragma unroll
-            for (int u = 16; u > 0; u >>= 1)
-#pragma unroll
-                for (int v = 0; v < u; ++v) x[v] += x[v + u];
-            acc += x[0];
-        }
-        part[slice][c] = acc;
-        __syncthreads();
-        if (slice == 0 && live) {
-            float sum = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) sum += part[q][c];
-            (k < H ? g_v_t : g_v_v)[k < H ? k : k - H] += sum;
-        }
+        for (int col = lane; col < 4 * H; col += 64) acc = fmaf(dwc[v * 4 * H + col], w_o2h[(int64_t)j * 4 * H + o2h_column(col, H)], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) g_w_h2o[out] += acc;
         return;
     }
-    const int n = H * 4 * H;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nperm_blocks * blockDim.x) {
-        const int row = i / (4 * H), col = i % (4 * H);
-        const int seg = col / H, k = col % H;
-        const int dst = (seg == 0 ? 0 : seg == 1 ? 2 * H : seg == 2 ? 3 * H : H) + k;
-        g_w_o2h[(int64_t)row * 4 * H + dst] += dwo_perm[i];
+    // a workgroup takes 32 columns of [dv_text | dv_vis]; a thread = (column, one of 8 slices of the batch rows): up to
+    // 32 rows per pass, all loads of a pass in flight, then the 8 slice sums are added in a fixed order
+    __shared__ float part[8][32];
+    const int c = threadIdx.x & 31, slice = threadIdx.x >> 5, k = (blk - n_o2h_blocks - n_h2o_blocks) * 32 + c;
+    const bool live = k < 2 * H;
+    const float *src = (k < H ? dv_t_rows : dv_v_rows) + (live ? (k < H ? k : k - H) : 0);
+    const int per = (B + 7) / 8, r0 = slice * per, r1 = min(B, r0 + per);
+    float acc = 0.f;
+    for (int base = r0; base < r1; base += 32) {
+        float x[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) x[u] = (live && base + u < r1) ? src[(int64_t)(base + u) * H] : 0.f;
+#pragma unroll
+        for (int u = 16; u > 0; u >>= 1)
+#pragma unroll
+            for (int v = 0; v < u; ++v) x[v] += x[v + u];
+        acc += x[0];
+    }
+    part[slice][c] = acc;
+    __syncthreads();
+    if (slice == 0 && live) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += part[q][c];
+        (k < H ? g_v_t : g_v_v)[k < H ? k : k - H] += sum;
     }
 }
 
-int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream, const float *dv_t_rows,
-                  const float *dv_v_rows, int B, float *g_v_t, float *g_v_v, const LossStatsArgs *loss_stats) {
-    const int nperm = cdiv(H * 4 * H, 256), nsum = dv_t_rows ? cdiv(2 * H, 32) : 0;
-    LossStatsArgs ls{};
-    if (loss_stats) ls = *loss_stats;
-    hipLaunchKernelGGL(unpermute_add_kernel, dim3(nperm + nsum + (loss_stats ? 1 : 0)), dim3(256), 0, stream, dwo_perm, g_w_o2h,
-                       H, nperm, dv_t_rows, dv_v_rows, B, g_v_t, g_v_v, nsum, ls);
-    GSCAN_LAUNCHED("unpermute_add_kernel");
+int head_grad_finish(const float *dwc, const float *w_h2o, const float *w_o2h, float *g_w_o2h, float *g_w_h2o, int H, int V,
+                     hipStream_t stream, const float *dv_t_rows, const float *dv_v_rows, int B, float *g_v_t, float *g_v_v) {
+    const int n_o2h = cdiv(H * 4 * H, 256), n_h2o = cdiv(V * H, 4), nsum = dv_t_rows ? cdiv(2 * H, 32) : 0;
+    hipLaunchKernelGGL(head_grad_finish_kernel, dim3(n_o2h + n_h2o + nsum), dim3(256), 0, stream, dwc, w_h2o, w_o2h, g_w_o2h,
+                       g_w_h2o, H, V, n_o2h, n_h2o, dv_t_rows, dv_v_rows, B, g_v_t, g_v_v);
+    GSCAN_LAUNCHED("head_grad_finish_kernel");
     return 0;
 }
 

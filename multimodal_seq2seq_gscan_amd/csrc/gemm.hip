@@ -428,6 +428,15 @@ int GemmBatch::launch_macro_tiles(hipStream_t stream) {
     return 0;
 }
 
+// GSCAN_GEMM_MT if set (0 never, 1 always), else 1 in deterministic mode (GSCAN_DETERMINISTIC=1), else -1 (by rule)
+int gemm_macro_tile_mode() {
+    static const int mode = [] {
+        const char *e = getenv("GSCAN_GEMM_MT"), *d = getenv("GSCAN_DETERMINISTIC");
+        return e ? atoi(e) : (d && atoi(d) ? 1 : -1);
+    }();
+    return mode;
+}
+
 // Launches with at least this many 128-row macro tiles take gemm_mt.hip by rule (4096^3: 105 TFLOP/s there against 94
 // on the 64 x 64 tiles below); none of the training step's launches at batch 256 comes near (its largest has 642).
 constexpr int kMacroMinTiles = 1024;
@@ -443,10 +452,8 @@ int GemmBatch::launch(hipStream_t stream) {
     // DETERMINISTIC mode (GSCAN_DETERMINISTIC=1, or GSCAN_GEMM_MT=1), where their split-K partial tiles are added in a
     // fixed order instead of with float atomics — bitwise reproducible weight gradients for 4 % of step time.
     // GSCAN_GEMM_MT=0: never.
-    static const int mt_mode = [] {
-        const char *e = getenv("GSCAN_GEMM_MT"), *d = getenv("GSCAN_DETERMINISTIC");
-        return e ? atoi(e) : (d && atoi(d) ? 1 : -1);
-    }();
+    // A launch that was handed scratch for split-K slabs asked for the fixed-order sums: macro tiles too.
+    const int mt_mode = scratch_ ? 1 : gemm_macro_tile_mode();
     if (mt_mode != 0) {
         int macro_tiles = 0;
         for (int i = 0; i < grp_.count; ++i) {

@@ -12,11 +12,25 @@ __device__ __forceinline__ void prologue_element(const PrologueArgs &a, int64_t 
     if (idx < a.end[0]) {
         a.bsum[idx] = a.b_ih[idx] + a.b_hh[idx];
     } else if (idx < a.end[1]) {
+        // the output head as ONE matrix (seq2seq_model.py:421-424 applies two bias-free Linears back to back):
+        // head_wc[v, col] = sum_j W_h2o[v, j] . W_o2h[j, src(col)], columns in S order [e | ctx_t | ctx_v | h]
+        // (W_o2h's own order is [e | h | ctx_t | ctx_v]).  Twenty products fetched per pass, as the composites below.
         const int64_t i = idx - a.end[0];
-        const int row = (int)(i / (4 * H)), col = (int)(i % (4 * H));     // col in S order
+        const int v = (int)(i / (4 * H)), col = (int)(i % (4 * H));
         const int seg = col / H, k = col % H;
         const int src = (seg == 0 ? 0 : seg == 1 ? 2 * H : seg == 2 ? 3 * H : H) + k;
-        a.wo_perm[i] = a.w_o2h[(int64_t)row * 4 * H + src];
+        const float *hrow = a.w_h2o + (int64_t)v * H, *ocol = a.w_o2h + src;
+        float acc0 = 0.f, acc1 = 0.f;
+        int j = 0;
+        for (; j + U - 1 < H; j += U) {
+            float x[U], y[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { x[u] = hrow[j + u]; y[u] = ocol[(int64_t)(j + u) * 4 * H]; }
+#pragma unroll
+            for (int u = 0; u < U; u += 2) { acc0 = fmaf(x[u], y[u], acc0); acc1 = fmaf(x[u + 1], y[u + 1], acc1); }
+        }
+        for (; j < H; ++j) acc0 = fmaf(hrow[j], ocol[(int64_t)j * 4 * H], acc0);
+        a.head_wc[i] = acc0 + acc1;
     } else if (idx < a.end[2]) {
         const int64_t i = idx - a.end[1];
         const int64_t per = (int64_t)4 * a.He * a.E, nw = (int64_t)a.D * per;
@@ -34,7 +48,7 @@ __device__ __forceinline__ void prologue_element(const PrologueArgs &a, int64_t 
                 dir ? a.enc_b_ih_r[r] + a.enc_b_hh_r[r] : a.enc_b_ih_f[r] + a.enc_b_hh_f[r];
         }
     } else if (idx < a.end[3]) {
-        a.dwo_perm[idx - a.end[2]] = 0.f;
+        a.dwc[idx - a.end[2]] = 0.f;
     } else if (idx < a.end[4]) {
         const int64_t i = idx - a.end[3];
         const int64_t row = i / a.E;

@@ -40,6 +40,7 @@ struct GemmProblem {
 // descriptors: six dependent scalar-load round trips, ~1500 cycles, before the first global load could be issued).
 struct GemmGroup { int count; int tile_begin[kMaxGroup]; int xcd_per[kMaxGroup]; GemmProblem p[kMaxGroup]; };
 
+int gemm_macro_tile_mode();      // gemm.hip: 1 = every launch on the macro tiles (deterministic mode), 0 never, -1 by rule
 // gemm_mt.hip: floats of one split-K partial tile (slab); a scratch region holds kGemmSlabs of them (GemmBatch::launch
 // never plans more slices than fit)
 size_t gemm_slab_floats();
@@ -56,9 +57,13 @@ public:
     // images computed in place of per-step context products that the decoder kernel is charged with): it still
     // counts as executed work.
     void overhead() { alg_flops_ -= last_flops_; last_flops_ = 0.0; }
+    // Algorithmic flops of reference products that the launch obtains by cheaper algebra: counted as
+    // algorithmic, not as executed.
+    void credit(double alg_flops) { alg_flops_ += alg_flops; }
     // Scratch for the split-K slabs of the macro-tile kernel (gemm_mt.hip): with it split products are added in a fixed
     // order (bitwise reproducible); without it they fall back to float atomics.  One region per launch IN FLIGHT:
-    // launches that may overlap on different streams must not share one.
+    // launches that may overlap on different streams must not share one.  Handing a launch scratch puts it on the macro
+    // tiles whatever its size; the training step does so in deterministic mode only (step.hip).
     void scratch(float *ptr, size_t floats) { scratch_ = ptr; scratch_floats_ = floats; }
     int launch(hipStream_t stream);
 private:
@@ -81,7 +86,6 @@ DecoderGeometry decoder_geometry(int H, bool cond);
 //     (task r = slot*256 + decoder_pair_of(tid), position kk = decoder_half_of(tid)*K0 + i along the dot; gate rows
 //     of the forward image unit-major: decoder_gate_row); forward: row q of block sg of
 //     [W_hh (4 blocks) | W_query_text | W_q2k[:, :H] or W_query_vis | W_query_vis]; backward: column q of block sg;
-//   head image[((i/4)*512 + tid)*4 + i%4] = MFMA B fragment of the permuted output_to_hidden: wo_perm[16 w + fr][4 i + fg].
 // Lane pairs of the decoder kernels: lane s and lane 7-s of every group of eight lanes (one DPP row_half_mirror apart)
 // hold the two halves of a weight row.  pair = 4 (tid / 8) + min(s, 7 - s), half = s / 4.
 __host__ __device__ inline int decoder_pair_of(int tid) { const int s = tid & 7; return 4 * (tid >> 3) + (s < 4 ? s : 7 - s); }
@@ -95,26 +99,14 @@ __host__ __device__ inline int decoder_gate_row(int r, int H) {
 }
 struct DecoderImageArgs {
     const float *w_hh, *w_qt, *w_qv, *w_q2k, *w_o2h;
-    float *fwd_image, *bwd_image, *head_image;
+    float *fwd_image, *bwd_image;
     int H, cond, slots, k0;
 };
 #ifdef __HIPCC__
-// element e of the concatenation [fwd image | bwd image | head image]
+// element e of the concatenation [fwd image | bwd image]
 __device__ __forceinline__ void decoder_image_element(const DecoderImageArgs &a, int e) {
     const int H = a.H, total = a.slots * a.k0 * kDecThreads;
     // every image is stored in 16-byte groups: element i of thread tid sits at ((i / 4) * 512 + tid) * 4 + i % 4
-    if (e >= 2 * total) {
-        const int x = e - 2 * total, tid = (x >> 2) % kDecThreads, i = 4 * (x / (4 * kDecThreads)) + (x & 3);
-        const int n = 16 * (tid >> 6) + (tid & 15), k = 4 * i + ((tid >> 4) & 3);     // wo_perm[n][k], k in S order
-        float v = 0.f;
-        if (n < H) {
-            const int seg = k / H, kk = k - seg * H;                                   // [e | ctx_t | ctx_v | h]
-            const int src = (seg == 0 ? 0 : seg == 1 ? 2 * H : seg == 2 ? 3 * H : H) + kk;   // W_o2h: [e | h | ctx_t | ctx_v]
-            v = a.w_o2h[(int64_t)n * 4 * H + src];
-        }
-        a.head_image[x] = v;
-        return;
-    }
     const bool bwd = e >= total;
     const int x = bwd ? e - total : e;
     const int tid = (x >> 2) % kDecThreads, f = 4 * (x / (4 * kDecThreads)) + (x & 3), i = f % a.k0, s = f / a.k0;
@@ -145,9 +137,9 @@ int embed_rows(const int64_t *tok, const float *table, int vocab, const float *m
 int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mask, int rows, int D, int vocab,
                int pad, float *dtable, hipStream_t stream);
 struct PrologueArgs {
-    const float *b_ih, *b_hh, *w_o2h, *w_ih_f, *w_ih_r, *enc_emb, *dec_emb, *mask_enc, *mask_dec;
+    const float *b_ih, *b_hh, *w_o2h, *w_h2o, *w_ih_f, *w_ih_r, *enc_emb, *dec_emb, *mask_enc, *mask_dec;
     const int64_t *commands, *targets;
-    float *bsum, *wo_perm, *wih_stack, *wih_t, *dwo_perm, *xe, *S, *wcat5, *zero_extra;
+    float *bsum, *head_wc, *wih_stack, *wih_t, *dwc, *xe, *S, *wcat5, *zero_extra;
     const float *w_ih_dec, *w_q2k;
     int cond;
     int64_t zero_extra_count;
@@ -171,12 +163,12 @@ struct PrologueArgs {
     int F;
 };
 int step_prologue(const PrologueArgs &args, hipStream_t stream);
-// loss_stats (optional): one more workgroup adds up the forward pass's per-row loss partials (the fused decoder launch
-// cannot: decoder.hip, decoder_fwdbwd_kernel)
-struct LossStatsArgs { const float *row_stats; int B, nll_mode, has_aux; float w_aux; float *stats_out, *seeds_out; };
-int unpermute_add(const float *dwo_perm, float *g_w_o2h, int H, hipStream_t stream, const float *dv_t_rows = nullptr,
-                  const float *dv_v_rows = nullptr, int B = 0, float *g_v_t = nullptr, float *g_v_v = nullptr,
-                  const LossStatsArgs *loss_stats = nullptr);
+// The head's weight gradients from d Wc = dlogits^T . S ([V, 4H], S order): g_w_o2h += W_h2o^T . dWc (columns back in
+// the reference's order), g_w_h2o += dWc . W_o2h^T; and, in further workgroups of the same launch, the energy-vector
+// gradients: the per-row sums of the decoder's reverse kernel added up over the batch in a fixed order.
+int head_grad_finish(const float *dwc, const float *w_h2o, const float *w_o2h, float *g_w_o2h, float *g_w_h2o, int H, int V,
+                     hipStream_t stream, const float *dv_t_rows = nullptr, const float *dv_v_rows = nullptr, int B = 0,
+                     float *g_v_t = nullptr, float *g_v_v = nullptr);
 int adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
               float beta2, float eps, float lr_decay, float lr_decay_steps, int64_t step, const float *grad_scale,
               const float *dev_scalars, int zero_grad, hipStream_t stream);   // zero_grad bit 1: grad_scale divides
@@ -294,21 +286,18 @@ struct DecoderArgs {
     float *att_sum;                    // [B,M] sum_t alpha_s (auxiliary head input)
     // fused output head (seq2seq_model.py:421-424, model.py:203): forward epilogue / backward prologue
     int V;
-    const float *head_image;           // register image of the permuted output_to_hidden rows [H][512]
-    const float *wo_perm, *w_h2o;      // [H,4H] (columns in S order), [V,H]
-    float *preo, *logits;              // [B,T,H] [B,T,V]
+    const float *head_wc;              // [V,4H] the head as ONE matrix: W_h2o . W_o2h, columns in S order (step prologue)
+    float *logits;                     // [B,T,V]
     float *logp_saved, *logp_out;      // [B,T,V] workspace copy and the caller's output
     float *aux_saved, *aux_out;        // [B,M] log_softmax(att_sum), or NULL without the auxiliary task
     // backward only
     const float *dlogp, *daux, *seeds; // incoming gradients ([B,T,V], [B,M] or NULL) and optional device scales [2]
-    float *dlogits, *dpreo;            // [B,T,V] [B,T,H] saved for the head's weight gradients
+    float *dlogits;                    // [B,T,V] saved for the head's weight gradients
     float *ds;                         // [B,T,4H] head gradient wrt [e | ctx_text | ctx_vis | h_t] (written first)
     // fused training loss (model.py:147-164): forward leaves per-row partial sums, backward starts from them
     const int64_t *targets, *positions;   // [B,T]; [B] or NULL
     int pad_tgt, B;
     float *row_stats;                  // [B,4] = [sum NLL, live tokens, aux NLL, 1] of the row, or NULL
-    int fused;                         // backward in the forward pass's launch (decoder_run_fused): the seed's token count
-                                       // comes from the targets, stats_out / seeds_out are left to the leaf launch
     int nll_mode;                      // backward: seed from row_stats / targets instead of dlogp / daux / seeds
                                        // (1: mean loss as the reference's, 2: sum loss for the data-parallel step)
     float w_aux;                       // weight of the auxiliary loss (train.py:105-107)
@@ -320,7 +309,6 @@ struct DecoderArgs {
     float *stamps;                     // diagnostics: [2][16] per-phase cycle sums of workgroup 0, or NULL
     // greedy decoding (forward kernel, GREEDY instantiation; selected by tokens_out != NULL): T = step limit,
     // ge = [V,4H] table Emb . W_ih[:, :H]^T + biases, hprev = h0 [B,H]
-    const float *head_wc;              // [V,4H] composite W_h2o . W_o2h with columns in S order
     const float *dec_emb;              // [V,H]
     int sos, eos;
     int64_t *tokens_out;               // [B,T] tokens produced (the <EOS> included)
@@ -329,8 +317,6 @@ struct DecoderArgs {
 bool decoder_hidden_supported(int h);
 size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward);
 int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
-bool decoder_fused_supported(int H, int L, int M, int V, bool cond);
-int decoder_run_fused(int B, int H, bool cond, const DecoderArgs &forward, const DecoderArgs &backward, hipStream_t stream);
 
 // attention_grad.hip: value path of both attentions + key layers + bridge, one workgroup per batch row
 struct KeysBackwardArgs {
@@ -370,11 +356,11 @@ int probe_read(const char *name, double *total_ms, double *flops, double *alg_fl
 struct WorkspaceSlot { const char *name; int64_t offset, count; };
 struct Workspace {
     int64_t feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
-        ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, preo, logits, logp_saved, aux_saved, row_stats, dlogits, dpreo,
+        ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, logits, logp_saved, aux_saved, row_stats, dlogits,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
-        wo_perm, dwo_perm, wih_stack, wih_t, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_head, enc_w_image, conv_img, conv_flags, conv_lists, wcat5,
+        dwc, wih_stack, wih_t, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, enc_w_image, conv_img, conv_flags, conv_lists, wcat5,
         deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image,   // encoder layers below the last
-        ge_table, head_wc,        // greedy decoding: [V,4H] tables
+        ge_table, head_wc,        // [V,4H] tables: greedy decoding's embedded gates; the composite head
         gemm_slabs_side, gemm_slabs_main;
     WorkspaceSlot slot[96];
     int nslots;
@@ -396,8 +382,8 @@ int step_greedy(const gscan_dims &d, int max_steps, const gscan_params &p, const
                 hipStream_t st);
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                   const float *dlogp, const float *daux, const float *seeds, const NllSeed *nll, const gscan_params &g,
-                  hipStream_t st, const DecoderArgs *fused_forward = nullptr);
-// forward + training loss + backward as one sequence (the decoder's two recurrences in one launch where the shape allows)
+                  hipStream_t st);
+// forward + training loss + backward as one sequence
 int step_train_nll(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                    float *logp, float *aux_logp, const NllSeed &nll, const gscan_params &g, hipStream_t st);
 

@@ -58,8 +58,7 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(ut, B * L * 4 * H);
     SLOT(u2t, B * L * H);
     SLOT(bsum, 4 * H);
-    SLOT(wo_perm, H * 4 * H);
-    SLOT(dwo_perm, H * 4 * H);
+    SLOT(dwc, V * 4 * H);                            // gradient of the composite head (head_wc below)
     SLOT(wih_stack, D * 4 * He * E);
     SLOT(wih_t, D * 4 * He * (E + 1));
     SLOT(w_sk, 4 * H * F);
@@ -67,7 +66,6 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(w_2kk, H * He);
     SLOT(dec_w_fwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
     SLOT(dec_w_bwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
-    SLOT(dec_w_head, H * kDecThreads);
     SLOT(enc_w_image, D * 4 * He * He);
     SLOT(hprev, B * T * H);
     SLOT(S, B * T * 4 * H);
@@ -81,14 +79,12 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(qv, B * T * H);
     SLOT(att_sum, B * M);
     SLOT(wcat5, 5 * H * 3 * H);
-    SLOT(preo, B * T * H);
     SLOT(logits, B * T * V);
     SLOT(logp_saved, B * T * V);
     SLOT(aux_saved, B * M);
     SLOT(row_stats, B * 4);                          // per-row [sum NLL, live tokens, aux NLL, 1]
     // backward scratch
     SLOT(dlogits, B * T * V);
-    SLOT(dpreo, B * T * H);
     SLOT(dS, B * T * 4 * H);
     SLOT(datt, B * M);
     SLOT(delta, B * T * 5 * H);                      // [delta (4H) | dzq (H)] per (b,t)
@@ -107,8 +103,10 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(stamps, 64);
     // split-K slabs of the macro-tile GEMM (gemm_mt.hip): one region per stream that carries split products (side 1:
     // decoder leaves, then key leaves; the caller's: the encoder's weight gradients), kGemmSlabs partial tiles each
-    SLOT(gemm_slabs_side, kGemmSlabs * (int64_t)gemm_slab_floats());
-    SLOT(gemm_slabs_main, kGemmSlabs * (int64_t)gemm_slab_floats());
+    // (deterministic mode only: GSCAN_DETERMINISTIC=1 is read once per process, so the layout is the same for every call)
+    const int64_t slabs = gemm_macro_tile_mode() > 0 ? kGemmSlabs * (int64_t)gemm_slab_floats() : 0;
+    SLOT(gemm_slabs_side, slabs);
+    SLOT(gemm_slabs_main, slabs);
     // encoder layers below the last one (num_encoder_layers > 1): saved activations, outputs (= the next layer's
     // input, [B,L,D*He]) and their gradients per layer; register images of W_hh for layers 1..
     const int64_t deep = enc_layers(d) - 1;
@@ -120,7 +118,7 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(deep_delta, deep * B * L * D * 4 * He);
     SLOT(deep_image, deep * D * 4 * He * He);
     SLOT(ge_table, V * 4 * H);                       // greedy decoding: Emb . W_ih[:, :H]^T + biases
-    SLOT(head_wc, V * 4 * H);                        // greedy decoding: W_h2o . W_o2h (S order)
+    SLOT(head_wc, V * 4 * H);                        // the output head as one matrix: W_h2o . W_o2h (S order), step prologue
 #undef SLOT
     ws->nslots = n;
     ws->total_floats = p;
@@ -185,8 +183,8 @@ static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, cons
     a.hprev = w + ws.hprev; a.s = w + ws.S; a.cells = w + ws.cells; a.gates = w + ws.gates;
     a.alpha_c = w + ws.alpha_c; a.alpha_s = w + ws.alpha_s;
     a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
-    a.V = d.V; a.head_image = w + ws.dec_w_head; a.wo_perm = w + ws.wo_perm; a.w_h2o = p.hid2out_w;
-    a.preo = w + ws.preo; a.logits = w + ws.logits; a.logp_saved = w + ws.logp_saved;
+    a.V = d.V; a.head_wc = w + ws.head_wc;
+    a.logits = w + ws.logits; a.logp_saved = w + ws.logp_saved;
     a.aux_saved = d.auxiliary ? w + ws.aux_saved : nullptr;
     a.targets = bt.targets; a.positions = d.auxiliary ? bt.target_positions : nullptr;
     a.pad_tgt = d.pad_tgt; a.B = d.B; a.row_stats = w + ws.row_stats;
@@ -279,19 +277,19 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     // take the convolution weight image off the prologue's index space; returns -1 if that launch does not fit the shape
     auto prologue = [&](int which, hipStream_t stream, bool fuse_world = false) -> int {
         PrologueArgs a{};
-        a.b_ih = p.dec_b_ih; a.b_hh = p.dec_b_hh; a.w_o2h = p.out2hid_w;
+        a.b_ih = p.dec_b_ih; a.b_hh = p.dec_b_hh; a.w_o2h = p.out2hid_w; a.w_h2o = p.hid2out_w;
         a.w_ih_f = p.enc_w_ih; a.w_ih_r = p.enc_w_ih_rev; a.enc_emb = p.enc_emb; a.dec_emb = p.dec_emb;
         a.mask_enc = mk.enc; a.mask_dec = mk.dec; a.commands = bt.commands;
         a.targets = teacher_forced ? bt.targets : nullptr;
-        a.bsum = w + ws.bsum; a.wo_perm = w + ws.wo_perm; a.wih_stack = w + ws.wih_stack; a.wih_t = w + ws.wih_t;
-        a.dwo_perm = w + ws.dwo_perm; a.xe = w + ws.xe; a.S = w + ws.S;
+        a.bsum = w + ws.bsum; a.head_wc = w + ws.head_wc; a.wih_stack = w + ws.wih_stack; a.wih_t = w + ws.wih_t;
+        a.dwc = w + ws.dwc; a.xe = w + ws.xe; a.S = w + ws.S;
         a.H = H; a.He = He; a.E = E; a.D = D; a.BL = B * L; a.BT = B * T; a.Vi = d.Vi; a.V = V;
         a.wcat5 = w + ws.wcat5; a.w_ih_dec = p.dec_w_ih; a.w_q2k = p.q2k_w; a.cond = cond ? 1 : 0;
         a.zero_extra = w + ws.enc_out;                     // adjacent slots enc_out | hN | dxe
         a.zero_extra_count = (ws.dxe + (int64_t)B * L * E) - ws.enc_out;
         const DecoderGeometry geo = decoder_geometry(H, cond);
         a.img = DecoderImageArgs{p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, p.out2hid_w, w + ws.dec_w_fwd,
-                                 w + ws.dec_w_bwd, w + ws.dec_w_head, H, cond ? 1 : 0, geo.slots, geo.k0};
+                                 w + ws.dec_w_bwd, H, cond ? 1 : 0, geo.slots, geo.k0};
         a.enc_w_hh_f = p.enc_w_hh; a.enc_w_hh_r = p.enc_w_hh_rev; a.enc_image = w + ws.enc_w_image;
         a.enc_b_ih_f = p.enc_b_ih; a.enc_b_hh_f = p.enc_b_hh; a.enc_b_ih_r = p.enc_b_ih_rev; a.enc_b_hh_r = p.enc_b_hh_rev;
         a.enc_rows = encoder_rows_per_thread(He);
@@ -299,9 +297,9 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.conv_img = w + ws.conv_img; a.cC = C; a.cCo = Co; a.cK3 = d.K3;
         a.w_key_vis = p.vis_key_w; a.w_key_txt = p.txt_key_w; a.F = F;
         a.w_sk = w + ws.w_sk; a.w_ck = w + ws.w_ck; a.w_2kk = w + ws.w_2kk;
-        const int64_t n[14] = {4 * H, (int64_t)H * 4 * H, (int64_t)D * 4 * He * (E + 1), (int64_t)H * 4 * H,
+        const int64_t n[14] = {4 * H, (int64_t)V * 4 * H, (int64_t)D * 4 * He * (E + 1), (int64_t)V * 4 * H,
                                given ? 0 : (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
-                               a.zero_extra_count, 2 * geo.image_floats + (int64_t)H * kDecThreads,
+                               a.zero_extra_count, 2 * geo.image_floats,
                                (int64_t)D * 4 * He * He, (given || fuse_world) ? 0 : conv_image_floats(C, Co, d.K3),
                                (int64_t)4 * H * F, (int64_t)4 * H * He, cond ? (int64_t)H * He : 0};
         int64_t acc = 0;
@@ -459,7 +457,7 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     TRY(encode_branches(d, p, bt, mk, w, ws, true, st, have ? &given : nullptr));
 
     // ---- the T-step recurrence; its epilogue is the output head, which does not feed back
-    // (seq2seq_model.py:421-424: S . wo_perm^T, then W_h2o) and log_softmax (model.py:203, :166-170) of the row's
+    // (seq2seq_model.py:421-424 as the one matrix W_h2o . W_o2h) and log_softmax (model.py:203, :166-170) of the row's
     // T steps, and the auxiliary log_softmax over the summed visual attention (model.py:205)
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.w_image = w + ws.dec_w_fwd;
@@ -471,32 +469,12 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
 }
 
 // One training step's forward pass, loss and backward pass (train.py:96-110) as one call: the prelude, the decoder's two
-// recurrences, the rest of the backward pass.  GSCAN_FUSED_DECODER=1 runs the two recurrences as ONE launch
-// (decoder_fwdbwd_kernel; shapes whose backward layout needs the visual gate images streamed from L2 keep two).  That
-// launch is correct (the whole GPU suite passes on it) and OFF by default: it removes the 7 us boundary between the
-// recurrences, but the kernel takes 243 us against 106.5 + 124.5 for the two (rocprofv3; 103 spilled SGPRs against
-// 49 / 42, seven spilled VGPRs: one register allocation for two loops that each fill the file) and the step 0.501
-// against 0.490 ms (profiles/r03_h_fused_decoder_ab.txt).
+// recurrences, the rest of the backward pass.  (Round 3 also ran the two recurrences as ONE launch behind this entry:
+// correct, and slower — one register allocation for two loops that each fill the file; DESIGN.md 6.  Removed.)
 int step_train_nll(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                    float *logp, float *aux_logp, const NllSeed &nll, const gscan_params &g, hipStream_t st) {
-    TRY(check_dims(d));
-    static const int fused = [] { const char *e = getenv("GSCAN_FUSED_DECODER"); return e ? atoi(e) : 0; }();
-    const bool cond = d.conditional != 0;
-    if (!fused || !decoder_fused_supported(d.H, d.L, d.G * d.G, d.V, cond)) {
-        TRY(step_forward(d, p, bt, mk, w, logp, aux_logp, st));
-        return step_backward(d, p, bt, mk, w, nullptr, nullptr, nullptr, &nll, g, st);
-    }
-    Workspace ws;
-    TRY(workspace_layout(d, &ws));
-    GSCAN_CHECK(logp != nullptr, "forward: logp is NULL");
-    GSCAN_CHECK(!d.auxiliary || aux_logp, "forward: auxiliary task set but aux_logp is NULL");
-    TRY(encode_branches(d, p, bt, mk, w, ws, true, st));
-    DecoderArgs a = decoder_args(d, p, bt, w, ws);
-    a.w_image = w + ws.dec_w_fwd;
-    a.logp_out = logp;
-    a.aux_out = d.auxiliary ? aux_logp : nullptr;
-    a.stamps = probe_stamps_enabled() ? w + ws.stamps : nullptr;
-    return step_backward(d, p, bt, mk, w, nullptr, nullptr, nullptr, &nll, g, st, &a);
+    TRY(step_forward(d, p, bt, mk, w, logp, aux_logp, st));
+    return step_backward(d, p, bt, mk, w, nullptr, nullptr, nullptr, &nll, g, st);
 }
 
 // --------------------------------------------------------------------------------------
@@ -557,14 +535,12 @@ int step_greedy(const gscan_dims &d, int max_steps, const gscan_params &p, const
     {
         GemmBatch g;
         g.add(V, 4 * H, H, p.dec_emb, H, 1, p.dec_w_ih, 1, 3 * H, w + ws.ge_table, 4 * H, 0.f, w + ws.bsum);
-        g.add(V, 4 * H, H, p.hid2out_w, H, 1, w + ws.wo_perm, 4 * H, 1, w + ws.head_wc, 4 * H);
         TRY(g.launch(st));
     }
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.T = max_steps;
     a.w_image = w + ws.dec_w_fwd;
     a.ge = w + ws.ge_table;
-    a.head_wc = w + ws.head_wc;
     a.dec_emb = p.dec_emb;
     a.sos = sos; a.eos = eos;
     a.tokens_out = tokens; a.steps_out = steps;
@@ -579,7 +555,7 @@ int step_greedy(const gscan_dims &d, int max_steps, const gscan_params &p, const
 // --------------------------------------------------------------------------------------
 int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk, float *w,
                   const float *dlogp, const float *daux, const float *seeds, const NllSeed *nll, const gscan_params &g,
-                  hipStream_t st, const DecoderArgs *fused_forward) {
+                  hipStream_t st) {
     TRY(check_dims(d));
     Workspace ws;
     TRY(workspace_layout(d, &ws));
@@ -588,7 +564,6 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     const int BT = B * T, BL = B * L, BM_ = B * M;
     const bool cond = d.conditional != 0;
     GSCAN_CHECK(dlogp || nll, "backward: dlogp is NULL");
-    GSCAN_CHECK(!fused_forward || nll, "backward: the fused decoder launch seeds itself from the training loss");
     TRY(side_init());
     hipStream_t sd = g_side.single ? st : g_side.stream, sd2 = g_side.single ? st : g_side.stream2;
     float *S = w + ws.S, *dS = w + ws.dS;
@@ -612,23 +587,13 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.dlogp = dlogp; a.daux = use_aux ? daux : nullptr; a.seeds = seeds;
     if (nll) { a.nll_mode = nll->sum ? 2 : 1; a.w_aux = nll->w_aux; a.stats_out = nll->stats_out; a.seeds_out = nll->seeds_out; }
-    a.dlogits = w + ws.dlogits; a.dpreo = w + ws.dpreo; a.ds = dS;
+    a.dlogits = w + ws.dlogits; a.ds = dS;
     a.delta = w + ws.delta; a.dqt = w + ws.dqt; a.dqv = w + ws.dqv;
     a.dpk_t = w + ws.dpk_t; a.dpk_v = w + ws.dpk_v; a.dv_t = w + ws.dv_t; a.dv_v = w + ws.dv_v;
     a.dh0 = w + ws.dh0;
     a.w_image = w + ws.dec_w_bwd;
     a.stamps = probe_stamps_enabled() ? w + ws.stamps + 16 : nullptr;
-    if (fused_forward) {           // both recurrences in one launch (step_train_nll)
-        a.fused = 1;
-        TRY(decoder_run_fused(B, H, cond, *fused_forward, a, st));
-    } else {
-        TRY(decoder_run(true, B, H, cond, a, st));
-    }
-    // the fused launch leaves the batch's loss statistics to the leaf launch behind the decoder's weight gradients
-    LossStatsArgs loss_stats{};
-    if (fused_forward)
-        loss_stats = LossStatsArgs{w + ws.row_stats, B, nll->sum ? 2 : 1, d.auxiliary ? 1 : 0, nll->w_aux, nll->stats_out,
-                                   nll->seeds_out};
+    TRY(decoder_run(true, B, H, cond, a, st));
     // where the decoder's weight-gradient leaves fork off the chain (GSCAN_LEAVES_FORK, A/B): 0 behind the recurrence,
     // 1 behind the dS += product, 2 behind keys_backward (one fork event in the whole backward pass)
     static const int leaves_fork = [] { const char *e = getenv("GSCAN_LEAVES_FORK"); return e ? atoi(e) : 0; }();
@@ -636,11 +601,15 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         {   // leaves: head weights (the permuted W_o2h gradient is scattered back below) and the decoder parameter
             // gradients (dense products over the B*T saved rows)
             GemmBatch b;
-            b.scratch(w + ws.gemm_slabs_side, (size_t)kGemmSlabs * gemm_slab_floats());
+            if (gemm_macro_tile_mode() > 0) b.scratch(w + ws.gemm_slabs_side, (size_t)kGemmSlabs * gemm_slab_floats());
             static const int dec_split = [] { const char *e = getenv("GSCAN_SPLIT_DEC"); return e ? atoi(e) : 0; }();
             g_split_override = dec_split;
-            add_grad(b, V, H, BT, w + ws.dlogits, 1, V, w + ws.preo, H, 1, g.hid2out_w, H);
-            add_grad(b, H, 4 * H, BT, w + ws.dpreo, 1, H, S, 4 * H, 1, w + ws.dwo_perm, 4 * H);
+            // the head as one matrix Wc = W_h2o . W_o2h (decoder.hip): d Wc = dlogits^T . S, and both Linears'
+            // gradients follow from it in head_grad_finish below.  These V x 4H x BT multiply-adds stand in for the
+            // reference's two products (H x 4H and V x H over the same BT rows), whose algorithmic flops (SURVEY.md
+            // 8d) the launch is credited with.
+            add_grad(b, V, 4 * H, BT, w + ws.dlogits, 1, V, S, 4 * H, 1, w + ws.dwc, 4 * H);
+            b.credit(2.0 * BT * ((double)H * 4 * H + (double)V * H) - 2.0 * BT * (double)V * 4 * H);
             add_grad(b, 4 * H, 3 * H, BT, delta, 1, 5 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
             add_grad(b, 4 * H, H, BT, delta, 1, 5 * H, hprev, H, 1, g.dec_w_hh, H, g.dec_b_ih, g.dec_b_hh);
             add_grad(b, H, H, BT, w + ws.dqt, 1, H, hprev, H, 1, g.txt_query_w, H);
@@ -656,8 +625,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
             g_split_override = 0;
             b.add(BT, H, 4 * H, delta, 5 * H, 1, w + ws.wcat5, 3 * H, 1, dS, 4 * H, 1.f);
             TRY(b.launch(sd));
-            TRY(unpermute_add(w + ws.dwo_perm, g.out2hid_w, H, sd, w + ws.dv_t, w + ws.dv_v, B, g.txt_energy_w, g.vis_energy_w,
-                              fused_forward ? &loss_stats : nullptr));
+            TRY(head_grad_finish(w + ws.dwc, p.hid2out_w, p.out2hid_w, g.out2hid_w, g.hid2out_w, H, V, sd, w + ws.dv_t,
+                                 w + ws.dv_v, B, g.txt_energy_w, g.vis_energy_w));
             TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd));
         }
         return 0;
@@ -685,7 +654,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     if (leaves_fork == 2) TRY(decoder_leaves());
     {   // leaves: key and bridge weights
         GemmBatch b;
-        b.scratch(w + ws.gemm_slabs_side, (size_t)kGemmSlabs * gemm_slab_floats());     // same stream as the decoder leaves
+        if (gemm_macro_tile_mode() > 0)      // same stream as the decoder leaves: the same region
+            b.scratch(w + ws.gemm_slabs_side, (size_t)kGemmSlabs * gemm_slab_floats());
         add_grad(b, H, He, BL, w + ws.dpk_t, 1, H, w + ws.enc_out, He, 1, g.txt_key_w, He);
         add_grad(b, H, He, B, w + ws.dh0, 1, H, w + ws.hN, He, 1, g.bridge_w, He, g.bridge_b);
         add_grad(b, H, F, BM_, w + ws.dpk_v, 1, H, w + ws.feat, F, 1, g.vis_key_w, F);
@@ -725,7 +695,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         const int Din = l == 0 ? E : D * He;
         const float *x = l == 0 ? w + ws.xe : w + ws.deep_y + (l - 1) * lay_h;
         GemmBatch b;
-        b.scratch(w + ws.gemm_slabs_main, (size_t)kGemmSlabs * gemm_slab_floats());
+        if (gemm_macro_tile_mode() > 0) b.scratch(w + ws.gemm_slabs_main, (size_t)kGemmSlabs * gemm_slab_floats());
         // this launch ends the step on an otherwise idle chip: its split is its own knob (GSCAN_SPLIT_ENC)
         static const int enc_split = [] { const char *e = getenv("GSCAN_SPLIT_ENC"); return e ? atoi(e) : 0; }();
         g_split_override = enc_split;
