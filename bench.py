@@ -71,6 +71,19 @@ def pmc_traffic(kernel_family: str, workload: str):
         return None, f"unreadable PMC profile: {e}", {}
 
 
+def step_traffic(workload: str, mflop_per_example: float, B: int):
+    """Measured HBM-side bytes of ONE step over every profiled kernel (PMC passes of tools/gpu_round.sh, bound to the
+    kernel sources by hash) next to SURVEY.md 8d's algorithmic figure (0.1-0.15 MB per example at T = 20)."""
+    _, source, per = pmc_traffic("gemm", workload)
+    if not per:
+        return None
+    launches = {"gemm_group_kernel": 5, "embed_grad_kernel": 2}
+    total = sum(v * launches.get(k, 1) for k, v in per.items())
+    return {"measured_bytes_per_step": round(total), "kernels_profiled": sorted(per),
+            "algorithmic_bytes_per_step": [round(0.10e6 * B), round(0.15e6 * B)],
+            "measured_over_algorithmic": round(total / (0.125e6 * B), 2), "source": source}
+
+
 def algorithmic_mflop_per_example(cfg: dict, G: int, L: int, T: int) -> float:
     """F_train of SURVEY.md §8(d): 6 x forward MACs, valid convolution taps only."""
     C_, Co, k3 = cfg["num_cnn_channels"], cfg["cnn_hidden_num_channels"], cfg["cnn_kernel_size"]
@@ -558,6 +571,7 @@ def main():
                        "rccl_nranks": step.exchange.comm.nranks if step.exchange.comm is not None else None},
             "roofline": roofline_block(dominant),
             "roofline_gemm": roofline_block("gemm") if dominant != "gemm" and "gemm" in merged else None,
+            "step_hbm_traffic": step_traffic(pmc_workload, mflop, B),
             "families_ranked": ranked,
             "kernel_families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in families.items()},
             "step_algorithmic_tflops": round(ex_per_s * mflop / 1e6, 3),

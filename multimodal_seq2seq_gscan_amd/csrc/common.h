@@ -26,9 +26,14 @@ void set_error(const char *fmt, ...);
         }                                                                           \
     } while (0)
 
+// GSCAN_ROCTX=1: every launch of the library leaves a named roctx marker (probe.hip; rocprofv3 --marker-trace shows
+// them next to the kernel rows, so the step's seventeen launches read as what they are); otherwise a flag test.
+void roctx_mark(const char *name);
+
 // Launch check: a bad configuration surfaces at launch, not at the next sync.
 #define GSCAN_LAUNCHED(name)                                                        \
     do {                                                                            \
+        ::gscan::roctx_mark(name);                                                  \
         hipError_t e_ = hipGetLastError();                                          \
         if (e_ != hipSuccess) {                                                     \
             ::gscan::set_error("launch of %s failed: %s", name, hipGetErrorString(e_)); \

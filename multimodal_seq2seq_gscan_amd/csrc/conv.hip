@@ -240,10 +240,11 @@ __device__ __forceinline__ void world_conv_fwd_body(const ConvArgs &a, const T *
                 }
             }
         }
-        // The image is read with ordinary loads.  With GSCAN_FUSED_ACQUIRE=1 one lane issues an agent-scope acquire
-        // first (invalidates this CU's L1: cdna_hip_programming.md Guideline 16's consumer form); without it the
-        // reads are fresh because no cache holds a line of the image when they are issued: L1 and L2 are invalidated
-        // at the launch boundary and nothing in this launch reads the image before the flags are up.
+        // The image is read with ordinary loads behind ONE agent-scope acquire by one lane (invalidates this CU's L1;
+        // the wait holds the barrier until the invalidate has completed): cdna_hip_programming.md Guideline 16's
+        // consumer form.  (Without it — GSCAN_FUSED_ACQUIRE=0 — the reads rely on no cache holding a line of the
+        // image when they are issued: caches are invalidated at the launch boundary and nothing in this launch reads
+        // the image before the flags are up.)
         if (acquire && threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -532,7 +533,10 @@ int prologue_world_forward(const PrologueArgs &pa, const void *world, int world_
     f.epoch = epoch.fetch_add(2u);
     // ~100 cycles per poll: 2 000 polls are some 80 us, ten times the longest wait seen in dispatch order
     static const int late_after = [] { const char *e = getenv("GSCAN_FUSED_LATE_AFTER"); return e ? atoi(e) : 2000; }();
-    static const int acquire = [] { const char *e = getenv("GSCAN_FUSED_ACQUIRE"); return e ? atoi(e) : 0; }();
+    // acquire between the flags and the image reads: ON (cdna_hip_programming.md Guideline 16's consumer form).  It costs
+    // 1-4 us of the ~5 the one launch saves (profiles/r04_fused_prologue_acquire_ab.txt: 0.4785 ms per step without,
+    // 0.4810 with, 0.4823 as two launches); GSCAN_FUSED_ACQUIRE=0 for A/B runs.
+    static const int acquire = [] { const char *e = getenv("GSCAN_FUSED_ACQUIRE"); return e ? atoi(e) : 1; }();
     static const int skip = [] { const char *e = getenv("GSCAN_FUSED_SKIP_IMAGE"); return e ? atoi(e) : 0; }();
     f.late_after = late_after; f.acquire = acquire; f.skip_image = skip;
     ProbeScope probe(P_CONV_FWD, stream, 0.0, conv_algorithmic_flops(B, G, C, Co, K3));

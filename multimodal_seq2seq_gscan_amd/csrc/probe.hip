@@ -2,6 +2,8 @@
 // numbers).  Off by default; when on, each probed launch is bracketed by two hipEventRecord
 // calls on its own stream and the elapsed times are summed at read time.  Not usable while
 // the stream is being captured into a graph.
+#include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -42,6 +44,22 @@ ProbeScope::~ProbeScope() {
     ProbeState &p = g_probe[id_];
     hipEventRecord(p.end[p.used], st_);
     ++p.used;
+}
+
+// Named markers for profilers (tracing): roctxMarkA from the roctx library, bound at run time and only
+// when GSCAN_ROCTX=1 (no link dependency; the ranges ProbeScope would give bracket the ENQUEUE of asynchronous
+// launches, which says nothing a marker does not).
+void roctx_mark(const char *name) {
+    using MarkFn = void (*)(const char *);
+    static const MarkFn mark = []() -> MarkFn {
+        const char *e = getenv("GSCAN_ROCTX");
+        if (!e || atoi(e) == 0) return nullptr;
+        for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"})
+            if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL))
+                if (void *f = dlsym(h, "roctxMarkA")) return (MarkFn)f;
+        return nullptr;
+    }();
+    if (mark) mark(name);
 }
 
 bool probe_stamps_enabled() { return g_stamps_on; }

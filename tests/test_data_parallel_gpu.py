@@ -205,3 +205,37 @@ def test_command_line_training_on_a_dataset_file_with_two_ranks(tmp_path):
     # (a checkpoint is written only when the dev exact match improves, train.py:141-149: not after 12 iterations)
     assert os.path.exists(data_dir / "training_input_vocab.txt") and os.path.exists(data_dir / "training_target_vocab.txt")
     assert logs[0].count("Evaluation Accuracy") == 2 and "Finished training." in logs[0] and "Finished training." in logs[1]
+
+
+def test_bench_under_a_launcher_environment_runs_the_nccl_path_on_one_rank():
+    """The RCCL branch of bench.py on the box's one GPU: an explicit launcher environment (WORLD_SIZE=1, as
+    torch.distributed.run would set it), --backend nccl and --always-collective, so that the process group is "nccl",
+    the library's own communicator is created from it (collective transport decision included) and every step's
+    all-reduce goes through gscan_allreduce_f32 on the step's stream.  The line must say so: rccl_nranks is what
+    ncclCommCount reports for the communicator the step used."""
+    import json
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--always-collective",
+                        "--steps", "5", "--warmup", "2", "--min-warmup-steps", "5", "--windows", "0", "--cpu-seconds", "0",
+                        "--batch", "64"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["gradient_exchange"] == "gscan_allreduce_f32: RCCL on the step's stream"
+    assert out["config"]["rccl_nranks"] == 1
+
+
+def test_bench_strong_scaling_line_splits_a_fixed_global_batch():
+    """--global-batch N (SURVEY.md 8d's secondary line): the ranks share a FIXED global batch and the line says
+    "scaling": "strong".  Two ranks on the one device (gloo rehearsal)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--global-batch", "64",
+                        "--steps", "3", "--warmup", "2", "--min-warmup-steps", "3", "--windows", "0", "--cpu-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 64 and out["n_gpus"] == 2

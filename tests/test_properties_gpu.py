@@ -128,3 +128,87 @@ def test_training_memorises_one_batch():
                     target_lengths=batch["tgt_lengths"].tolist())
     accuracy, exact_match = model.get_metrics(logp, batch["targets"])
     assert exact_match == 100.0 and accuracy > 99.9, (accuracy, exact_match)
+
+
+def _forward_logp(model, batch):
+    model.eval()
+    with torch.no_grad():
+        logp, _ = model(commands_input=batch["commands"], commands_lengths=batch["cmd_lengths"], situations_input=batch["world"],
+                        target_batch=batch["targets"], target_lengths=batch["tgt_lengths"])
+    return logp
+
+
+def _selfserved(model, batch):
+    """Chunks of the convolution weight image that waiting world-encoder workgroups wrote themselves (conv.hip): the
+    word behind the 512 flags of the fused prologue launch in the workspace, a running count."""
+    B, L = batch["commands"].shape
+    dims = model._dims(B, L, batch["targets"].shape[1], batch["world"].shape[1])
+    return int(model.workspace_view(dims, "conv_flags").view(torch.int32)[512].item())
+
+
+def test_fused_prologue_launch_on_eight_compute_units(tmp_path):
+    """The prologue + world encoder launch (conv.hip) waits, inside the launch, for the workgroups that write the
+    convolution weight image.  On a stream restricted to EIGHT compute units (hipExtStreamCreateWithCUMask) a few
+    thousand workgroups queue for 8 CUs: 1 000 forward passes must finish and equal the unrestricted result bit for
+    bit — the wait is bounded and cannot depend on dispatch order (a waiter that runs out of patience writes the chunk
+    itself)."""
+    import ctypes as C
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+    from multimodal_seq2seq_gscan_amd.model import Model
+    cfg = model_kwargs("compositional")
+    torch.manual_seed(3)
+    model = Model(**cfg).cuda()
+    shape = Shape(batch=64, grid=6, channels=16, input_vocab=cfg["input_vocabulary_size"],
+                  target_vocab=cfg["target_vocabulary_size"], max_command=10, max_target=12)
+    batch = {k: v.cuda() for k, v in make_batch(shape, 11).items()}
+    ref = _forward_logp(model, batch).clone()
+    hip = C.CDLL("libamdhip64.so")
+    handle = C.c_void_p()
+    mask = (C.c_uint32 * 8)(0xFF, 0, 0, 0, 0, 0, 0, 0)            # CUs 0..7 of 256
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(handle), 8, mask) == 0
+    stream = torch.cuda.ExternalStream(handle.value)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for i in range(1000):
+            out = _forward_logp(model, batch)
+            if i % 250 == 0:
+                assert torch.equal(out, ref), i
+        assert torch.equal(out, ref)
+    torch.cuda.synchronize()
+    assert hip.hipStreamDestroy(handle) == 0
+
+
+def test_fused_prologue_waiters_serve_themselves_when_the_image_workgroups_do_nothing(tmp_path):
+    """GSCAN_FUSED_SKIP_IMAGE=1 (test hook) makes the image workgroups of the fused launch return at once — what an
+    adversarial dispatch order would look like to the world encoder's workgroups.  After a short wait
+    (GSCAN_FUSED_LATE_AFTER polls) they write the missing chunks themselves: same log-probabilities, bit for bit, and
+    the self-service counter moves."""
+    import os, subprocess, sys
+    worker = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from test_properties_gpu import _forward_logp, _selfserved, model_kwargs
+from multimodal_seq2seq_gscan_amd.model import Model
+from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+cfg = model_kwargs("compositional")
+torch.manual_seed(3)
+model = Model(**cfg).cuda()
+shape = Shape(batch=32, grid=6, channels=16, input_vocab=cfg["input_vocabulary_size"], target_vocab=cfg["target_vocabulary_size"], max_command=10, max_target=12)
+batch = {k: v.cuda() for k, v in make_batch(shape, 11).items()}
+out = _forward_logp(model, batch)
+before = _selfserved(model, batch)
+for _ in range(20):
+    out = _forward_logp(model, batch)
+torch.save({"logp": out.cpu(), "selfserved": _selfserved(model, batch) - before}, sys.argv[3])
+"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for name, extra in (("normal", {}), ("skip", {"GSCAN_FUSED_SKIP_IMAGE": "1", "GSCAN_FUSED_LATE_AFTER": "50"})):
+        path = str(tmp_path / f"{name}.pt")
+        r = subprocess.run([sys.executable, "-c", worker, os.path.dirname(here), here, path], env=dict(os.environ, **extra),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[name] = torch.load(path)
+    assert torch.equal(res["normal"]["logp"], res["skip"]["logp"])
+    assert res["normal"]["selfserved"] == 0, res["normal"]["selfserved"]
+    assert res["skip"]["selfserved"] > 0
