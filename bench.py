@@ -353,8 +353,6 @@ def main():
                     help="untimed warm-up runs at least this many steps (0.15 s at S1), whatever --warmup says")
     ap.add_argument("--windows", type=int, default=4, help="extra timed windows of K steps for the spread (0 = none)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay captured HIP graphs instead of launching eagerly (pays off once the host is the limiter)")
     ap.add_argument("--rotate", type=int, default=4,
                     help="distinct resident batches the steps cycle through (1 = the same batch every step)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -422,7 +420,7 @@ def main():
         taken[0] += 1
         return batches[taken[0] % len(batches)]
 
-    step = TrainStep(model, learning_rate=1e-3, graph=args.graph, always_collective=args.always_collective)
+    step = TrainStep(model, learning_rate=1e-3, always_collective=args.always_collective)
 
     def fence():
         torch.cuda.synchronize()
@@ -460,9 +458,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         windows.append(1e3 * float(t.item()) / args.steps)
 
-    # second pass over the same K steps, launched eagerly, with HIP-event probes around each kernel family
-    # (events cannot be read back from inside a captured graph)
-    probe_step = TrainStep(model, learning_rate=1e-3, graph=False) if args.graph else step
+    # second pass over the same K steps with HIP-event probes around each kernel family
+    probe_step = step
     for _ in range(3):
         probe_step(next_batch())
     torch.cuda.synchronize()
@@ -560,7 +557,7 @@ def main():
                                    f"dropout {cfg['encoder_dropout_p']}/{cfg['decoder_dropout_p']}/{cfg['cnn_dropout_p']}, "
                                    f"conditional attention{', auxiliary head' if args.auxiliary else ''}, Adam+LR step included",
                        "global_batch": world * B, "parallelism": f"dp{world}", "parameters": model.parameter_count,
-                       "launch": "hipGraph replay (3 graphs per step)" if args.graph else "eager (forward on the caller's stream, backward on 3 streams)",
+                       "launch": "eager (forward on the caller's stream, backward on 3 streams)",
                        "resident_batches": len(batches),
                        "value_window": "median of the timed windows of K steps each" if len(windows) > 1 else "the one timed window",
                        "warmup_steps_run": max(args.warmup, args.min_warmup_steps),

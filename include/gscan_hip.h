@@ -209,8 +209,7 @@ int gscan_adam_step_masks(float *param, float *grad, float *exp_avg, float *exp_
                           float *mask_out, size_t n_cnn, size_t n_enc, size_t n_dec, float p_cnn, float p_enc, float p_dec,
                           uint64_t seed, uint64_t stream_id, void *stream);
 
-/* ---- the same loop body for a captured (hipGraph) step: everything that changes from step to step is read from
- * device memory, so one captured sequence can be replayed unchanged ---- */
+/* ---- the loop body's remaining pieces as launches of their own ---- */
 
 /* Both losses in one launch: stats[4] = [sum NLL, tokens, sum aux NLL, rows] and the unit seeds
  * dlogp = d(sum NLL)/d(logp), daux = d(sum aux NLL)/d(aux_logp).  aux_logp/positions/daux may be NULL. */
@@ -249,14 +248,6 @@ int gscan_backward_nll(const gscan_dims *dims, const gscan_params *params, const
 int gscan_train_step_nll(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
                          const gscan_masks *masks, void *workspace, float *logp, float *aux_logp, float weight_target_loss,
                          int sum_reduction, float *stats, float *seeds, const gscan_params *grads, void *stream);
-
-/* Adam with the step-dependent scalars [lr_t / (1 - beta1^t), 1 / sqrt(1 - beta2^t)] read from device memory
- * (gscan_adam_scalars computes them on the host); zero_grad != 0 also clears the gradient buffer
- * (optimizer.zero_grad(), train.py:113). */
-int gscan_adam_step_graph(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float beta1,
-                          float beta2, float eps, const float *dev_scalars, int zero_grad, void *stream);
-void gscan_adam_scalars(float lr, float beta1, float beta2, float lr_decay, float lr_decay_steps, int64_t step,
-                        float *scalars2_host);
 
 /* The three dropout masks of one step (contiguous: cnn | enc | dec) in one launch; the Philox stream id is
  * dev_stream_id[0] when that device pointer is not NULL. */

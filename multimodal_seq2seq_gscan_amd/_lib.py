@@ -102,8 +102,6 @@ PROTOTYPES = {
                                    _vp, _vp, C.POINTER(Params), _vp]),
     "gscan_adam_step_masks": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i64, _vp, _vp, _sz, _sz, _sz, _f, _f, _f,
                                    _u64, _u64, _vp]),
-    "gscan_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _vp, _i, _vp]),
-    "gscan_adam_scalars": (None, [_f, _f, _f, _f, _f, _i64, _vp]),
     "gscan_trace_set": (_i, [_vp]),
     "gscan_dropout_masks": (_i, [_vp, _sz, _sz, _sz, _f, _f, _f, _u64, _u64, _vp, _vp]),
     "gscan_comm_unique_id": (_i, [_vp]),

@@ -154,18 +154,6 @@ int gscan_loss_seeds(const float *stats, float weight_target_loss, int auxiliary
     return loss_seeds(stats, weight_target_loss, auxiliary, seeds, (hipStream_t)stream);
 }
 
-int gscan_adam_step_graph(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float beta1,
-                          float beta2, float eps, const float *dev_scalars, int zero_grad, void *stream) {
-    ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && dev_scalars, "adam_step_graph: bad argument");
-    return adam_step(param, grad, exp_avg, exp_avg_sq, n, 0.f, beta1, beta2, eps, 0.f, 1.f, 0, nullptr, dev_scalars,
-                     zero_grad, (hipStream_t)stream);
-}
-
-void gscan_adam_scalars(float lr, float beta1, float beta2, float lr_decay, float lr_decay_steps, int64_t step,
-                        float *scalars2_host) {
-    adam_scalars(lr, beta1, beta2, lr_decay, lr_decay_steps, step, scalars2_host, scalars2_host + 1);
-}
-
 int gscan_dropout_masks(float *out, size_t n_cnn, size_t n_enc, size_t n_dec, float p_cnn, float p_enc, float p_dec,
                         uint64_t seed, uint64_t stream_id, const uint64_t *dev_stream_id, void *stream) {
     ARG(out, "dropout_masks: NULL output");

@@ -187,9 +187,8 @@ struct DecoderLds {
 // uv_in_lds = false: the gate images of the visual memories U_vis [M,4H] (the largest resident block: 102 KB for an
 // 8x8 grid at H = 100) stay in global memory and the two phases that read them stream them from L2 every step.
 __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bool cond, bool backward,
-                                                  bool uv_in_lds = true, bool waves16 = false) {
-    // padded length of every vector a dot reads: two halves (a row over a lane pair) or four quarters (16-wave kernel)
-    const int HP = waves16 ? 4 * dec16_k0(H) : 2 * (((H / 2 + 3) / 4) * 4);
+                                                  bool uv_in_lds = true) {
+    const int HP = 2 * (((H / 2 + 3) / 4) * 4);       // padded length of every vector a half_dot reads
     DecoderLds o;
     int p = 0;
     o.uv = p;  p += uv_in_lds ? M * 4 * H : 0;
@@ -200,7 +199,7 @@ __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bo
     o.dpkv = p; p += backward ? M * H : 0;
     o.dpkt = p; p += backward ? L * H : 0;
     o.vec = p;
-    p += (backward ? 7 * HP + 19 * H : 2 * HP + (waves16 ? 9 : 6) * H) + 256;      // 16 waves: + gh_s [H][4] behind the 256
+    p += (backward ? 7 * HP + 19 * H : 2 * HP + 6 * H) + 256;
     // scratch of the fused output head, overlaid on the memories (forward: after the loop; backward: before staging)
     const int head = backward ? kHeadChunk * V + V * 4 * H + 32 : kHeadChunk * (4 * H + 4 + V) + V * 4 * H;
     o.total = p > head ? p : head;
@@ -703,310 +702,6 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
     decoder_fwd_body<H, COND, GREEDY, UVL>(a);
 }
 
-// ------------------------------------------------------------------------------------------
-// The teacher-forced forward recurrence on SIXTEEN waves (1024 threads, 128 VGPRs: four waves per SIMD instead of
-// two).  Same phases, same barriers, same saved activations and the same epilogue as decoder_fwd_body; what changes is
-// how a phase's work is cut, so that every wave's dependent chains are about half as long and four waves per SIMD
-// cover each other's waits (the 8-wave kernel: VALU busy 49 % of SIMD cycles, 44 % of a wave's life waiting):
-//   * a weight row lives in the FOUR lanes of a quad (K0 = 28 floats each at H = 100, three slots = 84 registers; task
-//     map dec16_task in step.h); the dot phase ends in a quad butterfly, and the products with h go to LDS
-//     (gh_s [unit][gate], the projected queries) instead of staying in the owning lanes' registers;
-//   * scores: a wave per memory, 16 waves (the 36 cells of a 6 x 6 grid are three memories per wave, not five);
-//   * column sums: unit u belongs to the EIGHT lanes 8u .. 8u + 7, which split the memories eight ways (five 16-byte
-//     reads per lane over 36 cells, not nine) and add up with three DPP steps; the half-rows past the hidden size sum
-//     the context columns (as quads of four lanes over the command, as half-rows over the cells);
-//   * gates: lane (gate = lane % 4) of the unit's lanes activates one gate, lane 0 updates the cell.
-// ------------------------------------------------------------------------------------------
-template <int G = 8>
-__device__ __forceinline__ f32x4 group_sum4(f32x4 v) {     // sum over the 4 (G = 4) or 8 (G = 8) lanes of an aligned group
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        v[c] += dpp_move<0xb1, 0xf>(v[c]);        // quad_perm [1,0,3,2]
-        v[c] += dpp_move<0x4e, 0xf>(v[c]);        // quad_perm [2,3,0,1]
-        if (G == 8) v[c] += dpp_move<0x141, 0xf>(v[c]);   // row_half_mirror: the other quad of the eight
-    }
-    return v;
-}
-// sum_m alpha_m X[m][4c .. 4c+3] over m < n by the G lanes of a group: lane i of the group takes m = i, i + G, ...;
-// `rounds` (wave-uniform) >= ceil(n / G).  alpha_m lives in lane m of `alpha`; stride 0 = no column quad (result unused).
-template <int G>
-__device__ __forceinline__ f32x4 group_column_sum(const float *base, int stride, int n, int i, int rounds, float alpha) {
-    constexpr int U = 2;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < rounds; r += U) {
-        f32x4 x[U];
-        float am[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int m = (r + u) * G + i, mc = min(m, n - 1);
-            x[u] = *reinterpret_cast<const f32x4 *>(base + __mul24(mc, stride));
-            const float al = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mc, __float_as_int(alpha)));
-            am[u] = (m < n && r + u < rounds) ? al : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc += am[u] * x[u];
-    }
-    return group_sum4<G>(acc);
-}
-__device__ __forceinline__ float pick4(const f32x4 &v, int j) { return j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : v[3]; }
-
-// NS dots of register-resident quarter rows (KQ = H / 4 weights each) with the same LDS vector, whose quarters start
-// K0 = roundup(KQ, 4) floats apart (16-byte reads; the padding is never multiplied): two 16-byte reads in flight.
-template <int NS, int KQ, int K0>
-__device__ __forceinline__ void quarter_dots(const float (&w)[NS][KQ], const float *v, float (&out)[NS]) {
-    const float4 *v4 = reinterpret_cast<const float4 *>(v);
-    f32x2 a01[NS], a23[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) { a01[s] = f32x2{0.f, 0.f}; a23[s] = f32x2{0.f, 0.f}; }
-    float4 cur = v4[0];
-#pragma unroll
-    for (int q = 0; q < K0 / 4; ++q) {
-        const float4 nxt = q + 1 < K0 / 4 ? v4[q + 1] : cur;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int i0 = 4 * q, i1 = 4 * q + 1, i2 = 4 * q + 2, i3 = 4 * q + 3;
-            if (i0 < KQ) a01[s] += f32x2{w[s][i0 < KQ ? i0 : 0], i1 < KQ ? w[s][i1 < KQ ? i1 : 0] : 0.f} * f32x2{cur.x, cur.y};
-            if (i2 < KQ) a23[s] += f32x2{w[s][i2 < KQ ? i2 : 0], i3 < KQ ? w[s][i3 < KQ ? i3 : 0] : 0.f} * f32x2{cur.z, cur.w};
-        }
-        cur = nxt;
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) out[s] = (a01[s].x + a01[s].y) + (a23[s].x + a23[s].y);
-}
-
-template <int H, bool COND>
-__device__ __forceinline__ void decoder_fwd16_body(const DecoderArgs &a) {
-    constexpr int NT = kDec16Threads, K0 = dec16_k0(H), KQ = H / 4, HP = 4 * K0, NS = dec16_slots(H, COND);
-    constexpr int NQ2 = (COND ? 2 : 1) * H / 4;   // column quads of [PK_t | U2_t]
-    static_assert(H <= 100 && H % 4 == 0, "hidden size too large for the half-row roles");
-    static_assert(NQ2 <= 2 * (128 - H) && H / 4 <= 128 - H, "not enough spare half-rows for the context columns");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, nwave = NT / 64;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = a.T, L = a.L, M = a.M;
-    const DecoderLds o = decoder_lds(H, L, M, a.V, COND, false, true, true);
-    float *PKv = smem + o.pkv, *PKt = smem + o.pkt;
-    float *vec = smem + o.vec;
-    float *h_s = vec;                                       // dot input, zero-padded to HP
-    float *qt_s = vec + HP, *qv_s = qt_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H;
-    float *qh_s = vv_s + H;                                 // W_q2k[:, :H] h (conditional)
-    float *q2_s = qh_s + H;                                 // dot input, zero-padded to HP
-    float *sc_s = q2_s + HP, *bq_s = sc_s + 64, *stamp_acc = sc_s + 192, *gh_s = sc_s + 256;   // gh_s [H][4]: W_hh h, unit-major
-    long long stamp_prev = a.stamps ? clock64() : 0;
-    int len = a.cmd_lengths[b];
-    len = max(1, min(len, L));
-    // A wave's column-sum rounds: eight lanes per unit; the waves that hold spare quads walk the command four ways
-    const bool wave_has_spare = 8 * wave + 7 >= H;          // wave-uniform
-    // Everything a lane derives from its thread number (roles, LDS column addresses, gate constants) is recomputed
-    // where it is used from an opaque copy of tid: kept live across the loop those twenty-odd values push the
-    // 75 weight registers of the lane out to scratch memory (128-VGPR budget).
-
-    // ---- one-time loads: register image of the weights (coalesced), memories -> LDS -----------
-    float w[NS][KQ];                                        // the image pads a quarter row to K0 floats: the padding is not kept
-    {
-        const float4 *img4 = reinterpret_cast<const float4 *>(a.w_image16);
-#pragma unroll
-        for (int q = 0; q < NS * K0 / 4; ++q) {
-            const float4 v = img4[q * NT + tid];
-            const int s = (4 * q) / K0, i = (4 * q) % K0;
-            if (i < KQ) w[s][i] = v.x;
-            if (i + 1 < KQ) w[s][i + 1] = v.y;
-            if (i + 2 < KQ) w[s][i + 2] = v.z;
-            if (i + 3 < KQ) w[s][i + 3] = v.w;
-        }
-    }
-    stage_all<NT>(smem, stage_list(a, o, b, H, L, M, COND, true), tid);
-    if (tid < HP) { h_s[tid] = 0.f; q2_s[tid] = 0.f; }      // zero the padding of the dot inputs
-    if (tid < 16) stamp_acc[tid] = 0.f;
-    lds_barrier();
-    float c = 0.f;                                          // cell state: lane 0 of the unit's half-row
-    // the dot inputs h_s / q2_s keep element k at k + (K0 - KQ) (k / KQ): quarter j starts at j K0 (16-byte reads)
-    if (tid < H) {
-        h_s[tid + (K0 - KQ) * (tid / KQ)] = a.hprev[(int64_t)b * T * H + tid];
-        vt_s[tid] = a.v_t[tid];
-        vv_s[tid] = a.v_v[tid];
-    }
-    if ((tid >> 3) < H && (tid & 7) == 0)                   // c0 = h0 unless given (seq2seq_model.py:494-504)
-        c = a.c0 ? a.c0[(int64_t)b * H + (tid >> 3)] : a.hprev[(int64_t)b * T * H + (tid >> 3)];
-    if (COND && tid < H) bq_s[tid] = a.b_q2k[tid];
-    float att_acc = 0.f;                                    // wave 0, lane m
-    lds_barrier();
-    __builtin_amdgcn_s_waitcnt(kWaitVmcnt0);                // the weight registers are complete (see decoder_fwd_body)
-    GSCAN_STAMP_ONCE(10)
-
-    for (int t = 0; t < T; ++t) {
-        GSCAN_STAMP(0)
-        const unsigned bt = (unsigned)b * T + t;
-        // embedding part of this lane's gate (+ both biases): issued first, consumed in phase F
-        float ge;
-        {
-            const int x = opaque(tid), hr = x >> 3;
-            ge = a.ge[bt * 4 * H + (hr < H ? (x & 3) * H + hr : 0)];
-        }
-
-        // ---- A: everything that multiplies h_{t-1} -------------------------------------------
-        {
-            const int x = opaque(tid), j4 = x & 3, quad = x >> 2;
-            float gh[NS];
-            quarter_dots<NS, KQ, K0>(w, h_s + j4 * K0, gh);  // rows >= 6H (phase D rows) compute an unused value
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const float acc = quad_sum(gh[s]);
-                const int r = dec16_task(s, quad, H, COND);
-                if (j4 == 0 && r >= 0 && r < 6 * H) {
-                    if (r < 4 * H) { const int g = r / H; gh_s[4 * (r - g * H) + g] = acc; }
-                    else if (r < 5 * H) qt_s[r - 4 * H] = acc;
-                    else if (COND) qh_s[r - 5 * H] = acc;
-                    else qv_s[r - 5 * H] = acc;
-                }
-            }
-        }
-        lds_barrier();
-        GSCAN_STAMP(1)
-
-        // ---- B: textual scores s_m = v . tanh(q + PK_m), m < len (seq2seq_model.py:129-135) --
-        attention_scores<H>(vt_s, qt_s, PKt, len, sc_s, wave, nwave, opaque(tid) & 63);
-        lds_barrier();
-        GSCAN_STAMP(2)
-        // ---- C: softmax over the command in every wave's registers (lane m holds alpha_m), then the column sums
-        // sum_m alpha_m [U_t | PK_t | U2_t][m, :]
-        float uct_g;                                         // this lane's gate of its unit, textual part
-        {
-            const int x = opaque(tid), lane = x & 63, j4 = x & 3, hrow = x >> 3;
-            float alpha;
-            {
-                const float sx = (lane < len) ? sc_s[lane] : -INFINITY;
-                const float mx = wave_max(sx);
-                const float e = (lane < len) ? __expf(sx - mx) : 0.f;
-                alpha = e * __builtin_amdgcn_rcpf(wave_sum(e));
-            }
-            const bool unit_role = hrow < H;
-            if (!wave_has_spare) {
-                uct_g = pick4(group_column_sum<8>(smem + o.ut + 4 * hrow, 4 * H, len, x & 7, (len + 7) >> 3, alpha), j4);
-            } else {
-                // a wave with spare quads: every lane walks the command four ways (ceil(len / 4) rounds); the unit lanes
-                // read their U_t column quad (the two quads of a unit do the same work), the spare quads theirs
-                const int sq = (x >> 2) - 2 * H;                // spare quad index
-                const bool has2 = sq >= 0 && sq < NQ2;
-                const int off = unit_role ? o.ut + 4 * hrow : (!has2 ? o.pkt : (4 * sq < H ? o.pkt + 4 * sq : o.u2t + (4 * sq - H)));
-                const int stride = unit_role ? 4 * H : (has2 ? H : 0);
-                uct_g = pick4(group_column_sum<4>(smem + off, stride, len, j4, (len + 3) >> 2, alpha), j4);
-                const int colq = 4 * sq + j4;
-                if (has2) {
-                    if (colq < H) {
-                        a.s[bt * 4 * H + H + colq] = uct_g;
-                        a.qt[bt * H + colq] = qt_s[colq];
-                    } else {                                    // conditional query (seq2seq_model.py:394-396)
-                        const float q = tanhf_(uct_g + qh_s[colq - H] + bq_s[colq - H]);
-                        q2_s[colq - H + (K0 - KQ) * ((colq - H) / KQ)] = q;
-                        a.q2[bt * H + colq - H] = q;
-                    }
-                }
-            }
-            if (wave == 0 && lane < L) a.alpha_c[bt * L + lane] = alpha;
-        }
-        if (COND) {
-            lds_barrier();
-            GSCAN_STAMP(3)
-            // ---- D: visual query from the conditional query ---------------------------------
-            const int x = opaque(tid), j4 = x & 3, quad = x >> 2;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (dec16_spares_before(s + 1, H) > 2 * H) {            // this slot holds rows of [6H, 7H) (folds at compile time)
-                    float o1[1];
-                    quarter_dots<1, KQ, K0>(reinterpret_cast<const float(&)[1][KQ]>(w[s]), q2_s + j4 * K0, o1);
-                    const float acc = quad_sum(o1[0]);
-                    const int r = dec16_task(s, quad, H, COND);
-                    if (j4 == 0 && r >= 6 * H) { qv_s[r - 6 * H] = acc; a.qv[bt * H + r - 6 * H] = acc; }
-                }
-            }
-        } else if (tid < H) {
-            a.qv[bt * H + tid] = qv_s[tid];
-        }
-        lds_barrier();
-        GSCAN_STAMP(5)
-
-        // ---- E: visual scores over all M cells (no mask: every row has M memories) -----------
-        attention_scores<H>(vv_s, qv_s, PKv, M, sc_s, wave, nwave, opaque(tid) & 63);
-        lds_barrier();
-        GSCAN_STAMP(6)
-        // ---- F: softmax, column sums over the cells, gates, cell update (seq2seq_model.py:414) ----
-        {
-            const int x = opaque(tid), lane = x & 63, gate = x & 3, i8 = x & 7, hrow = x >> 3;
-            float alpha;
-            {
-                const float sx = (lane < M) ? sc_s[lane] : -INFINITY;
-                const float mx = wave_max(sx);
-                const float e = (lane < M) ? __expf(sx - mx) : 0.f;
-                alpha = e * __builtin_amdgcn_rcpf(wave_sum(e));
-                if (wave == 0) {
-                    if (lane < M) a.alpha_s[bt * M + lane] = alpha;
-                    att_acc += alpha;                          // seq2seq_model.py:479,490
-                }
-            }
-            // unit half-rows sum their U_v column quad, the first H/4 half-rows behind them the PK_v column quads (= the
-            // visual context)
-            const bool unit_role = hrow < H;
-            const int sh = hrow - H;
-            const bool ctx_role = sh >= 0 && sh < H / 4;
-            const int off = unit_role ? o.uv + 4 * hrow : o.pkv + (ctx_role ? 4 * sh : 0);
-            const int stride = unit_role ? 4 * H : (ctx_role ? H : 0);
-            const f32x4 ucv = group_column_sum<8>(smem + off, stride, M, i8, (M + 7) >> 3, alpha);
-            if (unit_role) {
-                // one gate per lane (both quads of the half-row do the same): i, f, o = sigmoid, g = tanh, as a * sigmoid(s x) + c
-                const float act_s = gate == 2 ? -2.8853900817779268f : -1.4426950408889634f;
-                const float act_a = gate == 2 ? 2.f : 1.f, act_c = gate == 2 ? -1.f : 0.f;
-                const float pre = ge + gh_s[4 * hrow + gate] + uct_g + pick4(ucv, gate);
-                const float act = fmaf(act_a, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(act_s * pre)), act_c);
-                const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
-                if (i8 < 4) a.gates[bt * 4 * H + gate * H + hrow] = act;
-                if (i8 == 0) {
-                    c = gf * c + gi * gg;
-                    const float h = go * tanhf_(c);
-                    h_s[hrow + (K0 - KQ) * (hrow / KQ)] = h;
-                    a.cells[bt * H + hrow] = c;
-                    a.s[bt * 4 * H + 3 * H + hrow] = h;
-                    if (t + 1 < T) a.hprev[(bt + 1) * H + hrow] = h;
-                }
-            } else if (ctx_role && i8 < 4) {
-                a.s[bt * 4 * H + 2 * H + 4 * sh + i8] = pick4(ucv, i8);
-            }
-        }
-        lds_barrier();
-        GSCAN_STAMP(7)
-    }
-    const int lane = tid & 63;
-    if (a.h_last && tid < H) a.h_last[(int64_t)b * H + tid] = h_s[tid + (K0 - KQ) * (tid / KQ)];   // h_T (behind the loop's last barrier)
-    if (wave == 0) {
-        if (lane < M) a.att_sum[(int64_t)b * M + lane] = att_acc;
-        if (a.aux_saved) {                                   // auxiliary head: log_softmax over the cells (model.py:205)
-            const float x = (lane < M) ? att_acc : -INFINITY;
-            const float mx = wave_max(x);
-            const float lse = mx + logf(wave_sum((lane < M) ? expf(x - mx) : 0.f));
-            if (lane < M) {
-                a.aux_saved[(int64_t)b * M + lane] = x - lse;
-                a.aux_out[(int64_t)b * M + lane] = x - lse;
-            }
-            if (a.row_stats) {                               // get_auxiliary_loss (model.py:162-164), this row's term
-                const int64_t pos = a.positions ? a.positions[b] : (int64_t)-1;
-                const float nll = wave_sum((lane < M && lane == pos) ? lse - x : 0.f);
-                if (lane == 0) a.row_stats[4 * b + 2] = nll;
-            }
-        } else if (a.row_stats && lane == 0) {
-            a.row_stats[4 * b + 2] = 0.f;
-        }
-    }
-    if (a.stamps && blockIdx.x == 0 && tid < 10) a.stamps[tid] = stamp_acc[tid];
-    head_epilogue<H, NT>(a, smem, b, tid, lane, wave, T);
-    GSCAN_STAMP_ONCE(11)
-}
-
-template <int H, bool COND>
-__global__ __launch_bounds__(kDec16Threads) void decoder_fwd16_kernel(DecoderArgs a) {
-    TraceScope trace_scope(TK_DECODER_FWD);
-    decoder_fwd16_body<H, COND>(a);
-}
-
 // Backward of s_m = v . tanh(q + PK_m) for one attention.  Lane m of `dsm` holds d s_m.  Wave w owns the memories
 // w, w+nwave, ...; a lane owns features (lane, lane+64):  dPK[m][k] += ds_m v_k (1 - th^2)  (accumulated over the
 // T steps in LDS), the same term summed over this wave's memories goes to part_s[wave][k] (-> d q_k after the
@@ -1441,15 +1136,6 @@ __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a)
 // ------------------------------------------------------------------------------------------
 constexpr size_t kLdsLimit = 160 * 1024;
 
-// Hidden sizes with a 16-wave forward kernel (the benchmark's; each one is two more kernels to compile)
-constexpr bool dec16_compiled(int H) { return H == 100; }
-// GSCAN_DEC16=1: teacher-forced forward passes of a compiled hidden size whose memories fit LDS take the 16-wave kernel
-bool decoder_fwd16_enabled(const gscan_dims &d) {
-    static const int on = [] { const char *e = getenv("GSCAN_DEC16"); return e ? atoi(e) : 0; }();
-    if (!on || !dec16_compiled(d.H) || d.L > 64 || d.G * d.G > 64) return false;
-    return (size_t)decoder_lds(d.H, d.L, d.G * d.G, d.V, d.conditional != 0, false, true, true).total * sizeof(float) <= kLdsLimit;
-}
-
 constexpr int kStreamMinHidden = 84;   // hidden sizes from here on have a U_vis-streaming instantiation
 
 template <int H, bool COND>
@@ -1484,21 +1170,6 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
         return 0;
     };
     if (greedy) GSCAN_CHECK(a.V <= 64 && a.head_wc && a.dec_emb && a.steps_out, "greedy decoder: missing tables or V > 64");
-    if constexpr (dec16_compiled(H)) {
-        if (!backward && !greedy && a.w_image16) {          // the 16-wave forward kernel (decoder_fwd16_enabled said yes)
-            const size_t bytes16 = (size_t)decoder_lds(H, a.L, a.M, a.V, COND, false, true, true).total * sizeof(float);
-            GSCAN_CHECK(bytes16 <= kLdsLimit, "16-wave decoder: %zu bytes of LDS per row", bytes16);
-            static bool attr16 = false;
-            if (!attr16) {
-                GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fwd16_kernel<H, COND>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-                attr16 = true;
-            }
-            hipLaunchKernelGGL((decoder_fwd16_kernel<H, COND>), dim3(B), dim3(kDec16Threads), bytes16, stream, a);
-            GSCAN_LAUNCHED("decoder_fwd16_kernel");
-            return 0;
-        }
-    }
     if constexpr (H >= kStreamMinHidden) {
         if (!uvl) {
             if (backward) return launch(decoder_bwd_kernel<H, COND, false>, "decoder_bwd_kernel");

@@ -97,62 +97,16 @@ __host__ __device__ inline int decoder_gate_row(int r, int H) {
     const int slot = r / kDecPairs, pr = r % kDecPairs, unit = 64 * slot + pr / 4, gate = slot ? 3 - pr % 4 : pr % 4;
     return gate * H + unit;
 }
-// ---- the 16-wave forward kernel (decoder.hip, decoder_fwd16_kernel): 1024 threads, a weight row over the FOUR lanes of a
-// quad.  Tasks of (slot, quad), quad = tid / 4 in 0..255, row = quad / 4 (a DPP row of sixteen lanes), g = quad % 4:
-//   slots 0 and 1: W_hh row of (gate g, unit 64 slot + row) where that unit exists;
-//   every other (slot, quad), in (slot, quad) order: the query rows 4H, 4H + 1, ... (W_query_text, then W_q2k[:, :H] or
-//   W_query_vis, then W_query_vis of the conditional query), until they run out.
-constexpr int kDec16Threads = 1024, kDec16Quads = 256;
-__host__ __device__ constexpr int dec16_k0(int H) { return ((H + 3) / 4 + 3) / 4 * 4; }      // quarter row, padded to 16 bytes
-__host__ __device__ constexpr int dec16_spares_before(int slot, int H) {                      // query-row slots in slots < slot
-    int n = 0;
-    for (int s = 0; s < slot; ++s) {
-        const int lo = s < 2 ? (H - 64 * s < 0 ? 0 : (H - 64 * s > 64 ? 64 : H - 64 * s)) : 0;   // rows [0, lo) hold gate rows
-        n += (64 - lo) * 4;
-    }
-    return n;
-}
-__host__ __device__ constexpr int dec16_task(int slot, int quad, int H, bool cond) {          // weight row r, or -1
-    const int row = quad >> 2, g = quad & 3;
-    const int lo = slot < 2 ? (H - 64 * slot < 0 ? 0 : (H - 64 * slot > 64 ? 64 : H - 64 * slot)) : 0;
-    if (row < lo) return g * H + 64 * slot + row;
-    const int e = dec16_spares_before(slot, H) + (row - lo) * 4 + g;
-    return e < (cond ? 3 : 2) * H ? 4 * H + e : -1;
-}
-__host__ __device__ constexpr int dec16_slots(int H, bool cond) {
-    int s = H > 64 ? 2 : 1;
-    while (dec16_spares_before(s, H) < (cond ? 3 : 2) * H) ++s;
-    return s;
-}
-static inline int64_t dec16_image_floats(int H, bool cond) { return (int64_t)dec16_slots(H, cond) * dec16_k0(H) * kDec16Threads; }
-
 struct DecoderImageArgs {
     const float *w_hh, *w_qt, *w_qv, *w_q2k, *w_o2h;
     float *fwd_image, *bwd_image;
     int H, cond, slots, k0;
-    float *fwd16_image;     // image of the 16-wave forward kernel: element i of thread tid at ((i / 4) * 1024 + tid) * 4 + i % 4
 };
 #ifdef __HIPCC__
 // element e of the concatenation [fwd image | bwd image]
 __device__ __forceinline__ void decoder_image_element(const DecoderImageArgs &a, int e) {
     const int H = a.H, total = a.slots * a.k0 * kDecThreads;
     // every image is stored in 16-byte groups: element i of thread tid sits at ((i / 4) * 512 + tid) * 4 + i % 4
-    if (e >= 2 * total) {        // the 16-wave forward kernel's image: quarter j = tid % 4 of the row of (slot, quad)
-        const int x = e - 2 * total, k0 = dec16_k0(H);
-        const int tid = (x >> 2) % kDec16Threads, f = 4 * (x / (4 * kDec16Threads)) + (x & 3), i = f % k0, sl = f / k0;
-        // quarter j = tid % 4 of a row holds elements [j H/4, (j + 1) H/4), padded to k0 floats
-        const int r = dec16_task(sl, tid >> 2, H, a.cond != 0), kk = (tid & 3) * (H / 4) + i;
-        float v = 0.f;
-        if (r >= 0 && i < H / 4) {
-            const int sg = r / H, q = r % H;
-            if (sg < 4) v = a.w_hh[(int64_t)r * H + kk];
-            else if (sg == 4) v = a.w_qt[(int64_t)q * H + kk];
-            else if (sg == 5) v = a.cond ? a.w_q2k[(int64_t)q * 2 * H + kk] : a.w_qv[(int64_t)q * H + kk];
-            else v = a.w_qv[(int64_t)q * H + kk];
-        }
-        a.fwd16_image[x] = v;
-        return;
-    }
     const bool bwd = e >= total;
     const int x = bwd ? e - total : e;
     const int tid = (x >> 2) % kDecThreads, f = 4 * (x / (4 * kDecThreads)) + (x & 3), i = f % a.k0, s = f / a.k0;
@@ -321,7 +275,6 @@ struct DecoderArgs {
     const float *pk_v, *u_v;           // [B,M,H] [B,M,4H]
     const float *ge;                   // [B,T,4H] embedding part of the gates + both biases
     const float *w_image;              // register image of the recurrent weights (decoder_image_element)
-    const float *w_image16;            // the same for the 16-wave forward kernel, or NULL: the 8-wave kernel runs
     const float *b_q2k, *v_t, *v_v;
     float *hprev;                      // [B,T,H]  hprev[b,0] = h0 (= c0 unless c0 is given) on entry; kernel fills t+1
     const float *c0;                   // [B,H] initial cell state, or NULL for c0 = h0 (seq2seq_model.py:494-504)
@@ -362,7 +315,6 @@ struct DecoderArgs {
     int32_t *steps_out;                // [B] steps taken
 };
 bool decoder_hidden_supported(int h);
-bool decoder_fwd16_enabled(const gscan_dims &d);      // the teacher-forced forward pass of this shape takes the 16-wave kernel
 size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward);
 int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
 
@@ -406,7 +358,7 @@ struct Workspace {
     int64_t feat, pkv, uv, xe, gx, enc_out, hN, enc_gates, enc_cells, enc_hprev, pkt, ut, u2t, bsum, hprev, S,
         ge, cells, gates, alpha_c, alpha_s, q2, qt, qv, att_sum, logits, logp_saved, aux_saved, row_stats, dlogits,
         dS, datt, delta, dzq, dqt, dqv, dpk_t, dpk_v, dv_t, dv_v, dh0, denc, dhN, enc_delta, dxe, dfeat, stamps,
-        dwc, wih_stack, wih_t, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, dec_w_fwd16, enc_w_image, conv_img, conv_flags, conv_lists, wcat5,
+        dwc, wih_stack, wih_t, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, enc_w_image, conv_img, conv_flags, conv_lists, wcat5,
         deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image,   // encoder layers below the last
         ge_table, head_wc,        // [V,4H] tables: greedy decoding's embedded gates; the composite head
         gemm_slabs_side, gemm_slabs_main;

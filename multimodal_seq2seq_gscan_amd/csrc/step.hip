@@ -66,7 +66,6 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(w_2kk, H * He);
     SLOT(dec_w_fwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
     SLOT(dec_w_bwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
-    SLOT(dec_w_fwd16, decoder_fwd16_enabled(d) ? dec16_image_floats(d.H, d.conditional != 0) : 0);
     SLOT(enc_w_image, D * 4 * He * He);
     SLOT(hprev, B * T * H);
     SLOT(S, B * T * 4 * H);
@@ -290,8 +289,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.zero_extra_count = (ws.dxe + (int64_t)B * L * E) - ws.enc_out;
         const DecoderGeometry geo = decoder_geometry(H, cond);
         a.img = DecoderImageArgs{p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, p.out2hid_w, w + ws.dec_w_fwd,
-                                 w + ws.dec_w_bwd, H, cond ? 1 : 0, geo.slots, geo.k0, w + ws.dec_w_fwd16};
-        const int64_t img16 = decoder_fwd16_enabled(d) ? dec16_image_floats(H, cond) : 0;
+                                 w + ws.dec_w_bwd, H, cond ? 1 : 0, geo.slots, geo.k0};
         a.enc_w_hh_f = p.enc_w_hh; a.enc_w_hh_r = p.enc_w_hh_rev; a.enc_image = w + ws.enc_w_image;
         a.enc_b_ih_f = p.enc_b_ih; a.enc_b_hh_f = p.enc_b_hh; a.enc_b_ih_r = p.enc_b_ih_rev; a.enc_b_hh_r = p.enc_b_hh_rev;
         a.enc_rows = encoder_rows_per_thread(He);
@@ -301,7 +299,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.w_sk = w + ws.w_sk; a.w_ck = w + ws.w_ck; a.w_2kk = w + ws.w_2kk;
         const int64_t n[14] = {4 * H, (int64_t)V * 4 * H, (int64_t)D * 4 * He * (E + 1), (int64_t)V * 4 * H,
                                given ? 0 : (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
-                               a.zero_extra_count, 2 * geo.image_floats + img16,
+                               a.zero_extra_count, 2 * geo.image_floats,
                                (int64_t)D * 4 * He * He, (given || fuse_world) ? 0 : conv_image_floats(C, Co, d.K3),
                                (int64_t)4 * H * F, (int64_t)4 * H * He, cond ? (int64_t)H * He : 0};
         int64_t acc = 0;
@@ -463,7 +461,6 @@ int step_forward(const gscan_dims &d, const gscan_params &p, const gscan_batch &
     // T steps, and the auxiliary log_softmax over the summed visual attention (model.py:205)
     DecoderArgs a = decoder_args(d, p, bt, w, ws);
     a.w_image = w + ws.dec_w_fwd;
-    a.w_image16 = decoder_fwd16_enabled(d) ? w + ws.dec_w_fwd16 : nullptr;
     a.logp_out = logp;
     a.aux_out = d.auxiliary ? aux_logp : nullptr;
     a.stamps = probe_stamps_enabled() ? w + ws.stamps : nullptr;

@@ -264,7 +264,6 @@ class Model(nn.Module):
         self._mask_buffer_deep = None
         self._dummy_aux = None
         self._mask_key = None
-        self._mask_stream_id = None      # device uint64 holding the Philox stream id (graph replay), or None
         self._anchor = None
         self._decode_state = None        # dims / batch of the last encode_input (greedy decoding)
         self._flatten()
@@ -399,7 +398,7 @@ class Model(nn.Module):
             self._predrawn = None
             _lib.check(lib.gscan_dropout_masks(buf.data_ptr(), sizes[0], sizes[1], sizes[2], self.dropout_p[0],
                                                self.dropout_p[1], self.dropout_p[2], self._dropout_seed,
-                                               self._philox_stream(), _lib.ptr(self._mask_stream_id),
+                                               self._philox_stream(), None,
                                                torch.cuda.current_stream().cuda_stream), "gscan_dropout_masks")
         deep_stream = self._philox_stream(deep=True)
         self._dropout_calls += 1
@@ -409,9 +408,6 @@ class Model(nn.Module):
             off += n
         if h["NL"] > 1 and self.dropout_p[1] > 0.0:
             # nn.LSTM(dropout=p) drops the outputs of every layer but the last (seq2seq_model.py:44-45)
-            if self._mask_stream_id is not None:
-                raise NotImplementedError("graph replay with more than one encoder layer: the inter-layer masks "
-                                          "are drawn with a host-side Philox stream id")
             D = 2 if self.encoder_bidirectional else 1
             shape = (h["NL"] - 1, B, L, D * h["He"])
             n = shape[0] * shape[1] * shape[2] * shape[3]
@@ -530,8 +526,6 @@ class Model(nn.Module):
         device = commands_input.device
         lengths = _as_int32_lengths(commands_lengths, device)
         B, L = commands_input.shape
-        if self._mask_stream_id is not None:      # a TrainStep owns the device-side Philox stream id: keep it moving
-            self._mask_stream_id.fill_(self._philox_stream())
         masks = self._draw_masks(B, L, target_batch.shape[1], situations_input.shape[1] ** 2, device)
         if torch.is_grad_enabled():
             logp, aux = _NetworkFunction.apply(self._anchor, self, commands_input, lengths, situations_input,

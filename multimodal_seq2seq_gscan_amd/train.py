@@ -34,9 +34,7 @@ logger = logging.getLogger(__name__)
 class FlatAdam:
     """torch.optim.Adam(lr, betas) + LambdaLR(lr_decay ** (t / lr_decay_steps)) of train.py:67-70 over
     the model's flat parameter buffer: one fused HIP kernel per step, which also clears the gradient buffer
-    (optimizer.zero_grad(), train.py:113).  Launched eagerly the step-dependent scalars are kernel arguments;
-    for a captured graph they live in a two-float device buffer refreshed from the host before each replay,
-    so the captured launch is identical every step."""
+    (optimizer.zero_grad(), train.py:113).  The step-dependent scalars are kernel arguments."""
 
     def __init__(self, model: Model, learning_rate: float, adam_beta_1: float = 0.9, adam_beta_2: float = 0.999,
                  lr_decay: float = 0.9, lr_decay_steps: float = 20000.0, eps: float = 1e-8):
@@ -51,8 +49,6 @@ class FlatAdam:
         flat = model.flat_parameters
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
-        self._host_scalars = torch.zeros(2, dtype=torch.float32).pin_memory() if flat.is_cuda else torch.zeros(2)
-        self._dev_scalars = torch.zeros(2, dtype=torch.float32, device=flat.device)
 
     def current_lr(self) -> float:
         """What scheduler.get_lr()[0] prints at train.py:123 after `steps_taken` scheduler steps."""
@@ -72,22 +68,14 @@ class FlatAdam:
             return self._resume_lr
         return self.lr * self.lr_decay ** ((self.lr_steps - 1) / self.lr_decay_steps)
 
-    def stage_scalars(self) -> None:
-        """Host side of one step: advance the counters, push [lr_t/(1-b1^t), 1/sqrt(1-b2^t)] to the device."""
-        lib = _lib.load()
-        self.advance()
-        lib.gscan_adam_scalars(self._lr_of_this_step(), self.betas[0], self.betas[1], 1.0, 1.0,
-                               self.steps_taken, self._host_scalars.data_ptr())
-        self._dev_scalars.copy_(self._host_scalars, non_blocking=True)
-
     def launch_with_next_masks(self, count: Optional[torch.Tensor]) -> bool:
         """Adam + zero_grad (divided by `count` when given) AND the dropout masks of the next step in one launch
         (`gscan_adam_step_masks`), for a next batch of the shape the model saw last: the masks depend on a counter
         only, so the launch at the head of the next step disappears.  Returns False (nothing launched) when there
-        are no device-drawn masks to draw ahead (eval / p = 0 / host masks / graph replay / deeper encoders)."""
+        are no device-drawn masks to draw ahead (eval / p = 0 / host masks / deeper encoders)."""
         m = self.model
         if (m._mask_key is None or m._mask_buffer is None or m._host_masks is not None or not m.training
-                or max(m.dropout_p) <= 0.0 or m._mask_stream_id is not None or m._hyper["NL"] > 1):
+                or max(m.dropout_p) <= 0.0 or m._hyper["NL"] > 1):
             return False
         lib = _lib.load()
         sizes = m._mask_key
@@ -111,25 +99,18 @@ class FlatAdam:
                                             self.betas[1], self.eps, 1.0, 1.0, self.steps_taken, count.data_ptr(),
                                             torch.cuda.current_stream().cuda_stream), "gscan_adam_step_mean")
 
-    def launch(self, zero_grad: bool = True, device_scalars: bool = True) -> None:
+    def launch(self, zero_grad: bool = True) -> None:
         lib = _lib.load()
         m = self.model
-        if not device_scalars:
-            fn = lib.gscan_adam_step_zero_grad if zero_grad else lib.gscan_adam_step
-            _lib.check(fn(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(), self.exp_avg.data_ptr(),
-                          self.exp_avg_sq.data_ptr(), m.flat_parameters.numel(), self._lr_of_this_step(), self.betas[0],
-                          self.betas[1], self.eps, 1.0, 1.0, self.steps_taken, None,
-                          torch.cuda.current_stream().cuda_stream), "gscan_adam_step")
-            return
-        _lib.check(lib.gscan_adam_step_graph(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(),
-                                             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                             m.flat_parameters.numel(), self.betas[0], self.betas[1], self.eps,
-                                             self._dev_scalars.data_ptr(), int(zero_grad),
-                                             torch.cuda.current_stream().cuda_stream), "gscan_adam_step_graph")
+        fn = lib.gscan_adam_step_zero_grad if zero_grad else lib.gscan_adam_step
+        _lib.check(fn(m.flat_parameters.data_ptr(), m.flat_gradients.data_ptr(), self.exp_avg.data_ptr(),
+                      self.exp_avg_sq.data_ptr(), m.flat_parameters.numel(), self._lr_of_this_step(), self.betas[0],
+                      self.betas[1], self.eps, 1.0, 1.0, self.steps_taken, None,
+                      torch.cuda.current_stream().cuda_stream), "gscan_adam_step")
 
     def step(self, zero_grad: bool = True) -> None:
         self.advance()
-        self.launch(zero_grad, device_scalars=False)
+        self.launch(zero_grad)
 
     # ---- checkpoint interop with torch.optim.Adam (model.py:246-261 stores optimizer.state_dict()) ----
     def state_dict(self) -> dict:
@@ -300,14 +281,12 @@ class GradientExchange:
 class TrainStep:
     """One iteration of the reference loop (train.py:96-114) for this rank's rows of the minibatch.
 
-    `graph=True` captures the launch sequence of a step once per batch shape into HIP graphs
-    (torch.cuda.CUDAGraph is the stream-capture plumbing) and replays it: masks + forward + losses |
-    seeds + backward | Adam, cut only where the data-parallel all-reduces sit.  Everything that differs
-    between steps (Adam scalars, Philox stream id, the batch itself) is read from fixed device buffers."""
+    Launches are eager: replaying captured HIP graphs was built in round 2 and measured slower on this stack
+    (DESIGN.md 6), and is gone."""
 
     def __init__(self, model: Model, learning_rate: float = 1e-3, adam_beta_1: float = 0.9,
                  adam_beta_2: float = 0.999, lr_decay: float = 0.9, lr_decay_steps: float = 20000.0,
-                 weight_target_loss: float = 0.3, process_group=None, graph: bool = False,
+                 weight_target_loss: float = 0.3, process_group=None,
                  fused_loss: Optional[bool] = None, single_exchange: Optional[bool] = None,
                  always_collective: bool = False, on_gradients=None,
                  native_allreduce: Optional[bool] = None, **_):
@@ -317,7 +296,6 @@ class TrainStep:
         self.exchange = GradientExchange(process_group, always_collective, native_allreduce)
         # every rank draws its own dropout masks (Philox streams keyed by seed, rank and step)
         model.set_dropout_rank(self.exchange.rank)
-        self.graph = bool(graph)
         # on_gradients(flat mean-loss gradient of the global batch): called between the exchange and the optimiser
         # (which clears the buffer); diagnostics and tests only — it costs a device pass in the one-collective form
         self.on_gradients = on_gradients
@@ -329,25 +307,20 @@ class TrainStep:
         # Several processes, no auxiliary loss: every rank back-propagates its SUM loss, the statistics ride behind
         # the gradients in one all-reduce and Adam divides by the global token count.
         if single_exchange is None:
-            single_exchange = self.exchange.collective and not model.auxiliary_task and not self.graph
-        elif single_exchange and (model.auxiliary_task or self.graph):
-            raise ValueError("the one-collective step needs a single loss term and eager launches")
+            single_exchange = self.exchange.collective and not model.auxiliary_task
+        elif single_exchange and model.auxiliary_task:
+            raise ValueError("the one-collective step needs a single loss term")
         self.single_exchange = bool(single_exchange)
         if self.single_exchange:
             self.fused_loss = False
         # eager steps whose backward pass seeds itself (fused_loss, or the one-collective data-parallel form) make ONE
         # library call per iteration (gscan_train_step_nll; GSCAN_ONE_CALL=0: gscan_forward + gscan_backward_nll)
-        self.one_call = (not self.graph) and os.environ.get("GSCAN_ONE_CALL", "1") != "0"
+        self.one_call = os.environ.get("GSCAN_ONE_CALL", "1") != "0"
         device = model.flat_parameters.device
         self.stats = torch.zeros(4, dtype=torch.float32, device=device)
         self.seeds = torch.zeros(3, dtype=torch.float32, device=device)
-        self._graphs: Dict[tuple, dict] = {}
         model.flat_gradients.zero_()
         model.attach_gradients(zero=False)
-        if device.type == "cuda" and self.graph:
-            if model._mask_stream_id is None:     # one device slot per model: captured graphs keep its address
-                model._mask_stream_id = torch.zeros(1, dtype=torch.int64, device=device)
-            self._host_stream_id = torch.zeros(1, dtype=torch.int64).pin_memory()
 
     # ---- the three launch sections of a step ------------------------------------------------
     def _section_forward(self, batch, train_nll=None) -> dict:
@@ -387,15 +360,8 @@ class TrainStep:
         self.model._launch_backward(fw["call"], fw["dlogp"], fw["daux"], seeds=self.seeds, attach=False)
 
     def _host_prologue(self) -> None:
-        """Per-step host work.  Eager: only the step counter moves (scalars travel as kernel arguments).
-        Graph replay: optimizer scalars and the Philox stream id go to their device slots."""
-        if not self.graph:
-            self.optimizer.advance()
-            return
-        self.optimizer.stage_scalars()
-        self._host_stream_id[0] = self.model._philox_stream()
-        self.model._mask_stream_id.copy_(self._host_stream_id, non_blocking=True)
-        self.model._dropout_calls += 1
+        """Per-step host work: only the step counter moves (the scalars travel as kernel arguments)."""
+        self.optimizer.advance()
 
     def _result(self, fw: dict) -> Dict[str, torch.Tensor]:
         self.model.update_state(is_best=False)
@@ -406,7 +372,7 @@ class TrainStep:
         dist.destroy_process_group() / interpreter exit (bench.py and train_on_dataset do)."""
         self.exchange.close()
 
-    # ---- eager and captured execution -----------------------------------------------------------
+    # ---- execution ------------------------------------------------------------------------------
     def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """batch: commands [B,L] i64, cmd_lengths [B], world [B,G,G,C] f32, targets [B,T] i64 and, with the
         auxiliary task, target_positions [B] i64 — all on the HIP device.  Returns device scalars
@@ -415,8 +381,6 @@ class TrainStep:
         model.train()
         device = batch["commands"].device
         batch = dict(batch, cmd_lengths=_as_int32_lengths(batch["cmd_lengths"], device))
-        if self.graph:
-            return self._replay(batch)
         self._host_prologue()
         if self.single_exchange:
             store = model._grad_store
@@ -442,64 +406,8 @@ class TrainStep:
         if self.on_gradients is not None:
             self.on_gradients(model.flat_gradients)
         if not self.optimizer.launch_with_next_masks(None):
-            self.optimizer.launch(zero_grad=True, device_scalars=False)
+            self.optimizer.launch(zero_grad=True)
         return self._result(fw)
-
-    def _replay(self, batch) -> Dict[str, torch.Tensor]:
-        key = tuple((k, tuple(v.shape)) for k, v in sorted(batch.items()))
-        entry = self._graphs.get(key)
-        if entry is None:
-            entry = self._capture(batch)
-            self._graphs[key] = entry
-        for k, v in batch.items():
-            if entry["static"][k].data_ptr() != v.data_ptr():
-                entry["static"][k].copy_(v, non_blocking=True)
-        self._host_prologue()
-        entry["g_forward"].replay()
-        self.exchange.all_reduce(self.stats)
-        entry["g_backward"].replay()
-        self.exchange.all_reduce(self.model.flat_gradients)
-        entry["g_adam"].replay()
-        return self._result(entry["fw"])
-
-    def _capture(self, batch) -> dict:
-        static = {k: v.clone() for k, v in batch.items()}
-        # Captured launches keep the device addresses they were recorded with, so every shape's graphs get their OWN
-        # workspace and mask buffer, held by the entry: the model would otherwise replace (and the allocator recycle)
-        # the buffers of an earlier shape the moment a larger shape arrives.
-        model = self.model
-        model._workspace = model._mask_buffer = model._mask_key = None
-        # warm-up on a side stream (first launches set kernel attributes, allocate the workspace and masks)
-        saved_steps, saved_calls = (self.optimizer.steps_taken, self.optimizer.lr_steps), self.model._dropout_calls
-        params = self.model.flat_parameters.clone()
-        m, v = self.optimizer.exp_avg.clone(), self.optimizer.exp_avg_sq.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._host_prologue()
-            fw = self._section_forward(static)
-            self._section_backward(fw)
-            self.optimizer.launch(zero_grad=True)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        # the warm-up step must not count: restore parameters, moments and counters
-        self.model.flat_parameters.copy_(params)
-        self.optimizer.exp_avg.copy_(m)
-        self.optimizer.exp_avg_sq.copy_(v)
-        (self.optimizer.steps_taken, self.optimizer.lr_steps), self.model._dropout_calls = saved_steps, saved_calls
-        self.model.flat_gradients.zero_()
-        g_forward, g_backward, g_adam = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g_forward, pool=pool):
-            fw = self._section_forward(static)
-        with torch.cuda.graph(g_backward, pool=pool):
-            self._section_backward(fw)
-        with torch.cuda.graph(g_adam, pool=pool):
-            self.optimizer.launch(zero_grad=True)
-        self.model.flat_gradients.zero_()
-        self.model._dropout_calls = saved_calls
-        return {"static": static, "fw": fw, "g_forward": g_forward, "g_backward": g_backward, "g_adam": g_adam,
-                "buffers": (model._workspace, model._mask_buffer)}
 
 
 def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world_size: int) -> Dict[str, torch.Tensor]:

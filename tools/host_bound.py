@@ -15,7 +15,7 @@ torch.manual_seed(42)
 model = Model(**cfg).cuda()
 batch = {k: v.cuda() for k, v in make_batch(shape, seed=1234).items()}
 batch["cmd_lengths"] = batch["cmd_lengths"].to(torch.int32)
-step = TrainStep(model, learning_rate=1e-3, graph="--graph" in sys.argv)
+step = TrainStep(model, learning_rate=1e-3)
 for _ in range(10):
     step(batch)
 torch.cuda.synchronize()
