@@ -184,6 +184,66 @@ __global__ __launch_bounds__(kKbThreads, 4) void keys_backward_kernel(KeysBackwa
     }
 }
 
+// The same launch for ANY decoder hidden size (the kernel above is compiled for the sizes whose recurrent weights fit
+// the decoder's register file): plain loops, a thread per (memory, feature) of the tile in stage 1 and per (memory,
+// output column) in stage 2, the tile's dPK in LDS between the two.  Correctness first (decoder_any.hip's companion).
+__global__ __launch_bounds__(kKbThreads) void keys_backward_any_kernel(KeysBackwardArgs a, int H) {
+    TraceScope trace_scope(TK_KEYS_BWD);
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int T = a.T, L = a.L, M = a.M;
+    const int MTV = (M + 15) / 16, MTT = (L + 15) / 16, MT = MTV + MTT;
+    const int mt = blockIdx.y;
+    if (mt == MT) {              // bridge: d h_N[e] = sum_k d h0[k] * W_bridge[k][e]
+        float *dh_s = sm;
+        for (int k = tid; k < H; k += kKbThreads) dh_s[k] = a.dh0[(int64_t)b * H + k];
+        __syncthreads();
+        for (int e = tid; e < a.He; e += kKbThreads) {
+            float s0 = 0.f;
+            for (int k = 0; k < H; ++k) s0 = fmaf(dh_s[k], a.w_b[(int64_t)k * a.He + e], s0);
+            a.dhN[(int64_t)b * a.He + e] = s0;
+        }
+        return;
+    }
+    float *dpk_s = sm;                                   // [16][H]
+    const bool vis = mt < MTV;
+    const int mx = vis ? M : L, mbase = 16 * (vis ? mt : mt - MTV);
+    float *dpk_g = (vis ? a.dpk_v : a.dpk_t) + (int64_t)b * mx * H;
+    const float *alpha = vis ? a.alpha_s : a.alpha_c;
+    const int dcol = vis ? 2 * H : H;
+    // stage 1: dPK = (score path) + alpha^T . dctx
+    for (int idx = tid; idx < 16 * H; idx += kKbThreads) {
+        const int q = idx / H, k = idx - q * H, m = mbase + q;
+        float acc = 0.f;
+        if (m < mx) {
+            acc = dpk_g[(int64_t)m * H + k];
+            for (int t = 0; t < T; ++t) {
+                const int64_t bt = (int64_t)b * T + t;
+                acc = fmaf(alpha[bt * mx + m], a.ds[bt * 4 * H + dcol + k], acc);
+            }
+            dpk_g[(int64_t)m * H + k] = acc;
+        }
+        dpk_s[idx] = acc;
+    }
+    __syncthreads();
+    // stage 2: through the key layer
+    const int ncols = vis ? a.F : a.He;
+    const float *wsrc = vis ? a.w_kv : a.w_kt;
+    for (int idx = tid; idx < 16 * ncols; idx += kKbThreads) {
+        const int q = idx / ncols, col = idx - q * ncols, m = mbase + q;
+        if (m >= mx) continue;
+        float acc = 0.f;
+        for (int k = 0; k < H; ++k) acc = fmaf(dpk_s[q * H + k], wsrc[(int64_t)k * ncols + col], acc);
+        const int64_t at = ((int64_t)b * mx + m) * ncols + col;
+        if (vis) {               // feat = relu(conv) * mask  =>  d conv = (feat != 0) ? d feat * mask : 0
+            const float gate = a.feat[at], mk = a.mask ? a.mask[at] : 1.f;
+            a.dfeat[at] = (gate == 0.f) ? 0.f : acc * mk;
+        } else {
+            a.denc[at] = acc;
+        }
+    }
+}
+
 template <int H>
 static int launch_keys_backward(int B, const KeysBackwardArgs &a, hipStream_t stream) {
     const size_t bytes = (size_t)keys_lds(H).total * sizeof(float);
@@ -208,7 +268,20 @@ int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream) {
 #undef X
         default: break;
     }
-    GSCAN_CHECK(false, "keys backward: decoder_hidden_size %d has no compiled kernel (" GSCAN_DEC_HIDDEN_LIST ")", H);
+    {   // any other hidden size
+        const size_t bytes = (size_t)16 * H * sizeof(float);
+        GSCAN_CHECK(H >= 1 && bytes <= 160 * 1024, "keys backward: decoder_hidden_size %d", H);
+        static bool attr_set = false;
+        if (!attr_set) {
+            GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(keys_backward_any_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        const int tiles = (a.M + 15) / 16 + (a.L + 15) / 16;
+        hipLaunchKernelGGL(keys_backward_any_kernel, dim3(B, tiles + 1), dim3(kKbThreads), bytes, stream, a, H);
+        GSCAN_LAUNCHED("keys_backward_any_kernel");
+    }
+    return 0;
 }
 
 GSCAN_TRACE_TU(attention_grad)

@@ -170,7 +170,7 @@ int gscan_trace_set(unsigned long long *device_buffer) {
 #endif
     GSCAN_HIP(hipDeviceSynchronize());
     int rc = trace_set_gemm(device_buffer) | trace_set_gemm_mt(device_buffer) | trace_set_elementwise(device_buffer) | trace_set_loss(device_buffer) |
-             trace_set_lstm_encoder(device_buffer) | trace_set_decoder(device_buffer) |
+             trace_set_lstm_encoder(device_buffer) | trace_set_decoder(device_buffer) | trace_set_decoder_any(device_buffer) |
              trace_set_attention_grad(device_buffer) | trace_set_conv(device_buffer);
     GSCAN_CHECK(rc == 0, "trace_set: hipMemcpyToSymbol failed");
     GSCAN_HIP(hipDeviceSynchronize());
@@ -298,11 +298,11 @@ int gscan_encoder_lstm_forward(int B, int L, int He, int D, const float *gx, con
     ARG(gx && lengths && w_hh_fwd && b_hh_fwd && out && h_final && gates && cells && hprev && w_image_scratch,
         "encoder_lstm_forward: NULL argument");
     ARG(B > 0 && L > 0 && He > 0 && (D == 1 || D == 2), "encoder_lstm_forward: bad dims");
-    ARG(hidden_size_supported(He), "encoder_lstm_forward: hidden size has no compiled kernel");
     // the kernel accumulates the direction sums into out / h_final and reads its weights from a register image
     GSCAN_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * L * He, (hipStream_t)stream));
     GSCAN_HIP(hipMemsetAsync(h_final, 0, sizeof(float) * (size_t)B * He, (hipStream_t)stream));
-    if (int rc = encoder_weight_image(w_hh_fwd, w_hh_rev, He, D, w_image_scratch, (hipStream_t)stream)) return rc;
+    if (encoder_fast_supported(He, L, 0))
+        if (int rc = encoder_weight_image(w_hh_fwd, w_hh_rev, He, D, w_image_scratch, (hipStream_t)stream)) return rc;
     return encoder_lstm_forward(B, L, He, D, gx, lengths, w_hh_fwd, b_hh_fwd, w_hh_rev, b_hh_rev, out, h_final, gates,
                                 cells, hprev, w_image_scratch, (hipStream_t)stream);
 }

@@ -1196,10 +1196,18 @@ size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward) {
     return (size_t)decoder_lds(H, L, M, V, cond, backward, false).total * sizeof(float);
 }
 
+// The kernels of this file hold a row's memories in LDS and its attention distributions in the 64 lanes of a wave, and
+// are compiled for the hidden sizes whose recurrent weights fit the register file; every other shape runs on
+// decoder_any.hip's kernels (GSCAN_DECODER_ANY=1: every shape does, for tests).
+bool decoder_fast_supported(int H, int L, int M, int V, bool cond) {
+    static const int force_any = [] { const char *e = getenv("GSCAN_DECODER_ANY"); return e ? atoi(e) : 0; }();
+    if (force_any || !decoder_hidden_supported(H) || L > 64 || M > 64) return false;
+    return decoder_lds_bytes(H, L, M, V, cond, true) <= kLdsLimit && decoder_lds_bytes(H, L, M, V, cond, false) <= kLdsLimit;
+}
+
 int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream) {
     GSCAN_CHECK(B > 0 && a.T > 0 && a.L > 0 && a.M > 0, "decoder: bad dims B=%d T=%d L=%d M=%d", B, a.T, a.L, a.M);
-    GSCAN_CHECK(a.L <= 64 && a.M <= 64, "decoder: at most 64 command tokens / grid cells per row (L=%d, cells=%d)",
-                a.L, a.M);
+    if (!decoder_fast_supported(H, a.L, a.M, a.V, cond)) return decoder_run_any(backward, B, H, cond, a, stream);
     switch (H) {
 #define X(n) case n: return cond ? launch_decoder<n, true>(backward, B, a, stream) : launch_decoder<n, false>(backward, B, a, stream);
         GSCAN_DEC_HIDDEN_SIZES(X)

@@ -1,0 +1,527 @@
+// The decoder recurrence for ANY shape (seq2seq/seq2seq_model.py:359-492): every --decoder_hidden_size, command
+// length and grid size the reference accepts, where decoder.hip's kernels (weights in registers, memories in LDS, the
+// attention distribution in the 64 lanes of a wave) are compiled for hidden sizes up to 100 and hold at most 64
+// memories per attention.  Correctness first: one 256-thread workgroup per batch row as there, but
+//   * the weights are STREAMED from L2 every step, in the reference's own [out, in] layouts (no register images):
+//     a product with a vector is either "rows" (sixteen lanes per output row, 256-byte pieces of the row, a DPP sum)
+//     or "columns" (a lane per output column of the transposed product, coalesced across lanes);
+//   * the projected keys are read from global memory (no LDS residency: any number of memories), the attention
+//     distribution lives in LDS;
+//   * nothing depends on the hidden size at compile time except a 16-byte-load variant for multiples of 4.
+// Same arguments (DecoderArgs), same saved activations and the same outputs as the fast kernels — the two are
+// interchangeable per launch, and every launch behind them (the dS += product, keys backward, the weight-gradient
+// GEMMs) is unchanged.  At the benchmark shape this path is ~10 x slower than the fast one; it is what runs when the
+// fast one has no kernel for the shape (decoder_run picks).
+#include "anyshape.h"
+
+namespace gscan {
+
+// softmax of sc[0..n) in place (LDS) by wave 0; returns nothing, the caller synchronises
+__device__ __forceinline__ void softmax_lds(float *sc, int n) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        float mx = -INFINITY;
+        for (int m = tid; m < n; m += 64) mx = fmaxf(mx, sc[m]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int m = tid; m < n; m += 64) { const float e = __expf(sc[m] - mx); sc[m] = e; sum += e; }
+        const float inv = 1.f / wave_sum(sum);
+        for (int m = tid; m < n; m += 64) sc[m] *= inv;
+    }
+}
+
+// additive-attention scores sc[m] = v . tanh(q + PK[m]) for m < n: a wave per memory, lanes over the features
+__device__ __forceinline__ void scores_any(const float *v_s, const float *q_s, const float *__restrict__ pk, int n, int H,
+                                           float *sc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int m0 = 0; m0 < n; m0 += kAnyWaves) {
+        const int m = m0 + wave, mc = min(m, n - 1);
+        float p = 0.f;
+        for (int k = lane; k < H; k += 64) p = fmaf(v_s[k], tanhf_(q_s[k] + pk[(int64_t)mc * H + k]), p);
+        p = wave_sum(p);
+        if (lane == 0 && m < n) sc[m] = p;
+    }
+}
+
+struct AnyLds { int hc, qt, q2, qv, vt, vv, bq, pre, cell, sc, misc, total; };
+__host__ __device__ inline AnyLds any_lds_fwd(int H, int L, int M) {
+    const int HP = (H + 3) / 4 * 4, NM = ((L > M ? L : M) + 3) / 4 * 4;
+    AnyLds o;
+    int p = 0;
+    o.hc = p; p += 3 * HP + 4;         // [h | ctx_text | ctx_vis], contiguous: the inputs of W_q2k and of W_ih[:, H:3H]
+    o.qt = p; p += HP; o.q2 = p; p += HP; o.qv = p; p += HP; o.vt = p; p += HP; o.vv = p; p += HP; o.bq = p; p += HP;
+    o.pre = p; p += 4 * HP;            // gate pre-activations
+    o.cell = p; p += HP;
+    o.sc = p; p += NM;
+    o.misc = p; p += 64;
+    o.total = p;
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward (teacher forcing, or GREEDY: the row feeds its own argmax back and stops at <EOS>; predict.py:101-112)
+// ------------------------------------------------------------------------------------------
+template <bool V4, bool GREEDY>
+__global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArgs a, int H, int cond) {
+    TraceScope trace_scope(TK_DECODER_FWD);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = a.T, L = a.L, M = a.M, V = a.V;
+    const AnyLds o = any_lds_fwd(H, L, M);
+    float *hc = smem + o.hc, *qt_s = smem + o.qt, *q2_s = smem + o.q2, *qv_s = smem + o.qv, *vt_s = smem + o.vt,
+          *vv_s = smem + o.vv, *bq_s = smem + o.bq, *pre_s = smem + o.pre, *c_s = smem + o.cell, *sc = smem + o.sc;
+    int *tok_s = reinterpret_cast<int *>(smem + o.misc);
+    float *h_s = hc, *ctxt_s = hc + H, *ctxv_s = hc + 2 * H;
+    int len = a.cmd_lengths[b];
+    len = max(1, min(len, L));
+    const float *pk_t = a.pk_t + (int64_t)b * L * H, *pk_v = a.pk_v + (int64_t)b * M * H;
+    // the reference's own parameter layouts (row-major [out, in]), carried in the argument struct by decoder_run
+    const float *W_hh = a.any_w_hh, *W_ih = a.any_w_ih, *W_qt = a.any_w_qt, *W_qv = a.any_w_qv, *W_q2k = a.any_w_q2k;
+
+    for (int k = tid; k < H; k += kAnyThreads) {
+        const float h0 = a.hprev[(int64_t)b * (GREEDY ? 1 : T) * H + k];
+        h_s[k] = h0;
+        c_s[k] = a.c0 ? a.c0[(int64_t)b * H + k] : h0;                 // c0 = h0 unless given (seq2seq_model.py:494-504)
+        vt_s[k] = a.v_t[k];
+        vv_s[k] = a.v_v[k];
+        bq_s[k] = cond ? a.b_q2k[k] : 0.f;
+    }
+    if (tid == 0) tok_s[0] = GREEDY ? a.sos : 0;
+    for (int m = tid; m < M; m += kAnyThreads) a.att_sum[(int64_t)b * M + m] = 0.f;
+    __syncthreads();
+    int steps_done = 0;
+
+    for (int t = 0; t < T; ++t) {
+        const int64_t bt = (int64_t)b * T + t;
+        // ---- everything that multiplies h_{t-1}: W_query_text h, the gates' recurrent part
+        matvec_rows<V4>(W_qt, H, H, H, h_s, [&](int r, float v) { qt_s[r] = v; });
+        {
+            const int64_t ge_row = GREEDY ? (int64_t)tok_s[0] : bt;    // greedy: row of the [V, 4H] table of the token fed in
+            const float *ge = a.ge + ge_row * 4 * H;
+            matvec_rows<V4>(W_hh, H, 4 * H, H, h_s, [&](int r, float v) { pre_s[r] = v + ge[r]; });
+        }
+        __syncthreads();
+        // ---- textual attention (seq2seq_model.py:129-139)
+        scores_any(vt_s, qt_s, pk_t, len, H, sc);
+        __syncthreads();
+        softmax_lds(sc, len);
+        __syncthreads();
+        for (int m = tid; m < L; m += kAnyThreads) a.alpha_c[bt * L + m] = m < len ? sc[m] : 0.f;
+        for (int k = tid; k < H; k += kAnyThreads) {
+            float acc = 0.f;
+            for (int m = 0; m < len; ++m) acc = fmaf(sc[m], pk_t[(int64_t)m * H + k], acc);
+            ctxt_s[k] = acc;
+            if (!GREEDY) { a.s[bt * 4 * H + H + k] = acc; a.qt[bt * H + k] = qt_s[k]; }
+        }
+        __syncthreads();
+        // ---- the query of the visual attention: conditional (tanh(W_q2k [h; ctx_text] + b), :394-396) or h itself
+        if (cond) {
+            matvec_rows<V4>(W_q2k, 2 * H, H, 2 * H, hc, [&](int r, float v) {
+                const float q = tanhf_(v + bq_s[r]);
+                q2_s[r] = q;
+                if (!GREEDY) a.q2[bt * H + r] = q;
+            });
+            __syncthreads();
+        }
+        matvec_rows<V4>(W_qv, H, H, H, cond ? q2_s : h_s, [&](int r, float v) {
+            qv_s[r] = v;
+            if (!GREEDY) a.qv[bt * H + r] = v;
+        });
+        __syncthreads();
+        // ---- visual attention over all M cells
+        scores_any(vv_s, qv_s, pk_v, M, H, sc);
+        __syncthreads();
+        softmax_lds(sc, M);
+        __syncthreads();
+        for (int m = tid; m < M; m += kAnyThreads) {
+            a.alpha_s[bt * M + m] = sc[m];
+            a.att_sum[(int64_t)b * M + m] += sc[m];                    // seq2seq_model.py:479,490 (this thread's element)
+        }
+        for (int k = tid; k < H; k += kAnyThreads) {
+            float acc = 0.f;
+            for (int m = 0; m < M; ++m) acc = fmaf(sc[m], pk_v[(int64_t)m * H + k], acc);
+            ctxv_s[k] = acc;
+            if (!GREEDY) a.s[bt * 4 * H + 2 * H + k] = acc;
+        }
+        __syncthreads();
+        // ---- LSTM cell (seq2seq_model.py:414): the context part of the input product, then the gates
+        matvec_rows<V4>(W_ih + H, 3 * H, 4 * H, 2 * H, ctxt_s, [&](int r, float v) { pre_s[r] += v; });
+        __syncthreads();
+        for (int u = tid; u < H; u += kAnyThreads) {
+            const float ig = sigmoidf_(pre_s[u]), fg = sigmoidf_(pre_s[H + u]), gg = tanhf_(pre_s[2 * H + u]),
+                        og = sigmoidf_(pre_s[3 * H + u]);
+            const float c = fg * c_s[u] + ig * gg;
+            const float h = og * tanhf_(c);
+            c_s[u] = c;
+            h_s[u] = h;
+            if (!GREEDY) {
+                a.gates[bt * 4 * H + u] = ig; a.gates[bt * 4 * H + H + u] = fg;
+                a.gates[bt * 4 * H + 2 * H + u] = gg; a.gates[bt * 4 * H + 3 * H + u] = og;
+                a.cells[bt * H + u] = c;
+                a.s[bt * 4 * H + 3 * H + u] = h;
+                if (t + 1 < T) a.hprev[(bt + 1) * H + u] = h;
+            }
+        }
+        __syncthreads();
+        if (GREEDY) {
+            // output head on [e | ctx_text | ctx_vis | h] as the one matrix Wc = W_h2o . W_o2h ([V, 4H], S order), argmax
+            // (the first of equal maxima), feed back, stop at <EOS>
+            const int tok = tok_s[0];
+            float *logit_s = pre_s;                                    // the gates are done with it
+            for (int v = wave; v < V; v += kAnyWaves) {
+                const float *wrow = a.head_wc + (int64_t)v * 4 * H;
+                float p = 0.f;
+                for (int k = lane; k < H; k += 64)
+                    p += wrow[k] * a.dec_emb[(int64_t)tok * H + k] + wrow[H + k] * ctxt_s[k] + wrow[2 * H + k] * ctxv_s[k] +
+                         wrow[3 * H + k] * h_s[k];
+                p = wave_sum(p);
+                if (lane == 0) logit_s[v] = p;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int best = 0;
+                float top = logit_s[0];
+                for (int v = 1; v < V; ++v)
+                    if (logit_s[v] > top) { top = logit_s[v]; best = v; }
+                tok_s[0] = best;
+                a.tokens_out[bt] = best;
+            }
+            steps_done = t + 1;
+            __syncthreads();
+            if (tok_s[0] == a.eos) break;                              // uniform: every thread reads the same LDS word
+        }
+    }
+    if (GREEDY) {
+        if (tid == 0) a.steps_out[b] = steps_done;
+        return;
+    }
+    if (a.h_last) for (int k = tid; k < H; k += kAnyThreads) a.h_last[(int64_t)b * H + k] = h_s[k];
+    __syncthreads();                                                   // the row's S and att_sum are complete
+    // ---- auxiliary head: log_softmax over the cells of the summed visual attention (model.py:205) and this row's
+    //      get_auxiliary_loss term (model.py:162-164)
+    if (a.aux_saved) {
+        const float *att = a.att_sum + (int64_t)b * M;
+        if (tid < 64) {
+            float mx = -INFINITY;
+            for (int m = tid; m < M; m += 64) mx = fmaxf(mx, att[m]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int m = tid; m < M; m += 64) sum += expf(att[m] - mx);
+            const float lse = mx + logf(wave_sum(sum));
+            for (int m = tid; m < M; m += 64) {
+                a.aux_saved[(int64_t)b * M + m] = att[m] - lse;
+                a.aux_out[(int64_t)b * M + m] = att[m] - lse;
+            }
+            if (a.row_stats && tid == 0) {
+                const int64_t pos = a.positions ? a.positions[b] : (int64_t)-1;
+                a.row_stats[4 * b + 2] = (pos >= 0 && pos < M) ? lse - att[pos] : 0.f;
+            }
+        }
+    } else if (a.row_stats && tid == 0) {
+        a.row_stats[4 * b + 2] = 0.f;
+    }
+    // ---- output head of the row's T steps: logits_t = Wc . S_t (a wave per logit), log_softmax (model.py:203), and the
+    //      row's get_loss partial sums (model.py:147-160)
+    for (int q = wave; q < T * V; q += kAnyWaves) {
+        const int tt = q / V, v = q - tt * V;
+        const float *srow = a.s + ((int64_t)b * T + tt) * 4 * H, *wrow = a.head_wc + (int64_t)v * 4 * H;
+        float p = 0.f;
+        for (int k = lane; k < 4 * H; k += 64) p = fmaf(wrow[k], srow[k], p);
+        p = wave_sum(p);
+        if (lane == 0) a.logits[((int64_t)b * T + tt) * V + v] = p;
+    }
+    __syncthreads();
+    float nll_acc = 0.f, cnt_acc = 0.f;
+    for (int tt = tid; tt < T; tt += kAnyThreads) {
+        const float *row = a.logits + ((int64_t)b * T + tt) * V;
+        float mx = -INFINITY;
+        for (int j = 0; j < V; ++j) mx = fmaxf(mx, row[j]);
+        float sum = 0.f;
+        for (int j = 0; j < V; ++j) sum += expf(row[j] - mx);
+        const float lse = mx + logf(sum);
+        for (int j = 0; j < V; ++j) {
+            const float y = row[j] - lse;
+            a.logp_saved[((int64_t)b * T + tt) * V + j] = y;
+            a.logp_out[((int64_t)b * T + tt) * V + j] = y;
+        }
+        if (a.row_stats) {
+            const int64_t tgt = (tt + 1 < T) ? a.targets[(int64_t)b * T + tt + 1] : (int64_t)0;
+            if (tgt != a.pad_tgt && tgt >= 0 && tgt < V) { nll_acc += lse - row[tgt]; cnt_acc += 1.f; }
+        }
+    }
+    if (a.row_stats) {
+        float *red = pre_s;
+        nll_acc = wave_sum(nll_acc);
+        cnt_acc = wave_sum(cnt_acc);
+        if (lane == 0) { red[2 * wave] = nll_acc; red[2 * wave + 1] = cnt_acc; }
+        __syncthreads();
+        if (tid == 0) {
+            float n0 = 0.f, n1 = 0.f;
+            for (int i = 0; i < kAnyWaves; ++i) { n0 += red[2 * i]; n1 += red[2 * i + 1]; }
+            a.row_stats[4 * b + 0] = n0;
+            a.row_stats[4 * b + 1] = n1;
+            a.row_stats[4 * b + 3] = 1.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward through time: same outputs as decoder_bwd_kernel (decoder.hip) — per-step pre-activation gradients
+// delta = [gate deltas (4H) | dzq (H)], dqt, dqv, the score-path key gradients, the energy-vector gradients per row,
+// d h0 — and dS holds the head's part only: the LSTM-input and conditional-query parts of the context gradients are
+// added by the dense product behind this kernel, as for the fast kernel.
+// ------------------------------------------------------------------------------------------
+struct AnyLdsB { int dh, dc, dl, dctx, dq, dqv, q, v1, v2, al, sc, datt, red, total; };
+__host__ __device__ inline AnyLdsB any_lds_bwd(int H, int L, int M) {
+    const int HP = (H + 3) / 4 * 4, NM = ((L > M ? L : M) + 3) / 4 * 4;
+    AnyLdsB o;
+    int p = 0;
+    o.dh = p; p += HP; o.dc = p; p += HP;
+    o.dl = p; p += 5 * HP;             // delta (4H) | dzq (H)
+    o.dctx = p; p += 2 * HP;           // d ctx_text | d ctx_vis (head + LSTM input + conditional query)
+    o.dq = p; p += HP;                 // d (projected query) of the attention being processed
+    o.dqv = p; p += HP;                // d (projected visual query), kept until the dh sum
+    o.q = p; p += HP;                  // the saved projected query
+    o.v1 = p; p += HP; o.v2 = p; p += HP;      // energy vectors
+    o.al = p; p += NM; o.sc = p; p += NM; o.datt = p; p += NM;
+    o.red = p; p += 64;
+    o.total = p;
+    return o;
+}
+
+// one attention's backward at one step (row-local): d alpha_m = dctx . PK[m] (+ datt[m]), softmax backward, then through
+// v . tanh(q + PK[m]): dq, the score-path dPK (accumulated in global memory over the steps: thread k owns column k
+// of every memory) and the energy-vector gradient (per-thread register sums `dv`, one per owned feature).
+__device__ __forceinline__ void attention_bwd_any(const float *dctx, const float *q_s, const float *v_s, const float *al,
+                                                  const float *datt, const float *__restrict__ pk, float *dpk, int n, int H,
+                                                  float *sc, float *dq_s, float *red, float (&dv)[8]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int m0 = 0; m0 < n; m0 += kAnyWaves) {                        // d alpha_m, a wave per memory
+        const int m = m0 + wave, mc = min(m, n - 1);
+        float p = 0.f;
+        for (int k = lane; k < H; k += 64) p = fmaf(dctx[k], pk[(int64_t)mc * H + k], p);
+        p = wave_sum(p);
+        if (lane == 0 && m < n) sc[m] = p + (datt ? datt[m] : 0.f);
+    }
+    __syncthreads();
+    if (tid < 64) {                                                    // ds_m = alpha_m (dalpha_m - sum alpha dalpha)
+        float s = 0.f;
+        for (int m = tid; m < n; m += 64) s = fmaf(al[m], sc[m], s);
+        s = wave_sum(s);
+        if (tid == 0) red[0] = s;
+    }
+    __syncthreads();
+    const float s = red[0];
+    int i = 0;
+    for (int k = tid; k < H; k += kAnyThreads, ++i) {
+        const float qk = q_s[k], vk = v_s[k];
+        float dq = 0.f, dvk = 0.f;
+        for (int m = 0; m < n; ++m) {
+            const float ds = al[m] * (sc[m] - s);
+            const float th = tanhf_(qk + pk[(int64_t)m * H + k]);
+            const float g = ds * vk * (1.f - th * th);
+            dpk[(int64_t)m * H + k] += g;
+            dq += g;
+            dvk = fmaf(ds, th, dvk);
+        }
+        dq_s[k] = dq;
+        if (i < 8) dv[i] += dvk;
+    }
+    __syncthreads();
+}
+
+template <bool V4>
+__global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArgs a, int H, int cond) {
+    TraceScope trace_scope(TK_DECODER_BWD);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = a.T, L = a.L, M = a.M, V = a.V;
+    const AnyLdsB o = any_lds_bwd(H, L, M);
+    float *dh_s = smem + o.dh, *dc_s = smem + o.dc, *dl_s = smem + o.dl, *dctx_s = smem + o.dctx, *dq_s = smem + o.dq,
+          *dqv_s = smem + o.dqv, *q_s = smem + o.q, *vt_s = smem + o.v1, *vv_s = smem + o.v2, *al_s = smem + o.al, *sc = smem + o.sc,
+          *datt_s = smem + o.datt, *red = smem + o.red;
+    int len = a.cmd_lengths[b];
+    len = max(1, min(len, L));
+    const float *pk_t = a.pk_t + (int64_t)b * L * H, *pk_v = a.pk_v + (int64_t)b * M * H;
+    float *dpk_t = a.dpk_t + (int64_t)b * L * H, *dpk_v = a.dpk_v + (int64_t)b * M * H;
+    const float *W_hh = a.any_w_hh, *W_ih = a.any_w_ih, *W_qt = a.any_w_qt, *W_qv = a.any_w_qv, *W_q2k = a.any_w_q2k;
+
+    // ---- seeds and the head's backward (as decoder_bwd_kernel's prologue): dlogits, dS = Wc^T dlogits
+    float aux_scale = (a.seeds && a.daux) ? a.seeds[1] : 1.f;
+    float scl = a.seeds ? a.seeds[0] : 1.f;
+    if (a.nll_mode) {
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+        for (int r = tid; r < a.B; r += kAnyThreads) {
+            const float4 x = *reinterpret_cast<const float4 *>(a.row_stats + 4 * r);
+            p0 += x.x; p1 += x.y; p2 += x.z;
+        }
+        p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+        if (lane == 0) { red[3 * wave] = p0; red[3 * wave + 1] = p1; red[3 * wave + 2] = p2; }
+        __syncthreads();
+        p0 = p1 = p2 = 0.f;
+        for (int i = 0; i < kAnyWaves; ++i) { p0 += red[3 * i]; p1 += red[3 * i + 1]; p2 += red[3 * i + 2]; }
+        scl = (a.nll_mode == 2) ? 1.f : 1.f / p1;
+        aux_scale = a.aux_saved ? ((a.nll_mode == 2) ? a.w_aux : a.w_aux / (float)a.B) : 0.f;
+        if (b == 0 && tid == 0) {
+            a.stats_out[0] = p0; a.stats_out[1] = p1; a.stats_out[2] = p2; a.stats_out[3] = (float)a.B;
+            a.seeds_out[0] = scl; a.seeds_out[1] = aux_scale;
+            a.seeds_out[2] = p0 * scl + p2 * aux_scale;
+        }
+        __syncthreads();
+    }
+    for (int tt = tid; tt < T; tt += kAnyThreads) {
+        const int64_t bt = (int64_t)b * T + tt;
+        const float *y = a.logp_saved + bt * V;
+        if (a.nll_mode) {
+            const int64_t tgt = (tt + 1 < T) ? a.targets[(int64_t)b * T + tt + 1] : (int64_t)0;
+            const bool live = tgt != a.pad_tgt && tgt >= 0 && tgt < V;
+            for (int j = 0; j < V; ++j) a.dlogits[bt * V + j] = live ? scl * (expf(y[j]) - (j == tgt ? 1.f : 0.f)) : 0.f;
+        } else {
+            const float *dy = a.dlogp + bt * V;
+            float sum = 0.f;
+            for (int j = 0; j < V; ++j) sum += dy[j];
+            for (int j = 0; j < V; ++j) a.dlogits[bt * V + j] = scl * (dy[j] - expf(y[j]) * sum);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < T * 4 * H; idx += kAnyThreads) {
+        const int tt = idx / (4 * H), col = idx - tt * 4 * H;
+        const float *dl = a.dlogits + ((int64_t)b * T + tt) * V;
+        float acc = 0.f;
+        for (int v = 0; v < V; ++v) acc = fmaf(dl[v], a.head_wc[(int64_t)v * 4 * H + col], acc);
+        a.ds[((int64_t)b * T + tt) * 4 * H + col] = acc;
+    }
+    // auxiliary head backward: d att_sum = seed1 * (daux - exp(aux_logp) sum daux)  (model.py:205)
+    {
+        const bool has_aux = a.nll_mode ? (a.aux_saved != nullptr) : (a.daux != nullptr);
+        const int64_t pos = a.positions ? a.positions[b] : (int64_t)-1;
+        if (tid < 64) {
+            float sum = 0.f;
+            if (has_aux)
+                for (int m = tid; m < M; m += 64) sum += a.nll_mode ? (m == pos ? -1.f : 0.f) : a.daux[(int64_t)b * M + m];
+            sum = wave_sum(sum);
+            if (tid == 0) red[0] = sum;
+        }
+        __syncthreads();
+        const float sum = red[0];
+        for (int m = tid; m < M; m += kAnyThreads) {
+            float da = 0.f;
+            if (has_aux) {
+                const float dy = a.nll_mode ? (m == pos ? -1.f : 0.f) : a.daux[(int64_t)b * M + m];
+                da = aux_scale * (dy - expf(a.aux_saved[(int64_t)b * M + m]) * sum);
+            }
+            datt_s[m] = da;
+        }
+    }
+    for (int k = tid; k < H; k += kAnyThreads) { dh_s[k] = 0.f; dc_s[k] = 0.f; vt_s[k] = a.v_t[k]; vv_s[k] = a.v_v[k]; }
+    for (int i = tid; i < M * H; i += kAnyThreads) dpk_v[i] = 0.f;
+    for (int i = tid; i < L * H; i += kAnyThreads) dpk_t[i] = 0.f;
+    float dvt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dvv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        const int64_t bt = (int64_t)b * T + t;
+        // ---- LSTM cell backward (dh_t = head part + what step t+1 passed back)
+        for (int u = tid; u < H; u += kAnyThreads) {
+            const float dh = a.ds[bt * 4 * H + 3 * H + u] + dh_s[u];
+            const float ig = a.gates[bt * 4 * H + u], fg = a.gates[bt * 4 * H + H + u], gg = a.gates[bt * 4 * H + 2 * H + u],
+                        og = a.gates[bt * 4 * H + 3 * H + u];
+            const float c = a.cells[bt * H + u];
+            const float c_prev = t > 0 ? a.cells[(bt - 1) * H + u]
+                                       : (a.c0 ? a.c0[(int64_t)b * H + u] : a.hprev[(int64_t)b * T * H + u]);   // c_0 = h_0 (model.py:195)
+            const float tc = tanhf_(c);
+            const float dct = dc_s[u] + dh * og * (1.f - tc * tc);
+            const float di = dct * gg * ig * (1.f - ig), df = dct * c_prev * fg * (1.f - fg), dg = dct * ig * (1.f - gg * gg),
+                        d_o = dh * tc * og * (1.f - og);
+            dc_s[u] = dct * fg;
+            dl_s[u] = di; dl_s[H + u] = df; dl_s[2 * H + u] = dg; dl_s[3 * H + u] = d_o;
+            a.delta[bt * 5 * H + u] = di; a.delta[bt * 5 * H + H + u] = df;
+            a.delta[bt * 5 * H + 2 * H + u] = dg; a.delta[bt * 5 * H + 3 * H + u] = d_o;
+        }
+        __syncthreads();
+        // ---- d [ctx_text | ctx_vis] = head part + W_ih[:, H:3H]^T delta
+        matvec_cols(W_ih, 3 * H, H, 4 * H, 2 * H, dl_s, [&](int c, float v) { dctx_s[c] = v + a.ds[bt * 4 * H + H + c]; });
+        for (int m = tid; m < M; m += kAnyThreads) al_s[m] = a.alpha_s[bt * M + m];
+        for (int k = tid; k < H; k += kAnyThreads) q_s[k] = a.qv[bt * H + k];
+        __syncthreads();
+        // ---- visual attention backward
+        attention_bwd_any(dctx_s + H, q_s, vv_s, al_s, datt_s, pk_v, dpk_v, M, H, sc, dq_s, red, dvv);
+        for (int k = tid; k < H; k += kAnyThreads) { const float v = dq_s[k]; dqv_s[k] = v; a.dqv[bt * H + k] = v; }
+        __syncthreads();
+        if (cond) {
+            // d q2 = W_qv^T dqv, through tanh; the conditional query's share of d ctx_text
+            matvec_cols(W_qv, H, 0, H, H, dqv_s, [&](int c, float v) {
+                const float q = a.q2[bt * H + c];
+                const float dz = v * (1.f - q * q);
+                dl_s[4 * H + c] = dz;
+                a.delta[bt * 5 * H + 4 * H + c] = dz;
+            });
+            __syncthreads();
+            matvec_cols(W_q2k, 2 * H, H, H, H, dl_s + 4 * H, [&](int c, float v) { dctx_s[c] += v; });
+        }
+        for (int m = tid; m < L; m += kAnyThreads) al_s[m] = a.alpha_c[bt * L + m];
+        for (int k = tid; k < H; k += kAnyThreads) q_s[k] = a.qt[bt * H + k];
+        __syncthreads();
+        // ---- textual attention backward
+        attention_bwd_any(dctx_s, q_s, vt_s, al_s, nullptr, pk_t, dpk_t, len, H, sc, dq_s, red, dvt);
+        for (int k = tid; k < H; k += kAnyThreads) a.dqt[bt * H + k] = dq_s[k];
+        // ---- dh_{t-1} = W_hh^T delta + W_qt^T dqt + (W_q2k[:, :H]^T dzq  or  W_qv^T dqv)
+        matvec_cols(W_hh, H, 0, 4 * H, H, dl_s, [&](int c, float v) { dh_s[c] = v; });
+        __syncthreads();
+        matvec_cols(W_qt, H, 0, H, H, dq_s, [&](int c, float v) { dh_s[c] += v; });
+        __syncthreads();
+        if (cond) matvec_cols(W_q2k, 2 * H, 0, H, H, dl_s + 4 * H, [&](int c, float v) { dh_s[c] += v; });
+        else matvec_cols(W_qv, H, 0, H, H, dqv_s, [&](int c, float v) { dh_s[c] += v; });
+        __syncthreads();
+    }
+    // ---- epilogue: initial-state gradient through the bridge tanh (h0 = c0 = tanh(.), model.py:195), energy vectors
+    for (int k = tid; k < H; k += kAnyThreads) {
+        const float h0 = a.hprev[(int64_t)b * T * H + k];
+        a.dh0[(int64_t)b * H + k] = (dh_s[k] + dc_s[k]) * (1.f - h0 * h0);
+    }
+    for (int i = tid; i < (L - len) * H; i += kAnyThreads) dpk_t[(int64_t)len * H + i] = 0.f;
+    {
+        int i = 0;
+        for (int k = tid; k < H; k += kAnyThreads, ++i) {
+            a.dv_t[(int64_t)b * H + k] = dvt[i < 8 ? i : 7];
+            a.dv_v[(int64_t)b * H + k] = dvv[i < 8 ? i : 7];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+constexpr int kAnyMaxHidden = 8 * kAnyThreads;     // a thread keeps the energy-vector sums of at most eight features
+
+int decoder_run_any(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream) {
+    GSCAN_CHECK(H >= 1 && H <= kAnyMaxHidden, "decoder: decoder_hidden_size %d is outside 1..%d", H, kAnyMaxHidden);
+    GSCAN_CHECK(a.any_w_hh && a.any_w_ih && a.any_w_qt && a.any_w_qv && (!cond || a.any_w_q2k),
+                "decoder (any shape): the parameter pointers are missing");
+    const bool greedy = !backward && a.tokens_out != nullptr;
+    const size_t bytes = (size_t)(backward ? any_lds_bwd(H, a.L, a.M).total : any_lds_fwd(H, a.L, a.M).total) * sizeof(float);
+    GSCAN_CHECK(bytes <= 160 * 1024, "decoder (any shape): %zu bytes of LDS per row (hidden %d, %d + %d memories)", bytes, H,
+                a.L, a.M);
+    if (greedy) {
+        GSCAN_CHECK(a.head_wc && a.dec_emb && a.steps_out, "greedy decoder: missing tables");
+        GSCAN_CHECK(a.V <= 4 * H, "greedy decoder (any shape): a vocabulary of %d needs decoder_hidden_size >= %d", a.V, (a.V + 3) / 4);
+    }
+    const bool v4 = H % 4 == 0;
+    const double macs = (double)H * H + 2.0 * a.L * H + (cond ? 2.0 * H * H : 0.0) + (double)H * H + 2.0 * a.M * H +
+                        4.0 * H * 3.0 * H + 4.0 * H * H + (double)H * a.V;
+    ProbeScope probe(backward ? P_DECODER_BWD : P_DECODER_FWD, stream, 2.0 * macs * B * a.T);
+    auto launch = [&](auto kernel, const char *name) -> int {
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024));
+        hipLaunchKernelGGL(kernel, dim3(B), dim3(kAnyThreads), bytes, stream, a, H, cond ? 1 : 0);
+        GSCAN_LAUNCHED(name);
+        return 0;
+    };
+    if (backward) return v4 ? launch(decoder_bwd_any_kernel<true>, "decoder_bwd_any_kernel") : launch(decoder_bwd_any_kernel<false>, "decoder_bwd_any_kernel");
+    if (greedy) return v4 ? launch(decoder_fwd_any_kernel<true, true>, "decoder_fwd_any_kernel") : launch(decoder_fwd_any_kernel<false, true>, "decoder_fwd_any_kernel");
+    return v4 ? launch(decoder_fwd_any_kernel<true, false>, "decoder_fwd_any_kernel") : launch(decoder_fwd_any_kernel<false, false>, "decoder_fwd_any_kernel");
+}
+
+GSCAN_TRACE_TU(decoder_any)
+
+}  // namespace gscan

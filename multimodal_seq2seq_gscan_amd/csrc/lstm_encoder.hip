@@ -12,7 +12,7 @@
 // dh_{t-1}[k] = sum_j W_hh[j][k] * delta[j] is four in-register partial dots plus one LDS sum.
 // The kernel emits only the gate pre-activation gradients delta[b,t,dir,4He]; all weight
 // gradients are dense GEMMs over those afterwards.
-#include "step.h"
+#include "anyshape.h"
 
 namespace gscan {
 
@@ -320,6 +320,114 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_ke
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same two recurrences for ANY encoder hidden size and command length (the kernels above keep W_hh in registers —
+// hidden sizes up to 128 — and the whole command's history in LDS — L . He <= ~6 800): W_hh (and, for the first layer,
+// W_ih) streamed from L2 in the reference's layout, one step's vectors in LDS, saved activations written straight to
+// global memory.  grid (B, D), 256 threads, same arguments and outputs.  Correctness first.
+// ------------------------------------------------------------------------------------------
+template <bool V4>
+__global__ __launch_bounds__(kAnyThreads) void encoder_lstm_fwd_any_kernel(int L, int D, int HE, const float *__restrict__ gx,
+                                        const int32_t *__restrict__ lengths, const float *__restrict__ w_hh_f,
+                                        const float *__restrict__ b_hh_f, const float *__restrict__ w_hh_r,
+                                        const float *__restrict__ b_hh_r, float *__restrict__ out,
+                                        float *__restrict__ h_final, float *__restrict__ gates,
+                                        float *__restrict__ cells, float *__restrict__ hprev, float *__restrict__ hcat,
+                                        const float *__restrict__ hcat_mask, EncInput in) {
+    TraceScope trace_scope(TK_ENCODER_FWD);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    int len = lengths[b];
+    len = max(0, min(len, L));
+    const int HP = (HE + 3) / 4 * 4;
+    float *h_s = lds, *pre_s = h_s + HP, *c_s = pre_s + 4 * HP, *x_s = c_s + HP;      // x_s [E]
+    const int64_t row0 = (int64_t)b * L;
+    const float *w_hh = dir ? w_hh_r : w_hh_f, *b_hh = dir ? b_hh_r : b_hh_f;
+    const float *w_ih = dir ? in.w_ih_r : in.w_ih_f, *b_ih = dir ? in.b_ih_r : in.b_ih_f;
+    for (int k = tid; k < HE; k += kAnyThreads) { h_s[k] = 0.f; c_s[k] = 0.f; }
+    for (int idx = tid; idx < (L - len) * HE; idx += kAnyThreads) {       // padded positions: zero saved h_prev; out stays zero
+        const int t = len + idx / HE, k = idx % HE;
+        hprev[((row0 + t) * D + dir) * HE + k] = 0.f;
+        if (hcat) hcat[((row0 + t) * D + dir) * HE + k] = 0.f;
+    }
+    __syncthreads();
+    for (int s = 0; s < len; ++s) {
+        const int t = dir ? (len - 1 - s) : s;
+        const int64_t row = (row0 + t) * D + dir;
+        for (int k = tid; k < HE; k += kAnyThreads) hprev[row * HE + k] = h_s[k];     // h entering this step (0 at the first)
+        if (in.x) {
+            for (int e = tid; e < in.E; e += kAnyThreads) x_s[e] = in.x[(row0 + t) * in.E + e];
+            __syncthreads();
+            // E is small and W_ih rows need not be 16-byte aligned (E = 25): scalar loads
+            matvec_rows<false>(w_ih, in.E, 4 * HE, in.E, x_s, [&](int r, float v) { pre_s[r] = v + b_ih[r] + b_hh[r]; });
+        } else {
+            for (int r = tid; r < 4 * HE; r += kAnyThreads) pre_s[r] = gx[row * 4 * HE + r] + b_hh[r];
+        }
+        __syncthreads();
+        matvec_rows<V4>(w_hh, HE, 4 * HE, HE, h_s, [&](int r, float v) { pre_s[r] += v; });
+        __syncthreads();
+        for (int k = tid; k < HE; k += kAnyThreads) {
+            const float ig = sigmoidf_(pre_s[k]), fg = sigmoidf_(pre_s[HE + k]), gg = tanhf_(pre_s[2 * HE + k]),
+                        og = sigmoidf_(pre_s[3 * HE + k]);
+            const float c = fg * c_s[k] + ig * gg, h = og * tanhf_(c);
+            c_s[k] = c;
+            h_s[k] = h;
+            gates[row * 4 * HE + k] = ig; gates[row * 4 * HE + HE + k] = fg;
+            gates[row * 4 * HE + 2 * HE + k] = gg; gates[row * 4 * HE + 3 * HE + k] = og;
+            cells[row * HE + k] = c;
+            if (out) atomicAdd(out + (row0 + t) * HE + k, h);
+            if (hcat) hcat[row * HE + k] = hcat_mask ? h * hcat_mask[row * HE + k] : h;
+        }
+        __syncthreads();
+    }
+    if (h_final && len > 0)
+        for (int k = tid; k < HE; k += kAnyThreads) atomicAdd(h_final + (int64_t)b * HE + k, h_s[k]);
+}
+
+__global__ __launch_bounds__(kAnyThreads) void encoder_lstm_bwd_any_kernel(int L, int D, int HE, const int32_t *__restrict__ lengths,
+                                        const float *__restrict__ w_hh_f, const float *__restrict__ w_hh_r,
+                                        const float *__restrict__ gates, const float *__restrict__ cells,
+                                        const float *__restrict__ d_out, const float *__restrict__ d_h_final,
+                                        float *__restrict__ delta, int d_out_row, int d_out_dir,
+                                        const float *__restrict__ d_out_mask) {
+    TraceScope trace_scope(TK_ENCODER_BWD);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    int len = lengths[b];
+    len = max(0, min(len, L));
+    const int HP = (HE + 3) / 4 * 4;
+    float *dh_s = lds, *dc_s = dh_s + HP, *dl_s = dc_s + HP;           // dl_s [4 HP]
+    const int64_t row0 = (int64_t)b * L;
+    const float *w_hh = dir ? w_hh_r : w_hh_f;
+    for (int k = tid; k < HE; k += kAnyThreads) { dh_s[k] = d_h_final ? d_h_final[(int64_t)b * HE + k] : 0.f; dc_s[k] = 0.f; }
+    for (int idx = tid; idx < (L - len) * 4 * HE; idx += kAnyThreads)   // padded positions get delta = 0
+        delta[((row0 + len + idx / (4 * HE)) * D + dir) * 4 * HE + idx % (4 * HE)] = 0.f;
+    __syncthreads();
+    for (int s = len - 1; s >= 0; --s) {
+        const int t = dir ? (len - 1 - s) : s;
+        const int64_t row = (row0 + t) * D + dir;
+        for (int k = tid; k < HE; k += kAnyThreads) {
+            const int64_t at = (row0 + t) * d_out_row + dir * d_out_dir + k;
+            const float dh = dh_s[k] + (d_out_mask ? d_out[at] * d_out_mask[at] : d_out[at]);
+            const float ig = gates[row * 4 * HE + k], fg = gates[row * 4 * HE + HE + k], gg = gates[row * 4 * HE + 2 * HE + k],
+                        og = gates[row * 4 * HE + 3 * HE + k];
+            const float c = cells[row * HE + k];
+            const float c_prev = s > 0 ? cells[((row0 + (dir ? t + 1 : t - 1)) * D + dir) * HE + k] : 0.f;
+            const float tc = tanhf_(c);
+            const float dct = dc_s[k] + dh * og * (1.f - tc * tc);
+            dc_s[k] = dct * fg;
+            const float di = dct * gg * ig * (1.f - ig), df = dct * c_prev * fg * (1.f - fg), dg = dct * ig * (1.f - gg * gg),
+                        d_o = dh * tc * og * (1.f - og);
+            dl_s[k] = di; dl_s[HE + k] = df; dl_s[2 * HE + k] = dg; dl_s[3 * HE + k] = d_o;
+            delta[row * 4 * HE + k] = di; delta[row * 4 * HE + HE + k] = df;
+            delta[row * 4 * HE + 2 * HE + k] = dg; delta[row * 4 * HE + 3 * HE + k] = d_o;
+        }
+        __syncthreads();
+        matvec_cols(w_hh, HE, 0, 4 * HE, HE, dl_s, [&](int c, float v) { dh_s[c] = v; });
+        __syncthreads();
+    }
+}
+
 template <typename K>
 static int encoder_lds_attr(K kernel, size_t bytes, bool &attr_set) {
     GSCAN_CHECK(bytes <= kEncLdsLimit, "encoder lstm: a command of this length needs %zu bytes of LDS (limit %zu)", bytes,
@@ -388,6 +496,14 @@ int encoder_weight_image(const float *w_hh_f, const float *w_hh_r, int He, int D
     return 0;
 }
 
+// The register/LDS-resident kernels take the compiled hidden sizes and commands whose whole history fits LDS; every
+// other shape runs on the streaming kernels (GSCAN_ENCODER_ANY=1: every shape does, for tests).
+bool encoder_fast_supported(int He, int L, int E) {
+    static const int force_any = [] { const char *e = getenv("GSCAN_ENCODER_ANY"); return e ? atoi(e) : 0; }();
+    if (force_any || !hidden_size_supported(He)) return false;
+    return encoder_fwd_lds(L, He, E) <= kEncLdsLimit && encoder_bwd_lds(L, He) <= kEncLdsLimit;
+}
+
 int encoder_rows_per_thread(int He) {
     switch (He) {
 #define X(n) case n: return EncShape<n>::R;
@@ -404,20 +520,37 @@ int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int
     GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm: bad dims B=%d L=%d D=%d", B, L, D);
     EncInput in{};
     if (input) in = *input;
-    GSCAN_CHECK(!in.x || (in.E > 0 && in.w_ih_t),
-                "encoder lstm: the first layer's own input projection needs the column-major image of [W_ih | b_ih + b_hh]");
+    GSCAN_CHECK(!in.x || in.E > 0, "encoder lstm: the first layer's own input projection needs its input width");
     GSCAN_CHECK(in.x || gx, "encoder lstm: neither input projections nor inputs given");
     GSCAN_CHECK(hcat || (out && h_final), "encoder lstm: neither direction sums nor per-direction outputs requested");
     GSCAN_CHECK(D == 1 || (w_hh_r && b_hh_r), "encoder lstm: reverse weights missing");
-    GSCAN_CHECK(w_image, "encoder lstm: weight image missing");
-    GSCAN_CHECK(((in.x ? 0 : (uintptr_t)gx) | (uintptr_t)gates) % 16 == 0, "encoder lstm: gx and gates must be 16-byte aligned");
-    switch (He) {
+    if (encoder_fast_supported(He, L, in.x ? in.E : 0)) {
+        GSCAN_CHECK(((in.x ? 0 : (uintptr_t)gx) | (uintptr_t)gates) % 16 == 0, "encoder lstm: gx and gates must be 16-byte aligned");
+        GSCAN_CHECK(w_image && (!in.x || in.w_ih_t), "encoder lstm: weight image missing (W_hh registers; the first layer's "
+                    "column-major [W_ih | b_ih + b_hh])");
+        switch (He) {
 #define X(n) case n: return launch_fwd<n>(B, L, D, gx, lengths, b_hh_f, b_hh_r, out, h_final, gates, cells, hprev, w_image, hcat, hcat_mask, in, stream);
-        GSCAN_HIDDEN_SIZES(X)
+            GSCAN_HIDDEN_SIZES(X)
 #undef X
-        default: break;
+            default: break;
+        }
     }
-    GSCAN_CHECK(false, "encoder_hidden_size %d has no compiled kernel (supported: " GSCAN_ENC_HIDDEN_LIST ")", He);
+    {   // any other hidden size / command length: weights streamed, one step's vectors in LDS
+        GSCAN_CHECK(He >= 1 && w_hh_f && b_hh_f && (!in.x || (in.w_ih_f && in.b_ih_f && (D == 1 || (in.w_ih_r && in.b_ih_r)))),
+                    "encoder lstm: encoder_hidden_size %d / weights missing", He);
+        const int HP = (He + 3) / 4 * 4;
+        const size_t lds = (size_t)(6 * HP + (in.x ? (in.E + 3) / 4 * 4 : 0)) * sizeof(float);
+        GSCAN_CHECK(lds <= kEncLdsLimit, "encoder lstm: encoder_hidden_size %d needs %zu bytes of LDS", He, lds);
+        ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * He * (He + (in.x ? in.E : 0)));
+        if (He % 4 == 0)
+            hipLaunchKernelGGL(encoder_lstm_fwd_any_kernel<true>, dim3(B, D), dim3(kAnyThreads), lds, stream, L, D, He, gx, lengths,
+                               w_hh_f, b_hh_f, w_hh_r, b_hh_r, out, h_final, gates, cells, hprev, hcat, hcat_mask, in);
+        else
+            hipLaunchKernelGGL(encoder_lstm_fwd_any_kernel<false>, dim3(B, D), dim3(kAnyThreads), lds, stream, L, D, He, gx, lengths,
+                               w_hh_f, b_hh_f, w_hh_r, b_hh_r, out, h_final, gates, cells, hprev, hcat, hcat_mask, in);
+        GSCAN_LAUNCHED("encoder_lstm_fwd_any_kernel");
+    }
+    return 0;
 }
 
 int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_f,
@@ -426,17 +559,28 @@ int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, c
                           const float *d_out_mask) {
     GSCAN_CHECK(B > 0 && L > 0 && (D == 1 || D == 2), "encoder lstm bwd: bad dims B=%d L=%d D=%d", B, L, D);
     if (d_out_row == 0) d_out_row = He;                      // the last layer: one gradient for both directions
-    GSCAN_CHECK(d_out_row % 4 == 0 && d_out_dir % 4 == 0 && ((uintptr_t)d_out_mask % 16) == 0,
-                "encoder lstm bwd: d_out strides / mask must keep 16-byte alignment");
-    GSCAN_CHECK(((uintptr_t)gates | (uintptr_t)cells | (uintptr_t)d_out | (uintptr_t)delta) % 16 == 0,
-                "encoder lstm bwd: gates, cells, d_out and delta must be 16-byte aligned");
-    switch (He) {
+    if (encoder_fast_supported(He, L, 0)) {
+        GSCAN_CHECK(d_out_row % 4 == 0 && d_out_dir % 4 == 0 && ((uintptr_t)d_out_mask % 16) == 0,
+                    "encoder lstm bwd: d_out strides / mask must keep 16-byte alignment");
+        GSCAN_CHECK(((uintptr_t)gates | (uintptr_t)cells | (uintptr_t)d_out | (uintptr_t)delta) % 16 == 0,
+                    "encoder lstm bwd: gates, cells, d_out and delta must be 16-byte aligned");
+        switch (He) {
 #define X(n) case n: return launch_bwd<n>(B, L, D, lengths, w_hh_f, w_hh_r, gates, cells, d_out, d_h_final, delta, d_out_row, d_out_dir, d_out_mask, stream);
-        GSCAN_HIDDEN_SIZES(X)
+            GSCAN_HIDDEN_SIZES(X)
 #undef X
-        default: break;
+            default: break;
+        }
     }
-    GSCAN_CHECK(false, "encoder_hidden_size %d has no compiled kernel (supported: " GSCAN_ENC_HIDDEN_LIST ")", He);
+    {
+        const int HP = (He + 3) / 4 * 4;
+        const size_t lds = (size_t)6 * HP * sizeof(float);
+        GSCAN_CHECK(He >= 1 && lds <= kEncLdsLimit, "encoder lstm bwd: encoder_hidden_size %d", He);
+        ProbeScope probe(P_ENCODER_BWD, stream, 2.0 * B * L * D * 4 * He * He);
+        hipLaunchKernelGGL(encoder_lstm_bwd_any_kernel, dim3(B, D), dim3(kAnyThreads), lds, stream, L, D, He, lengths, w_hh_f, w_hh_r,
+                           gates, cells, d_out, d_h_final, delta, d_out_row, d_out_dir, d_out_mask);
+        GSCAN_LAUNCHED("encoder_lstm_bwd_any_kernel");
+    }
+    return 0;
 }
 
 GSCAN_TRACE_TU(lstm_encoder)

@@ -188,6 +188,7 @@ int trace_set_elementwise(unsigned long long *buf);
 int trace_set_loss(unsigned long long *buf);
 int trace_set_lstm_encoder(unsigned long long *buf);
 int trace_set_decoder(unsigned long long *buf);
+int trace_set_decoder_any(unsigned long long *buf);
 int trace_set_attention_grad(unsigned long long *buf);
 
 // conv.hip: the world encoder (cnn_model.py:22-36) and its weight gradients, input-sparse
@@ -258,6 +259,7 @@ int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int
                          const float *b_hh_f, const float *w_hh_r, const float *b_hh_r, float *out, float *h_final,
                          float *gates, float *cells, float *hprev, const float *w_image, hipStream_t stream,
                          float *hcat = nullptr, const float *hcat_mask = nullptr, const EncInput *input = nullptr);
+bool encoder_fast_supported(int He, int L, int E);   // false: the streaming any-size kernels run (no weight images)
 int encoder_rows_per_thread(int He);   // rows of W_hh a thread of the forward kernel keeps (layout of its image)
 int encoder_weight_image(const float *w_hh_f, const float *w_hh_r, int He, int D, float *image, hipStream_t stream);
 int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, const float *w_hh_f,
@@ -276,6 +278,9 @@ struct DecoderArgs {
     const float *ge;                   // [B,T,4H] embedding part of the gates + both biases
     const float *w_image;              // register image of the recurrent weights (decoder_image_element)
     const float *b_q2k, *v_t, *v_v;
+    // the same weights in the reference's own layouts, for the any-shape kernels (decoder_any.hip): lstm.weight_hh
+    // [4H,H], lstm.weight_ih [4H,3H], the attentions' query layers [H,H], queries_to_keys.weight [H,2H] or NULL
+    const float *any_w_hh, *any_w_ih, *any_w_qt, *any_w_qv, *any_w_q2k;
     float *hprev;                      // [B,T,H]  hprev[b,0] = h0 (= c0 unless c0 is given) on entry; kernel fills t+1
     const float *c0;                   // [B,H] initial cell state, or NULL for c0 = h0 (seq2seq_model.py:494-504)
     float *h_last;                     // [B,H] h after the last step, or NULL
@@ -317,6 +322,10 @@ struct DecoderArgs {
 bool decoder_hidden_supported(int h);
 size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward);
 int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
+// decoder_any.hip: the same launches for any hidden size / number of memories (weights streamed, memories in global)
+int decoder_run_any(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
+// does decoder.hip have kernels for this shape (a compiled hidden size, <= 64 memories per attention, LDS fits)?
+bool decoder_fast_supported(int H, int L, int M, int V, bool cond);
 
 // attention_grad.hip: value path of both attentions + key layers + bridge, one workgroup per batch row
 struct KeysBackwardArgs {

@@ -130,19 +130,17 @@ int check_dims(const gscan_dims &d) {
                 "dims: non-positive dimension (B=%d L=%d T=%d G=%d C=%d Co=%d E=%d V=%d Vi=%d)", d.B, d.L, d.T, d.G,
                 d.C, d.Co, d.E, d.V, d.Vi);
     GSCAN_CHECK(d.K3 > 0 && (d.K3 & 1), "dims: cnn_kernel_size must be odd (got %d)", d.K3);
-    GSCAN_CHECK(hidden_size_supported(d.He), "dims: encoder_hidden_size %d has no compiled kernel (" GSCAN_ENC_HIDDEN_LIST ")",
-                d.He);
-    GSCAN_CHECK(decoder_hidden_supported(d.H), "dims: decoder_hidden_size %d has no compiled kernel (" GSCAN_DEC_HIDDEN_LIST ")",
-                d.H);
+    // Hidden sizes, command lengths and grid sizes outside what the register/LDS-resident kernels take run on the
+    // streaming kernels (decoder_any.hip, lstm_encoder.hip's *_any kernels); what remains are the limits of those.
+    GSCAN_CHECK(d.He >= 1 && d.He <= 2048, "dims: encoder_hidden_size %d is outside 1..2048", d.He);
+    GSCAN_CHECK(d.H >= 1 && d.H <= 256, "dims: decoder_hidden_size %d is outside 1..256 (the target embedding's width: "
+                "the embedding-gradient kernel takes up to 256 columns)", d.H);
+    GSCAN_CHECK(d.E <= 256, "dims: embedding_dimension %d is outside 1..256", d.E);
     GSCAN_CHECK((int64_t)d.B * d.T * 4 * d.H < (1ll << 31) && (int64_t)d.B * d.G * d.G * 4 * d.H < (1ll << 31),
                 "dims: batch too large for 32-bit activation offsets (B=%d T=%d H=%d)", d.B, d.T, d.H);
     GSCAN_CHECK(d.enc_layers >= 0 && d.enc_layers <= GSCAN_MAX_ENC_LAYERS,
                 "dims: at most %d encoder layers are supported (got %d)", GSCAN_MAX_ENC_LAYERS, d.enc_layers);
-    GSCAN_CHECK(d.L <= 64, "dims: commands longer than 64 tokens are not supported (L=%d)", d.L);
-    GSCAN_CHECK(d.G * d.G <= 64, "dims: grids larger than 8x8 are not supported (G=%d)", d.G);
-    const size_t lds = decoder_lds_bytes(d.H, d.L, d.G * d.G, d.V, d.conditional != 0, true);
-    GSCAN_CHECK(lds <= 160 * 1024, "dims: the decoder needs %zu bytes of LDS per row (limit 163840) even with the visual "
-                "gate images streamed from L2: L=%d G=%d H=%d", lds, d.L, d.G, d.H);
+    GSCAN_CHECK(d.L <= 4096 && d.G * d.G <= 4096, "dims: more than 4096 memories per attention (L=%d, G=%d)", d.L, d.G);
     return 0;
 }
 
@@ -180,6 +178,8 @@ static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, cons
     a.pk_v = w + ws.pkv; a.u_v = w + ws.uv;
     a.ge = w + ws.ge;
     a.b_q2k = p.q2k_b; a.v_t = p.txt_energy_w; a.v_v = p.vis_energy_w;
+    a.any_w_hh = p.dec_w_hh; a.any_w_ih = p.dec_w_ih; a.any_w_qt = p.txt_query_w; a.any_w_qv = p.vis_query_w;
+    a.any_w_q2k = p.q2k_w;
     a.hprev = w + ws.hprev; a.s = w + ws.S; a.cells = w + ws.cells; a.gates = w + ws.gates;
     a.alpha_c = w + ws.alpha_c; a.alpha_s = w + ws.alpha_s;
     a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
@@ -272,6 +272,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     // cross-stream events themselves to be the cost.  Measured and dropped (profiles/r02_ab_*): forking behind L1 or
     // behind the prologue (+20..30 us: the event latency lands on the critical path), host issue order (no effect).
     hipStream_t sd2 = g_side.single ? st : g_side.stream2;
+    const bool fast_decoder = decoder_fast_supported(H, L, M, V, cond);
     // one prologue launch with the segments of `which` (0: caller's stream, 1: side 1, 2: side 2); the others stay empty
     // fuse_world: the world encoder runs in the same launch (conv.hip, prologue_world_kernel), whose image workgroups
     // take the convolution weight image off the prologue's index space; returns -1 if that launch does not fit the shape
@@ -288,6 +289,8 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.zero_extra = w + ws.enc_out;                     // adjacent slots enc_out | hN | dxe
         a.zero_extra_count = (ws.dxe + (int64_t)B * L * E) - ws.enc_out;
         const DecoderGeometry geo = decoder_geometry(H, cond);
+        // the register images, the U images and the composite weights behind them belong to the fast decoder kernels
+        const bool fast = decoder_fast_supported(H, L, M, V, cond);
         a.img = DecoderImageArgs{p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, p.out2hid_w, w + ws.dec_w_fwd,
                                  w + ws.dec_w_bwd, H, cond ? 1 : 0, geo.slots, geo.k0};
         a.enc_w_hh_f = p.enc_w_hh; a.enc_w_hh_r = p.enc_w_hh_rev; a.enc_image = w + ws.enc_w_image;
@@ -299,9 +302,10 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.w_sk = w + ws.w_sk; a.w_ck = w + ws.w_ck; a.w_2kk = w + ws.w_2kk;
         const int64_t n[14] = {4 * H, (int64_t)V * 4 * H, (int64_t)D * 4 * He * (E + 1), (int64_t)V * 4 * H,
                                given ? 0 : (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
-                               a.zero_extra_count, 2 * geo.image_floats,
-                               (int64_t)D * 4 * He * He, (given || fuse_world) ? 0 : conv_image_floats(C, Co, d.K3),
-                               (int64_t)4 * H * F, (int64_t)4 * H * He, cond ? (int64_t)H * He : 0};
+                               a.zero_extra_count, fast ? 2 * geo.image_floats : 0,
+                               encoder_fast_supported(He, L, E) ? (int64_t)D * 4 * He * He : 0,
+                               (given || fuse_world) ? 0 : conv_image_floats(C, Co, d.K3),
+                               fast ? (int64_t)4 * H * F : 0, fast ? (int64_t)4 * H * He : 0, (fast && cond) ? (int64_t)H * He : 0};
         int64_t acc = 0;
         for (int i = 0; i < 14; ++i) {
             // side 1: decoder bias sum, embedded targets; side 2: convolution weight image, visual composite weight
@@ -320,6 +324,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     // the dense products of the prelude, each added to whichever launch the schedule below puts it in
     auto add_visual = [&](GemmBatch &k) {     // projected visual keys (seq2seq_model.py:466-467) and their gate images
         k.add(B * M, H, F, w + ws.feat, F, 1, p.vis_key_w, 1, F, w + ws.pkv, H);
+        if (!fast_decoder) return;
         k.add(B * M, 4 * H, F, w + ws.feat, F, 1, w + ws.w_sk, 1, F, w + ws.uv, 4 * H);
         k.overhead();     // U image: its algorithmic counterpart, W_ih[:, ctx_vis] . ctx_vis per step, is charged to the decoder kernel
     };
@@ -329,9 +334,11 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     };
     auto add_textual = [&](GemmBatch &g) {    // projected textual keys (:468-469), their images, and the bridge (model.py:195)
         g.add(B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H);
-        g.add(B * L, 4 * H, He, w + ws.enc_out, He, 1, w + ws.w_ck, 1, He, w + ws.ut, 4 * H);
-        g.overhead();     // U images of the textual memories: charged to the decoder kernel as the context terms they replace
-        if (cond) { g.add(B * L, H, He, w + ws.enc_out, He, 1, w + ws.w_2kk, 1, He, w + ws.u2t, H); g.overhead(); }
+        if (fast_decoder) {
+            g.add(B * L, 4 * H, He, w + ws.enc_out, He, 1, w + ws.w_ck, 1, He, w + ws.ut, 4 * H);
+            g.overhead(); // U images of the textual memories: charged to the decoder kernel as the context terms they replace
+        }
+        if (cond && fast_decoder) { g.add(B * L, H, He, w + ws.enc_out, He, 1, w + ws.w_2kk, 1, He, w + ws.u2t, H); g.overhead(); }
         g.add(B, H, He, w + ws.hN, He, 1, p.bridge_w, 1, He, w + ws.hprev, (int64_t)T * H, 0.f, p.bridge_b, 2);
     };
     auto world_encoder = [&](hipStream_t stream) -> int {      // cnn_model.py:22-36, input-sparse kernel (conv.hip)
@@ -410,7 +417,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
                           q.b_ih_rev);
                 TRY(g.launch(st));
                 float *img = w + ws.deep_image + (l - 1) * lay_img;
-                TRY(encoder_weight_image(q.w_hh, q.w_hh_rev, He, D, img, st));
+                if (encoder_fast_supported(He, L, 0)) TRY(encoder_weight_image(q.w_hh, q.w_hh_rev, He, D, img, st));
                 image = img;
             }
             // the first layer projects its own input (the embedded command, E floats per token) inside the recurrent

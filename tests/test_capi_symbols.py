@@ -51,10 +51,19 @@ def test_workspace_query_and_errors(lib):
     assert cnt.value == 256 * 20 * 400 and off.value % 256 == 0
     assert lib.gscan_workspace_find(ctypes.byref(d), b"nope", ctypes.byref(off), ctypes.byref(cnt)) != 0
     assert b"nope" in lib.gscan_last_error()
-    bad = _lib.Dims(B=4, L=10, T=20, G=6, C=16, Co=50, K3=7, E=25, He=100, H=77, Vi=21, V=9, conditional=1,
+    # shapes the register/LDS-resident kernels have no variant for are sized too (they run on the streaming kernels) ...
+    for odd in (dict(H=77), dict(H=256, He=256), dict(G=12), dict(L=128)):
+        kw = dict(B=4, L=10, T=20, G=6, C=16, Co=50, K3=7, E=25, He=100, H=100, Vi=21, V=9, conditional=1,
+                  auxiliary=0, bidirectional=1, pad_in=0, pad_tgt=0)
+        kw.update(odd)
+        dd = _lib.Dims(**kw)
+        assert lib.gscan_workspace_bytes(ctypes.byref(dd)) > 0, odd
+    # ... and what no kernel takes fails with the reason
+    bad = _lib.Dims(B=4, L=10, T=20, G=6, C=16, Co=50, K3=7, E=25, He=100, H=300, Vi=21, V=9, conditional=1,
                     auxiliary=0, bidirectional=1, pad_in=0, pad_tgt=0)
     assert lib.gscan_workspace_bytes(ctypes.byref(bad)) == 0
-    assert b"decoder_hidden_size 77" in lib.gscan_last_error()
-    big = _lib.Dims(B=4, L=10, T=20, G=12, C=16, Co=50, K3=7, E=25, He=100, H=100, Vi=21, V=9, conditional=1,
-                    auxiliary=0, bidirectional=1, pad_in=0, pad_tgt=0)
-    assert lib.gscan_workspace_bytes(ctypes.byref(big)) == 0
+    assert b"decoder_hidden_size 300" in lib.gscan_last_error()
+    even = _lib.Dims(B=4, L=10, T=20, G=6, C=16, Co=50, K3=4, E=25, He=100, H=100, Vi=21, V=9, conditional=1,
+                     auxiliary=0, bidirectional=1, pad_in=0, pad_tgt=0)
+    assert lib.gscan_workspace_bytes(ctypes.byref(even)) == 0
+    assert b"cnn_kernel_size" in lib.gscan_last_error()

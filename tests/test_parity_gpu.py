@@ -627,6 +627,25 @@ EDGE_CASES = [
                                               "embedding_dimension": 25, "auxiliary_task": True},
      dict(batch=3, grid=8, max_target=6), None),
     ("all_pad_targets_row", {}, dict(batch=3), "pad_row"),
+    # round 4 — shapes the reference takes that the register/LDS-resident kernels have no variant for: they run on the
+    # streaming kernels (decoder_any.hip, encoder_lstm_*_any_kernel, keys_backward_any_kernel)
+    ("hidden128_decoder_streams", {"encoder_hidden_size": 128, "decoder_hidden_size": 128, "embedding_dimension": 25},
+     dict(batch=3, max_target=6), None),
+    ("hidden200_aux", {"encoder_hidden_size": 200, "decoder_hidden_size": 200, "embedding_dimension": 25,
+                       "auxiliary_task": True}, dict(batch=2, grid=6, max_target=5), None),
+    ("hidden256_nocond_unidirectional", {"encoder_hidden_size": 256, "decoder_hidden_size": 256, "embedding_dimension": 32,
+                                         "conditional_attention": False, "encoder_bidirectional": False},
+     dict(batch=2, max_target=4), None),
+    ("hidden50_encoder30_not_multiples_of_4", {"encoder_hidden_size": 30, "decoder_hidden_size": 50, "embedding_dimension": 5},
+     dict(batch=3), None),
+    ("grid12_144_cells_aux", {"encoder_hidden_size": 100, "decoder_hidden_size": 100, "embedding_dimension": 25,
+                              "auxiliary_task": True}, dict(batch=2, grid=12, max_target=5), None),
+    ("command_of_100_tokens", {"encoder_hidden_size": 100, "decoder_hidden_size": 100, "embedding_dimension": 25},
+     dict(batch=3, max_command=100, max_target=5), None),
+    ("command_of_128_tokens_two_layers_hidden256", {"encoder_hidden_size": 256, "decoder_hidden_size": 64,
+                                                     "embedding_dimension": 16, "num_encoder_layers": 2},
+     dict(batch=2, max_command=128, max_target=4), None),
+    ("grid10_command70_hidden20", {}, dict(batch=3, grid=10, max_command=70), None),
 ]
 
 
