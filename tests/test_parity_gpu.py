@@ -507,6 +507,57 @@ def test_persistent_greedy_decoder_equals_the_stepwise_loop_and_stops_at_the_lim
         assert torch.allclose(one["att_sum"], ref["att_sum"], atol=1e-4)
 
 
+@pytest.mark.parametrize("overrides,shape_kw", [
+    ({"encoder_hidden_size": 128, "decoder_hidden_size": 128, "embedding_dimension": 25}, dict(grid=6)),
+    ({"encoder_hidden_size": 100, "decoder_hidden_size": 100, "embedding_dimension": 25, "conditional_attention": False},
+     dict(grid=12, max_command=90)),
+    ({"encoder_hidden_size": 30, "decoder_hidden_size": 50, "embedding_dimension": 5, "encoder_bidirectional": False},
+     dict(grid=4)),
+], ids=["hidden128", "grid12_command90", "hidden50_encoder30"])
+def test_greedy_decoding_on_streamed_shapes_against_oracle(overrides, shape_kw):
+    """predict.py:57-128 on shapes only the streaming kernels take: the one-launch greedy decoder and the stepwise
+    decode_input loop against the oracle's per-row loop — same tokens, same attention rows."""
+    from multimodal_seq2seq_gscan_amd.predict import greedy_decode, greedy_decode_stepwise
+    from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+    from oracle import seq2seq_oracle as oracle
+    from weights import golden_weights
+    cfg = model_kwargs("demo", cnn_dropout_p=0.0, encoder_dropout_p=0.0, decoder_dropout_p=0.0, **overrides)
+    kw = dict(batch=5, grid=4, channels=15, input_vocab=14, target_vocab=6, max_command=7, max_target=10, ragged=True)
+    kw.update(shape_kw)
+    batch = make_batch(Shape(**kw), seed=11)
+    params = {k: torch.from_numpy(v) for k, v in golden_weights(cfg, 23).items()}
+    model = build_model(cfg, params).eval()
+    sos, limit = 1, 9
+    for eos in (2, 4):
+        args = (model, batch["commands"].cuda(), batch["cmd_lengths"].tolist(), batch["world"].cuda(), sos, eos, limit)
+        with torch.no_grad():
+            one, step = greedy_decode(*args), greedy_decode_stepwise(*args)
+        ref = oracle.greedy_decode(params, batch["commands"], batch["cmd_lengths"], batch["world"], sos, eos, limit,
+                                   conditional=cfg["conditional_attention"], bidirectional=cfg["encoder_bidirectional"])
+        for r, row in enumerate(ref):
+            assert one["tokens"][r] == row["tokens"] == step["tokens"][r], (eos, r)
+            n, L = len(row["tokens"]), int(batch["cmd_lengths"][r])
+            a_t = torch.stack([a.flatten()[:L] for a in row["alpha_text"]])
+            a_v = torch.stack([a.flatten() for a in row["alpha_vis"]])
+            assert torch.allclose(torch.tensor(one["alpha_text"][r])[:n, :L], a_t, atol=1e-4)
+            assert torch.allclose(torch.tensor(one["alpha_vis"][r])[:n], a_v, atol=1e-4)
+
+
+def test_fixture_suite_on_the_streaming_kernels():
+    """GSCAN_DECODER_ANY=1 GSCAN_ENCODER_ANY=1 (read once per process, hence the child process): the reference's own
+    outputs — training step fixtures, the greedy fixture, the decode_input sequences — through the streaming kernels
+    instead of the register/LDS-resident ones."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GSCAN_DECODER_ANY="1", GSCAN_ENCODER_ANY="1")
+    pick = ("demo_variants or more_than_one_encoder_layer or geca_aux or greedy_predict_matches or decode_input or "
+            "persistent_greedy or one_call_train_step")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", pick,
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_command_line_train_then_test_modes(tmp_path):
     """`python -m seq2seq --mode=train ... --synthetic_data` then `--mode=test` (seq2seq/__main__.py:21-167): the
     training loop runs, writes the reference's checkpoint dictionary, and the test mode decodes greedily from it

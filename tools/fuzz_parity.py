@@ -22,6 +22,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=40)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--extremes", action="store_true", help="a fixed list of degenerate / limit shapes instead of random ones")
+ap.add_argument("--wide", action="store_true",
+                help="sample the whole range the reference accepts (hidden sizes to 256 incl. sizes that are not multiples "
+                     "of 4, grids to 12x12, commands to 128 tokens): most cases then run on the streaming kernels")
 ap.add_argument("--train-step", action="store_true",
                 help="also run train.TrainStep's ONE library call (gscan_train_step_nll, learning rate 0) on a second model "
                      "with the same weights: its loss and gradients must equal the oracle's too")
@@ -32,7 +35,10 @@ EXTREMES = [
     (100, 100, 25, 7, 50, 1, 1, 1, 1, 2, 2, 2, 1),
     (100, 100, 25, 7, 50, 1, 0, 1, 1, 1, 6, 64, 2),      # the longest command supported
     (100, 100, 25, 7, 50, 1, 0, 1, 1, 2, 8, 10, 3),      # the largest grid supported (gate images streamed from L2)
-    (100, 100, 25, 7, 50, 1, 0, 1, 1, 1, 8, 64, 2),      # both at once: must be REJECTED (240 KB of LDS per row)
+    (100, 100, 25, 7, 50, 1, 0, 1, 1, 1, 8, 64, 2),      # both at once: 240 KB of LDS per row in the resident kernels -> streaming kernels
+    (256, 256, 64, 7, 50, 1, 1, 1, 2, 2, 12, 128, 3),    # round 4: the widest of everything at once (streaming kernels)
+    (255, 255, 63, 7, 50, 1, 0, 1, 1, 2, 3, 5, 3),       # odd widths
+    (1, 1, 1, 1, 1, 1, 1, 0, 1, 2, 2, 2, 2),             # hidden size 1
     (100, 100, 25, 13, 50, 0, 0, 0, 1, 3, 2, 1, 40),
     (4, 4, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2),             # every width at its minimum
     (100, 128, 64, 7, 50, 1, 0, 1, 2, 2, 6, 10, 5),      # embedding wider than one 32-column block of the projection
@@ -48,6 +54,9 @@ bad = 0
 for case in range(args.cases):
     H = rng.choice(list(range(4, 101, 4)))              # every compiled decoder size
     He = rng.choice(list(range(4, 129, 4)))             # every compiled encoder size
+    if args.wide:
+        H = rng.choice([rng.randint(1, 256), rng.choice([128, 200, 256]), rng.choice(list(range(4, 101, 4)))])
+        He = rng.choice([rng.randint(1, 256), rng.choice([128, 200, 256]), rng.choice(list(range(4, 129, 4)))])
     if args.extremes:
         xH, xHe, xE, xk, xCo, xcond, xaux, xbi, xlayers, xB, xG, xL, xT = EXTREMES[case]
         H, He = xH, xHe
@@ -70,6 +79,11 @@ for case in range(args.cases):
                       input_vocab=cfg["input_vocabulary_size"], target_vocab=cfg["target_vocabulary_size"],
                       max_command=rng.choice([2, 3, 7, 10, 17]), max_target=rng.choice([2, 3, 10, 17, 33]),
                       ragged=rng.random() < 0.7)
+        if args.wide:
+            import dataclasses
+            shape = dataclasses.replace(shape, grid=rng.choice([2, 4, 6, 8, 9, 10, 12]),
+                                        max_command=rng.choice([2, 7, 17, 40, 65, 100, 128]),
+                                        max_target=rng.choice([2, 3, 10, 17]))
     batch = make_batch(shape, seed=1000 + case)
     params = {k: torch.from_numpy(v) for k, v in golden_weights(cfg, 100 + case).items()}
     try:
