@@ -1,7 +1,7 @@
 // The decoder recurrence for ANY shape (seq2seq/seq2seq_model.py:359-492): every --decoder_hidden_size, command
 // length and grid size the reference accepts, where decoder.hip's kernels (weights in registers, memories in LDS, the
 // attention distribution in the 64 lanes of a wave) are compiled for hidden sizes up to 100 and hold at most 64
-// memories per attention.  Correctness first: one 256-thread workgroup per batch row as there, but
+// memories per attention.  One 1024-thread workgroup per batch row, and
 //   * the weights are STREAMED from L2 every step, in the reference's own [out, in] layouts (no register images):
 //     a product with a vector is either "rows" (sixteen lanes per output row, 256-byte pieces of the row, a DPP sum)
 //     or "columns" (a lane per output column of the transposed product, coalesced across lanes);
@@ -43,7 +43,7 @@ __device__ __forceinline__ void scores_any(const float *v_s, const float *q_s, c
     }
 }
 
-struct AnyLds { int hc, qt, q2, qv, vt, vv, bq, pre, cell, sc, misc, total; };
+struct AnyLds { int hc, qt, q2, qv, vt, vv, bq, pre, cell, sc, misc, scr, total; };
 __host__ __device__ inline AnyLds any_lds_fwd(int H, int L, int M) {
     const int HP = (H + 3) / 4 * 4, NM = ((L > M ? L : M) + 3) / 4 * 4;
     AnyLds o;
@@ -54,6 +54,7 @@ __host__ __device__ inline AnyLds any_lds_fwd(int H, int L, int M) {
     o.cell = p; p += HP;
     o.sc = p; p += NM;
     o.misc = p; p += 64;
+    o.scr = p; p += kAnyThreads;       // partial sums of the column products
     o.total = p;
     return o;
 }
@@ -69,7 +70,8 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
     const int T = a.T, L = a.L, M = a.M, V = a.V;
     const AnyLds o = any_lds_fwd(H, L, M);
     float *hc = smem + o.hc, *qt_s = smem + o.qt, *q2_s = smem + o.q2, *qv_s = smem + o.qv, *vt_s = smem + o.vt,
-          *vv_s = smem + o.vv, *bq_s = smem + o.bq, *pre_s = smem + o.pre, *c_s = smem + o.cell, *sc = smem + o.sc;
+          *vv_s = smem + o.vv, *bq_s = smem + o.bq, *pre_s = smem + o.pre, *c_s = smem + o.cell, *sc = smem + o.sc,
+          *scr = smem + o.scr;
     int *tok_s = reinterpret_cast<int *>(smem + o.misc);
     float *h_s = hc, *ctxt_s = hc + H, *ctxv_s = hc + 2 * H;
     int len = a.cmd_lengths[b];
@@ -107,13 +109,10 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
         softmax_lds(sc, len);
         __syncthreads();
         for (int m = tid; m < L; m += kAnyThreads) a.alpha_c[bt * L + m] = m < len ? sc[m] : 0.f;
-        for (int k = tid; k < H; k += kAnyThreads) {
-            float acc = 0.f;
-            for (int m = 0; m < len; ++m) acc = fmaf(sc[m], pk_t[(int64_t)m * H + k], acc);
+        matvec_cols(pk_t, H, 0, len, H, sc, scr, [&](int k, float acc) {      // context = alpha . PK (:138-139)
             ctxt_s[k] = acc;
             if (!GREEDY) { a.s[bt * 4 * H + H + k] = acc; a.qt[bt * H + k] = qt_s[k]; }
-        }
-        __syncthreads();
+        });
         // ---- the query of the visual attention: conditional (tanh(W_q2k [h; ctx_text] + b), :394-396) or h itself
         if (cond) {
             matvec_rows<V4>(W_q2k, 2 * H, H, 2 * H, hc, [&](int r, float v) {
@@ -137,13 +136,10 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
             a.alpha_s[bt * M + m] = sc[m];
             a.att_sum[(int64_t)b * M + m] += sc[m];                    // seq2seq_model.py:479,490 (this thread's element)
         }
-        for (int k = tid; k < H; k += kAnyThreads) {
-            float acc = 0.f;
-            for (int m = 0; m < M; ++m) acc = fmaf(sc[m], pk_v[(int64_t)m * H + k], acc);
+        matvec_cols(pk_v, H, 0, M, H, sc, scr, [&](int k, float acc) {
             ctxv_s[k] = acc;
             if (!GREEDY) a.s[bt * 4 * H + 2 * H + k] = acc;
-        }
-        __syncthreads();
+        });
         // ---- LSTM cell (seq2seq_model.py:414): the context part of the input product, then the gates
         matvec_rows<V4>(W_ih + H, 3 * H, 4 * H, 2 * H, ctxt_s, [&](int r, float v) { pre_s[r] += v; });
         __syncthreads();
@@ -271,7 +267,7 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
 // d h0 — and dS holds the head's part only: the LSTM-input and conditional-query parts of the context gradients are
 // added by the dense product behind this kernel, as for the fast kernel.
 // ------------------------------------------------------------------------------------------
-struct AnyLdsB { int dh, dc, dl, dctx, dq, dqv, q, v1, v2, al, sc, datt, red, total; };
+struct AnyLdsB { int dh, dc, dl, dctx, dq, dqv, q, v1, v2, al, sc, datt, red, scr, total; };
 __host__ __device__ inline AnyLdsB any_lds_bwd(int H, int L, int M) {
     const int HP = (H + 3) / 4 * 4, NM = ((L > M ? L : M) + 3) / 4 * 4;
     AnyLdsB o;
@@ -285,16 +281,19 @@ __host__ __device__ inline AnyLdsB any_lds_bwd(int H, int L, int M) {
     o.v1 = p; p += HP; o.v2 = p; p += HP;      // energy vectors
     o.al = p; p += NM; o.sc = p; p += NM; o.datt = p; p += NM;
     o.red = p; p += 64;
+    o.scr = p; p += kAnyThreads;
     o.total = p;
     return o;
 }
 
 // one attention's backward at one step (row-local): d alpha_m = dctx . PK[m] (+ datt[m]), softmax backward, then through
-// v . tanh(q + PK[m]): dq, the score-path dPK (accumulated in global memory over the steps: thread k owns column k
-// of every memory) and the energy-vector gradient (per-thread register sums `dv`, one per owned feature).
+// v . tanh(q + PK[m]): dq, the score-path dPK (accumulated in global memory over the steps) and the energy-vector
+// gradient.  Thread (k, p) owns feature k of the memories m = p, p + P, ... (P = kAnyThreads / CB thread groups per
+// feature block, as in matvec_cols): its dPK elements are its own, its share of dq goes through `scratch`, its share
+// of the energy-vector gradient stays in its register `dv` until the end of the kernel.  Requires H <= kAnyThreads.
 __device__ __forceinline__ void attention_bwd_any(const float *dctx, const float *q_s, const float *v_s, const float *al,
                                                   const float *datt, const float *__restrict__ pk, float *dpk, int n, int H,
-                                                  float *sc, float *dq_s, float *red, float (&dv)[8]) {
+                                                  float *sc, float *dq_s, float *red, float *scratch, float &dv) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int m0 = 0; m0 < n; m0 += kAnyWaves) {                        // d alpha_m, a wave per memory
         const int m = m0 + wave, mc = min(m, n - 1);
@@ -312,11 +311,13 @@ __device__ __forceinline__ void attention_bwd_any(const float *dctx, const float
     }
     __syncthreads();
     const float s = red[0];
-    int i = 0;
-    for (int k = tid; k < H; k += kAnyThreads, ++i) {
+    const int CB = min((H + 63) & ~63, kAnyThreads), P = kAnyThreads / CB;
+    const int k = tid % CB, p = tid / CB;
+    float dq = 0.f;
+    if (p < P && k < H) {
         const float qk = q_s[k], vk = v_s[k];
-        float dq = 0.f, dvk = 0.f;
-        for (int m = 0; m < n; ++m) {
+        float dvk = 0.f;
+        for (int m = p; m < n; m += P) {
             const float ds = al[m] * (sc[m] - s);
             const float th = tanhf_(qk + pk[(int64_t)m * H + k]);
             const float g = ds * vk * (1.f - th * th);
@@ -324,8 +325,14 @@ __device__ __forceinline__ void attention_bwd_any(const float *dctx, const float
             dq += g;
             dvk = fmaf(ds, th, dvk);
         }
-        dq_s[k] = dq;
-        if (i < 8) dv[i] += dvk;
+        dv += dvk;
+    }
+    scratch[tid] = dq;
+    __syncthreads();
+    if (tid < CB && tid < H) {
+        float sum = 0.f;
+        for (int q = 0; q < P; ++q) sum += scratch[q * CB + tid];
+        dq_s[tid] = sum;
     }
     __syncthreads();
 }
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
     const AnyLdsB o = any_lds_bwd(H, L, M);
     float *dh_s = smem + o.dh, *dc_s = smem + o.dc, *dl_s = smem + o.dl, *dctx_s = smem + o.dctx, *dq_s = smem + o.dq,
           *dqv_s = smem + o.dqv, *q_s = smem + o.q, *vt_s = smem + o.v1, *vv_s = smem + o.v2, *al_s = smem + o.al, *sc = smem + o.sc,
-          *datt_s = smem + o.datt, *red = smem + o.red;
+          *datt_s = smem + o.datt, *red = smem + o.red, *scr = smem + o.scr;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
     const float *pk_t = a.pk_t + (int64_t)b * L * H, *pk_v = a.pk_v + (int64_t)b * M * H;
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
     for (int k = tid; k < H; k += kAnyThreads) { dh_s[k] = 0.f; dc_s[k] = 0.f; vt_s[k] = a.v_t[k]; vv_s[k] = a.v_v[k]; }
     for (int i = tid; i < M * H; i += kAnyThreads) dpk_v[i] = 0.f;
     for (int i = tid; i < L * H; i += kAnyThreads) dpk_t[i] = 0.f;
-    float dvt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dvv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dvt = 0.f, dvv = 0.f;                     // this thread's share of the energy-vector gradients (attention_bwd_any)
     __syncthreads();
 
     for (int t = T - 1; t >= 0; --t) {
@@ -440,38 +447,38 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
         }
         __syncthreads();
         // ---- d [ctx_text | ctx_vis] = head part + W_ih[:, H:3H]^T delta
-        matvec_cols(W_ih, 3 * H, H, 4 * H, 2 * H, dl_s, [&](int c, float v) { dctx_s[c] = v + a.ds[bt * 4 * H + H + c]; });
+        matvec_cols(W_ih, 3 * H, H, 4 * H, 2 * H, dl_s, scr, [&](int c, float v) { dctx_s[c] = v + a.ds[bt * 4 * H + H + c]; });
         for (int m = tid; m < M; m += kAnyThreads) al_s[m] = a.alpha_s[bt * M + m];
         for (int k = tid; k < H; k += kAnyThreads) q_s[k] = a.qv[bt * H + k];
         __syncthreads();
         // ---- visual attention backward
-        attention_bwd_any(dctx_s + H, q_s, vv_s, al_s, datt_s, pk_v, dpk_v, M, H, sc, dq_s, red, dvv);
+        attention_bwd_any(dctx_s + H, q_s, vv_s, al_s, datt_s, pk_v, dpk_v, M, H, sc, dq_s, red, scr, dvv);
         for (int k = tid; k < H; k += kAnyThreads) { const float v = dq_s[k]; dqv_s[k] = v; a.dqv[bt * H + k] = v; }
         __syncthreads();
         if (cond) {
             // d q2 = W_qv^T dqv, through tanh; the conditional query's share of d ctx_text
-            matvec_cols(W_qv, H, 0, H, H, dqv_s, [&](int c, float v) {
+            matvec_cols(W_qv, H, 0, H, H, dqv_s, scr, [&](int c, float v) {
                 const float q = a.q2[bt * H + c];
                 const float dz = v * (1.f - q * q);
                 dl_s[4 * H + c] = dz;
                 a.delta[bt * 5 * H + 4 * H + c] = dz;
             });
             __syncthreads();
-            matvec_cols(W_q2k, 2 * H, H, H, H, dl_s + 4 * H, [&](int c, float v) { dctx_s[c] += v; });
+            matvec_cols(W_q2k, 2 * H, H, H, H, dl_s + 4 * H, scr, [&](int c, float v) { dctx_s[c] += v; });
         }
         for (int m = tid; m < L; m += kAnyThreads) al_s[m] = a.alpha_c[bt * L + m];
         for (int k = tid; k < H; k += kAnyThreads) q_s[k] = a.qt[bt * H + k];
         __syncthreads();
         // ---- textual attention backward
-        attention_bwd_any(dctx_s, q_s, vt_s, al_s, nullptr, pk_t, dpk_t, len, H, sc, dq_s, red, dvt);
+        attention_bwd_any(dctx_s, q_s, vt_s, al_s, nullptr, pk_t, dpk_t, len, H, sc, dq_s, red, scr, dvt);
         for (int k = tid; k < H; k += kAnyThreads) a.dqt[bt * H + k] = dq_s[k];
         // ---- dh_{t-1} = W_hh^T delta + W_qt^T dqt + (W_q2k[:, :H]^T dzq  or  W_qv^T dqv)
-        matvec_cols(W_hh, H, 0, 4 * H, H, dl_s, [&](int c, float v) { dh_s[c] = v; });
+        matvec_cols(W_hh, H, 0, 4 * H, H, dl_s, scr, [&](int c, float v) { dh_s[c] = v; });
         __syncthreads();
-        matvec_cols(W_qt, H, 0, H, H, dq_s, [&](int c, float v) { dh_s[c] += v; });
+        matvec_cols(W_qt, H, 0, H, H, dq_s, scr, [&](int c, float v) { dh_s[c] += v; });
         __syncthreads();
-        if (cond) matvec_cols(W_q2k, 2 * H, 0, H, H, dl_s + 4 * H, [&](int c, float v) { dh_s[c] += v; });
-        else matvec_cols(W_qv, H, 0, H, H, dqv_s, [&](int c, float v) { dh_s[c] += v; });
+        if (cond) matvec_cols(W_q2k, 2 * H, 0, H, H, dl_s + 4 * H, scr, [&](int c, float v) { dh_s[c] += v; });
+        else matvec_cols(W_qv, H, 0, H, H, dqv_s, scr, [&](int c, float v) { dh_s[c] += v; });
         __syncthreads();
     }
     // ---- epilogue: initial-state gradient through the bridge tanh (h0 = c0 = tanh(.), model.py:195), energy vectors
@@ -480,11 +487,17 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
         a.dh0[(int64_t)b * H + k] = (dh_s[k] + dc_s[k]) * (1.f - h0 * h0);
     }
     for (int i = tid; i < (L - len) * H; i += kAnyThreads) dpk_t[(int64_t)len * H + i] = 0.f;
-    {
-        int i = 0;
-        for (int k = tid; k < H; k += kAnyThreads, ++i) {
-            a.dv_t[(int64_t)b * H + k] = dvt[i < 8 ? i : 7];
-            a.dv_v[(int64_t)b * H + k] = dvv[i < 8 ? i : 7];
+    {   // energy-vector gradients of the row: the thread groups' shares of feature k
+        const int CB = min((H + 63) & ~63, kAnyThreads), P = kAnyThreads / CB;
+        for (int which = 0; which < 2; ++which) {
+            __syncthreads();
+            scr[tid] = which ? dvv : dvt;
+            __syncthreads();
+            if (tid < H) {
+                float sum = 0.f;
+                for (int q = 0; q < P; ++q) sum += scr[q * CB + tid];
+                (which ? a.dv_v : a.dv_t)[(int64_t)b * H + tid] = sum;
+            }
         }
     }
 }
@@ -492,7 +505,7 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-constexpr int kAnyMaxHidden = 8 * kAnyThreads;     // a thread keeps the energy-vector sums of at most eight features
+constexpr int kAnyMaxHidden = kAnyThreads;         // the backward pass gives every feature of an attention a thread
 
 int decoder_run_any(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream) {
     GSCAN_CHECK(H >= 1 && H <= kAnyMaxHidden, "decoder: decoder_hidden_size %d is outside 1..%d", H, kAnyMaxHidden);

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_ke
 // The same two recurrences for ANY encoder hidden size and command length (the kernels above keep W_hh in registers —
 // hidden sizes up to 128 — and the whole command's history in LDS — L . He <= ~6 800): W_hh (and, for the first layer,
 // W_ih) streamed from L2 in the reference's layout, one step's vectors in LDS, saved activations written straight to
-// global memory.  grid (B, D), 256 threads, same arguments and outputs.  Correctness first.
+// global memory.  grid (B, D), 1024 threads, same arguments and outputs.
 // ------------------------------------------------------------------------------------------
 template <bool V4>
 __global__ __launch_bounds__(kAnyThreads) void encoder_lstm_fwd_any_kernel(int L, int D, int HE, const float *__restrict__ gx,
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kAnyThreads) void encoder_lstm_bwd_any_kernel(int L
     int len = lengths[b];
     len = max(0, min(len, L));
     const int HP = (HE + 3) / 4 * 4;
-    float *dh_s = lds, *dc_s = dh_s + HP, *dl_s = dc_s + HP;           // dl_s [4 HP]
+    float *dh_s = lds, *dc_s = dh_s + HP, *dl_s = dc_s + HP, *scr = dl_s + 4 * HP;   // dl_s [4 HP], scr [kAnyThreads]
     const int64_t row0 = (int64_t)b * L;
     const float *w_hh = dir ? w_hh_r : w_hh_f;
     for (int k = tid; k < HE; k += kAnyThreads) { dh_s[k] = d_h_final ? d_h_final[(int64_t)b * HE + k] : 0.f; dc_s[k] = 0.f; }
@@ -423,8 +423,7 @@ __global__ __launch_bounds__(kAnyThreads) void encoder_lstm_bwd_any_kernel(int L
             delta[row * 4 * HE + 2 * HE + k] = dg; delta[row * 4 * HE + 3 * HE + k] = d_o;
         }
         __syncthreads();
-        matvec_cols(w_hh, HE, 0, 4 * HE, HE, dl_s, [&](int c, float v) { dh_s[c] = v; });
-        __syncthreads();
+        matvec_cols(w_hh, HE, 0, 4 * HE, HE, dl_s, scr, [&](int c, float v) { dh_s[c] = v; });
     }
 }
 
@@ -573,7 +572,7 @@ int encoder_lstm_backward(int B, int L, int He, int D, const int32_t *lengths, c
     }
     {
         const int HP = (He + 3) / 4 * 4;
-        const size_t lds = (size_t)6 * HP * sizeof(float);
+        const size_t lds = (size_t)(6 * HP + kAnyThreads) * sizeof(float);
         GSCAN_CHECK(He >= 1 && lds <= kEncLdsLimit, "encoder lstm bwd: encoder_hidden_size %d", He);
         ProbeScope probe(P_ENCODER_BWD, stream, 2.0 * B * L * D * 4 * He * He);
         hipLaunchKernelGGL(encoder_lstm_bwd_any_kernel, dim3(B, D), dim3(kAnyThreads), lds, stream, L, D, He, lengths, w_hh_f, w_hh_r,

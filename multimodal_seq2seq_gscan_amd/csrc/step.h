@@ -309,7 +309,7 @@ struct DecoderArgs {
     float *stats_out, *seeds_out;      // [4] batch sums, [3] = [1/tokens, w/rows, loss]; written by workgroup 0
     float *delta, *dqt, *dqv;          // [B,T,5H] = [gate deltas (4H) | dzq (H)], [B,T,H], [B,T,H]
     float *dpk_t, *dpk_v;              // [B,L,H] [B,M,H]  score-path key gradients
-    float *dv_t, *dv_v;                // [B,H] energy-vector gradients of every row (summed by unpermute_add's launch)
+    float *dv_t, *dv_v;                // [B,H] energy-vector gradients of every row (summed by head_grad_finish's launch)
     float *dh0;                        // [B,H] gradient wrt the bridge pre-activation
     float *stamps;                     // diagnostics: [2][16] per-phase cycle sums of workgroup 0, or NULL
     // greedy decoding (forward kernel, GREEDY instantiation; selected by tokens_out != NULL): T = step limit,

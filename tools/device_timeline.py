@@ -35,7 +35,7 @@ from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
 from multimodal_seq2seq_gscan_amd.train import TrainStep
 
 NAMES = {1: "dropout_mask", 2: "conv_fwd", 3: "prologue", 4: "gemm", 5: "encoder_fwd", 6: "decoder_fwd",
-         7: "decoder_bwd", 8: "keys_backward", 9: "unpermute_add", 10: "embed_grad", 11: "encoder_bwd",
+         7: "decoder_bwd", 8: "keys_backward", 9: "head_grad_finish", 10: "embed_grad", 11: "encoder_bwd",
          12: "conv_bwd", 13: "adam", 14: "loss", 15: "other"}
 RECORDS = 256
 
