@@ -437,9 +437,13 @@ int gemm_macro_tile_mode() {
     return mode;
 }
 
-// Launches with at least this many 128-row macro tiles take gemm_mt.hip by rule (4096^3: 105 TFLOP/s there against 94
-// on the 64 x 64 tiles below); none of the training step's launches at batch 256 comes near (its largest has 642).
-constexpr int kMacroMinTiles = 1024;
+// Launches with at least this many 128-row macro tiles whose products are all at least kMacroMinK deep take gemm_mt.hip
+// by rule (4096^3: 105 TFLOP/s there against 94 on the 64 x 64 tiles below).  The depth condition keeps the training
+// step's launches off it at every batch size: its many-tile launches are the forward products with K = 100-150 (four
+// K rounds, then a 16 K-float epilogue per workgroup), and with them on the macro tiles S3 (T = 120: 1 400 macro tiles in
+// the forward launch) ran 1.817 ms per step against 1.783, S1 at 1 024 rows 1.776 against 1.745
+// (profiles/r04_gemm_macro_rule_ab.txt).
+constexpr int kMacroMinTiles = 1024, kMacroMinK = 512;
 
 int GemmBatch::launch(hipStream_t stream) {
     if (bad_) return 1;
@@ -455,13 +459,14 @@ int GemmBatch::launch(hipStream_t stream) {
     // A launch that was handed scratch for split-K slabs asked for the fixed-order sums: macro tiles too.
     const int mt_mode = scratch_ ? 1 : gemm_macro_tile_mode();
     if (mt_mode != 0) {
-        int macro_tiles = 0;
+        int macro_tiles = 0, k_min = INT_MAX;
         for (int i = 0; i < grp_.count; ++i) {
             int tn, nf;
             gemm_mt_columns(grp_.p[i].N + (grp_.p[i].asum1 ? 1 : 0), &tn, &nf);
             macro_tiles += tn * cdiv(grp_.p[i].M, 128);
+            k_min = std::min(k_min, grp_.p[i].K);
         }
-        if (mt_mode > 0 || macro_tiles >= kMacroMinTiles) return launch_macro_tiles(stream);
+        if (mt_mode > 0 || (macro_tiles >= kMacroMinTiles && k_min >= kMacroMinK)) return launch_macro_tiles(stream);
     }
     static const int forced = [] { const char *e = getenv("GSCAN_GEMM_TMW"); return e ? atoi(e) : 0; }();
     // Launches whose 64-row tiling has fewer workgroups than this use 32-row tiles (see kWideTileMinGroups above)

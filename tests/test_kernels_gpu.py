@@ -108,14 +108,16 @@ def test_gemm_macro_tiles_with_slabs_are_exact_and_reproducible(lib, M, N, K, la
 
 
 @pytest.mark.parametrize("M,N,K,layout,split", [
-    (32768, 400, 150, "nt", 1),     # 256 x 4 macro tiles, 8-byte loads (rows of 150 floats), seven fragments of columns
+    (32768, 400, 600, "nt", 1),     # 256 x 4 macro tiles, K >= 512: the rule's launch; seven fragments of columns
+    (32768, 400, 150, "nt", 1),     # as many tiles but a short K: stays on the small tiles (the training step's forward products)
     (32768, 100, 100, "nt", 1),     # too few tiles for the rule: rides on the small tiles
-    (65536, 240, 96, "nn", 1),      # 512 x 2 tiles, row-contiguous B
-    (4096, 4096, 70, "tn", 1),      # both operands row-contiguous (weight-gradient layout), ragged K
+    (65536, 240, 518, "nn", 1),     # 512 x 2 tiles, row-contiguous B, 8-byte loads (rows of 518 floats)
+    (4096, 4096, 515, "tn", 1),     # both operands row-contiguous (weight-gradient layout), ragged K
     (2048, 1040, 4096, "tn", 8),    # the rule's launch with split-K and no scratch: atomics on macro tiles
 ])
 def test_gemm_large_launches_take_macro_tiles(lib, M, N, K, layout, split):
-    """Launches with >= 1024 macro tiles go to gemm_mt_kernel (csrc/gemm_mt.hip) by rule; same contract."""
+    """Launches with >= 1024 macro tiles of products at least 512 deep go to gemm_mt_kernel (csrc/gemm_mt.hip) by rule;
+    same contract on both sides of the rule."""
     import gpu_ops
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
