@@ -457,7 +457,7 @@ int GemmBatch::launch(hipStream_t stream) {
     // fixed order instead of with float atomics — bitwise reproducible weight gradients for 4 % of step time.
     // GSCAN_GEMM_MT=0: never.
     // A launch that was handed scratch for split-K slabs asked for the fixed-order sums: macro tiles too.
-    const int mt_mode = scratch_ ? 1 : gemm_macro_tile_mode();
+    const int mt_mode = (scratch_ || (force_mt_ && gemm_macro_tile_mode() != 0)) ? 1 : gemm_macro_tile_mode();
     if (mt_mode != 0) {
         int macro_tiles = 0, k_min = INT_MAX;
         for (int i = 0; i < grp_.count; ++i) {

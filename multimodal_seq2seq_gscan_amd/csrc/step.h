@@ -65,12 +65,14 @@ public:
     // launches that may overlap on different streams must not share one.  Handing a launch scratch puts it on the macro
     // tiles whatever its size; the training step does so in deterministic mode only (step.hip).
     void scratch(float *ptr, size_t floats) { scratch_ = ptr; scratch_floats_ = floats; }
+    // This launch on the macro tiles whatever the rule says (split products without scratch: float atomics).
+    void prefer_macro_tiles() { force_mt_ = true; }
     int launch(hipStream_t stream);
 private:
     GemmGroup grp_{};
     int tiles_ = 0;
     double flops_ = 0.0, alg_flops_ = 0.0, last_flops_ = 0.0;
-    bool bad_ = false;
+    bool bad_ = false, force_mt_ = false;
     float *scratch_ = nullptr;
     size_t scratch_floats_ = 0;
     int launch_macro_tiles(hipStream_t stream);

@@ -609,6 +609,10 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
             // gradients (dense products over the B*T saved rows)
             GemmBatch b;
             if (gemm_macro_tile_mode() > 0) b.scratch(w + ws.gemm_slabs_side, (size_t)kGemmSlabs * gemm_slab_floats());
+            // (the leaves on the macro tiles, GSCAN_LEAVES_MT=<rows>, measured for S3: the family's time drops 0.78 ->
+            // 0.65 ms and the step gets SLOWER, 1.777 -> 1.822 ms — their workgroups crowd the chain's kernels)
+            static const int leaves_mt = [] { const char *e = getenv("GSCAN_LEAVES_MT"); return e ? atoi(e) : 0; }();
+            if (leaves_mt > 0 && BT >= leaves_mt) b.prefer_macro_tiles();
             static const int dec_split = [] { const char *e = getenv("GSCAN_SPLIT_DEC"); return e ? atoi(e) : 0; }();
             g_split_override = dec_split;
             // the head as one matrix Wc = W_h2o . W_o2h (decoder.hip): d Wc = dlogits^T . S, and both Linears'
@@ -651,8 +655,17 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     if (leaves_fork == 0) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
     // chain: gradient wrt [ctx_text | ctx_vis] through the LSTM input and the conditional query
     // (one product: [delta | dzq] . [W_ih[:, ctx] ; (W_q2k[:, ctx_text] | 0)], K = 5H when conditional)
-    TRY(gemm_f32(BT, 2 * H, cond ? 5 * H : 4 * H, 1.f, delta, 5 * H, 1, w + ws.wcat5 + H, 3 * H, 1, 1.f, dS + H, 4 * H,
-                 nullptr, 0, nullptr, 1, st));
+    {
+        // From ~10 000 decoder rows on (S3: 30 720; S1 from 512 rows per GPU) this product — alone in its launch, on the
+        // critical chain, 500 deep — is faster on the macro tiles of gemm_mt.hip: S3 1.777 -> 1.750 ms per step, S1 at
+        // 512 / 1 024 rows 0.909 -> 0.891 / 1.740 -> 1.713; at 5 120 / 7 680 rows it loses 1 %
+        // (profiles/r04_ds_product_macro_tiles_ab.txt).  GSCAN_DS_MT=<rows> moves the threshold, 0 = never.
+        static const int ds_mt = [] { const char *e = getenv("GSCAN_DS_MT"); return e ? atoi(e) : 10000; }();
+        GemmBatch b;
+        if (ds_mt > 0 && BT >= ds_mt) b.prefer_macro_tiles();
+        b.add(BT, 2 * H, cond ? 5 * H : 4 * H, delta, 5 * H, 1, w + ws.wcat5 + H, 3 * H, 1, dS + H, 4 * H, 1.f);
+        TRY(b.launch(st));
+    }
     if (leaves_fork == 1) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
     // chain: value path of both attentions (dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]), then through the
     // key layers and the bridge to the encoder outputs / final state / conv features — one launch, row per WG
