@@ -86,6 +86,20 @@ struct TraceScope {
         return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; \
     }
 
+// sum_{c < chunks} part[c * stride + idx] in chunk order, sixteen loads in flight (the fixed-order second phase of the
+// deterministic mode's reductions: one thread per output element)
+__device__ __forceinline__ float ordered_chunk_sum(const float *__restrict__ part, int chunks, int64_t stride, int64_t idx) {
+    float s = 0.f;
+    for (int c0 = 0; c0 < chunks; c0 += 16) {
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = (c0 + u < chunks) ? part[(int64_t)(c0 + u) * stride + idx] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += x[u];
+    }
+    return s;
+}
+
 // sigmoid / tanh through v_exp_f32 (2^x) and v_rcp_f32 (1 ulp each): absolute error ~1e-7, two transcendental
 // issues and two (sigmoid) / three (tanh) plain VALU operations per call; both saturate cleanly for large |x|
 // (2^(+big) = inf, rcp(inf) = 0).  tanh x = 2 sigmoid(2x) - 1: the recurrent kernels are bound by VALU issue, and

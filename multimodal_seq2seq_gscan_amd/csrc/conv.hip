@@ -66,6 +66,7 @@ struct ConvArgs {
     uint32_t *seg_keys;          // backward: per (channel, segment) lists of non-zeros [C][kConvSegments][slice * G*G]
     float *seg_vals;
     int *seg_count;              // [C][kConvSegments]
+    float *bias_part;            // backward, fixed-order sums: per-chunk bias partials [chunks][3Co] (NULL: float atomics)
 };
 
 // Compaction of the non-zeros among n elements into LDS by the whole workgroup, in scan order (deterministic).
@@ -404,7 +405,8 @@ __global__ __launch_bounds__(kConvThreads) void world_conv_bwd_kernel(ConvArgs a
                 float s = 0.f;
 #pragma unroll
                 for (int q = 0; q < kSl; ++q) s += bsl[q][fl];
-                atomicAdd(&a.gb[f / Co][f % Co], s);
+                if (a.bias_part) a.bias_part[(int64_t)chunk * F + f] = s;      // added in chunk order by conv_bias_reduce_kernel
+                else atomicAdd(&a.gb[f / Co][f % Co], s);
             }
             __syncthreads();
         }
@@ -585,9 +587,23 @@ int world_conv_lists(const void *world, int world_is_u8, int B, int G, int C, fl
     return 0;
 }
 
-// Pass 2: kernel and bias gradients from the lists of world_conv_lists and d(features).
+// fixed-order form of the bias gradients: thread f adds the chunks' partial sums of column f in chunk order
+__global__ void conv_bias_reduce_kernel(const float *__restrict__ part, int chunks, int F, int Co, float *gb0, float *gb1,
+                                        float *gb2) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const float s = ordered_chunk_sum(part, chunks, F, f);
+    float *gb = f / Co == 0 ? gb0 : (f / Co == 1 ? gb1 : gb2);
+    gb[f % Co] += s;
+}
+
+size_t world_conv_bias_partial_floats(int B, int G, int Co) { return (size_t)cdiv((int64_t)B * G * G, 64) * 3 * Co; }
+
+// Pass 2: kernel and bias gradients from the lists of world_conv_lists and d(features).  bias_part (optional,
+// world_conv_bias_partial_floats): the bias gradients are then added in a fixed order (a second, tiny launch) instead
+// of with float atomics — the deterministic mode of the training step.
 int world_conv_backward(const float *dfeat, int B, int G, int C, int Co, int K3, float *scratch,
-                        float *const (&gw)[3], float *const (&gb)[3], hipStream_t stream) {
+                        float *const (&gw)[3], float *const (&gb)[3], hipStream_t stream, float *bias_part) {
     TRY_RC(conv_check(B, G, C, Co, K3));
     GSCAN_CHECK(B < 65536, "world encoder: more than 65535 examples per call (B=%d)", B);
     ConvArgs a = conv_backward_args(B, G, C, Co, K3, scratch);
@@ -597,8 +613,14 @@ int world_conv_backward(const float *dfeat, int B, int G, int C, int Co, int K3,
     a.nw_blocks = C * cdiv(npairs, kConvWaves / kConvSegments);
     const dim3 grid(a.nw_blocks + cdiv((int64_t)B * G * G, 64));
     ProbeScope probe(P_CONV_BWD, stream, 0.0, conv_algorithmic_flops(B, G, C, Co, K3));
+    a.bias_part = bias_part;
     hipLaunchKernelGGL(world_conv_bwd_kernel<0>, grid, dim3(kConvThreads), 0, stream, a);
     GSCAN_LAUNCHED("world_conv_bwd_kernel");
+    if (bias_part) {
+        hipLaunchKernelGGL(conv_bias_reduce_kernel, dim3(cdiv(3 * Co, 64)), dim3(64), 0, stream, bias_part,
+                           cdiv((int64_t)B * G * G, 64), 3 * Co, Co, gb[0], gb[1], gb[2]);
+        GSCAN_LAUNCHED("conv_bias_reduce_kernel");
+    }
     return 0;
 }
 

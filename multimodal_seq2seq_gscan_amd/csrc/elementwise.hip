@@ -46,7 +46,7 @@ constexpr int kEmbedRows = 32;
 constexpr int kEmbedThreads = 256;
 __global__ __launch_bounds__(kEmbedThreads) void embed_grad_kernel(const int64_t *__restrict__ tok, const float *__restrict__ g, int64_t ldg,
                                   const float *__restrict__ mask, int rows, int D, int DP, int v0, int vocab, int pad,
-                                  float *__restrict__ dtable) {   // tokens v0 .. v0 + vocab - 1
+                                  float *__restrict__ dtable, float *__restrict__ part, int vocab_all) {   // tokens v0 .. v0 + vocab - 1
     TraceScope trace_scope(TK_EMBED_GRAD);
     extern __shared__ float priv[];                       // [vocab][kEmbedThreads]
     const int tid = threadIdx.x, d = tid & (DP - 1), slot = tid / DP, slots = kEmbedThreads / DP;
@@ -79,12 +79,23 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_grad_kernel(const int64_t
         const int v = i / D, c = i - v * D;
         float sum = 0.f;
         for (int s = 0; s < slots; ++s) sum += priv[v * kEmbedThreads + s * DP + c];
-        if (sum != 0.f) atomicAdd(&dtable[(int64_t)v0 * D + i], sum);
+        if (part) part[((int64_t)blockIdx.x * vocab_all + v0) * D + i] = sum;
+        else if (sum != 0.f) atomicAdd(&dtable[(int64_t)v0 * D + i], sum);
     }
 }
 
+// Fixed-order form (the deterministic mode of the training step): the workgroups of embed_grad_kernel write their sums
+// to part[workgroup][vocab][D] instead of adding them to the table with atomics, and one thread per table element adds
+// the workgroups' sums in workgroup order.
+__global__ void embed_grad_reduce_kernel(const float *__restrict__ part, int chunks, int n, float *__restrict__ dtable) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dtable[i] += ordered_chunk_sum(part, chunks, n, i);
+}
+
+size_t embed_grad_partial_floats(int rows, int D, int vocab) { return (size_t)cdiv(rows, kEmbedRows) * vocab * D; }
+
 int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mask, int rows, int D, int vocab,
-               int pad, float *dtable, hipStream_t stream) {
+               int pad, float *dtable, hipStream_t stream, float *part) {
     GSCAN_CHECK(D >= 1 && D <= kEmbedThreads, "embed_grad: embedding dimension %d is not supported (1..%d)", D, kEmbedThreads);
     int DP = 1;
     while (DP < D) DP <<= 1;
@@ -93,8 +104,13 @@ int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mas
         const int n = std::min(kChunk, vocab - v0);
         hipLaunchKernelGGL(embed_grad_kernel, dim3(cdiv(rows, kEmbedRows)), dim3(kEmbedThreads),
                            (size_t)n * kEmbedThreads * sizeof(float), stream, tok, g, ldg, mask, rows, D, DP, v0, n, pad,
-                           dtable);
+                           dtable, part, vocab);
         GSCAN_LAUNCHED("embed_grad_kernel");
+    }
+    if (part) {
+        hipLaunchKernelGGL(embed_grad_reduce_kernel, dim3(cdiv(vocab * D, 64)), dim3(64), 0, stream, part,
+                           cdiv(rows, kEmbedRows), vocab * D, dtable);
+        GSCAN_LAUNCHED("embed_grad_reduce_kernel");
     }
     return 0;
 }

@@ -137,7 +137,8 @@ __device__ __forceinline__ void decoder_image_element(const DecoderImageArgs &a,
 int embed_rows(const int64_t *tok, const float *table, int vocab, const float *mask, int rows, int D, float *out,
                int64_t ldo, hipStream_t stream);
 int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mask, int rows, int D, int vocab,
-               int pad, float *dtable, hipStream_t stream);
+               int pad, float *dtable, hipStream_t stream, float *part = nullptr);   // part: embed_grad_partial_floats, fixed-order sums
+size_t embed_grad_partial_floats(int rows, int D, int vocab);
 struct PrologueArgs {
     const float *b_ih, *b_hh, *w_o2h, *w_h2o, *w_ih_f, *w_ih_r, *enc_emb, *dec_emb, *mask_enc, *mask_dec;
     const int64_t *commands, *targets;
@@ -224,8 +225,9 @@ int prologue_world_forward(const PrologueArgs &pa, const void *world, int world_
                            hipStream_t stream);
 size_t world_conv_backward_scratch_floats(int B, int G, int C);
 int world_conv_lists(const void *world, int world_is_u8, int B, int G, int C, float *scratch, hipStream_t stream);
+size_t world_conv_bias_partial_floats(int B, int G, int Co);
 int world_conv_backward(const float *dfeat, int B, int G, int C, int Co, int K3, float *scratch,
-                        float *const (&gw)[3], float *const (&gb)[3], hipStream_t stream);
+                        float *const (&gw)[3], float *const (&gb)[3], hipStream_t stream, float *bias_part = nullptr);
 int trace_set_conv(unsigned long long *buf);
 
 // loss.hip
@@ -372,7 +374,7 @@ struct Workspace {
         dwc, wih_stack, wih_t, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, enc_w_image, conv_img, conv_flags, conv_lists, wcat5,
         deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image,   // encoder layers below the last
         ge_table, head_wc,        // [V,4H] tables: greedy decoding's embedded gates; the composite head
-        gemm_slabs_side, gemm_slabs_main;
+        gemm_slabs_side, gemm_slabs_main, conv_bias_part, embed_part_dec, embed_part_enc;
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;

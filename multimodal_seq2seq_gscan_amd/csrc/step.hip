@@ -43,6 +43,10 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(conv_img, conv_image_floats(d.C, d.Co, d.K3));
     SLOT(conv_flags, kFusedMaxFlags + 64);           // 32-bit flags of the prologue + world encoder launch, then its count of self-served chunks (conv.hip)
     SLOT(conv_lists, (int64_t)world_conv_backward_scratch_floats(d.B, d.G, d.C));
+    // per-chunk partial sums of the convolution bias gradients: the fixed-order form (deterministic mode only)
+    SLOT(conv_bias_part, gemm_macro_tile_mode() > 0 ? (int64_t)world_conv_bias_partial_floats(d.B, d.G, d.Co) : 0);
+    SLOT(embed_part_dec, gemm_macro_tile_mode() > 0 ? (int64_t)embed_grad_partial_floats(B * T, H, V) : 0);
+    SLOT(embed_part_enc, gemm_macro_tile_mode() > 0 ? (int64_t)embed_grad_partial_floats(B * L, d.E, d.Vi) : 0);
     SLOT(feat, B * M * F);
     SLOT(pkv, B * M * H);
     SLOT(uv, B * M * 4 * H);
@@ -571,6 +575,9 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     const int BT = B * T, BL = B * L, BM_ = B * M;
     const bool cond = d.conditional != 0;
     GSCAN_CHECK(dlogp || nll, "backward: dlogp is NULL");
+    // deterministic mode (GSCAN_DETERMINISTIC=1): every sum formed across workgroups in a fixed order — split-K partial
+    // tiles through slabs (gemm_mt.hip), embedding and convolution-bias gradients by their ordered kernels
+    const bool ordered_sums = gemm_macro_tile_mode() > 0;
     TRY(side_init());
     hipStream_t sd = g_side.single ? st : g_side.stream, sd2 = g_side.single ? st : g_side.stream2;
     float *S = w + ws.S, *dS = w + ws.dS;
@@ -638,7 +645,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
             TRY(b.launch(sd));
             TRY(head_grad_finish(w + ws.dwc, p.hid2out_w, p.out2hid_w, g.out2hid_w, g.hid2out_w, H, V, sd, w + ws.dv_t,
                                  w + ws.dv_v, B, g.txt_energy_w, g.vis_energy_w));
-            TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd));
+            TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd,
+                           ordered_sums ? w + ws.embed_part_dec : nullptr));
         }
         return 0;
     };
@@ -687,7 +695,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         // and the 17 us this leaf starts earlier are lost again because it then overlaps the encoder's weight-gradient
         // launch, which stretches 19 -> 41 us: this stretch of the step is throughput-bound, 0.541 vs 0.538 ms.)
         if (!early_lists) TRY(world_conv_lists(world, bt.world_u8 != nullptr, B, d.G, C, w + ws.conv_lists, sd2));
-        TRY(world_conv_backward(w + ws.dfeat, B, d.G, C, Co, d.K3, w + ws.conv_lists, gw, gb, sd2));
+        TRY(world_conv_backward(w + ws.dfeat, B, d.G, C, Co, d.K3, w + ws.conv_lists, gw, gb, sd2,
+                                ordered_sums ? w + ws.conv_bias_part : nullptr));
     }
     // ---- command encoder BPTT (chain), last layer first.  Per layer: the reverse recurrence, then ONE launch on the
     // caller's stream (the leaf streams are still busy with the key / conv gradients and would finish last
@@ -735,7 +744,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         g_split_override = 0;
         TRY(b.launch(st));
     }
-    TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st));
+    TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st,
+                   ordered_sums ? w + ws.embed_part_enc : nullptr));
     // join: every gradient is complete when the caller's stream continues.  Side 1 (done long before) waits for side 2,
     // the caller's stream for side 1: ONE wait packet in front of the optimiser instead of two (each costs the queue
     // ~2.5 us even when its event completed long ago)

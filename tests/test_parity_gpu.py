@@ -558,6 +558,20 @@ def test_fixture_suite_on_the_streaming_kernels():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+def test_fixture_suite_in_deterministic_mode():
+    """GSCAN_DETERMINISTIC=1 (read once per process, hence the child process): split-K partial tiles added in slice order,
+    embedding and convolution-bias gradients by their ordered kernels — the reference's own outputs through that path."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GSCAN_DETERMINISTIC="1")
+    pick = ("demo_variants or more_than_one_encoder_layer or geca_aux or compositional_all_grads or target_length_t120 or "
+            "one_call_train_step or train_step_matches_reference_adam")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", pick,
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_command_line_train_then_test_modes(tmp_path):
     """`python -m seq2seq --mode=train ... --synthetic_data` then `--mode=test` (seq2seq/__main__.py:21-167): the
     training loop runs, writes the reference's checkpoint dictionary, and the test mode decodes greedily from it

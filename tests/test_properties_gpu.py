@@ -212,3 +212,45 @@ torch.save({"logp": out.cpu(), "selfserved": _selfserved(model, batch) - before}
     assert torch.equal(res["normal"]["logp"], res["skip"]["logp"])
     assert res["normal"]["selfserved"] == 0, res["normal"]["selfserved"]
     assert res["skip"]["selfserved"] > 0
+
+
+def test_deterministic_mode_gives_bitwise_reproducible_training_steps(tmp_path):
+    """GSCAN_DETERMINISTIC=1: every sum the step forms across workgroups is added in a fixed order (split-K partial tiles
+    through slabs, embedding gradients by one workgroup per vocabulary chunk), so the same step from the same state gives
+    the same bits: loss, every gradient, and the parameters after three Adam steps.  (The default mode adds with float
+    atomics: results differ in the last bits from run to run.)"""
+    import os, subprocess, sys
+    worker = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from multimodal_seq2seq_gscan_amd.config import model_kwargs
+from multimodal_seq2seq_gscan_amd.model import Model
+from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
+from multimodal_seq2seq_gscan_amd.train import TrainStep
+cfg = model_kwargs("compositional", auxiliary_task=True)
+shape = Shape(batch=96, input_vocab=cfg["input_vocabulary_size"], target_vocab=cfg["target_vocabulary_size"], ragged=True)
+batch = {k: v.cuda() for k, v in make_batch(shape, 5).items() if k in ("commands", "cmd_lengths", "world", "targets", "target_positions")}
+runs = []
+for rep in range(3):
+    torch.manual_seed(7)
+    model = Model(**cfg).cuda()
+    step = TrainStep(model, learning_rate=1e-3, weight_target_loss=0.3)
+    grads = []
+    step.on_gradients = lambda g: grads.append(g.detach().clone())
+    losses = [step(batch)["loss"].item() for _ in range(3)]
+    torch.cuda.synchronize()
+    runs.append({"losses": losses, "grads": [g.cpu() for g in grads], "params": model.flat_parameters.detach().cpu().clone()})
+    step.close()
+torch.save(runs, sys.argv[3])
+"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = str(tmp_path / "runs.pt")
+    r = subprocess.run([sys.executable, "-c", worker, os.path.dirname(here), here, path],
+                       env=dict(os.environ, GSCAN_DETERMINISTIC="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    runs = torch.load(path)
+    for other in runs[1:]:
+        assert other["losses"] == runs[0]["losses"]
+        for g0, g1 in zip(runs[0]["grads"], other["grads"]):
+            assert torch.equal(g0, g1), (g0 - g1).abs().max().item()
+        assert torch.equal(other["params"], runs[0]["params"])
