@@ -284,109 +284,6 @@ int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream) {
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------
-// keys_sums: the value path of both attentions as sums over the steps alone (KeysSumsArgs, step.h).  One workgroup per
-// (batch row, attention, chunk of 128 columns of Y): wave w owns two 16-column tiles and every 16-memory tile of the
-// attention (at most four: the resident decoder kernels hold <= 64 memories), Y tile += alpha^T (memories x 4 steps) .
-// Z (4 steps x 16 columns) on the matrix cores with BOTH operand fragments read straight from global memory — Z is read
-// exactly once per launch (the column chunks partition it), alpha by the few workgroups of its row.  No LDS.
-// Z(t, c) = dS_head[t, ctx + c] (c < H) | delta[t, perm(c - H)] (c < 5H) | dzq[t, c - 5H].
-// ------------------------------------------------------------------------------------------
-constexpr int kKsThreads = 256, kKsCols = 128, kKsMaxTiles = 4;
-__global__ __launch_bounds__(kKsThreads, 4) void keys_sums_kernel(KeysSumsArgs a, int H, int chunks_v) {
-    TraceScope trace_scope(TK_KEYS_BWD);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6),
-              fr = lane & 15, fg = lane >> 4;
-    const bool vis = (int)blockIdx.y < chunks_v;
-    const int chunk = vis ? blockIdx.y : blockIdx.y - chunks_v;
-    const int T = a.T, mx = vis ? a.M : a.L, NC = (vis || !a.cond) ? 5 * H : 6 * H;
-    const int ntile = (mx + 15) >> 4;
-    const float *alpha = (vis ? a.alpha_s : a.alpha_c) + (int64_t)b * T * mx;
-    const int dcol = vis ? 2 * H : H;
-    // this lane's column of each of the wave's two tiles: where Z(t, col) lives and its stride between steps
-    const float *zp[2];
-    int zs[2], col[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = chunk * kKsCols + 16 * (2 * wave + j) + fr;
-        col[j] = c;
-        const int cc = min(c, NC - 1);
-        if (cc < H) { zp[j] = a.ds + (int64_t)b * T * 4 * H + dcol + cc; zs[j] = 4 * H; }
-        else {
-            const int r = cc - H;
-            zp[j] = a.delta + (int64_t)b * T * 5 * H + (r < 4 * H ? (r & 3) * H + (r >> 2) : r);
-            zs[j] = 5 * H;
-        }
-    }
-    f32x4 acc[2][kKsMaxTiles];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < kKsMaxTiles; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool col_ok[2] = {col[0] < NC, col[1] < NC};
-    for (int t0 = 0; t0 < T; t0 += 16) {                      // four groups of four steps per pass: every load in flight
-        float zb[4][2], ab[4][kKsMaxTiles];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int t = t0 + 4 * g + fg;
-            const bool live = t < T;
-            const int tc = live ? t : T - 1;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { const float v = zp[j][(int64_t)tc * zs[j]]; zb[g][j] = (live && col_ok[j]) ? v : 0.f; }
-#pragma unroll
-            for (int i = 0; i < kKsMaxTiles; ++i) {
-                const int m = 16 * i + fr;
-                const float v = alpha[(int64_t)tc * mx + min(m, mx - 1)];
-                ab[g][i] = (live && m < mx && i < ntile) ? v : 0.f;
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < kKsMaxTiles; ++i)
-                    if (i < ntile) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[g][i], zb[g][j], acc[j][i], 0, 0, 0);
-    }
-    float *y = (vis ? a.y_v : a.y_t) + (int64_t)b * mx * NC;
-    float *dpk = (vis ? a.dpk_v : a.dpk_t) + (int64_t)b * mx * H;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (!col_ok[j]) continue;
-#pragma unroll
-        for (int i = 0; i < kKsMaxTiles; ++i) {
-            if (i >= ntile) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = 16 * i + 4 * fg + r;
-                if (m >= mx) continue;
-                float v = acc[j][i][r];
-                if (col[j] < H) {                      // the score path joins here; the sum is the X block of dPK
-                    v += dpk[(int64_t)m * H + col[j]];
-                    dpk[(int64_t)m * H + col[j]] = v;
-                }
-                y[(int64_t)m * NC + col[j]] = v;
-            }
-        }
-    }
-}
-
-int keys_sums(int B, int H, const KeysSumsArgs &a, hipStream_t stream) {
-    GSCAN_CHECK(B > 0 && a.T > 0 && a.L > 0 && a.M > 0 && H > 0, "keys sums: bad dims B=%d T=%d L=%d cells=%d H=%d", B, a.T, a.L,
-                a.M, H);
-    GSCAN_CHECK(a.L <= 16 * kKsMaxTiles && a.M <= 16 * kKsMaxTiles, "keys sums: at most %d memories per attention (L=%d, cells=%d)",
-                16 * kKsMaxTiles, a.L, a.M);
-    const int chunks_v = cdiv(5 * H, kKsCols), chunks_t = cdiv((a.cond ? 6 : 5) * H, kKsCols);
-    // algorithmic flops: the data-gradient half of the two context reductions, 2 B T (L + M) H (the rest of what
-    // keys_backward is credited with moves to the dense products behind this launch)
-    const double alg = 2.0 * B * a.T * (double)(a.L + a.M) * H;
-    const double exec = 2.0 * B * a.T * ((double)a.M * 5 * H + (double)a.L * (a.cond ? 6 : 5) * H);
-    ProbeScope probe(P_KEYS_BWD, stream, exec, alg);
-    hipLaunchKernelGGL(keys_sums_kernel, dim3(B, chunks_v + chunks_t), dim3(kKsThreads), 0, stream, a, H, chunks_v);
-    GSCAN_LAUNCHED("keys_sums_kernel");
-    return 0;
-}
-
 GSCAN_TRACE_TU(attention_grad)
 
 }  // namespace gscan

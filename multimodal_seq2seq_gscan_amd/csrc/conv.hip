@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kConvThreads, 8) void prologue_world_kernel(Prologu
         is_conv = c1 > c0; cb = c0; pb = j - c0;
     }
     if (!is_conv) {
-        const int64_t total = pa.end[kPrologueSegments - 1];
+        const int64_t total = pa.end[13];
         for (int64_t idx = (int64_t)pb * kConvThreads + threadIdx.x; idx < total; idx += (int64_t)f.n_pro * kConvThreads)
             prologue_element<8>(pa, idx);
         return;
@@ -527,7 +527,7 @@ int prologue_world_forward(const PrologueArgs &pa, const void *world, int world_
     static const int pro_cap = [] { const char *e = getenv("GSCAN_PROLOGUE_BLOCKS"); return e ? atoi(e) : 1024; }();
     FusedPrologueArgs f{};
     f.n_img = n_img;
-    f.n_pro = (int)std::min<int64_t>(cdiv(pa.end[kPrologueSegments - 1], kConvThreads), pro_cap);
+    f.n_pro = (int)std::min<int64_t>(cdiv(pa.end[13], kConvThreads), pro_cap);
     f.n_examples = B; f.ny = 4; f.n_conv = B * f.ny;
     static const int order = [] { const char *e = getenv("GSCAN_FUSED_ORDER"); return e ? atoi(e) : 0; }();
     f.order = order;

@@ -322,14 +322,14 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 
 __global__ void prologue_kernel(PrologueArgs a) {
     TraceScope trace_scope(TK_PROLOGUE);
-    const int64_t total = a.end[kPrologueSegments - 1];
+    const int64_t total = a.end[13];
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x)
         prologue_element<20>(a, idx);
 }
 
 int step_prologue(const PrologueArgs &args, hipStream_t stream) {
-    const int64_t total = args.end[kPrologueSegments - 1];
+    const int64_t total = args.end[13];
     if (total == 0) return 0;
     // two passes per thread at most at the benchmark shape (the kernel is chains of dependent loads, not bandwidth;
     // 2048 / 4096 / 8192 / 16384 workgroups: 0.521 / 0.517 / 0.523 / 0.524 ms per step)

@@ -83,18 +83,6 @@ __device__ __forceinline__ void prologue_element(const PrologueArgs &a, int64_t 
     } else if (idx < a.end[10]) {
         const int i = (int)(idx - a.end[9]);
         a.conv_img[i] = conv_image_element(a.conv_w[0], a.conv_w[1], a.conv_w[2], a.cC, a.cCo, a.cK3, i);
-    } else if (idx >= a.end[13]) {
-        // operands of the attentions' backward value path as dense products (step.hip, keys_sums)
-        if (idx < a.end[14]) { const int64_t i = idx - a.end[13]; a.wkv_copy[i] = a.w_key_vis[i]; }
-        else if (idx < a.end[15]) { const int64_t i = idx - a.end[14]; a.wkt_copy[i] = a.w_key_txt[i]; }
-        else if (idx < a.end[16]) {              // wpk_v[r, n] = W_ih[perm(r), 2H + n]
-            const int i = (int)(idx - a.end[15]), r = i / H, n = i - r * H;
-            a.wpk_v[i] = a.w_ih_dec[(int64_t)((r & 3) * H + (r >> 2)) * 3 * H + 2 * H + n];
-        } else {                                 // wpk_t[r, n] = W_ih[perm(r), H + n] (r < 4H), W_q2k[r - 4H, H + n] behind
-            const int i = (int)(idx - a.end[16]), r = i / H, n = i - r * H;
-            a.wpk_t[i] = r < 4 * H ? a.w_ih_dec[(int64_t)((r & 3) * H + (r >> 2)) * 3 * H + H + n]
-                                   : a.w_q2k[(int64_t)(r - 4 * H) * 2 * H + H + n];
-        }
     } else {
         // composite weights: out[r, c] = sum_h A[r, col0 + h] * Wk[h, c].  Consecutive threads take consecutive c
         // (coalesced Wk rows, A broadcast); eight products are fetched before they are added, so the loop is

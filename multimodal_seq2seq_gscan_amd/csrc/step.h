@@ -139,7 +139,6 @@ int embed_rows(const int64_t *tok, const float *table, int vocab, const float *m
 int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mask, int rows, int D, int vocab,
                int pad, float *dtable, hipStream_t stream, float *part = nullptr);   // part: embed_grad_partial_floats, fixed-order sums
 size_t embed_grad_partial_floats(int rows, int D, int vocab);
-constexpr int kPrologueSegments = 18;
 struct PrologueArgs {
     const float *b_ih, *b_hh, *w_o2h, *w_h2o, *w_ih_f, *w_ih_r, *enc_emb, *dec_emb, *mask_enc, *mask_dec;
     const int64_t *commands, *targets;
@@ -148,7 +147,7 @@ struct PrologueArgs {
     int cond;
     int64_t zero_extra_count;
     int H, He, E, D, BL, BT, Vi, V;
-    int64_t end[kPrologueSegments];
+    int64_t end[14];
     DecoderImageArgs img;
     // seg 9: register image of the encoder's recurrent weights, [dir][r][k][thread] (lstm_encoder.hip)
     const float *enc_w_hh_f, *enc_w_hh_r;
@@ -165,11 +164,6 @@ struct PrologueArgs {
     const float *w_key_vis, *w_key_txt;
     float *w_sk, *w_ck, *w_2kk;
     int F;
-    // seg 14-17: what the value path of the attentions' backward needs as GEMM operands (keys_sums, attention_grad.hip):
-    // copies of W_key_vis / W_key_text in front of w_sk / w_ck (stacked weights [W_key; composite]), and the context columns
-    // of W_ih with their rows in the composites' unit-major order: wpk_v [4H, H] = W_ih[perm, 2H:3H],
-    // wpk_t [4H or 5H, H] = [W_ih[perm, H:2H] ; W_q2k[:, H:2H] (conditional)]
-    float *wkv_copy, *wkt_copy, *wpk_v, *wpk_t;
 };
 int step_prologue(const PrologueArgs &args, hipStream_t stream);
 // The head's weight gradients from d Wc = dlogits^T . S ([V, 4H], S order): g_w_o2h += W_h2o^T . dWc (columns back in
@@ -348,20 +342,6 @@ struct KeysBackwardArgs {
     float *denc, *dhN, *dfeat;             // [B,L,He] [B,He] [B,M,F]
 };
 int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream);
-// The value path as sums over the steps alone (no per-step context gradients, no dS += product in front):
-//   Y_vis[b,m,:]  = [ dPK_score + sum_t alpha_s[t,m] dS_head[t, ctx_vis] | sum_t alpha_s[t,m] delta[t, perm] ]           [B,M,5H]
-//   Y_text[b,m,:] = [ dPK_score + sum_t alpha_c[t,m] dS_head[t, ctx_text] | sum_t alpha_c[t,m] delta[t, perm] | sum_t alpha_c[t,m] dzq[t] ]
-// (perm: the gate rows unit-major, column 4 unit + gate, as the composite weights of the prologue).  Everything behind it
-// is a dense product of Y with stacked weights: d feat = Y_vis . [W_key_vis ; w_sk], d enc_out = Y_text . [W_key_text ;
-// w_ck ; w_2kk], dPK = Y[:, :H] + Y[:, H:] . W_ih[perm, ctx] (step.hip).  The first H columns are also written back to
-// dpk_t / dpk_v.
-struct KeysSumsArgs {
-    int T, L, M, cond;
-    const float *alpha_c, *alpha_s, *ds, *delta;   // [B,T,L] [B,T,M] [B,T,4H] (head part) [B,T,5H]
-    float *dpk_t, *dpk_v;                          // [B,L,H] [B,M,H] in: score path; out: + sum_t alpha dS_head
-    float *y_t, *y_v;                              // [B,L,(5|6)H] [B,M,5H]
-};
-int keys_sums(int B, int H, const KeysSumsArgs &a, hipStream_t stream);
 
 // comm.hip: RCCL all-reduce on the caller's stream (run-time binding)
 int comm_unique_id(void *id_host);
@@ -394,8 +374,7 @@ struct Workspace {
         dwc, wih_stack, wih_t, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, enc_w_image, conv_img, conv_flags, conv_lists, wcat5,
         deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image,   // encoder layers below the last
         ge_table, head_wc,        // [V,4H] tables: greedy decoding's embedded gates; the composite head
-        gemm_slabs_side, gemm_slabs_main, conv_bias_part, embed_part_dec, embed_part_enc,
-        wkv_stack, wkt_stack, wpk_v, wpk_t, y_v, y_t;     // keys_sums path (w_sk / w_ck / w_2kk point into the stacks)
+        gemm_slabs_side, gemm_slabs_main, conv_bias_part, embed_part_dec, embed_part_enc;
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;

@@ -65,17 +65,9 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(dwc, V * 4 * H);                            // gradient of the composite head (head_wc below)
     SLOT(wih_stack, D * 4 * He * E);
     SLOT(wih_t, D * 4 * He * (E + 1));
-    // stacked weights of the attentions' backward value path (keys_sums): [W_key_vis ; w_sk] (5H x F) and
-    // [W_key_text ; w_ck ; w_2kk] (6H x He) — the composites sit INSIDE these slots, behind a copy of the key weights
-    SLOT(wkv_stack, 5 * H * F);
-    ws->w_sk = ws->wkv_stack + (int64_t)H * F;
-    SLOT(wkt_stack, 6 * H * He);
-    ws->w_ck = ws->wkt_stack + (int64_t)H * He;
-    ws->w_2kk = ws->wkt_stack + (int64_t)5 * H * He;
-    SLOT(wpk_v, 4 * H * H);                          // W_ih[perm, 2H:3H]
-    SLOT(wpk_t, 5 * H * H);                          // [W_ih[perm, H:2H] ; W_q2k[:, H:2H]]
-    SLOT(y_v, B * M * 5 * H);                        // keys_sums outputs
-    SLOT(y_t, B * L * 6 * H);
+    SLOT(w_sk, 4 * H * F);
+    SLOT(w_ck, 4 * H * He);
+    SLOT(w_2kk, H * He);
     SLOT(dec_w_fwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
     SLOT(dec_w_bwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
     SLOT(enc_w_image, D * 4 * He * He);
@@ -179,14 +171,6 @@ static inline void add_grad(GemmBatch &g, int M, int N, int K, const float *a, i
     g.add(M, N, K, a, sam, sak, b, sbk, sbn, c, ldc, 1.f, nullptr, 0, nullptr, pick_split(K), bias1, bias2);
 }
 
-// The value path of the attentions' backward as sums over the steps + dense products (keys_sums, attention_grad.hip)
-// instead of the dS += product + keys_backward: with the resident decoder kernels (their composite weights exist) and at
-// most 64 memories per attention.  GSCAN_KEYS_SUMS=0: the round-2/3 path, for A/B runs.
-static bool keys_sums_path(int L, int M) {
-    static const int on = [] { const char *e = getenv("GSCAN_KEYS_SUMS"); return e ? atoi(e) : 1; }();
-    return on != 0 && L <= 64 && M <= 64;
-}
-
 #define TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 
 static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, float *w,
@@ -237,10 +221,8 @@ static int side_init() {
     // measured 0.5% faster than lowest priority
     int prio_least = 0, prio_greatest = 0;
     GSCAN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    static const int side_prio = [] { const char *e = getenv("GSCAN_SIDE_PRIO"); return e ? atoi(e) : 0; }();
-    const int prio = side_prio == 1 ? prio_least : (side_prio == 2 ? (prio_least + prio_greatest) / 2 : prio_greatest);
-    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, prio));
-    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream2, hipStreamNonBlocking, prio));
+    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, prio_greatest));
+    GSCAN_HIP(hipStreamCreateWithPriority(&g_side.stream2, hipStreamNonBlocking, prio_greatest));
     // The events order kernels of ONE device across streams: no system-scope fence (cache write-back / invalidate for
     // the host's benefit) is needed when one completes, and leaving it out takes 6 us off a step (0.5525 -> 0.546 ms,
     // profiles/r02_ab_event_flags.txt).  GSCAN_EVENT_FLAGS=0 restores the default fence.
@@ -322,18 +304,14 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.conv_img = w + ws.conv_img; a.cC = C; a.cCo = Co; a.cK3 = d.K3;
         a.w_key_vis = p.vis_key_w; a.w_key_txt = p.txt_key_w; a.F = F;
         a.w_sk = w + ws.w_sk; a.w_ck = w + ws.w_ck; a.w_2kk = w + ws.w_2kk;
-        a.wkv_copy = w + ws.wkv_stack; a.wkt_copy = w + ws.wkt_stack; a.wpk_v = w + ws.wpk_v; a.wpk_t = w + ws.wpk_t;
-        const bool sums = fast && keys_sums_path(L, M);
-        const int64_t n[kPrologueSegments] = {4 * H, (int64_t)V * 4 * H, (int64_t)D * 4 * He * (E + 1), (int64_t)V * 4 * H,
+        const int64_t n[14] = {4 * H, (int64_t)V * 4 * H, (int64_t)D * 4 * He * (E + 1), (int64_t)V * 4 * H,
                                given ? 0 : (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
                                a.zero_extra_count, fast ? 2 * geo.image_floats : 0,
                                encoder_fast_supported(He, L, E) ? (int64_t)D * 4 * He * He : 0,
                                (given || fuse_world) ? 0 : conv_image_floats(C, Co, d.K3),
-                               fast ? (int64_t)4 * H * F : 0, fast ? (int64_t)4 * H * He : 0, (fast && cond) ? (int64_t)H * He : 0,
-                               sums ? (int64_t)H * F : 0, sums ? (int64_t)H * He : 0, sums ? (int64_t)4 * H * H : 0,
-                               sums ? (int64_t)(cond ? 5 : 4) * H * H : 0};
+                               fast ? (int64_t)4 * H * F : 0, fast ? (int64_t)4 * H * He : 0, (fast && cond) ? (int64_t)H * He : 0};
         int64_t acc = 0;
-        for (int i = 0; i < kPrologueSegments; ++i) {
+        for (int i = 0; i < 14; ++i) {
             // side 1: decoder bias sum, embedded targets; side 2: convolution weight image, visual composite weight
             const int owner = (i == 0 || i == 5) ? 1 : ((i == 10 || i == 11) ? 2 : 0);
             acc += (owner == which || which == 3) ? n[i] : 0;   // which 3: every segment in one launch
@@ -683,65 +661,25 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     float *const gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
     const void *world = bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world;
     if (leaves_fork == 0) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
-    const bool sums = decoder_fast_supported(H, L, M, V, cond) && keys_sums_path(L, M);
-    if (sums) {
-        // ---- chain, round 4: the value path as sums over the steps + dense products.  d ctx_t is never formed: with
-        // A[m] = sum_t alpha_t[m] [delta_t | dzq_t] (keys_sums: one launch, matrix cores, reads delta once),
-        //   d feat    = [X | A] . [W_key_vis ; W_ih[:, ctx_vis] . W_key_vis]          (X = dPK_score + sum_t alpha_t dS_head_t)
-        //   d enc_out = [X | A | Az] . [W_key_text ; W_ih[:, ctx_text] . W_key_text ; W_q2k[:, ctx_text] . W_key_text]
-        // — the composites are the ones the forward pass built for its U images — so the chain carries ONE launch of
-        // B (M 5H F + L 6H He) multiply-adds whatever T is, instead of the dS += product's B T 2H 5H (S3: 0.85 against 3.07
-        // GMAC) and the key layers inside keys_backward.  The totals dPK (the key weights' gradients need them) are a leaf.
-        KeysSumsArgs ka{};
-        ka.T = T; ka.L = L; ka.M = M; ka.cond = cond ? 1 : 0;
-        ka.alpha_c = w + ws.alpha_c; ka.alpha_s = w + ws.alpha_s; ka.ds = dS; ka.delta = delta;
-        ka.dpk_t = w + ws.dpk_t; ka.dpk_v = w + ws.dpk_v; ka.y_t = w + ws.y_t; ka.y_v = w + ws.y_v;
-        TRY(keys_sums(B, H, ka, st));
-        if (leaves_fork == 1) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
-        const int NCv = 5 * H, NCt = (cond ? 6 : 5) * H;
-        {
-            GemmBatch b;
-            // executed: K = 5H / 6H deep; algorithmic: the key layers' data gradients (K = H), the bridge's,
-            // and the LSTM-input / conditional-query data gradients wrt the contexts that the dS += product used to carry
-            b.add(BM_, F, NCv, w + ws.y_v, NCv, 1, w + ws.wkv_stack, F, 1, w + ws.dfeat, F, 0.f, nullptr, 3, mk.cnn, 1, nullptr,
-                  nullptr, w + ws.feat);
-            b.add(BL, He, NCt, w + ws.y_t, NCt, 1, w + ws.wkt_stack, He, 1, w + ws.denc, He);
-            b.add(B, He, H, w + ws.dh0, H, 1, p.bridge_w, He, 1, w + ws.dhN, He);
-            b.credit(2.0 * BM_ * (double)F * (H - NCv) + 2.0 * BL * (double)He * (H - NCt) +
-                     2.0 * BT * (double)(2 * H) * (cond ? 5 * H : 4 * H));
-            TRY(b.launch(st));
-        }
-        TRY(order_after(sd, st, sd2));     // one event releases both leaf streams
-        if (leaves_fork == 2) TRY(decoder_leaves());
-        {   // leaf: the totals dPK = X + A . W_ih[perm, ctx] (+ Az . W_q2k[:, ctx_text]) on top of the X that keys_sums left
-            GemmBatch b;
-            b.add(BM_, H, 4 * H, w + ws.y_v + H, NCv, 1, w + ws.wpk_v, H, 1, w + ws.dpk_v, H, 1.f);
-            b.overhead();              // the reference never forms these: its dPK comes out of autograd's chain
-            b.add(BL, H, NCt - H, w + ws.y_t + H, NCt, 1, w + ws.wpk_t, H, 1, w + ws.dpk_t, H, 1.f);
-            b.overhead();
-            TRY(b.launch(sd));
-        }
-    } else {
-        // chain: gradient wrt [ctx_text | ctx_vis] through the LSTM input and the conditional query
-        // (one product: [delta | dzq] . [W_ih[:, ctx] ; (W_q2k[:, ctx_text] | 0)], K = 5H when conditional)
-        {
-            // From ~10 000 decoder rows on (S3: 30 720; S1 from 512 rows per GPU) this product — alone in its launch, on the
-            // critical chain, 500 deep — is faster on the macro tiles of gemm_mt.hip: S3 1.777 -> 1.750 ms per step, S1 at
-            // 512 / 1 024 rows 0.909 -> 0.891 / 1.740 -> 1.713; at 5 120 / 7 680 rows it loses 1 %
-            // (profiles/r04_ds_product_macro_tiles_ab.txt).  GSCAN_DS_MT=<rows> moves the threshold, 0 = never.
-            static const int ds_mt = [] { const char *e = getenv("GSCAN_DS_MT"); return e ? atoi(e) : 10000; }();
-            GemmBatch b;
-            if (ds_mt > 0 && BT >= ds_mt) b.prefer_macro_tiles();
-            b.add(BT, 2 * H, cond ? 5 * H : 4 * H, delta, 5 * H, 1, w + ws.wcat5 + H, 3 * H, 1, dS + H, 4 * H, 1.f);
-            TRY(b.launch(st));
-        }
-        if (leaves_fork == 1) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
-        // chain: value path of both attentions (dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]), then through the
-        // key layers and the bridge to the encoder outputs / final state / conv features — one launch, row per WG
-        TRY(keys_backward(B, H, k, st));
-        TRY(order_after(sd, st, sd2));     // one event releases both leaf streams
-        if (leaves_fork == 2) TRY(decoder_leaves());
+    // chain: gradient wrt [ctx_text | ctx_vis] through the LSTM input and the conditional query
+    // (one product: [delta | dzq] . [W_ih[:, ctx] ; (W_q2k[:, ctx_text] | 0)], K = 5H when conditional)
+    {
+        // From ~10 000 decoder rows on (S3: 30 720; S1 from 512 rows per GPU) this product — alone in its launch, on the
+        // critical chain, 500 deep — is faster on the macro tiles of gemm_mt.hip: S3 1.777 -> 1.750 ms per step, S1 at
+        // 512 / 1 024 rows 0.909 -> 0.891 / 1.740 -> 1.713; at 5 120 / 7 680 rows it loses 1 %
+        // (profiles/r04_ds_product_macro_tiles_ab.txt).  GSCAN_DS_MT=<rows> moves the threshold, 0 = never.
+        static const int ds_mt = [] { const char *e = getenv("GSCAN_DS_MT"); return e ? atoi(e) : 10000; }();
+        GemmBatch b;
+        if (ds_mt > 0 && BT >= ds_mt) b.prefer_macro_tiles();
+        b.add(BT, 2 * H, cond ? 5 * H : 4 * H, delta, 5 * H, 1, w + ws.wcat5 + H, 3 * H, 1, dS + H, 4 * H, 1.f);
+        TRY(b.launch(st));
     }
+    if (leaves_fork == 1) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
+    // chain: value path of both attentions (dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]), then through the
+    // key layers and the bridge to the encoder outputs / final state / conv features — one launch, row per WG
+    TRY(keys_backward(B, H, k, st));
+    TRY(order_after(sd, st, sd2));     // one event releases both leaf streams
+    if (leaves_fork == 2) TRY(decoder_leaves());
     {   // leaves: key and bridge weights
         GemmBatch b;
         if (gemm_macro_tile_mode() > 0)      // same stream as the decoder leaves: the same region
