@@ -14,6 +14,12 @@
 // fast one has no kernel for the shape (decoder_run picks).
 #include "anyshape.h"
 
+// The step loops below are long and nearly everything in them is an address derived from a handful of loop-invariant
+// scalars; hoisted out of the loop by the compiler those were ~290 scalar registers, spilled to vector registers and from
+// there to scratch (bwd: 44 VGPR spills, 164 B of scratch per lane).  LAUNDER makes a scalar opaque at the top of an
+// iteration, so what derives from it is recomputed per step (a few dozen SALU operations against 30+ us of streaming).
+#define LAUNDER(x) asm volatile("" : "+s"(x))
+
 namespace gscan {
 
 // softmax of sc[0..n) in place (LDS) by wave 0; returns nothing, the caller synchronises
@@ -77,8 +83,13 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
     const float *pk_t = a.pk_t + (int64_t)b * L * H, *pk_v = a.pk_v + (int64_t)b * M * H;
+    // gate images of the row's memories, U = PK . W_ih[:, ctx]^T (columns unit-major: 4 unit + gate) and, conditional,
+    // U2 = PK_text . W_q2k[:, H:]^T: W_ih[:, ctx] . ctx = sum_m alpha_m U[m] (a context is a convex combination of
+    // projected keys), so the 8 H^2 floats of W_ih's context columns are never streamed
+    const float *u_t = a.u_t + (int64_t)b * L * 4 * H, *u2_t = a.u2_t + (int64_t)b * L * H, *u_v = a.u_v + (int64_t)b * M * 4 * H;
     // the reference's own parameter layouts (row-major [out, in]), carried in the argument struct by decoder_run
     const float *W_hh = a.any_w_hh, *W_ih = a.any_w_ih, *W_qt = a.any_w_qt, *W_qv = a.any_w_qv, *W_q2k = a.any_w_q2k;
+    const bool use_u = a.any_use_u != 0;       // decoder_any_uses_gate_images: wide hidden sizes with few memories
 
     for (int k = tid; k < H; k += kAnyThreads) {
         const float h0 = a.hprev[(int64_t)b * (GREEDY ? 1 : T) * H + k];
@@ -93,7 +104,12 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
     __syncthreads();
     int steps_done = 0;
 
+    int Hl = H, Ll = L, Ml = M, lenl = len;
     for (int t = 0; t < T; ++t) {
+        LAUNDER(Hl); LAUNDER(Ll); LAUNDER(Ml); LAUNDER(lenl);
+        const int H = Hl, L = Ll, M = Ml, len = lenl;
+        const float *pk_t = a.pk_t + (int64_t)b * L * H, *pk_v = a.pk_v + (int64_t)b * M * H;
+        const float *u_t = a.u_t + (int64_t)b * L * 4 * H, *u2_t = a.u2_t + (int64_t)b * L * H, *u_v = a.u_v + (int64_t)b * M * 4 * H;
         const int64_t bt = (int64_t)b * T + t;
         // ---- everything that multiplies h_{t-1}: W_query_text h, the gates' recurrent part
         matvec_rows<V4>(W_qt, H, H, H, h_s, [&](int r, float v) { qt_s[r] = v; });
@@ -102,6 +118,7 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
             const float *ge = a.ge + ge_row * 4 * H;
             matvec_rows<V4>(W_hh, H, 4 * H, H, h_s, [&](int r, float v) { pre_s[r] = v + ge[r]; });
         }
+        if (cond && use_u) matvec_rows<V4>(W_q2k, 2 * H, H, H, h_s, [&](int r, float v) { q2_s[r] = v + bq_s[r]; });   // W_q2k[:, :H] h + b
         __syncthreads();
         // ---- textual attention (seq2seq_model.py:129-139)
         scores_any(vt_s, qt_s, pk_t, len, H, sc);
@@ -114,7 +131,16 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
             if (!GREEDY) { a.s[bt * 4 * H + H + k] = acc; a.qt[bt * H + k] = qt_s[k]; }
         });
         // ---- the query of the visual attention: conditional (tanh(W_q2k [h; ctx_text] + b), :394-396) or h itself
-        if (cond) {
+        if (use_u) {
+            // the textual part of the gates' input product and of the conditional query, through the gate images
+            matvec_cols(u_t, 4 * H, 0, len, 4 * H, sc, scr, [&](int c, float v) { pre_s[(c & 3) * H + (c >> 2)] += v; });
+            if (cond)
+                matvec_cols(u2_t, H, 0, len, H, sc, scr, [&](int k, float v) {
+                    const float q = tanhf_(q2_s[k] + v);
+                    q2_s[k] = q;
+                    if (!GREEDY) a.q2[bt * H + k] = q;
+                });
+        } else if (cond) {
             matvec_rows<V4>(W_q2k, 2 * H, H, 2 * H, hc, [&](int r, float v) {
                 const float q = tanhf_(v + bq_s[r]);
                 q2_s[r] = q;
@@ -141,8 +167,12 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
             if (!GREEDY) a.s[bt * 4 * H + 2 * H + k] = acc;
         });
         // ---- LSTM cell (seq2seq_model.py:414): the context part of the input product, then the gates
-        matvec_rows<V4>(W_ih + H, 3 * H, 4 * H, 2 * H, ctxt_s, [&](int r, float v) { pre_s[r] += v; });
-        __syncthreads();
+        if (use_u) {
+            matvec_cols(u_v, 4 * H, 0, M, 4 * H, sc, scr, [&](int c, float v) { pre_s[(c & 3) * H + (c >> 2)] += v; });
+        } else {
+            matvec_rows<V4>(W_ih + H, 3 * H, 4 * H, 2 * H, ctxt_s, [&](int r, float v) { pre_s[r] += v; });
+            __syncthreads();
+        }
         for (int u = tid; u < H; u += kAnyThreads) {
             const float ig = sigmoidf_(pre_s[u]), fg = sigmoidf_(pre_s[H + u]), gg = tanhf_(pre_s[2 * H + u]),
                         og = sigmoidf_(pre_s[3 * H + u]);
@@ -267,14 +297,15 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
 // d h0 — and dS holds the head's part only: the LSTM-input and conditional-query parts of the context gradients are
 // added by the dense product behind this kernel, as for the fast kernel.
 // ------------------------------------------------------------------------------------------
-struct AnyLdsB { int dh, dc, dl, dctx, dq, dqv, q, v1, v2, al, sc, datt, red, scr, total; };
+struct AnyLdsB { int dh, dc, dl, dlp, dctx, dq, dqv, q, v1, v2, al, sc, datt, red, scr, total; };
 __host__ __device__ inline AnyLdsB any_lds_bwd(int H, int L, int M) {
     const int HP = (H + 3) / 4 * 4, NM = ((L > M ? L : M) + 3) / 4 * 4;
     AnyLdsB o;
     int p = 0;
     o.dh = p; p += HP; o.dc = p; p += HP;
     o.dl = p; p += 5 * HP;             // delta (4H) | dzq (H)
-    o.dctx = p; p += 2 * HP;           // d ctx_text | d ctx_vis (head + LSTM input + conditional query)
+    o.dlp = p; p += 4 * HP;            // delta unit-major (4 unit + gate): the order of the gate images' columns
+    o.dctx = p; p += 2 * HP;           // d ctx_text | d ctx_vis: the head's part (the rest reaches d alpha through the gate images)
     o.dq = p; p += HP;                 // d (projected query) of the attention being processed
     o.dqv = p; p += HP;                // d (projected visual query), kept until the dh sum
     o.q = p; p += HP;                  // the saved projected query
@@ -286,23 +317,26 @@ __host__ __device__ inline AnyLdsB any_lds_bwd(int H, int L, int M) {
     return o;
 }
 
-// one attention's backward at one step (row-local): d alpha_m = dctx . PK[m] (+ datt[m]), softmax backward, then through
+// one attention's backward at one step (row-local): d alpha_m = dctx . PK[m] (+ datt[m]) — or, dctx == NULL, already in
+// sc[m] (the caller's, through the gate images) — softmax backward, then through
 // v . tanh(q + PK[m]): dq, the score-path dPK (accumulated in global memory over the steps) and the energy-vector
 // gradient.  Thread (k, p) owns feature k of the memories m = p, p + P, ... (P = kAnyThreads / CB thread groups per
 // feature block, as in matvec_cols): its dPK elements are its own, its share of dq goes through `scratch`, its share
 // of the energy-vector gradient stays in its register `dv` until the end of the kernel.  Requires H <= kAnyThreads.
-__device__ __forceinline__ void attention_bwd_any(const float *dctx, const float *q_s, const float *v_s, const float *al,
-                                                  const float *datt, const float *__restrict__ pk, float *dpk, int n, int H,
+__device__ __forceinline__ void attention_bwd_any(const float *dctx, const float *datt, const float *q_s, const float *v_s,
+                                                  const float *al, const float *__restrict__ pk, float *dpk, int n, int H,
                                                   float *sc, float *dq_s, float *red, float *scratch, float &dv) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int m0 = 0; m0 < n; m0 += kAnyWaves) {                        // d alpha_m, a wave per memory
-        const int m = m0 + wave, mc = min(m, n - 1);
-        float p = 0.f;
-        for (int k = lane; k < H; k += 64) p = fmaf(dctx[k], pk[(int64_t)mc * H + k], p);
-        p = wave_sum(p);
-        if (lane == 0 && m < n) sc[m] = p + (datt ? datt[m] : 0.f);
+    if (dctx) {                                                        // d alpha_m = dctx . PK[m] (+ datt[m]), a wave per memory
+        for (int m0 = 0; m0 < n; m0 += kAnyWaves) {
+            const int m = m0 + wave, mc = min(m, n - 1);
+            float p = 0.f;
+            for (int k = lane; k < H; k += 64) p = fmaf(dctx[k], pk[(int64_t)mc * H + k], p);
+            p = wave_sum(p);
+            if (lane == 0 && m < n) sc[m] = p + (datt ? datt[m] : 0.f);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (tid < 64) {                                                    // ds_m = alpha_m (dalpha_m - sum alpha dalpha)
         float s = 0.f;
         for (int m = tid; m < n; m += 64) s = fmaf(al[m], sc[m], s);
@@ -344,14 +378,16 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.T, L = a.L, M = a.M, V = a.V;
     const AnyLdsB o = any_lds_bwd(H, L, M);
-    float *dh_s = smem + o.dh, *dc_s = smem + o.dc, *dl_s = smem + o.dl, *dctx_s = smem + o.dctx, *dq_s = smem + o.dq,
+    float *dh_s = smem + o.dh, *dc_s = smem + o.dc, *dl_s = smem + o.dl, *dlp_s = smem + o.dlp, *dctx_s = smem + o.dctx, *dq_s = smem + o.dq,
           *dqv_s = smem + o.dqv, *q_s = smem + o.q, *vt_s = smem + o.v1, *vv_s = smem + o.v2, *al_s = smem + o.al, *sc = smem + o.sc,
           *datt_s = smem + o.datt, *red = smem + o.red, *scr = smem + o.scr;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
     const float *pk_t = a.pk_t + (int64_t)b * L * H, *pk_v = a.pk_v + (int64_t)b * M * H;
     float *dpk_t = a.dpk_t + (int64_t)b * L * H, *dpk_v = a.dpk_v + (int64_t)b * M * H;
+    const float *u_t = a.u_t + (int64_t)b * L * 4 * H, *u2_t = a.u2_t + (int64_t)b * L * H, *u_v = a.u_v + (int64_t)b * M * 4 * H;
     const float *W_hh = a.any_w_hh, *W_ih = a.any_w_ih, *W_qt = a.any_w_qt, *W_qv = a.any_w_qv, *W_q2k = a.any_w_q2k;
+    const bool use_u = a.any_use_u != 0;
 
     // ---- seeds and the head's backward (as decoder_bwd_kernel's prologue): dlogits, dS = Wc^T dlogits
     float aux_scale = (a.seeds && a.daux) ? a.seeds[1] : 1.f;
@@ -426,7 +462,13 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
     float dvt = 0.f, dvv = 0.f;                     // this thread's share of the energy-vector gradients (attention_bwd_any)
     __syncthreads();
 
+    int Hl = H, Ll = L, Ml = M, lenl = len;
     for (int t = T - 1; t >= 0; --t) {
+        LAUNDER(Hl); LAUNDER(Ll); LAUNDER(Ml); LAUNDER(lenl);
+        const int H = Hl, L = Ll, M = Ml, len = lenl;
+        const float *pk_t = a.pk_t + (int64_t)b * L * H, *pk_v = a.pk_v + (int64_t)b * M * H;
+        float *dpk_t = a.dpk_t + (int64_t)b * L * H, *dpk_v = a.dpk_v + (int64_t)b * M * H;
+        const float *u_t = a.u_t + (int64_t)b * L * 4 * H, *u2_t = a.u2_t + (int64_t)b * L * H, *u_v = a.u_v + (int64_t)b * M * 4 * H;
         const int64_t bt = (int64_t)b * T + t;
         // ---- LSTM cell backward (dh_t = head part + what step t+1 passed back)
         for (int u = tid; u < H; u += kAnyThreads) {
@@ -442,17 +484,28 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
                         d_o = dh * tc * og * (1.f - og);
             dc_s[u] = dct * fg;
             dl_s[u] = di; dl_s[H + u] = df; dl_s[2 * H + u] = dg; dl_s[3 * H + u] = d_o;
+            if (use_u) { dlp_s[4 * u] = di; dlp_s[4 * u + 1] = df; dlp_s[4 * u + 2] = dg; dlp_s[4 * u + 3] = d_o; }
             a.delta[bt * 5 * H + u] = di; a.delta[bt * 5 * H + H + u] = df;
             a.delta[bt * 5 * H + 2 * H + u] = dg; a.delta[bt * 5 * H + 3 * H + u] = d_o;
         }
         __syncthreads();
-        // ---- d [ctx_text | ctx_vis] = head part + W_ih[:, H:3H]^T delta
-        matvec_cols(W_ih, 3 * H, H, 4 * H, 2 * H, dl_s, scr, [&](int c, float v) { dctx_s[c] = v + a.ds[bt * 4 * H + H + c]; });
+        // ---- d alpha_vis[m] = delta . U_vis[m] + d ctx_vis(head) . PK_vis[m] + d att_sum[m]: the LSTM-input part of the context
+        //      gradient reaches d alpha through the gate images (delta . U[m] = (W_ih[:, ctx]^T delta) . PK[m]); the context
+        //      gradients themselves (the value path of the keys) are completed by the dS += product behind this kernel
+        //      (narrow hidden sizes / many memories, use_u false: d ctx = head part + W_ih[:, ctx]^T delta formed here, streamed)
+        if (use_u) for (int c = tid; c < 2 * H; c += kAnyThreads) dctx_s[c] = a.ds[bt * 4 * H + H + c];
+        else matvec_cols(W_ih, 3 * H, H, 4 * H, 2 * H, dl_s, scr, [&](int c, float v) { dctx_s[c] = v + a.ds[bt * 4 * H + H + c]; });
         for (int m = tid; m < M; m += kAnyThreads) al_s[m] = a.alpha_s[bt * M + m];
         for (int k = tid; k < H; k += kAnyThreads) q_s[k] = a.qv[bt * H + k];
         __syncthreads();
+        if (use_u) {
+            matvec_rows<true>(u_v, 4 * H, M, 4 * H, dlp_s, [&](int m, float v) { sc[m] = v + datt_s[m]; });
+            __syncthreads();
+            matvec_rows<V4>(pk_v, H, M, H, dctx_s + H, [&](int m, float v) { sc[m] += v; });
+            __syncthreads();
+        }
         // ---- visual attention backward
-        attention_bwd_any(dctx_s + H, q_s, vv_s, al_s, datt_s, pk_v, dpk_v, M, H, sc, dq_s, red, scr, dvv);
+        attention_bwd_any(use_u ? nullptr : dctx_s + H, datt_s, q_s, vv_s, al_s, pk_v, dpk_v, M, H, sc, dq_s, red, scr, dvv);
         for (int k = tid; k < H; k += kAnyThreads) { const float v = dq_s[k]; dqv_s[k] = v; a.dqv[bt * H + k] = v; }
         __syncthreads();
         if (cond) {
@@ -463,14 +516,24 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
                 dl_s[4 * H + c] = dz;
                 a.delta[bt * 5 * H + 4 * H + c] = dz;
             });
-            __syncthreads();
-            matvec_cols(W_q2k, 2 * H, H, H, H, dl_s + 4 * H, scr, [&](int c, float v) { dctx_s[c] += v; });
+            if (!use_u) matvec_cols(W_q2k, 2 * H, H, H, H, dl_s + 4 * H, scr, [&](int c, float v) { dctx_s[c] += v; });
         }
         for (int m = tid; m < L; m += kAnyThreads) al_s[m] = a.alpha_c[bt * L + m];
         for (int k = tid; k < H; k += kAnyThreads) q_s[k] = a.qt[bt * H + k];
         __syncthreads();
+        // ---- d alpha_text[m] = delta . U_text[m] + dzq . U2_text[m] + d ctx_text(head) . PK_text[m]
+        if (use_u) {
+            matvec_rows<true>(u_t, 4 * H, len, 4 * H, dlp_s, [&](int m, float v) { sc[m] = v; });
+            __syncthreads();
+            if (cond) {
+                matvec_rows<V4>(u2_t, H, len, H, dl_s + 4 * H, [&](int m, float v) { sc[m] += v; });
+                __syncthreads();
+            }
+            matvec_rows<V4>(pk_t, H, len, H, dctx_s, [&](int m, float v) { sc[m] += v; });
+            __syncthreads();
+        }
         // ---- textual attention backward
-        attention_bwd_any(dctx_s, q_s, vt_s, al_s, nullptr, pk_t, dpk_t, len, H, sc, dq_s, red, scr, dvt);
+        attention_bwd_any(use_u ? nullptr : dctx_s, nullptr, q_s, vt_s, al_s, pk_t, dpk_t, len, H, sc, dq_s, red, scr, dvt);
         for (int k = tid; k < H; k += kAnyThreads) a.dqt[bt * H + k] = dq_s[k];
         // ---- dh_{t-1} = W_hh^T delta + W_qt^T dqt + (W_q2k[:, :H]^T dzq  or  W_qv^T dqv)
         matvec_cols(W_hh, H, 0, 4 * H, H, dl_s, scr, [&](int c, float v) { dh_s[c] = v; });
@@ -507,7 +570,20 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
 // ------------------------------------------------------------------------------------------
 constexpr int kAnyMaxHidden = kAnyThreads;         // the backward pass gives every feature of an attention a thread
 
-int decoder_run_any(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream) {
+// The streaming kernels read the gate images U = PK . W_ih[:, ctx]^T ((L + M) . 4H floats of the ROW's own data per step)
+// in place of W_ih's context columns (8 H^2 floats every row's workgroup streams): a gain for wide hidden sizes with few
+// memories — B = 256, T = 20, ms per step: H 200 4.9 -> 3.8, H 256 6.0 -> 4.3 — and a loss otherwise (H 128 1.57 -> 1.68;
+// H 100 on a 12 x 12 grid 2.0 -> 2.2).  GSCAN_ANY_U=0/1 forces the choice (tests).
+bool decoder_any_uses_gate_images(int H, int L, int M) {
+    static const int forced = [] { const char *e = getenv("GSCAN_ANY_U"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced != 0;
+    return H >= 160 && L + M <= H;
+}
+
+int decoder_run_any(bool backward, int B, int H, bool cond, const DecoderArgs &a_in, hipStream_t stream) {
+    DecoderArgs a = a_in;
+    a.any_use_u = decoder_any_uses_gate_images(H, a.L, a.M) ? 1 : 0;
+    GSCAN_CHECK(!a.any_use_u || (a.u_t && a.u_v && (!cond || a.u2_t)), "decoder (any shape): gate images missing");
     GSCAN_CHECK(H >= 1 && H <= kAnyMaxHidden, "decoder: decoder_hidden_size %d is outside 1..%d", H, kAnyMaxHidden);
     GSCAN_CHECK(a.any_w_hh && a.any_w_ih && a.any_w_qt && a.any_w_qv && (!cond || a.any_w_q2k),
                 "decoder (any shape): the parameter pointers are missing");

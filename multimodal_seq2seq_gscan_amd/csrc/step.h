@@ -285,6 +285,7 @@ struct DecoderArgs {
     // the same weights in the reference's own layouts, for the any-shape kernels (decoder_any.hip): lstm.weight_hh
     // [4H,H], lstm.weight_ih [4H,3H], the attentions' query layers [H,H], queries_to_keys.weight [H,2H] or NULL
     const float *any_w_hh, *any_w_ih, *any_w_qt, *any_w_qv, *any_w_q2k;
+    int any_use_u;                      // set by decoder_run_any
     float *hprev;                      // [B,T,H]  hprev[b,0] = h0 (= c0 unless c0 is given) on entry; kernel fills t+1
     const float *c0;                   // [B,H] initial cell state, or NULL for c0 = h0 (seq2seq_model.py:494-504)
     float *h_last;                     // [B,H] h after the last step, or NULL
@@ -330,6 +331,7 @@ int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hi
 int decoder_run_any(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
 // does decoder.hip have kernels for this shape (a compiled hidden size, <= 64 memories per attention, LDS fits)?
 bool decoder_fast_supported(int H, int L, int M, int V, bool cond);
+bool decoder_any_uses_gate_images(int H, int L, int M);   // decoder_any.hip: the streaming kernels read U images too
 
 // attention_grad.hip: value path of both attentions + key layers + bridge, one workgroup per batch row
 struct KeysBackwardArgs {

@@ -276,7 +276,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     // cross-stream events themselves to be the cost.  Measured and dropped (profiles/r02_ab_*): forking behind L1 or
     // behind the prologue (+20..30 us: the event latency lands on the critical path), host issue order (no effect).
     hipStream_t sd2 = g_side.single ? st : g_side.stream2;
-    const bool fast_decoder = decoder_fast_supported(H, L, M, V, cond);
+    const bool gate_images = decoder_fast_supported(H, L, M, V, cond) || decoder_any_uses_gate_images(H, L, M);
     // one prologue launch with the segments of `which` (0: caller's stream, 1: side 1, 2: side 2); the others stay empty
     // fuse_world: the world encoder runs in the same launch (conv.hip, prologue_world_kernel), whose image workgroups
     // take the convolution weight image off the prologue's index space; returns -1 if that launch does not fit the shape
@@ -293,8 +293,10 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.zero_extra = w + ws.enc_out;                     // adjacent slots enc_out | hN | dxe
         a.zero_extra_count = (ws.dxe + (int64_t)B * L * E) - ws.enc_out;
         const DecoderGeometry geo = decoder_geometry(H, cond);
-        // the register images, the U images and the composite weights behind them belong to the fast decoder kernels
+        // the register images belong to the resident decoder kernels (the gate images U and the composite weights behind
+        // them are read by the streaming kernels too)
         const bool fast = decoder_fast_supported(H, L, M, V, cond);
+        const bool images = fast || decoder_any_uses_gate_images(H, L, M);     // gate images U and their composite weights
         a.img = DecoderImageArgs{p.dec_w_hh, p.txt_query_w, p.vis_query_w, p.q2k_w, p.out2hid_w, w + ws.dec_w_fwd,
                                  w + ws.dec_w_bwd, H, cond ? 1 : 0, geo.slots, geo.k0};
         a.enc_w_hh_f = p.enc_w_hh; a.enc_w_hh_r = p.enc_w_hh_rev; a.enc_image = w + ws.enc_w_image;
@@ -309,7 +311,8 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
                                a.zero_extra_count, fast ? 2 * geo.image_floats : 0,
                                encoder_fast_supported(He, L, E) ? (int64_t)D * 4 * He * He : 0,
                                (given || fuse_world) ? 0 : conv_image_floats(C, Co, d.K3),
-                               fast ? (int64_t)4 * H * F : 0, fast ? (int64_t)4 * H * He : 0, (fast && cond) ? (int64_t)H * He : 0};
+                               images ? (int64_t)4 * H * F : 0, images ? (int64_t)4 * H * He : 0,
+                               (images && cond) ? (int64_t)H * He : 0};
         int64_t acc = 0;
         for (int i = 0; i < 14; ++i) {
             // side 1: decoder bias sum, embedded targets; side 2: convolution weight image, visual composite weight
@@ -328,7 +331,7 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     // the dense products of the prelude, each added to whichever launch the schedule below puts it in
     auto add_visual = [&](GemmBatch &k) {     // projected visual keys (seq2seq_model.py:466-467) and their gate images
         k.add(B * M, H, F, w + ws.feat, F, 1, p.vis_key_w, 1, F, w + ws.pkv, H);
-        if (!fast_decoder) return;
+        if (!gate_images) return;
         k.add(B * M, 4 * H, F, w + ws.feat, F, 1, w + ws.w_sk, 1, F, w + ws.uv, 4 * H);
         k.overhead();     // U image: its algorithmic counterpart, W_ih[:, ctx_vis] . ctx_vis per step, is charged to the decoder kernel
     };
@@ -338,11 +341,11 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     };
     auto add_textual = [&](GemmBatch &g) {    // projected textual keys (:468-469), their images, and the bridge (model.py:195)
         g.add(B * L, H, He, w + ws.enc_out, He, 1, p.txt_key_w, 1, He, w + ws.pkt, H);
-        if (fast_decoder) {
+        if (gate_images) {
             g.add(B * L, 4 * H, He, w + ws.enc_out, He, 1, w + ws.w_ck, 1, He, w + ws.ut, 4 * H);
             g.overhead(); // U images of the textual memories: charged to the decoder kernel as the context terms they replace
         }
-        if (cond && fast_decoder) { g.add(B * L, H, He, w + ws.enc_out, He, 1, w + ws.w_2kk, 1, He, w + ws.u2t, H); g.overhead(); }
+        if (cond && gate_images) { g.add(B * L, H, He, w + ws.enc_out, He, 1, w + ws.w_2kk, 1, He, w + ws.u2t, H); g.overhead(); }
         g.add(B, H, He, w + ws.hN, He, 1, p.bridge_w, 1, He, w + ws.hprev, (int64_t)T * H, 0.f, p.bridge_b, 2);
     };
     auto world_encoder = [&](hipStream_t stream) -> int {      // cnn_model.py:22-36, input-sparse kernel (conv.hip)

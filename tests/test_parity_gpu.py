@@ -543,13 +543,15 @@ def test_greedy_decoding_on_streamed_shapes_against_oracle(overrides, shape_kw):
             assert torch.allclose(torch.tensor(one["alpha_vis"][r])[:n], a_v, atol=1e-4)
 
 
-def test_fixture_suite_on_the_streaming_kernels():
+@pytest.mark.parametrize("gate_images", ["0", "1"])
+def test_fixture_suite_on_the_streaming_kernels(gate_images):
     """GSCAN_DECODER_ANY=1 GSCAN_ENCODER_ANY=1 (read once per process, hence the child process): the reference's own
     outputs — training step fixtures, the greedy fixture, the decode_input sequences — through the streaming kernels
-    instead of the register/LDS-resident ones."""
+    instead of the register/LDS-resident ones, in both of their forms (GSCAN_ANY_U: W_ih's context columns streamed, or
+    the gate images U read in their place as the resident kernels do)."""
     import subprocess
     import sys
-    env = dict(os.environ, GSCAN_DECODER_ANY="1", GSCAN_ENCODER_ANY="1")
+    env = dict(os.environ, GSCAN_DECODER_ANY="1", GSCAN_ENCODER_ANY="1", GSCAN_ANY_U=gate_images)
     pick = ("demo_variants or more_than_one_encoder_layer or geca_aux or greedy_predict_matches or decode_input or "
             "persistent_greedy or one_call_train_step")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", pick,
