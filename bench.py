@@ -379,6 +379,11 @@ def main():
                          f"--nproc-per-node {args.gpus}, or without a launcher at all")
     if args.dry_launch:
         return dry_launch(args, world, rank)
+    # ONE JSON line on stdout is the contract, and native libraries write there too (RCCL prints a version banner when its
+    # first communicator comes up): from here on file descriptor 1 is stderr, and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the HIP device (the product path has no CPU fallback)")
     if args.backend == "gloo":
@@ -387,6 +392,10 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local)
     if world > 1 or args.always_collective:
+        if world == 1:                                        # --always-collective without a launcher: a one-rank group
+            for key, value in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"),
+                               ("MASTER_PORT", str(29500 + os.getpid() % 2000))):
+                os.environ.setdefault(key, value)
         # "nccl" IS RCCL on ROCm.  The process group carries the rendezvous, the barriers and the max-over-ranks of the
         # timings; the gradient all-reduce itself runs through the library's own communicator on the step's stream
         # (train.RcclCommunicator), created from this group.
@@ -580,7 +589,8 @@ def main():
             result["cpu_baseline"] = cpu_baseline(cfg, shape, args.cpu_seconds)
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     step.close()                       # the library's own RCCL communicator goes before the process group
     if dist.is_initialized():
         dist.barrier()
