@@ -30,7 +30,13 @@ extern "C" {
 #define GSCAN_ABI_VERSION 11
 #define GSCAN_MAX_ENC_LAYERS 4
 
-/* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102). */
+/* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102).
+ * Accepted (gscan_workspace_bytes returns 0 and gscan_last_error says why otherwise): H 1..256, He 1..2048, E 1..256,
+ * L and G*G up to 4096, K3 odd, up to GSCAN_MAX_ENC_LAYERS encoder layers, B*T*4H < 2^31.  Shapes outside what the
+ * register/LDS-resident kernels are compiled for (H a multiple of 4 up to 100, He a multiple of 4 up to 128, at most 64
+ * memories per attention) run on streaming kernels with the same results.
+ * Environment, read once per process: GSCAN_DETERMINISTIC=1 makes every sum that crosses workgroups fixed-order (bitwise
+ * reproducible training steps, +6 % time; it changes the workspace size: set it before gscan_workspace_bytes). */
 typedef struct gscan_dims {
     int32_t B;             /* rows in this batch                                   */
     int32_t L;             /* padded command length                                */
