@@ -572,8 +572,8 @@ constexpr int kAnyMaxHidden = kAnyThreads;         // the backward pass gives ev
 
 // The streaming kernels read the gate images U = PK . W_ih[:, ctx]^T ((L + M) . 4H floats of the ROW's own data per step)
 // in place of W_ih's context columns (8 H^2 floats every row's workgroup streams): a gain for wide hidden sizes with few
-// memories — B = 256, T = 20, ms per step: H 200 4.9 -> 3.8, H 256 6.0 -> 4.3 — and a loss otherwise (H 128 1.57 -> 1.68;
-// H 100 on a 12 x 12 grid 2.0 -> 2.2).  GSCAN_ANY_U=0/1 forces the choice (tests).
+// memories — B = 256, T = 20, ms per step: H 160 2.93 -> 2.70, H 200 4.9 -> 3.8, H 256 6.0 -> 4.3 — and a loss or a draw
+// otherwise (H 144 2.54 -> 2.56, H 128 1.57 -> 1.68; H 100 on a 12 x 12 grid 2.0 -> 2.2).  GSCAN_ANY_U=0/1 forces the choice (tests).
 bool decoder_any_uses_gate_images(int H, int L, int M) {
     static const int forced = [] { const char *e = getenv("GSCAN_ANY_U"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return forced != 0;

@@ -27,6 +27,8 @@ CASES = [
     ("hidden128", dict(encoder_hidden_size=128, decoder_hidden_size=128), {}),
     ("hidden200", dict(encoder_hidden_size=200, decoder_hidden_size=200), {}),
     ("hidden256", dict(encoder_hidden_size=256, decoder_hidden_size=256), {}),
+    ("hidden144", dict(encoder_hidden_size=144, decoder_hidden_size=144), {}),
+    ("hidden160", dict(encoder_hidden_size=160, decoder_hidden_size=160), {}),
     ("hidden100 grid12", {}, dict(grid=12)),
     ("hidden100 command128", {}, dict(max_command=128)),
     ("hidden100 encoder256", dict(encoder_hidden_size=256), {}),
