@@ -81,6 +81,7 @@ __device__ __forceinline__ void matvec_cols(const float *__restrict__ W, int ldw
         if (p < P && c < C) {
             const float *wcol = W + c0 + c;
             int r = p;
+#pragma unroll 2
             for (; r + 3 * P < R; r += 4 * P) {
                 const float w0 = wcol[(int64_t)r * ldw], w1 = wcol[(int64_t)(r + P) * ldw],
                             w2 = wcol[(int64_t)(r + 2 * P) * ldw], w3 = wcol[(int64_t)(r + 3 * P) * ldw];

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kAnyThreads) void encoder_lstm_fwd_any_kernel(int L
     int len = lengths[b];
     len = max(0, min(len, L));
     const int HP = (HE + 3) / 4 * 4;
-    float *h_s = lds, *pre_s = h_s + HP, *c_s = pre_s + 4 * HP, *x_s = c_s + HP;      // x_s [E]
+    float *h_s = lds, *pre_s = h_s + HP, *c_s = pre_s + 4 * HP, *x_s = c_s + HP;      // x_s [4 HP]: staged x, then gx of a step
     const int64_t row0 = (int64_t)b * L;
     const float *w_hh = dir ? w_hh_r : w_hh_f, *b_hh = dir ? b_hh_r : b_hh_f;
     const float *w_ih = dir ? in.w_ih_r : in.w_ih_f, *b_ih = dir ? in.b_ih_r : in.b_ih_f;
@@ -351,24 +351,35 @@ __global__ __launch_bounds__(kAnyThreads) void encoder_lstm_fwd_any_kernel(int L
         if (hcat) hcat[((row0 + t) * D + dir) * HE + k] = 0.f;
     }
     __syncthreads();
+    // ---- the first layer's input projections of the whole command, before the recurrence: they do not depend on h, so
+    //      nothing orders the steps' products (no barrier between them: many steps' loads in flight).  They go to the
+    //      row's slots of `gates`, where the recurrence reads them back and leaves the activated gates.
+    float *gx_s = x_s;                                        // recurrence: this step's input projection (4 HP floats)
+    if (in.x) {
+        const int E = in.E, chunk = max(1, (4 * HP) / E);     // the command's x, `chunk` steps at a time, in the gx_s region
+        for (int t0 = 0; t0 < len; t0 += chunk) {
+            const int nt = min(chunk, len - t0);
+            for (int i = tid; i < nt * E; i += kAnyThreads) x_s[i] = in.x[(row0 + t0) * E + i];
+            __syncthreads();
+            for (int tt = 0; tt < nt; ++tt) {
+                float *dst = gates + ((row0 + t0 + tt) * D + dir) * 4 * HE;
+                // E is small and W_ih rows need not be 16-byte aligned (E = 25): scalar loads
+                matvec_rows<false>(w_ih, E, 4 * HE, E, x_s + tt * E, [&](int r, float v) { dst[r] = v + b_ih[r] + b_hh[r]; });
+            }
+            __syncthreads();
+        }
+    }
+    const float *pre_g = in.x ? gates : gx;                   // [B, L, D, 4 HE] either way
     for (int s = 0; s < len; ++s) {
         const int t = dir ? (len - 1 - s) : s;
         const int64_t row = (row0 + t) * D + dir;
         for (int k = tid; k < HE; k += kAnyThreads) hprev[row * HE + k] = h_s[k];     // h entering this step (0 at the first)
-        if (in.x) {
-            for (int e = tid; e < in.E; e += kAnyThreads) x_s[e] = in.x[(row0 + t) * in.E + e];
-            __syncthreads();
-            // E is small and W_ih rows need not be 16-byte aligned (E = 25): scalar loads
-            matvec_rows<false>(w_ih, in.E, 4 * HE, in.E, x_s, [&](int r, float v) { pre_s[r] = v + b_ih[r] + b_hh[r]; });
-        } else {
-            for (int r = tid; r < 4 * HE; r += kAnyThreads) pre_s[r] = gx[row * 4 * HE + r] + b_hh[r];
-        }
-        __syncthreads();
-        matvec_rows<V4>(w_hh, HE, 4 * HE, HE, h_s, [&](int r, float v) { pre_s[r] += v; });
+        for (int r = tid; r < 4 * HE; r += kAnyThreads) gx_s[r] = pre_g[row * 4 * HE + r] + (in.x ? 0.f : b_hh[r]);
+        matvec_rows<V4>(w_hh, HE, 4 * HE, HE, h_s, [&](int r, float v) { pre_s[r] = v; });
         __syncthreads();
         for (int k = tid; k < HE; k += kAnyThreads) {
-            const float ig = sigmoidf_(pre_s[k]), fg = sigmoidf_(pre_s[HE + k]), gg = tanhf_(pre_s[2 * HE + k]),
-                        og = sigmoidf_(pre_s[3 * HE + k]);
+            const float ig = sigmoidf_(pre_s[k] + gx_s[k]), fg = sigmoidf_(pre_s[HE + k] + gx_s[HE + k]),
+                        gg = tanhf_(pre_s[2 * HE + k] + gx_s[2 * HE + k]), og = sigmoidf_(pre_s[3 * HE + k] + gx_s[3 * HE + k]);
             const float c = fg * c_s[k] + ig * gg, h = og * tanhf_(c);
             c_s[k] = c;
             h_s[k] = h;
@@ -538,7 +549,7 @@ int encoder_lstm_forward(int B, int L, int He, int D, const float *gx, const int
         GSCAN_CHECK(He >= 1 && w_hh_f && b_hh_f && (!in.x || (in.w_ih_f && in.b_ih_f && (D == 1 || (in.w_ih_r && in.b_ih_r)))),
                     "encoder lstm: encoder_hidden_size %d / weights missing", He);
         const int HP = (He + 3) / 4 * 4;
-        const size_t lds = (size_t)(6 * HP + (in.x ? (in.E + 3) / 4 * 4 : 0)) * sizeof(float);
+        const size_t lds = (size_t)(10 * HP + (in.x ? in.E : 0)) * sizeof(float);
         GSCAN_CHECK(lds <= kEncLdsLimit, "encoder lstm: encoder_hidden_size %d needs %zu bytes of LDS", He, lds);
         ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * He * (He + (in.x ? in.E : 0)));
         if (He % 4 == 0)
