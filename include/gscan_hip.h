@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 11
+#define GSCAN_ABI_VERSION 12
 #define GSCAN_MAX_ENC_LAYERS 4
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102).
@@ -248,9 +248,7 @@ int gscan_backward_nll(const gscan_dims *dims, const gscan_params *params, const
 
 /* One training iteration's forward pass, loss and backward pass (seq2seq/train.py:96-110: model(...), get_loss,
  * loss.backward()) as ONE call: what gscan_forward followed by gscan_backward_nll compute.  Arguments as in those two
- * calls; `logp` / `aux_logp` receive the forward pass's outputs.  With GSCAN_FUSED_DECODER=1 in the environment the
- * decoder's forward and reverse recurrences run as one launch (a row's workgroup runs both on the same CU) where the
- * row's memories fit LDS in both directions: an experiment, slower than two launches on MI355X. */
+ * calls; `logp` / `aux_logp` receive the forward pass's outputs. */
 int gscan_train_step_nll(const gscan_dims *dims, const gscan_params *params, const gscan_batch *batch,
                          const gscan_masks *masks, void *workspace, float *logp, float *aux_logp, float weight_target_loss,
                          int sum_reduction, float *stats, float *seeds, const gscan_params *grads, void *stream);
@@ -268,12 +266,16 @@ int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t st
  * is enqueued on the CALLER'S stream, between gscan_backward_nll and gscan_adam_step_mean, so the step needs no
  * hop to a communication stream.  RCCL is resolved at run time from the librccl.so.1 the process already holds
  * (PyTorch-ROCm's); these four calls fail with a message when there is none, nothing else in the library needs it.
+ *   every rank: gscan_comm_available() == 0 ?  -> agree on the answer over the side channel FIRST: a rank that cannot
+ *                                            load RCCL must not leave the others blocked inside gscan_comm_init
  *   rank 0:     gscan_comm_unique_id(id)  -> ship the GSCAN_COMM_ID_BYTES bytes to every rank (any side channel:
  *                                            the torch.distributed store, MPI, a file)
  *   every rank: hipSetDevice(local GPU); gscan_comm_init(&comm, nranks, rank, id)   (collective: blocks until all join)
  *   every step: gscan_allreduce_f32(comm, flat_gradients, n, stream)               (in place, sum)
  *   at exit:    gscan_comm_destroy(comm)                                                                            */
 #define GSCAN_COMM_ID_BYTES 128
+/* 0 when RCCL can be loaded in this process (dlopen + symbols only: no device call, nothing collective) */
+int gscan_comm_available(void);
 int gscan_comm_unique_id(void *id_host);
 int gscan_comm_init(void **comm, int nranks, int rank, const void *id_host);
 int gscan_allreduce_f32(void *comm, float *buf, size_t n, void *stream);

@@ -11,7 +11,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # GSCAN_HIP_LIB: development override, used by tools/variants.py to time experimental builds side by side
 LIB_PATH = os.environ.get("GSCAN_HIP_LIB") or os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_ENC_LAYERS = 4
 COMM_ID_BYTES = 128
 
@@ -104,6 +104,7 @@ PROTOTYPES = {
                                    _u64, _u64, _vp]),
     "gscan_trace_set": (_i, [_vp]),
     "gscan_dropout_masks": (_i, [_vp, _sz, _sz, _sz, _f, _f, _f, _u64, _u64, _vp, _vp]),
+    "gscan_comm_available": (_i, []),
     "gscan_comm_unique_id": (_i, [_vp]),
     "gscan_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),
     "gscan_allreduce_f32": (_i, [_vp, _vp, _sz, _vp]),

@@ -235,6 +235,7 @@ int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t st
     return dropout_mask(out, n, p, seed, stream_id, (hipStream_t)stream);
 }
 
+int gscan_comm_available(void) { return comm_available(); }
 int gscan_comm_unique_id(void *id_host) { return comm_unique_id(id_host); }
 int gscan_comm_init(void **comm, int nranks, int rank, const void *id_host) { return comm_init(comm, nranks, rank, id_host); }
 int gscan_allreduce_f32(void *comm, float *buf, size_t n, void *stream) {

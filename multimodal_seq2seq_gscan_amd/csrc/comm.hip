@@ -72,6 +72,11 @@ int rccl_load() {
     } while (0)
 }  // namespace
 
+// Can this process reach RCCL at all?  Loads the library and resolves the entry points, nothing else: no device call, no
+// communicator, nothing collective.  Every rank answers this BEFORE anyone enters ncclCommInitRank (which blocks until
+// all ranks have joined), so that a rank without RCCL cannot leave the others waiting inside it (train.RcclCommunicator).
+int comm_available() { return rccl_load(); }
+
 int comm_unique_id(void *id_host) {
     GSCAN_CHECK(id_host, "comm_unique_id: NULL buffer");
     TRY_RC(rccl_load());

@@ -351,6 +351,12 @@ int GemmBatch::launch_macro_tiles(hipStream_t stream) {
     static const int order = [] { const char *e = getenv("GSCAN_GEMM_ORDER"); return e ? atoi(e) : 1; }();
     const size_t slab = gemm_mt_slab_floats();
     const size_t slab_cap = scratch_ ? scratch_floats_ / slab : 0;
+    // Products that share their C with another product of the launch (split_ok == 2: float atomics, never slabs) are cut
+    // into K slices like any split product — except in a launch that was handed scratch, i.e. one that asked for
+    // fixed-order sums: there each of them stays ONE slice, so that an element of C receives exactly one add per
+    // product onto the zeroed buffer, and two float adds commute bit for bit (the deep encoder's dX products of the two
+    // directions, step.hip; with K = 4 He = 400 cut into six slices the last bits moved from run to run).
+    auto splittable = [&](const GemmProblem &p) { return p.split_ok == 1 || (p.split_ok == 2 && !scratch_); };
     // tiles of `bm` rows; returns the workgroups of the launch at R rounds per slice and the slabs that takes
     auto plan = [&](int bm, int R, size_t *slabs) {
         int total = 0;
@@ -360,7 +366,7 @@ int GemmBatch::launch_macro_tiles(hipStream_t stream) {
             int tn, nf;
             gemm_mt_columns(p.N + (p.asum1 ? 1 : 0), &tn, &nf);
             const int tiles = tn * cdiv(p.M, bm);
-            const int slices = p.split_ok ? cdiv(cdiv(p.K, 32), R) : 1;
+            const int slices = splittable(p) ? cdiv(cdiv(p.K, 32), R) : 1;
             total += tiles * slices;
             if (slices > 1 && p.split_ok == 1) *slabs += (size_t)tiles * slices;
         }
@@ -368,7 +374,7 @@ int GemmBatch::launch_macro_tiles(hipStream_t stream) {
     };
     int max_rounds = 1;
     for (int i = 0; i < grp_.count; ++i)
-        if (grp_.p[i].split_ok) max_rounds = std::max(max_rounds, cdiv(grp_.p[i].K, 32));
+        if (splittable(grp_.p[i])) max_rounds = std::max(max_rounds, cdiv(grp_.p[i].K, 32));
     auto pick_rounds = [&](int bm, int *total) {
         int R = max_rounds;
         size_t slabs = 0;
@@ -398,7 +404,7 @@ int GemmBatch::launch_macro_tiles(hipStream_t stream) {
         gemm_mt_columns(p.N + (p.asum1 ? 1 : 0), &p.tiles_n, &p.nf);
         p.tiles_m = cdiv(p.M, bm);
         p.tiles_mn = p.tiles_n * p.tiles_m;
-        p.k_chunk = p.split_ok ? 32 * R : cdiv(p.K, 32) * 32;
+        p.k_chunk = splittable(p) ? 32 * R : cdiv(p.K, 32) * 32;
         p.nsplit = cdiv(p.K, p.k_chunk);
         // several products of one launch adding into one C (split_k < 0 at add()): float atomics whatever the slice count
         p.atomic = p.split_ok == 2 ? 1 : (p.nsplit > 1 ? (use_slabs ? 2 : 1) : 0);

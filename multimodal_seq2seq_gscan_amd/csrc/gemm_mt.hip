@@ -293,12 +293,13 @@ __global__ __launch_bounds__(MTHREADS, WM == 4 ? 2 : 3) void gemm_mt_kernel(int 
             for (int j = 0; j < MWN; ++j) {
                 const int col = t.n0 + 16 * (t.fn0 + j) + fr;
                 if (j >= t.nfw || col >= t.NV) continue;
-                float v = alpha * acc[i][j][r];
-                if (col == N) {                        // the ones column: row sums of A (bias gradients)
-                    if (mode) { atomicAdd(asum1 + row, v); if (asum2) atomicAdd(asum2 + row, v); }
-                    else { asum1[row] += v; if (asum2) asum2[row] += v; }
+                if (col == N) {                        // the ones column: row sums of A (bias gradients), NOT scaled by
+                    const float sa = acc[i][j][r];     // alpha: asum += sum_k A(m,k), as the small-tile kernel and the header say
+                    if (mode) { atomicAdd(asum1 + row, sa); if (asum2) atomicAdd(asum2 + row, sa); }
+                    else { asum1[row] += sa; if (asum2) asum2[row] += sa; }
                     continue;
                 }
+                float v = alpha * acc[i][j][r];
                 const uint32_t at = roff + col;
                 if (mode) { atomicAdd(c + at, v); continue; }
                 if (!plain) {
@@ -380,8 +381,8 @@ __global__ __launch_bounds__(256) void gemm_mt_reduce_kernel(int tb0, int tb1, i
     for (int r = 0; r < 4; ++r) {
         const int row = m0 + 16 * (fm0 + i) + 4 * fg + r;
         if (row >= g.M) continue;
+        if (col == g.N) { g.asum1[row] += s[r]; if (g.asum2) g.asum2[row] += s[r]; continue; }   // row sums of A: unscaled
         const float v = g.alpha * s[r];
-        if (col == g.N) { g.asum1[row] += v; if (g.asum2) g.asum2[row] += v; continue; }
         const uint32_t at = (uint32_t)row * (uint32_t)g.ldc + col;
         gc[at] = g.beta != 0.f ? g.beta * gc[at] + v : v;
     }

@@ -346,6 +346,7 @@ struct KeysBackwardArgs {
 int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream);
 
 // comm.hip: RCCL all-reduce on the caller's stream (run-time binding)
+int comm_available();                  // 0: RCCL is loadable in this process (no device call, nothing collective)
 int comm_unique_id(void *id_host);
 int comm_init(void **comm, int nranks, int rank, const void *id_host);
 int comm_allreduce_f32(void *comm, float *buf, size_t n, hipStream_t stream);

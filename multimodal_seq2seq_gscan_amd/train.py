@@ -149,14 +149,21 @@ class RcclCommunicator:
         self.rank = dist.get_rank(process_group)
         self.world_size = dist.get_world_size(process_group)
         self._handle = C.c_void_p()
-        # The transport decision is COLLECTIVE: a rank that cannot load RCCL or create the communicator must not leave
-        # the others inside a broadcast or on another transport.  Rank 0 always broadcasts (None when it could not draw
-        # an id); after gscan_comm_init every rank contributes a success flag to a MIN all-reduce over the process
-        # group, and the communicator is kept only if every rank has one.
-        uid = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        # The transport decision is COLLECTIVE, and it is taken BEFORE anyone enters ncclCommInitRank (which blocks until
+        # every rank has joined): (1) every rank probes that it can load RCCL at all (gscan_comm_available: dlopen and
+        # symbols, no device call); (2) rank 0 ALWAYS broadcasts — the unique id, or None when it could not draw one;
+        # (3) every rank contributes "RCCL loadable here AND an id arrived" to a MIN all-reduce over the process group
+        # that is already up.  Only when every rank voted yes does anyone call gscan_comm_init; otherwise all of them
+        # raise (GradientExchange logs it and all fall back to torch.distributed together).  A second vote behind the
+        # init catches a rank whose init failed after joining (the others came back from ncclCommInitRank with it).
         failure = None
+        try:
+            _lib.check(lib.gscan_comm_available(), "gscan_comm_available")
+        except _lib.GscanError as e:
+            failure = str(e)
+        uid = C.create_string_buffer(_lib.COMM_ID_BYTES)
         box = [None]
-        if self.rank == 0:
+        if self.rank == 0 and failure is None:
             try:
                 _lib.check(lib.gscan_comm_unique_id(C.addressof(uid)), "gscan_comm_unique_id")
                 box = [bytes(uid.raw)]
@@ -166,20 +173,26 @@ class RcclCommunicator:
                                    group=process_group)
         if box[0] is None:
             failure = failure or "rank 0 could not draw an RCCL unique id"
-        else:
-            uid = C.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
-            try:
-                _lib.check(lib.gscan_comm_init(C.byref(self._handle), self.world_size, self.rank, C.addressof(uid)),
-                           "gscan_comm_init")
-            except _lib.GscanError as e:
-                failure = str(e)
-                self._handle = C.c_void_p()
-        ok = torch.tensor([0 if failure else 1], dtype=torch.int32,
-                          device="cuda" if dist.get_backend(process_group) == "nccl" else "cpu")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)
-        if int(ok.item()) == 0:
+        if not self._vote(failure is None, process_group):
+            raise RuntimeError(failure or "another rank cannot load RCCL or received no unique id")
+        uid = C.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
+        try:
+            _lib.check(lib.gscan_comm_init(C.byref(self._handle), self.world_size, self.rank, C.addressof(uid)),
+                       "gscan_comm_init")
+        except _lib.GscanError as e:
+            failure = str(e)
+            self._handle = C.c_void_p()
+        if not self._vote(failure is None, process_group):
             self.close()
             raise RuntimeError(failure or "another rank could not create its RCCL communicator")
+
+    @staticmethod
+    def _vote(ok: bool, process_group) -> bool:
+        """True when EVERY rank of the group passed True (a MIN all-reduce on the process group)."""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                            device="cuda" if dist.get_backend(process_group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+        return int(flag.item()) == 1
 
     @property
     def nranks(self) -> int:
@@ -289,7 +302,12 @@ class TrainStep:
                  weight_target_loss: float = 0.3, process_group=None,
                  fused_loss: Optional[bool] = None, single_exchange: Optional[bool] = None,
                  always_collective: bool = False, on_gradients=None,
-                 native_allreduce: Optional[bool] = None, **_):
+                 native_allreduce: Optional[bool] = None, **ignored):
+        if ignored.pop("graph", None):
+            # hipGraph replay left the product path in round 4 (slower than eager launches on this stack)
+            logger.warning("TrainStep(graph=True): graph replay is no longer available, the step launches eagerly")
+        if ignored:                                          # the reference's callers pass their whole flag dict (model.py:26-32)
+            logger.debug("TrainStep: ignoring arguments %s", sorted(ignored))
         self.model = model
         self.optimizer = FlatAdam(model, learning_rate, adam_beta_1, adam_beta_2, lr_decay, lr_decay_steps)
         self.weight_target_loss = float(weight_target_loss)

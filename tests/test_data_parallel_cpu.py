@@ -178,3 +178,62 @@ def test_two_ranks_single_exchange_of_sum_gradients_and_statistics(tmp_path):
     for r in range(world):
         text = open(tmp_path / f"rank{r}.txt").read()
         assert text.startswith("1 "), text
+
+
+def _worker_transport_vote(rank: int, world: int, port: int, failing_rank: int, stage: str, out_dir: str):
+    """RcclCommunicator's collective transport decision with a stand-in library: `failing_rank` cannot load RCCL
+    (stage "load") or fails inside its init (stage "init").  Every rank must raise, and with stage "load" NO rank may
+    have entered gscan_comm_init (the call that blocks until all ranks have joined)."""
+    sys.path[:0] = [ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodal_seq2seq_gscan_amd import _lib, train
+
+    calls = []
+
+    class FakeLib:
+        def gscan_comm_available(self):
+            calls.append("available")
+            return 1 if (stage == "load" and rank == failing_rank) else 0
+
+        def gscan_comm_unique_id(self, ptr):
+            calls.append("unique_id")
+            return 0
+
+        def gscan_comm_init(self, handle, nranks, rk, ptr):
+            calls.append("init")
+            return 1 if (stage == "init" and rank == failing_rank) else 0
+
+        def gscan_comm_destroy(self, handle):
+            calls.append("destroy")
+            return 0
+
+        def gscan_last_error(self):
+            return b"stand-in failure"
+
+    fake = FakeLib()
+    _lib.load = lambda: fake
+    train.torch.cuda.synchronize = lambda: None
+    raised = ""
+    try:
+        train.RcclCommunicator()
+    except RuntimeError as e:                                  # GscanError is a RuntimeError
+        raised = str(e)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(f"{int(bool(raised))} {','.join(calls)} | {raised}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stage,failing_rank", [("load", 1), ("load", 0), ("init", 1), ("none", -1)])
+def test_rccl_transport_vote_happens_before_the_collective_init(tmp_path, stage, failing_rank):
+    world, port = 2, _free_port()
+    mp.spawn(_worker_transport_vote, args=(world, port, failing_rank, stage, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        flag, rest = open(tmp_path / f"rank{r}.txt").read().split(" ", 1)
+        calls = rest.split(" | ")[0].split(",")
+        if stage == "none":
+            assert flag == "0" and "init" in calls, rest
+        else:
+            assert flag == "1", rest                           # EVERY rank falls back, not only the failing one
+            if stage == "load":
+                assert "init" not in calls, rest               # nobody waits inside ncclCommInitRank for the others

@@ -107,6 +107,25 @@ def test_gemm_macro_tiles_with_slabs_are_exact_and_reproducible(lib, M, N, K, la
         assert torch.equal(c, outs[0][0]) and torch.equal(sv, outs[0][1]), "slab reduction is not reproducible"
 
 
+@pytest.mark.parametrize("split", [1, 4])
+@pytest.mark.parametrize("macro", [False, True])
+def test_gemm_row_sums_are_not_scaled_by_alpha(lib, macro, split):
+    """include/gscan_hip.h: asum[m] += sum_k A(m,k), whatever alpha multiplies the product with — on the 32 x 64 tiles
+    (no scratch) and on the macro tiles (scratch handed in: atomics are replaced by slabs when split), both through
+    gscan_gemm_f32_scratch.  (the macro tiles' ones column used to be scaled by alpha.)"""
+    import gpu_ops
+    M, N, K, alpha = 96, 80, 1024, -0.375
+    g = torch.Generator().manual_seed(5)
+    A, B, C0, s0 = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g), torch.randn(M, N, generator=g), torch.randn(M, generator=g)
+    Ad, Bd, Cd, sd = dev(A).t(), dev(B), dev(C0.clone()), dev(s0.clone())
+    scratch = torch.full((8 << 20,), float("nan"), device="cuda") if macro else None
+    gpu_ops.gemm_scratch((Ad, 0, Ad.stride(0), Ad.stride(1)), (Bd, 0, Bd.stride(0), Bd.stride(1)), (Cd, 0, N), M, N, K,
+                         alpha=alpha, beta=1.0, split_k=split, asum=sd, scratch=scratch)
+    ref = C0.double() + alpha * (A.t().double() @ B.double())
+    assert (Cd.cpu().double() - ref).abs().max().item() < 1e-3
+    assert (sd.cpu().double() - (s0.double() + A.double().sum(0))).abs().max().item() < 1e-3
+
+
 @pytest.mark.parametrize("M,N,K,layout,split", [
     (32768, 400, 600, "nt", 1),     # 256 x 4 macro tiles, K >= 512: the rule's launch; seven fragments of columns
     (32768, 400, 150, "nt", 1),     # as many tiles but a short K: stays on the small tiles (the training step's forward products)

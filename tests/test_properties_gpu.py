@@ -214,7 +214,8 @@ torch.save({"logp": out.cpu(), "selfserved": _selfserved(model, batch) - before}
     assert res["skip"]["selfserved"] > 0
 
 
-def test_deterministic_mode_gives_bitwise_reproducible_training_steps(tmp_path):
+@pytest.mark.parametrize("deep", [False, True])
+def test_deterministic_mode_gives_bitwise_reproducible_training_steps(tmp_path, deep):
     """GSCAN_DETERMINISTIC=1: every sum the step forms across workgroups is added in a fixed order (split-K partial tiles
     through slabs, embedding gradients by one workgroup per vocabulary chunk), so the same step from the same state gives
     the same bits: loss, every gradient, and the parameters after three Adam steps.  (The default mode adds with float
@@ -228,6 +229,10 @@ from multimodal_seq2seq_gscan_amd.model import Model
 from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
 from multimodal_seq2seq_gscan_amd.train import TrainStep
 cfg = model_kwargs("compositional", auxiliary_task=True)
+if os.environ.get("GSCAN_TEST_DEEP_ENCODER") == "1":
+    # two bidirectional encoder layers: both directions' dX products of the upper layer add into ONE buffer from one launch
+    # (step.hip, split_k < 0) - one slice each in this mode, two commutative adds per element (ADVICE r4)
+    cfg["num_encoder_layers"] = 2
 shape = Shape(batch=96, input_vocab=cfg["input_vocabulary_size"], target_vocab=cfg["target_vocabulary_size"], ragged=True)
 batch = {k: v.cuda() for k, v in make_batch(shape, 5).items() if k in ("commands", "cmd_lengths", "world", "targets", "target_positions")}
 runs = []
@@ -246,7 +251,8 @@ torch.save(runs, sys.argv[3])
     here = os.path.dirname(os.path.abspath(__file__))
     path = str(tmp_path / "runs.pt")
     r = subprocess.run([sys.executable, "-c", worker, os.path.dirname(here), here, path],
-                       env=dict(os.environ, GSCAN_DETERMINISTIC="1"), capture_output=True, text=True, timeout=600)
+                       env=dict(os.environ, GSCAN_DETERMINISTIC="1", GSCAN_TEST_DEEP_ENCODER="1" if deep else "0"),
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     runs = torch.load(path)
     for other in runs[1:]:
