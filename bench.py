@@ -77,9 +77,19 @@ def step_traffic(workload: str, mflop_per_example: float, B: int):
     _, source, per = pmc_traffic("gemm", workload)
     if not per:
         return None
-    launches = {"gemm_group_kernel": 5, "embed_grad_kernel": 2}
-    total = sum(v * launches.get(k, 1) for k, v in per.items())
+    # launches per step come from the kernel trace of the SAME PMC pass (tools/pmc_traffic.py: launches of the kernel /
+    # launches of the optimiser), not from an assumed schedule; a profile without them yields null, not a guess
+    try:
+        with open(PMC_TRAFFIC) as f:
+            kernels = json.load(f).get("kernels", {})
+        launches = {k: kernels[k]["launches_per_step"] for k in per}
+    except (OSError, ValueError, KeyError):
+        return None
+    if any(v is None for v in launches.values()):
+        return None
+    total = sum(v * launches[k] for k, v in per.items())
     return {"measured_bytes_per_step": round(total), "kernels_profiled": sorted(per),
+            "launches_per_step": launches,
             "algorithmic_bytes_per_step": [round(0.10e6 * B), round(0.15e6 * B)],
             "measured_over_algorithmic": round(total / (0.125e6 * B), 2), "source": source}
 
@@ -351,6 +361,10 @@ def main():
     ap.add_argument("--batcher-examples", type=int, default=100000)
     ap.add_argument("--min-warmup-steps", type=int, default=300,
                     help="untimed warm-up runs at least this many steps (0.15 s at S1), whatever --warmup says")
+    ap.add_argument("--warmup-seconds", type=float, default=2.0,
+                    help="untimed warm-up lasts at least this long: rank 0 times a short calibration run, derives a STEP "
+                         "COUNT from it and broadcasts the count, so every rank still runs the same number of steps "
+                         "(a fresh box needs ~1 s of work before its first timed window is representative)")
     ap.add_argument("--windows", type=int, default=4, help="extra timed windows of K steps for the spread (0 = none)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--rotate", type=int, default=4,
@@ -440,8 +454,26 @@ def main():
     # untimed warm-up: W steps as asked, and at least --min-warmup-steps (ten steps are 5 ms, not enough for clocks and
     # allocator pools to settle: the first timed window used to be the slowest of the five).  A COUNT, not a duration:
     # every rank must run the same number of steps, each has a collective in it.
-    for _ in range(max(args.warmup, args.min_warmup_steps)):
+    # ... and a duration: on a fresh box 300 steps (0.15 s) left the first timed window 19 % above the median
+    # (BENCH_r04: 0.5805 against 0.486 ms).  The duration target becomes a step COUNT on rank 0 (from a timed calibration
+    # run every rank executes alike) and the count is broadcast: ranks never disagree on the number of collectives.
+    calibrate = max(args.warmup, 20)
+    for _ in range(calibrate):
         step(next_batch())
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(calibrate):
+        step(next_batch())
+    fence()
+    per_step_s = (time.perf_counter() - t0) / calibrate
+    warmup_steps = max(args.warmup, args.min_warmup_steps, min(100000, int(args.warmup_seconds / max(per_step_s, 1e-6)) + 1))
+    if world > 1:
+        count = torch.tensor([warmup_steps], dtype=torch.int64, device="cpu" if args.backend == "gloo" else "cuda")
+        dist.broadcast(count, src=0)
+        warmup_steps = int(count.item())
+    for _ in range(warmup_steps):
+        step(next_batch())
+    warmup_steps += 2 * calibrate
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -535,8 +567,8 @@ def main():
             if name == "decoder_pair":        # bytes per launch of the pair = the mean of its two kernels
                 pair = [traffic_all.get(k) for k in pmc_names["decoder_pair"]]
                 traffic = round(sum(pair) / 2) if all(v is not None for v in pair) else None
-            elif name != "gemm":
-                traffic = traffic_all.get(name)
+            elif name != "gemm":          # a family without its own PMC figure: null (the per-kernel table is beside it)
+                traffic = None
             return {"bound": "mfma", "kernel": name, "achieved": round(d["tflops"], 3), "peak": PEAK_FP32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": traffic_source, "traffic_by_kernel": traffic_all,
@@ -569,7 +601,7 @@ def main():
                        "launch": "eager (forward on the caller's stream, backward on 3 streams)",
                        "resident_batches": len(batches),
                        "value_window": "median of the timed windows of K steps each" if len(windows) > 1 else "the one timed window",
-                       "warmup_steps_run": max(args.warmup, args.min_warmup_steps),
+                       "warmup_steps_run": warmup_steps, "warmup_seconds_target": args.warmup_seconds,
                        "gradient_exchange": (None if not step.exchange.collective else
                                              "gscan_allreduce_f32: RCCL on the step's stream" if step.exchange.comm is not None
                                              else f"torch.distributed {args.backend}"),

@@ -17,6 +17,7 @@ void set_error(const char *fmt, ...);
         if (!(cond)) { ::gscan::set_error(__VA_ARGS__); return 1; }                 \
     } while (0)
 
+#ifndef GSCAN_PLAN_ONLY
 #define GSCAN_HIP(call)                                                             \
     do {                                                                            \
         hipError_t e_ = (call);                                                     \
@@ -25,6 +26,18 @@ void set_error(const char *fmt, ...);
             return 1;                                                               \
         }                                                                           \
     } while (0)
+#else
+// GSCAN_PLAN_ONLY: the HOST side of every source file, compiled without device code and with
+// -fsanitize=address,undefined (tests/planner/: build script, driver and shape lists; SURVEY.md 5 "sanitizers").  The
+// sequencing, planning and argument-checking code of the library runs on the CPU exactly as shipped — workspace_layout,
+// check_dims, pick_split, GemmBatch::add / launch / launch_macro_tiles, the decoder's LDS budgets, every C-ABI argument
+// check — while each device call succeeds without doing anything and each kernel launch is checked against the limits of
+// the hardware (plan_record: non-empty grid, <= 1024 threads, <= 160 KB of LDS) and counted instead of launched.
+#define GSCAN_HIP(call) do { } while (0)
+void plan_record(const char *kernel, dim3 grid, dim3 block, size_t lds_bytes);
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) ::gscan::plan_record(#kernel, grid, block, (size_t)(lds))
+#endif
 
 // GSCAN_ROCTX=1: every launch of the library leaves a named roctx marker (probe.hip; rocprofv3 --marker-trace shows
 // them next to the kernel rows, so the step's seventeen launches read as what they are); otherwise a flag test.
@@ -34,12 +47,18 @@ void roctx_mark(const char *name);
 #define GSCAN_LAUNCHED(name)                                                        \
     do {                                                                            \
         ::gscan::roctx_mark(name);                                                  \
-        hipError_t e_ = hipGetLastError();                                          \
+        hipError_t e_ = ::gscan::launch_status();                                   \
         if (e_ != hipSuccess) {                                                     \
             ::gscan::set_error("launch of %s failed: %s", name, hipGetErrorString(e_)); \
             return 1;                                                               \
         }                                                                           \
     } while (0)
+
+#ifndef GSCAN_PLAN_ONLY
+static inline hipError_t launch_status() { return hipGetLastError(); }
+#else
+static inline hipError_t launch_status() { return hipSuccess; }
+#endif
 
 #define TRY_RC(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 

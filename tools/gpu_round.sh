@@ -15,11 +15,11 @@ timeout -k 10 300 python bench.py --workload target_length --target-length 120 -
 timeout -k 10 300 python bench.py --auxiliary --cpu-seconds 0 > "$out/bench_S4.json" 2>> "$out/bench.err" || { tail -30 "$out/bench.err"; exit 1; }
 python -c "import json,sys; [print(f, json.load(open(f))['value'], json.load(open(f))['ms_per_step']) for f in sys.argv[1:]]" "$out/bench_S3.json" "$out/bench_S4.json"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -o run -- python3 bench.py --cpu-seconds 0 > "$out/prof_bench.log" 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_f" -o run -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$out/pmc_f.log" 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_w" -o run -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$out/pmc_w.log" 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_m" -o run -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$out/pmc_m.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_f" -o run -- python3 bench.py --steps 20 --warmup 5 --warmup-seconds 0.1 --cpu-seconds 0 > "$out/pmc_f.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_w" -o run -- python3 bench.py --steps 20 --warmup 5 --warmup-seconds 0.1 --cpu-seconds 0 > "$out/pmc_w.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_m" -o run -- python3 bench.py --steps 20 --warmup 5 --warmup-seconds 0.1 --cpu-seconds 0 > "$out/pmc_m.log" 2>&1
 python tools/pmc_mfma.py "$(find $out/pmc_m -name '*counter_collection.csv' | head -1)" > "$out/pmc_mfma.json"
-python tools/pmc_traffic.py "$(find $out/pmc_f -name '*counter_collection.csv' | head -1)" "$(find $out/pmc_w -name '*counter_collection.csv' | head -1)" gemm_group_kernel,decoder_fwd_kernel,decoder_bwd_kernel,keys_backward_kernel,prologue_world_kernel,encoder_lstm_fwd_kernel,encoder_lstm_bwd_kernel,world_conv_bwd_kernel,world_channel_lists_kernel,adam_masks_kernel,embed_grad_kernel,head_grad_finish_kernel "$tag" > "$out/pmc_traffic.json"
+python tools/pmc_traffic.py "$(find $out/pmc_f -name '*counter_collection.csv' | head -1)" "$(find $out/pmc_w -name '*counter_collection.csv' | head -1)" all "$tag" > "$out/pmc_traffic.json"
 cat "$out/pmc_traffic.json"
 cp "$(find $out/prof -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
 # a trap in that table: world_channel_lists_kernel is launched on a side stream BEFORE the decoder's reverse kernel and
