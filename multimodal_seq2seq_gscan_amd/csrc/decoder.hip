@@ -181,6 +181,12 @@ DecoderGeometry decoder_geometry(int H, bool cond) {
     return g;
 }
 
+constexpr int kHeadWcRows = 16;        // vocabulary rows of the head's LDS image (one MFMA tile of logits)
+constexpr int kHeadDlStride = 20;      // backward: row stride of the chunk's [32][16] dlogits tile (sixteen rows -> eight bank groups)
+__host__ __device__ inline int head_fwd_scratch_floats(int H) {
+    const int SS = 4 * H + 4, sch = kHeadChunk * SS > 2 * 8 * 256 ? kHeadChunk * SS : 2 * 8 * 256;
+    return sch + kHeadWcRows * SS + kHeadChunk * 16 + kHeadChunk;
+}
 struct DecoderLds {
     int uv, pkv, ut, pkt, u2t, dpkv, dpkt, vec, total;
 };
@@ -201,7 +207,7 @@ __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bo
     o.vec = p;
     p += (backward ? 7 * HP + 19 * H : 2 * HP + 6 * H) + 256;
     // scratch of the fused output head, overlaid on the memories (forward: after the loop; backward: before staging)
-    const int head = backward ? kHeadChunk * V + V * 4 * H + 32 : kHeadChunk * (4 * H + 4 + V) + V * 4 * H;
+    const int head = backward ? kHeadChunk * kHeadDlStride + kHeadWcRows * 4 * H + 32 : head_fwd_scratch_floats(H);
     o.total = p > head ? p : head;
     return o;
 }
@@ -235,26 +241,32 @@ struct StageList {       // plain scalars: arrays indexed by a per-lane segment 
     int e0, e1, e2, e3, e4;     // cumulative sizes in 16-byte units
 };
 using fvec4 = __attribute__((ext_vector_type(4))) float;
-template <int NT = kDecThreads>
-__device__ __forceinline__ void stage_all(float *smem, const StageList &sl, int tid) {
-    constexpr int U = 8 * kDecThreads / NT;
-    const int total = sl.e4;
-    for (int base = tid; base < total; base += U * NT) {
-        fvec4 x[U];
-        int at[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = min(base + u * NT, total - 1);                     // clamped: the load is unconditional
-            const float *src = i < sl.e0 ? sl.p0 : i < sl.e1 ? sl.p1 : i < sl.e2 ? sl.p2 : i < sl.e3 ? sl.p3 : sl.p4;
-            const int first = i < sl.e0 ? 0 : i < sl.e1 ? sl.e0 : i < sl.e2 ? sl.e1 : i < sl.e3 ? sl.e2 : sl.e3;
-            const int dst = i < sl.e0 ? sl.d0 : i < sl.e1 ? sl.d1 : i < sl.e2 ? sl.d2 : i < sl.e3 ? sl.d3 : sl.d4;
-            x[u] = ((const __attribute__((address_space(1))) fvec4 *)src)[i - first];
-            at[u] = dst + 4 * (i - first);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (base + u * NT < total) *reinterpret_cast<fvec4 *>(smem + at[u]) = x[u];
+// Round 5: the copies go from global memory STRAIGHT to LDS (global_load_lds_dwordx4, gfx950): no staging registers —
+// the register image of the weights (156 VGPRs) is in flight at the same time — and no wait per batch of loads: a thread
+// issues all of its loads (14 at the benchmark shape) in one go, behind whatever the kernel requested before, and the
+// caller waits ONCE (s_waitcnt vmcnt(0), then the workgroup barrier) before anyone reads the memories.  A wave
+// instruction writes 64 consecutive 16-byte units from a wave-uniform LDS base (M0), so each array is walked in chunks of
+// 64 units, wave w taking the chunks w, w + 8, ...; lanes past the array's end are masked off.
+__device__ __forceinline__ void stage_array(float *smem, const float *src, int dst, int units, int tid) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    for (int c = wave; c * 64 < units; c += kDecThreads / 64) {
+        const int u = c * 64 + lane;
+        if (u < units)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * (int64_t)u),
+                                             (__attribute__((address_space(3))) void *)(smem + dst + 256 * c), 16, 0, 0);
     }
+}
+__device__ __forceinline__ void stage_all(float *smem, const StageList &sl, int tid) {
+    stage_array(smem, sl.p0, sl.d0, sl.e0, tid);
+    stage_array(smem, sl.p1, sl.d1, sl.e1 - sl.e0, tid);
+    stage_array(smem, sl.p2, sl.d2, sl.e2 - sl.e1, tid);
+    stage_array(smem, sl.p3, sl.d3, sl.e3 - sl.e2, tid);
+    stage_array(smem, sl.p4, sl.d4, sl.e4 - sl.e3, tid);
+}
+// every load a wave issued before this point has landed (registers and LDS alike), and every wave's has: what the copies
+// above wrote may be read
+__device__ __forceinline__ void staged_barrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ StageList stage_list(const DecoderArgs &a, const DecoderLds &o, int b, int H, int L, int M,
                                                 bool cond, bool uv_lds) {
@@ -321,70 +333,109 @@ __device__ __forceinline__ float quad_column_sum(const float *base, int stride, 
     return j == 0 ? s0 : j == 1 ? s1 : j == 2 ? s2 : s3;
 }
 
-// The output head of a row's T steps (see the comment in decoder_fwd_body where it is called): NT threads.
+// The output head of a row's T steps (see the comment in decoder_fwd_body where it is called), on the matrix cores
+// (round 5): per chunk of 32 steps, logits[32, V] = S[32, 4H] . Wc^T as two 16 x 16 MFMA tiles whose K extent (H steps of
+// four) is dealt over the eight waves; the waves' partial tiles are added in wave order through LDS (a fixed order:
+// bitwise reproducible), then log_softmax per step and the row's loss terms.  Rounds 1-4 took the same dots as four lanes
+// per logit with both operands from LDS: two 16-byte LDS reads per four multiply-adds, 6 k cycles of LDS bandwidth.
 template <int H, int NT>
 __device__ __forceinline__ void head_epilogue(const DecoderArgs &a, float *smem, int b, int tid, int lane, int wave, int T) {
+    static_assert(NT == 512, "eight waves: the partial tiles are [8][2][256]");
     __syncthreads();                                         // the row's S is complete and visible to the workgroup
-    {
-        constexpr int SS = 4 * H + 4;
-        const int V = a.V;
-        float *S_ch = smem, *wc_s = S_ch + kHeadChunk * SS, *lg_ch = wc_s + V * 4 * H;
-        for (int i = tid; i < V * H; i += NT)       // 16-byte units
-            reinterpret_cast<float4 *>(wc_s)[i] = reinterpret_cast<const float4 *>(a.head_wc)[i];
-        float nll_acc = 0.f, cnt_acc = 0.f;                  // threads < kHeadChunk (all in wave 0): get_loss terms
-        for (int t0 = 0; t0 < T; t0 += kHeadChunk) {
-            const int n = min(kHeadChunk, T - t0);
-            const unsigned bt0 = (unsigned)b * T + t0;
-            {
-                const float4 *src4 = reinterpret_cast<const float4 *>(a.s + bt0 * 4 * H);
-                for (int idx = tid; idx < n * H; idx += NT) {
-                    const int row = idx / H, c4 = idx - row * H;
-                    *reinterpret_cast<float4 *>(S_ch + row * SS + 4 * c4) = src4[idx];
-                }
+    constexpr int SS = 4 * H + 4;                            // row stride of both LDS images (16-byte aligned rows)
+    constexpr int SCH = kHeadChunk * SS > 2 * 8 * 256 ? kHeadChunk * SS : 2 * 8 * 256;
+    const int V = a.V;
+    float *S_ch = smem, *red = smem, *wc_s = S_ch + SCH, *lg = wc_s + kHeadWcRows * SS, *lse_s = lg + kHeadChunk * 16;
+    for (int i = tid; i < kHeadWcRows * H; i += NT) {        // 16-byte units; rows past the vocabulary are zero
+        const int v = i / H, c4 = i - v * H;
+        *reinterpret_cast<float4 *>(wc_s + v * SS + 4 * c4) =
+            v < V ? reinterpret_cast<const float4 *>(a.head_wc)[i] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    float nll_acc = 0.f, cnt_acc = 0.f;                      // get_loss terms of this thread's (step mod 32, logit)
+    const int fi = lane & 15, fk = lane >> 4;                // MFMA 16x16x4: A[i = fi][k = fk] = S row, B[k = fk][j = fi] = Wc[j][k]
+    for (int t0 = 0; t0 < T; t0 += kHeadChunk) {
+        const int n = min(kHeadChunk, T - t0);
+        const unsigned bt0 = (unsigned)b * T + t0;
+        {
+            const float4 *src4 = reinterpret_cast<const float4 *>(a.s + bt0 * 4 * H);
+            for (int idx = tid; idx < n * H; idx += NT) {
+                const int row = idx / H, c4 = idx - row * H;
+                *reinterpret_cast<float4 *>(S_ch + row * SS + 4 * c4) = src4[idx];
             }
-            lds_barrier();
-            for (int q0 = 0; q0 < n * V; q0 += NT / 4) {
-                const int q = q0 + (tid >> 2), qc = min(q, n * V - 1), tt = qc / V, v = qc - tt * V;
-                const float4 *x4 = reinterpret_cast<const float4 *>(S_ch + tt * SS);
-                const float4 *w4 = reinterpret_cast<const float4 *>(wc_s + v * 4 * H);
-                float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll 5
-                for (int i = (tid & 3); i + 4 < H; i += 8) { acc0 = dot4(w4[i], x4[i], acc0); acc1 = dot4(w4[i + 4], x4[i + 4], acc1); }
-                if ((H / 4) & 1) { const int i = (tid & 3) + 4 * (H / 4 - 1); acc0 = dot4(w4[i], x4[i], acc0); }
-                const float sum = quad_sum(acc0 + acc1);
-                if ((tid & 3) == 0 && q < n * V) { lg_ch[q] = sum; a.logits[bt0 * V + q] = sum; }
-            }
-            lds_barrier();
-            if (tid < n) {
-                const float *row = lg_ch + tid * V;
-                float mx = -INFINITY;
-                for (int j = 0; j < V; ++j) mx = fmaxf(mx, row[j]);
-                float sum = 0.f;
-                for (int j = 0; j < V; ++j) sum += expf(row[j] - mx);
-                const float lse = mx + logf(sum);
-                for (int j = 0; j < V; ++j) {
-                    const float y = row[j] - lse;
-                    a.logp_saved[(bt0 + tid) * V + j] = y;
-                    a.logp_out[(bt0 + tid) * V + j] = y;
-                }
-                if (a.row_stats) {
-                    // the target of position t is token t+1, literal 0 after the last one (model.py:108-115);
-                    // pad targets are ignored (nn.NLLLoss(ignore_index=pad), model.py:100)
-                    const int t = t0 + tid;
-                    const int64_t tgt = (t + 1 < T) ? a.targets[(int64_t)b * T + t + 1] : (int64_t)0;
-                    if (tgt != a.pad_tgt && tgt >= 0 && tgt < V) { nll_acc += lse - row[tgt]; cnt_acc += 1.f; }
-                }
-            }
-            lds_barrier();
         }
-        if (a.row_stats && wave == 0) {
-            nll_acc = wave_sum(nll_acc);
-            cnt_acc = wave_sum(cnt_acc);
-            if (lane == 0) {
-                a.row_stats[4 * b + 0] = nll_acc;
-                a.row_stats[4 * b + 1] = cnt_acc;
-                a.row_stats[4 * b + 3] = 1.f;
+        lds_barrier();
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        {
+            const float *a0 = S_ch + fi * SS + fk, *a1 = a0 + 16 * SS, *bw = wc_s + fi * SS + fk;
+            if (n > 16) {
+                for (int ks = wave; ks < H; ks += NT / 64) {
+                    const float bv = bw[4 * ks];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * ks], bv, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * ks], bv, acc1, 0, 0, 0);
+                }
+            } else {
+                for (int ks = wave; ks < H; ks += NT / 64) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * ks], bw[4 * ks], acc0, 0, 0, 0);
             }
+        }
+        lds_barrier();                                       // every wave is done with the S rows: their place takes the partial tiles
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[(wave * 2 + 0) * 256 + r * 64 + lane] = acc0[r];
+            red[(wave * 2 + 1) * 256 + r * 64 + lane] = acc1[r];
+        }
+        lds_barrier();
+        {   // thread -> element of a C fragment: tile = tid >> 8, register = (tid >> 6) & 3, lane = tid & 63;
+            // row = 4 (lane >> 4) + register, column = lane & 15
+            const int tile = tid >> 8, r = (tid >> 6) & 3, l = tid & 63;
+            float sum = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < NT / 64; ++w8) sum += red[(w8 * 2 + tile) * 256 + (tid & 255)];
+            lg[(16 * tile + 4 * (l >> 4) + r) * 16 + (l & 15)] = sum;
+        }
+        lds_barrier();
+        {   // log_softmax of every step of the chunk at once: thread (step tid >> 4, logit tid & 15), the sixteen lanes of a
+            // step side by side in a wave: maximum and sum over the vocabulary on the DPP datapath (four in-row steps)
+            const int tt = tid >> 4, v = tid & 15;
+            const bool mine = tt < n && v < V;
+            const float x = mine ? lg[tt * 16 + v] : -INFINITY;
+            float mx = x;
+            mx = fmaxf(mx, dpp_move<0xb1, 0xf>(mx));
+            mx = fmaxf(mx, dpp_move<0x4e, 0xf>(mx));
+            mx = fmaxf(mx, dpp_move<0x124, 0xf>(mx));
+            mx = fmaxf(mx, dpp_move<0x128, 0xf>(mx));
+            float sum = mine ? __expf(x - mx) : 0.f;
+            sum += dpp_move<0xb1, 0xf>(sum);
+            sum += dpp_move<0x4e, 0xf>(sum);
+            sum += dpp_move<0x124, 0xf>(sum);
+            sum += dpp_move<0x128, 0xf>(sum);
+            const float lse = mx + __logf(sum);
+            if (mine) {
+                const unsigned at = (bt0 + tt) * V + v;
+                a.logits[at] = x;
+                a.logp_saved[at] = x - lse;
+                a.logp_out[at] = x - lse;
+            }
+            if (a.row_stats) {
+                // the target of position t is token t+1, literal 0 after the last one (model.py:108-115);
+                // pad targets are ignored (nn.NLLLoss(ignore_index=pad), model.py:100)
+                const int t = t0 + tt;
+                const int64_t tgt = (tt < n && t + 1 < T) ? a.targets[(int64_t)b * T + t + 1] : (int64_t)0;
+                if (mine && tgt != a.pad_tgt && tgt >= 0 && tgt == v) { nll_acc += lse - x; cnt_acc += 1.f; }
+            }
+        }
+        lds_barrier();
+    }
+    if (a.row_stats) {                                       // every thread holds the terms of its (step mod 32, logit)
+        nll_acc = wave_sum(nll_acc);
+        cnt_acc = wave_sum(cnt_acc);
+        if (lane == 0) { lse_s[2 * wave] = nll_acc; lse_s[2 * wave + 1] = cnt_acc; }
+        lds_barrier();
+        if (tid == 0) {
+            float n0 = 0.f, n1 = 0.f;
+            for (int i = 0; i < NT / 64; ++i) { n0 += lse_s[2 * i]; n1 += lse_s[2 * i + 1]; }
+            a.row_stats[4 * b + 0] = n0;
+            a.row_stats[4 * b + 1] = n1;
+            a.row_stats[4 * b + 3] = 1.f;
         }
     }
 }
@@ -456,7 +507,20 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
     const float act_s = gl.gate == 2 ? -2.8853900817779268f : -1.4426950408889634f;
     const float act_a = gl.gate == 2 ? 2.f : 1.f, act_c = gl.gate == 2 ? -1.f : 0.f;
 
-    // ---- one-time loads: register image of the weights (coalesced), memories -> LDS -----------
+    // ---- one-time loads, ONE queue and one wait (round 5): first the small per-row values into registers (initial state,
+    //      energy vectors, query bias), then the row's memories straight to LDS (they come from HBM: the longest
+    //      latency goes first), then the register image of the weights (L2 hits, 39 16-byte loads per thread).  Round 4
+    //      staged the memories through registers behind the image and fetched the small values behind a barrier after
+    //      that: three dependent round trips where one is enough.
+    const int64_t h0_at = (int64_t)b * (GREEDY ? 1 : T) * H;
+    const float h0_reg = tid < H ? a.hprev[h0_at + tid] : 0.f;
+    const float vt_reg = tid < H ? a.v_t[tid] : 0.f, vv_reg = tid < H ? a.v_v[tid] : 0.f;
+    const float bq_reg = (COND && tid < H) ? a.b_q2k[tid] : 0.f;
+    float c = 0.f;                                          // cell state: lane 0 of the quad of each unit
+    if (gl.valid && gl.gate == 0)                           // c0 = h0 unless given (seq2seq_model.py:494-504)
+        c = a.c0 ? a.c0[(int64_t)b * H + gl.unit] : a.hprev[h0_at + gl.unit];
+    stage_all(smem, stage_list(a, o, b, H, L, M, COND, uv_lds), tid);
+    if (GREEDY) stage_array(smem, a.head_wc, (int)(wc_s - smem), a.V * H, tid);   // the whole head [V, 4H] behind the memories
     float w[NS][K0];
     {   // 16-byte loads: a workgroup's request for one image step spans 8 KB (four times as many L2 channels busy as
         // with dword loads while all 256 workgroups walk the same image at the same time)
@@ -469,27 +533,17 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
             w[(4 * q) / K0][(4 * q) % K0 + 2] = v.z; w[(4 * q) / K0][(4 * q) % K0 + 3] = v.w;
         }
     }
-    stage_all(smem, stage_list(a, o, b, H, L, M, COND, uv_lds), tid);
-    if (tid < HP) { h_s[tid] = 0.f; q2_s[tid] = 0.f; }      // zero the padding of the dot inputs
+    if (tid < HP) { h_s[tid] = tid < H ? h0_reg : 0.f; q2_s[tid] = 0.f; }   // dot inputs, their padding zero
+    if (tid < H) { vt_s[tid] = vt_reg; vv_s[tid] = vv_reg; }
+    if (COND && tid < H) bq_s[tid] = bq_reg;
     if (tid < 16) stamp_acc[tid] = 0.f;
-    lds_barrier();
-    float c = 0.f;                                          // cell state: lane 0 of the quad of each unit
-    if (GREEDY) {
-        const int V = a.V;
-        for (int i = tid; i < V * 4 * H; i += kDecThreads) wc_s[i] = a.head_wc[i];
-        if (tid == 0) tok_s[0] = a.sos;
-    }
-    if (tid < H) {
-        const float h0 = a.hprev[(int64_t)b * (GREEDY ? 1 : T) * H + tid];
-        h_s[tid] = h0;
-        vt_s[tid] = a.v_t[tid];
-        vv_s[tid] = a.v_v[tid];
-    }
-    if (gl.valid && gl.gate == 0)                           // c0 = h0 unless given (seq2seq_model.py:494-504)
-        c = a.c0 ? a.c0[(int64_t)b * H + gl.unit] : a.hprev[(int64_t)b * (GREEDY ? 1 : T) * H + gl.unit];
-    if (COND && tid < H) bq_s[tid] = a.b_q2k[tid];
+    if (GREEDY && tid == 0) tok_s[0] = a.sos;
     float att_acc = 0.f;                                    // wave 0, lane m
-    lds_barrier();
+    // The weight registers are complete from here on (and the compiler's wait-count bookkeeping knows: without an
+    // explicit wait it re-checks "the first weight load may still be in flight" at the top of EVERY iteration with
+    // s_waitcnt vmcnt(2), which in steady state drains the previous step's stores: vmcnt counts in order), and so are the
+    // memories in LDS.
+    staged_barrier();
     if (GREEDY) {   // le[v][v'] = Wc[v', 0:H] . Emb[v]: what the token fed in contributes to the logits
         const int V = a.V;
         for (int i = tid; i < V * V; i += kDecThreads) {
@@ -501,10 +555,6 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
         lds_barrier();
     }
     int steps_done = 0;
-    // The weight registers are complete from here on, and the compiler's wait-count bookkeeping is told so: without
-    // this explicit wait it re-checks "the first weight load may still be in flight" at the top of EVERY iteration
-    // with s_waitcnt vmcnt(2), which in steady state drains the previous step's stores (vmcnt counts in order).
-    __builtin_amdgcn_s_waitcnt(kWaitVmcnt0);
     GSCAN_STAMP_ONCE(10)
 
     for (int t = 0; t < T; ++t) {
@@ -705,7 +755,9 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
 // Backward of s_m = v . tanh(q + PK_m) for one attention.  Lane m of `dsm` holds d s_m.  Wave w owns the memories
 // w, w+nwave, ...; a lane owns features (lane, lane+64):  dPK[m][k] += ds_m v_k (1 - th^2)  (accumulated over the
 // T steps in LDS), the same term summed over this wave's memories goes to part_s[wave][k] (-> d q_k after the
-// cross-wave sum), and dv_k += ds_m th is kept per lane.
+// cross-wave sum), and dv_k += ds_m th is kept per lane.  (Round 5 A/B: the two attentions' sums in LDS instead — four
+// registers fewer across the time loop, and no VGPR spill — cost the reverse kernel 1.8 us: two more LDS
+// read-modify-writes per phase outweigh one scratch store and load per step.)
 template <int H>
 __device__ __forceinline__ void score_backward(float dsm, const float *q_s, const float *v_s, const float *pk,
                                                float *dpk, int n, float *part_s, f32x2 &dv_acc, int wave, int nwave,
@@ -781,6 +833,8 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
                 }
             }
         }
+        // (the two sums one after the other, each only where its memory exists: interleaving them as wave_sum_n<2> —
+        // unconditionally, for the straight-line code that needs — made the reverse kernel 5.7 us SLOWER, round 5 A/B)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + i * nwave;
@@ -826,14 +880,18 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     float aux_scale = (a.seeds && a.daux) ? a.seeds[1] : 1.f;
     // ---- backward of the output head for the row's T steps: dlogits_t = seed * (dlogp_t - exp(logp_t) sum dlogp_t)
     //      through log_softmax, then through the composite head Wc = W_h2o . W_o2h ([V, 4H], S order; see the forward
-    //      epilogue): dS_t = Wc^T dlogits_t, V multiply-adds per element.  dlogits is kept for the weight gradients
-    //      (d Wc = dlogits^T . S, a GEMM behind this kernel); dS is what the loop below (and the LSTM-input product
-    //      after it) starts from.
+    //      epilogue): dS_t = Wc^T dlogits_t.  dlogits is kept for the weight gradients (d Wc = dlogits^T . S, a GEMM
+    //      behind this kernel); dS is what the loop below (and the LSTM-input product after it) starts from.
+    //      Round 5: a thread per (step, logit) of a 32-step chunk — coalesced loads, one exp each (it was a thread per
+    //      step, nine exps and stores in a row) — and dS[32, 4H] = dlogits[32, 16] . Wc[16, 4H] on the matrix cores, a
+    //      wave per 16-column tile (it was nine LDS float4 reads per output float4).
     {
+        static_assert(H % 4 == 0, "4H is a whole number of 16-column MFMA tiles");
+        constexpr int DS = kHeadDlStride;                    // row stride of the dlogits tile in LDS
         const int V = a.V;
-        float *dl_ch = smem, *wc_s = dl_ch + kHeadChunk * V, *red = wc_s + V * 4 * H;
-        for (int i = tid; i < V * H; i += kDecThreads)       // 16-byte units
-            reinterpret_cast<float4 *>(wc_s)[i] = reinterpret_cast<const float4 *>(a.head_wc)[i];
+        float *dl_ch = smem, *wc_s = dl_ch + kHeadChunk * DS, *red = wc_s + kHeadWcRows * 4 * H;
+        for (int i = tid; i < kHeadWcRows * H; i += kDecThreads)       // 16-byte units; rows past the vocabulary are zero
+            reinterpret_cast<float4 *>(wc_s)[i] = i < V * H ? reinterpret_cast<const float4 *>(a.head_wc)[i] : float4{0.f, 0.f, 0.f, 0.f};
         float sc = a.seeds ? a.seeds[0] : 1.f;
         if (a.nll_mode) {
             // the loss is mean-over-live-tokens NLL (+ w * mean-over-rows auxiliary NLL): every workgroup sums the
@@ -856,38 +914,49 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
                 a.seeds_out[2] = p0 * sc + p2 * aux_scale;
             }
         }
+        static_assert(kDecThreads == kHeadChunk * 16, "a thread per element of the chunk's 32 x 16 dlogits tile");
+        const int tt = tid >> 4, v16 = tid & 15;             // this thread's (step of the chunk, logit)
+        const int fi = lane & 15, fk = lane >> 4;            // MFMA 16x16x4 fragment coordinates
         for (int t0 = 0; t0 < T; t0 += kHeadChunk) {
             const int n = min(kHeadChunk, T - t0);
             const unsigned bt0 = (unsigned)b * T + t0;
-            if (tid < n) {
-                const float *y = a.logp_saved + (bt0 + tid) * V;
-                if (a.nll_mode) {                            // d(sum NLL)/d(logp) is -1 at the live target
-                    const int t = t0 + tid;
+            const bool mine = tt < n && v16 < V;
+            const unsigned at = (bt0 + tt) * V + v16;
+            float dl = 0.f;
+            if (a.nll_mode) {                                // d(sum NLL)/d(logp) is -1 at the live target
+                if (mine) {
+                    const int t = t0 + tt;
                     const int64_t tgt = (t + 1 < T) ? a.targets[(int64_t)b * T + t + 1] : (int64_t)0;
                     const bool live = tgt != a.pad_tgt && tgt >= 0 && tgt < V;
-                    for (int j = 0; j < V; ++j) {
-                        const float dl = live ? sc * (expf(y[j]) - (j == tgt ? 1.f : 0.f)) : 0.f;
-                        dl_ch[tid * V + j] = dl;
-                        a.dlogits[(bt0 + tid) * V + j] = dl;
-                    }
-                } else {
-                    const float *dy = a.dlogp + (bt0 + tid) * V;
-                    float sum = 0.f;
-                    for (int j = 0; j < V; ++j) sum += dy[j];
-                    for (int j = 0; j < V; ++j) {
-                        const float dl = sc * (dy[j] - expf(y[j]) * sum);
-                        dl_ch[tid * V + j] = dl;
-                        a.dlogits[(bt0 + tid) * V + j] = dl;
-                    }
+                    dl = live ? sc * (expf(a.logp_saved[at]) - (v16 == tgt ? 1.f : 0.f)) : 0.f;
                 }
+            } else {
+                // sum of the step's incoming gradients: the sixteen lanes of a step sit side by side in a wave
+                const float dy = mine ? a.dlogp[at] : 0.f;
+                float sum = dy;
+                sum += dpp_move<0xb1, 0xf>(sum);             // quad_perm [1,0,3,2]
+                sum += dpp_move<0x4e, 0xf>(sum);             // quad_perm [2,3,0,1]
+                sum += dpp_move<0x124, 0xf>(sum);            // row_ror:4
+                sum += dpp_move<0x128, 0xf>(sum);            // row_ror:8: every lane of the 16-lane row holds the total
+                if (mine) dl = sc * (dy - expf(a.logp_saved[at]) * sum);
             }
+            dl_ch[tt * DS + v16] = dl;                       // zero outside the chunk / the vocabulary
+            if (mine) a.dlogits[at] = dl;
             lds_barrier();
-            for (int idx = tid; idx < n * H; idx += kDecThreads) {       // one 16-byte piece of dS per thread and pass
-                const int tt = idx / H, c4 = idx - tt * H;
-                float4 acc = {0.f, 0.f, 0.f, 0.f};
-                for (int v = 0; v < V; ++v)
-                    acc = fma4(dl_ch[tt * V + v], *reinterpret_cast<const float4 *>(wc_s + v * 4 * H + 4 * c4), acc);
-                *reinterpret_cast<float4 *>(a.ds + (bt0 + tt) * 4 * H + 4 * c4) = acc;
+            const int ksteps = (V + 3) / 4;
+            for (int ct = wave; ct < H / 4; ct += kDecThreads / 64) {          // 16-column tiles of dS
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    const float bv = wc_s[(4 * ks + fk) * 4 * H + 16 * ct + fi];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dl_ch[fi * DS + 4 * ks + fk], bv, acc0, 0, 0, 0);
+                    if (n > 16) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dl_ch[(16 + fi) * DS + 4 * ks + fk], bv, acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                // C fragment: row = 4 (lane >> 4) + r, column = lane & 15
+                    const int row = 4 * fk + r;
+                    if (row < n) a.ds[(bt0 + row) * 4 * H + 16 * ct + fi] = acc0[r];
+                    if (16 + row < n) a.ds[(bt0 + 16 + row) * 4 * H + 16 * ct + fi] = acc1[r];
+                }
             }
             lds_barrier();
         }
@@ -895,43 +964,11 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     }
     GSCAN_STAMP_ONCE(10)
 
-    float wt[NS][K0];
-    {
-        static_assert(K0 % 4 == 0, "a thread's half-column is a whole number of 16-byte groups");
-        const float4 *img4 = reinterpret_cast<const float4 *>(a.w_image);
-#pragma unroll
-        for (int q = 0; q < NS * K0 / 4; ++q) {
-            const float4 v = img4[q * kDecThreads + tid];
-            wt[(4 * q) / K0][(4 * q) % K0] = v.x; wt[(4 * q) / K0][(4 * q) % K0 + 1] = v.y;
-            wt[(4 * q) / K0][(4 * q) % K0 + 2] = v.z; wt[(4 * q) / K0][(4 * q) % K0 + 3] = v.w;
-        }
-    }
-    stage_all(smem, stage_list(a, o, b, H, L, M, COND, uv_lds), tid);
-    for (int i = tid; i < M * H; i += kDecThreads) dPKv[i] = 0.f;
-    for (int i = tid; i < L * H; i += kDecThreads) dPKt[i] = 0.f;
-    for (int i = tid; i < 7 * HP; i += kDecThreads) vec[i] = 0.f;        // d_s / dqv_s incl. padding
-    for (int i = tid; i < 8 * H; i += kDecThreads) part_s[i] = 0.f;      // dh_T = 0 (summed at the top of the loop)
-    lds_barrier();
-    if (tid < H) { vt_s[tid] = a.v_t[tid]; vv_s[tid] = a.v_v[tid]; }
-    if (tid < 64) {       // auxiliary head backward: d att_sum = seed1 * (daux - exp(aux_logp) sum daux)  (model.py:205)
-        float da = 0.f;
-        if (a.nll_mode ? (a.aux_saved != nullptr) : (a.daux != nullptr)) {
-            float dy;
-            if (a.nll_mode) {
-                const int64_t pos = a.positions ? a.positions[b] : (int64_t)-1;
-                dy = (tid < M && tid == pos) ? -1.f : 0.f;
-            } else {
-                dy = (tid < M) ? a.daux[(int64_t)b * M + tid] : 0.f;
-            }
-            const float sum = wave_sum(dy);
-            const float y = (tid < M) ? a.aux_saved[(int64_t)b * M + tid] : 0.f;
-            da = (tid < M) ? aux_scale * (dy - expf(y) * sum) : 0.f;
-        }
-        datt_s[tid] = da;
-    }
-    if (tid >= 64 && tid < 80) stamp_acc[tid - 64] = 0.f;
+    // ---- set-up.  Everything small that the loop needs from global memory is requested FIRST, into registers — the
+    //      energy vectors, the auxiliary head's inputs, the saved activations of the last step — then the register image
+    //      of the weights (39 16-byte loads per thread) and the memories: one queue of loads, one wait.  (Round 4 issued
+    //      the small loads behind the wait for the image: two more dependent round trips to L2 / HBM, ~4 k cycles.)
     float dc = 0.f;
-    f32x2 dvv_acc = {0.f, 0.f}, dvt_acc = {0.f, 0.f};
     // saved activations of step t are fetched one iteration ahead (their HBM/L2 latency hides behind step t+1)
     float pf[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float alpha_v_pf = 0.f, alpha_c_pf = 0.f, alpha_v_nx = 0.f, alpha_c_nx = 0.f;   // lane m of every wave
@@ -959,9 +996,45 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             if (COND) pf[4] = a.q2[bt * uH + kk];
         }
     };
-    lds_barrier();
-    __builtin_amdgcn_s_waitcnt(kWaitVmcnt0);                // weights and staging complete (see the forward kernel)
-    prefetch(T - 1);
+    prefetch(T - 1);                                        // (the row's dS is this workgroup's own, complete behind the barrier above)
+    const float vt_reg = tid < H ? a.v_t[tid] : 0.f, vv_reg = tid < H ? a.v_v[tid] : 0.f;
+    // auxiliary head backward: d att_sum = seed1 * (daux - exp(aux_logp) sum daux)  (model.py:205): wave 0, lane = cell
+    const bool has_aux = a.nll_mode ? (a.aux_saved != nullptr) : (a.daux != nullptr);
+    float aux_dy = 0.f, aux_y = 0.f;
+    if (tid < 64 && has_aux) {
+        if (a.nll_mode) {
+            const int64_t pos = a.positions ? a.positions[b] : (int64_t)-1;
+            aux_dy = (tid < M && tid == pos) ? -1.f : 0.f;
+        } else {
+            aux_dy = (tid < M) ? a.daux[(int64_t)b * M + tid] : 0.f;
+        }
+        aux_y = (tid < M) ? a.aux_saved[(int64_t)b * M + tid] : 0.f;
+    }
+
+    float wt[NS][K0];
+    {
+        static_assert(K0 % 4 == 0, "a thread's half-column is a whole number of 16-byte groups");
+        const float4 *img4 = reinterpret_cast<const float4 *>(a.w_image);
+#pragma unroll
+        for (int q = 0; q < NS * K0 / 4; ++q) {
+            const float4 v = img4[q * kDecThreads + tid];
+            wt[(4 * q) / K0][(4 * q) % K0] = v.x; wt[(4 * q) / K0][(4 * q) % K0 + 1] = v.y;
+            wt[(4 * q) / K0][(4 * q) % K0 + 2] = v.z; wt[(4 * q) / K0][(4 * q) % K0 + 3] = v.w;
+        }
+    }
+    stage_all(smem, stage_list(a, o, b, H, L, M, COND, uv_lds), tid);
+    for (int i = tid; i < M * H; i += kDecThreads) dPKv[i] = 0.f;
+    for (int i = tid; i < L * H; i += kDecThreads) dPKt[i] = 0.f;
+    for (int i = tid; i < 7 * HP; i += kDecThreads) vec[i] = 0.f;        // d_s / dqv_s incl. padding
+    for (int i = tid; i < 8 * H; i += kDecThreads) part_s[i] = 0.f;      // dh_T = 0 (summed at the top of the loop)
+    f32x2 dvv_acc = {0.f, 0.f}, dvt_acc = {0.f, 0.f};
+    if (tid < H) { vt_s[tid] = vt_reg; vv_s[tid] = vv_reg; }
+    if (tid < 64) {
+        const float sum = wave_sum(aux_dy);
+        datt_s[tid] = (has_aux && tid < M) ? aux_scale * (aux_dy - expf(aux_y) * sum) : 0.f;
+    }
+    if (tid >= 64 && tid < 80) stamp_acc[tid - 64] = 0.f;
+    staged_barrier();                                       // weights, memories and the small loads above are complete
     GSCAN_STAMP_ONCE(11)
 
     for (int t = T - 1; t >= 0; --t) {
@@ -1100,6 +1173,9 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     // energy-vector gradients of this ROW (every wave holds partial sums for features (lane, lane+64)); the rows are
     // added up by a leaf launch (energy_grad_sum).  256 workgroups adding into the same 2H addresses with atomics kept
     // this kernel's last writes — and the whole critical chain behind it — waiting ~9 us (profiles/r03_c_*).
+    // energy-vector gradients of this ROW (every wave holds partial sums for features (lane, lane+64)); the rows are
+    // added up by a leaf launch (head_grad_finish).  256 workgroups adding into the same 2H addresses with atomics kept
+    // this kernel's last writes — and the whole critical chain behind it — waiting ~9 us (profiles/r03_c_*).
     lds_barrier();
     if (lane < H) part_s[wave * H + lane] = dvv_acc.x;
     if (lane + 64 < H) part_s[wave * H + lane + 64] = dvv_acc.y;
@@ -1201,7 +1277,7 @@ size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward) {
 // decoder_any.hip's kernels (GSCAN_DECODER_ANY=1: every shape does, for tests).
 bool decoder_fast_supported(int H, int L, int M, int V, bool cond) {
     static const int force_any = [] { const char *e = getenv("GSCAN_DECODER_ANY"); return e ? atoi(e) : 0; }();
-    if (force_any || !decoder_hidden_supported(H) || L > 64 || M > 64) return false;
+    if (force_any || !decoder_hidden_supported(H) || L > 64 || M > 64 || V > kHeadWcRows) return false;   // V: one MFMA tile of logits
     return decoder_lds_bytes(H, L, M, V, cond, true) <= kLdsLimit && decoder_lds_bytes(H, L, M, V, cond, false) <= kLdsLimit;
 }
 
