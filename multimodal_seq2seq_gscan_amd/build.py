@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgscan_hip.so")
-SOURCES = ["gemm.hip", "gemm_mt.hip", "conv.hip", "elementwise.hip", "loss.hip", "lstm_encoder.hip", "decoder.hip", "decoder_any.hip", "attention_grad.hip", "step.hip",
+SOURCES = ["gemm.hip", "gemm_mt.hip", "gemm_ws.hip", "conv.hip", "elementwise.hip", "loss.hip", "lstm_encoder.hip", "decoder.hip", "decoder_any.hip", "attention_grad.hip", "step.hip",
            "probe.hip", "comm.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          f"-I{INCLUDE}", f"-I{CSRC}"]

@@ -169,7 +169,7 @@ int gscan_trace_set(unsigned long long *device_buffer) {
                                           "-DGSCAN_TRACE: tools/device_timeline.py does)");
 #endif
     GSCAN_HIP(hipDeviceSynchronize());
-    int rc = trace_set_gemm(device_buffer) | trace_set_gemm_mt(device_buffer) | trace_set_elementwise(device_buffer) | trace_set_loss(device_buffer) |
+    int rc = trace_set_gemm(device_buffer) | trace_set_gemm_mt(device_buffer) | trace_set_gemm_ws(device_buffer) | trace_set_elementwise(device_buffer) | trace_set_loss(device_buffer) |
              trace_set_lstm_encoder(device_buffer) | trace_set_decoder(device_buffer) | trace_set_decoder_any(device_buffer) |
              trace_set_attention_grad(device_buffer) | trace_set_conv(device_buffer);
     GSCAN_CHECK(rc == 0, "trace_set: hipMemcpyToSymbol failed");

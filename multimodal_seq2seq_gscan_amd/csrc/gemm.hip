@@ -463,6 +463,30 @@ int GemmBatch::launch(hipStream_t stream) {
     // fixed order instead of with float atomics — bitwise reproducible weight gradients for 4 % of step time.
     // GSCAN_GEMM_MT=0: never.
     // A launch that was handed scratch for split-K slabs asked for the fixed-order sums: macro tiles too.
+    // The weights-stationary persistent kernel of gemm_ws.hip (built, parity-green, measured — and
+    // SLOWER than the 32 x 64 tiles on every launch of the step: forward launch 63 -> 46 us over three versions against
+    // 36-43 us, step 0.488-0.505 ms against 0.476; profiles/r05_gemm_weights_stationary_*.txt).  OFF unless
+    // GSCAN_GEMM_WS asks for it: 1 launches of tall-skinny forward products (every operand k-contiguous, nothing split,
+    // K <= 160) from 32 M multiply-adds on, 2 every eligible launch, 3 the same and an ineligible launch is an error (tests).
+    {
+        static const int ws_mode = [] { const char *e = getenv("GSCAN_GEMM_WS"); return e ? atoi(e) : 0; }();
+        if (ws_mode > 0 && !scratch_ && !force_mt_) {
+            bool all = true;
+            double macs = 0.0;
+            for (int i = 0; i < grp_.count; ++i) {
+                all = all && gemm_ws_eligible(grp_.p[i]);
+                macs += (double)grp_.p[i].M * grp_.p[i].N * grp_.p[i].K;
+            }
+            if (all && (ws_mode > 1 || macs >= 32e6)) {
+                ProbeScope probe(P_GEMM, stream, flops_, alg_flops_);
+                return gemm_ws_launch(grp_, stream);
+            }
+            if (ws_mode == 3) {                              // tests: the launch was meant for that kernel
+                set_error("gemm batch: GSCAN_GEMM_WS=3 but a product of the launch is not eligible for the weights-stationary kernel");
+                return 1;
+            }
+        }
+    }
     const int mt_mode = (scratch_ || (force_mt_ && gemm_macro_tile_mode() != 0)) ? 1 : gemm_macro_tile_mode();
     if (mt_mode != 0) {
         int macro_tiles = 0, k_min = INT_MAX;

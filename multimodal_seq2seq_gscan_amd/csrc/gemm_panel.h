@@ -208,6 +208,10 @@ struct PanelIter {
 #define GST(i)
 #endif
 
+// gemm_ws.hip: weights-stationary persistent kernel for launches of k-contiguous, unsplit, beta = 0 products with K <= 160
+bool gemm_ws_eligible(const GemmProblem &p);
+int gemm_ws_launch(const GemmGroup &grp, hipStream_t stream);
+
 // gemm_mt.hip
 bool gemm_mt_supports(const GemmProblem &p);
 void gemm_mt_columns(int NV, int *tiles_n, int *nf);

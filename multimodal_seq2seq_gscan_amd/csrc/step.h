@@ -187,6 +187,7 @@ int dropout_masks(float *out, const size_t (&n)[3], const float (&p)[3], uint64_
 // in-kernel timeline (common.h): one setter per translation unit with kernels
 int trace_set_gemm(unsigned long long *buf);
 int trace_set_gemm_mt(unsigned long long *buf);
+int trace_set_gemm_ws(unsigned long long *buf);
 int trace_set_elementwise(unsigned long long *buf);
 int trace_set_loss(unsigned long long *buf);
 int trace_set_lstm_encoder(unsigned long long *buf);

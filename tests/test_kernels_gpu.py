@@ -190,6 +190,52 @@ def test_gemm_short_k_products(lib, M, N, K, lda, ldb, epilogue):
     assert err < 2e-4 * max(1.0, K ** 0.5), f"{M}x{N}x{K}: max err {err}"
 
 
+WS_CASES = [  # M, N, K, lda, ldb, bias, act
+    (9216, 400, 150, 150, 150, 0, 0),   # visual gate images: contiguous rows of 150 floats (8-byte fragment reads), five 80-column blocks
+    (9216, 100, 150, 150, 150, 0, 0),   # visual keys: one block of seven fragments, 12 dead columns
+    (5120, 400, 100, 400, 300, 1, 0),   # embedded gates: A and B are column slices of wider buffers, bias
+    (2560, 100, 100, 100, 100, 0, 0),   # textual keys
+    (256, 100, 100, 100, 100, 1, 2),    # bridge: four tiles, tanh
+    (8200, 300, 152, 152, 160, 1, 2),   # ragged M (8200 = 128 x 64 + 8), 80 + 80 + 80 + 60 columns
+    (1000, 9, 26, 26, 26, 0, 0),        # one fragment, a K of three 8-blocks and a bit, M not a multiple of 64
+    (6000, 70, 36, 40, 40, 0, 0),       # strided A rows (16-byte aligned), K = 36
+    (3, 17, 160, 160, 160, 1, 0),       # fewer rows than a tile, the deepest K
+]
+
+
+def test_gemm_weights_stationary_kernel():
+    """gemm_ws.hip (GSCAN_GEMM_WS=3: every launch MUST take it, an ineligible one is an error) against float64 on the
+    forward launch's shapes and on the edges of what it takes: ragged M and N, one fragment, short tiles, both
+    fragment-read widths, and the step's own forward launch as ONE grouped launch (seven products, 19 column blocks)."""
+    import os, subprocess, sys
+    worker = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import gpu_ops
+from test_kernels_gpu import WS_CASES
+for M, N, K, lda, ldb, bias, act in WS_CASES:
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    Abig, Bbig = torch.randn(M, lda, generator=g), torch.randn(N, ldb, generator=g)
+    bv = torch.randn(N, generator=g)
+    Cd = torch.full((M, N + 3), 7.0, device="cuda")                  # wider than N: nothing may be written past column N
+    gpu_ops.gemm((Abig.cuda(), 0, lda, 1), (Bbig.cuda(), 0, 1, ldb), (Cd, 0, N + 3), M, N, K, bias=bv.cuda() if bias else None, act=act)
+    torch.cuda.synchronize()
+    ref = Abig[:, :K].double() @ Bbig[:, :K].double().t()
+    if bias: ref = ref + bv.double()
+    if act == 2: ref = torch.tanh(ref)
+    out = Cd.cpu().double()
+    err = (out[:, :N] - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, K ** 0.5), (M, N, K, err)
+    assert (out[:, N:] == 7.0).all(), (M, N, K)
+    print("ok", M, N, K, err, flush=True)
+print("all ok")
+"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", worker, os.path.dirname(here), here],
+                       env=dict(os.environ, GSCAN_GEMM_WS="3"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("B,G,Cc,K3,Co,density,u8", [
     (5, 6, 16, 7, 50, 0.2, False),        # the paper's shape, float32 world
     (37, 6, 16, 13, 50, 0.07, True),      # k = 13 (every cell reaches every cell), uint8 world, two backward slices

@@ -1,6 +1,6 @@
 """Development aid: build experimental copies of libgscan_hip.so that differ in -D flags for one source file.
 
-    python tools/variants.py name1:decoder.hip:-DFOO=1 name2:gemm.hip:-DBAR=2,-DBAZ name3:all:-DQUX ...
+    python tools/variants.py name1:decoder.hip:-DFOO=1 name2:gemm.hip+capi.hip:-DBAR=2,-DBAZ name3:all:-DQUX ...
 
 Each variant relinks the objects of the normal build with the one recompiled source and lands in
 variants/libgscan_hip.<name>.so (git-ignored; it travels with gpurun).  Select one at run time with
@@ -24,7 +24,7 @@ def main():
     procs = []
     for spec in sys.argv[1:]:
         name, src, flags = (spec.split(":") + [""])[:3]
-        srcs = B.SOURCES if src == "all" else [src]          # "all": every source with the flags
+        srcs = B.SOURCES if src == "all" else src.split("+")   # "all": every source with the flags; a+b: those sources
         jobs = []
         for one in srcs:
             obj = os.path.join(OUT, f"{name}.{one.replace('.hip', '.o')}")
