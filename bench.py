@@ -196,7 +196,7 @@ def batcher_leg(args, cfg: dict, n_params: int) -> dict:
         for i, b in enumerate(data.batches(B, stager=stager)):
             if b["commands"].shape[0] == B:
                 step({k: b[k] for k in keys})
-            if i >= (300 if bucket else args.warmup):
+            if i >= 300:      # (five batches for the reference order, as until round 4, left first-touch costs in the timed loop)
                 break
         data.shuffle_data(bucket_batches=bucket, batch_size=B)
         it = data.batches(B, stager=stager)
@@ -207,7 +207,7 @@ def batcher_leg(args, cfg: dict, n_params: int) -> dict:
                 continue
             step({k: b[k] for k in keys})
             n, rows, full = n + 1, rows + B, b
-            if n >= 4 * args.steps:
+            if n >= max(4 * args.steps, 300):      # at least 300 batches (0.15 s): a 40 ms loop is at the mercy of one hiccup
                 break
         torch.cuda.synchronize()
         el = time.perf_counter() - t0

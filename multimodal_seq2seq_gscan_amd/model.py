@@ -264,6 +264,7 @@ class Model(nn.Module):
         self._mask_buffer_deep = None
         self._dummy_aux = None
         self._mask_key = None
+        self._mask_caps = None           # capacities of the three mask segments (grow-only, _draw_masks)
         self._anchor = None
         self._decode_state = None        # dims / batch of the last encode_input (greedy decoding)
         self._flatten()
@@ -384,28 +385,37 @@ class Model(nn.Module):
         h = self._hyper
         shapes = ((B, M, 3 * h["Co"]), (B, L, h["E"]), (B, T, h["H"]))
         sizes = [s[0] * s[1] * s[2] for s in shapes]
-        # one buffer, grown when a larger batch shape arrives (never shrunk or replaced on a mere change of shape)
-        if self._mask_buffer is None or self._mask_buffer.numel() < sum(sizes) or self._mask_buffer.device != device:
-            self._mask_buffer = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        # One buffer of three segments (cnn | enc | dec), each with a CAPACITY that only grows: the largest mask of its kind
+        # seen so far.  A draw always fills the capacities, and a batch takes the first n elements of each segment — the
+        # elements of a counter-based mask are independent, any prefix of a segment is a mask.  So the masks that the
+        # optimiser launch of the previous step drew ahead (TrainStep, gscan_adam_step_masks) serve the next batch
+        # WHATEVER its padded lengths are: a file-fed loop, whose batches change shape from step to step (length buckets:
+        # every step), launches nothing here.  (Until round 4 they were keyed by the exact shape: a batch of another
+        # shape drew again, and the masks drawn ahead were wasted.)
+        caps = self._mask_caps
+        if caps is None or any(n > c for n, c in zip(sizes, caps)) or self._mask_buffer is None \
+                or self._mask_buffer.device != device:
+            caps = [max(n, c) for n, c in zip(sizes, caps or (0, 0, 0))]
+            self._mask_caps = caps
+            self._mask_buffer = torch.empty(sum(caps), dtype=torch.float32, device=device)
             self._predrawn = None
-        self._mask_key = tuple(sizes)
+        self._mask_key = tuple(caps)
         buf = self._mask_buffer
-        # drawn already, in the optimiser launch of the previous step (TrainStep, gscan_adam_step_masks), for exactly
-        # this shape and this position of the Philox counter?  Then there is nothing to launch.
-        if self._predrawn == (tuple(sizes), self._philox_stream(), device):
+        # drawn already for this position of the Philox counter?  Then there is nothing to launch.
+        if self._predrawn == (tuple(caps), self._philox_stream(), device):
             self._predrawn = None
         else:
             self._predrawn = None
-            _lib.check(lib.gscan_dropout_masks(buf.data_ptr(), sizes[0], sizes[1], sizes[2], self.dropout_p[0],
+            _lib.check(lib.gscan_dropout_masks(buf.data_ptr(), caps[0], caps[1], caps[2], self.dropout_p[0],
                                                self.dropout_p[1], self.dropout_p[2], self._dropout_seed,
                                                self._philox_stream(), None,
                                                torch.cuda.current_stream().cuda_stream), "gscan_dropout_masks")
         deep_stream = self._philox_stream(deep=True)
         self._dropout_calls += 1
         out, off = [], 0
-        for shape, n, p in zip(shapes, sizes, self.dropout_p):
+        for shape, n, cap, p in zip(shapes, sizes, caps, self.dropout_p):
             out.append(buf[off:off + n].view(shape) if p > 0.0 else None)
-            off += n
+            off += cap
         if h["NL"] > 1 and self.dropout_p[1] > 0.0:
             # nn.LSTM(dropout=p) drops the outputs of every layer but the last (seq2seq_model.py:44-45)
             D = 2 if self.encoder_bidirectional else 1
