@@ -19,6 +19,21 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgscan_hip.so")
 SOURCES = ["gemm.hip", "gemm_mt.hip", "gemm_ws.hip", "conv.hip", "elementwise.hip", "loss.hip", "lstm_encoder.hip", "decoder.hip", "decoder_any.hip", "attention_grad.hip", "step.hip",
            "probe.hip", "comm.hip", "capi.hip"]
+# decoder.hip is compiled as four translation units, a quarter of the hidden sizes each (-DGSCAN_DEC_PART=k, csrc/step.h):
+# on one core the file took 80 s of the build's 95
+PARTS = {"decoder.hip": 4}
+
+
+def units():
+    """(source file, object name, extra flags) of every translation unit of the library"""
+    out = []
+    for src in SOURCES:
+        n = PARTS.get(src, 1)
+        for k in range(n):
+            obj = src.replace(".hip", f"_p{k}.o" if n > 1 else ".o")
+            out.append((src, obj, EXTRA_FLAGS.get(src, []) + ([f"-DGSCAN_DEC_PART={k}"] if n > 1 else [])))
+    return out
+
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          f"-I{INCLUDE}", f"-I{CSRC}"]
 # per-source extras: the grouped GEMM's problem lookup reads its header from preloaded kernel-argument SGPRs
@@ -47,11 +62,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     headers.append(os.path.join(INCLUDE, "gscan_hip.h"))
     headers.append(os.path.abspath(__file__))
     jobs = []
-    for src in SOURCES:
+    for src, obj, extra in units():
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, obj)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *extra, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -62,9 +77,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose and r.stderr.strip():
             print(r.stderr, flush=True)
 
-    with ThreadPoolExecutor(max_workers=4) as pool:
+    with ThreadPoolExecutor(max_workers=6) as pool:
         list(pool.map(run, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(OBJ, obj) for _, obj, _ in units()]
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
     return LIB

@@ -170,7 +170,8 @@ int gscan_trace_set(unsigned long long *device_buffer) {
 #endif
     GSCAN_HIP(hipDeviceSynchronize());
     int rc = trace_set_gemm(device_buffer) | trace_set_gemm_mt(device_buffer) | trace_set_gemm_ws(device_buffer) | trace_set_elementwise(device_buffer) | trace_set_loss(device_buffer) |
-             trace_set_lstm_encoder(device_buffer) | trace_set_decoder(device_buffer) | trace_set_decoder_any(device_buffer) |
+             trace_set_lstm_encoder(device_buffer) | trace_set_decoder(device_buffer) | trace_set_decoder_p1(device_buffer) | trace_set_decoder_p2(device_buffer) |
+             trace_set_decoder_p3(device_buffer) | trace_set_decoder_any(device_buffer) |
              trace_set_attention_grad(device_buffer) | trace_set_conv(device_buffer);
     GSCAN_CHECK(rc == 0, "trace_set: hipMemcpyToSymbol failed");
     GSCAN_HIP(hipDeviceSynchronize());

@@ -31,6 +31,10 @@
 // The step prologue kernel writes both register images once per step ([slot][i][thread], coalesced; step.h).
 #include "step.h"
 
+#ifndef GSCAN_DEC_PART
+#define GSCAN_DEC_PART 0      // which quarter of the hidden sizes this translation unit instantiates (step.h)
+#endif
+
 namespace gscan {
 
 // Diagnostic phase stamps (off unless DecoderArgs::stamps is set): thread 0 of workgroup 0 adds the cycles since
@@ -172,6 +176,7 @@ __device__ __forceinline__ void attention_scores(const float *v_s, const float *
 // ------------------------------------------------------------------------------------------
 // geometry shared by the kernels, the weight-image kernel and the host
 // ------------------------------------------------------------------------------------------
+#if GSCAN_DEC_PART == 0
 DecoderGeometry decoder_geometry(int H, bool cond) {
     DecoderGeometry g;
     g.rows = (cond ? 7 : 6) * H;
@@ -180,6 +185,7 @@ DecoderGeometry decoder_geometry(int H, bool cond) {
     g.image_floats = (int64_t)g.slots * g.k0 * kDecThreads;
     return g;
 }
+#endif
 
 constexpr int kHeadWcRows = 16;        // vocabulary rows of the head's LDS image (one MFMA tile of logits)
 constexpr int kHeadDlStride = 20;      // backward: row stride of the chunk's [32][16] dlogits tile (sixteen rows -> eight bank groups)
@@ -1259,6 +1265,25 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
 }
 
 
+// the sizes of this translation unit's part
+#define GSCAN_DEC_CAT_(a, b) a##b
+#define GSCAN_DEC_CAT(a, b) GSCAN_DEC_CAT_(a, b)
+#define GSCAN_DEC_THIS_PART(X) GSCAN_DEC_CAT(GSCAN_DEC_HIDDEN_PART, GSCAN_DEC_PART)(X)
+int GSCAN_DEC_CAT(decoder_run_part, GSCAN_DEC_PART)(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream) {
+    switch (H) {
+#define X(n) case n: return cond ? launch_decoder<n, true>(backward, B, a, stream) : launch_decoder<n, false>(backward, B, a, stream);
+        GSCAN_DEC_THIS_PART(X)
+#undef X
+        default: break;
+    }
+    return -1;       // not a size of this part
+}
+
+#if GSCAN_DEC_PART == 0
+int decoder_run_part1(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
+int decoder_run_part2(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
+int decoder_run_part3(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream);
+
 bool decoder_hidden_supported(int h) {
 #define X(n) if (h == n) return true;
     GSCAN_DEC_HIDDEN_SIZES(X)
@@ -1266,6 +1291,7 @@ bool decoder_hidden_supported(int h) {
     return false;
 }
 
+// bytes of LDS a row's workgroup needs
 size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward) {
     const size_t full = (size_t)decoder_lds(H, L, M, V, cond, backward, true).total * sizeof(float);
     if (full <= kLdsLimit || H < kStreamMinHidden) return full;
@@ -1278,21 +1304,33 @@ size_t decoder_lds_bytes(int H, int L, int M, int V, bool cond, bool backward) {
 bool decoder_fast_supported(int H, int L, int M, int V, bool cond) {
     static const int force_any = [] { const char *e = getenv("GSCAN_DECODER_ANY"); return e ? atoi(e) : 0; }();
     if (force_any || !decoder_hidden_supported(H) || L > 64 || M > 64 || V > kHeadWcRows) return false;   // V: one MFMA tile of logits
-    return decoder_lds_bytes(H, L, M, V, cond, true) <= kLdsLimit && decoder_lds_bytes(H, L, M, V, cond, false) <= kLdsLimit;
+    // greedy decoding keeps the whole head and a [V, V] table behind the memories: it must fit too, if need be with the
+    // visual gate images streamed (a vocabulary of 64 at H = 96 did not, and the launch failed instead of taking the
+    // streaming kernels: found by the planner sanitizer run, tests/planner)
+    const size_t greedy_extra = ((size_t)V * 4 * H + (size_t)V * V + H + 64 + 16) * sizeof(float);
+    const size_t fwd_least = (size_t)decoder_lds(H, L, M, V, cond, false, H < kStreamMinHidden).total * sizeof(float);
+    return decoder_lds_bytes(H, L, M, V, cond, true) <= kLdsLimit && decoder_lds_bytes(H, L, M, V, cond, false) <= kLdsLimit &&
+           fwd_least + greedy_extra <= kLdsLimit;
 }
 
 int decoder_run(bool backward, int B, int H, bool cond, const DecoderArgs &a, hipStream_t stream) {
     GSCAN_CHECK(B > 0 && a.T > 0 && a.L > 0 && a.M > 0, "decoder: bad dims B=%d T=%d L=%d M=%d", B, a.T, a.L, a.M);
     if (!decoder_fast_supported(H, a.L, a.M, a.V, cond)) return decoder_run_any(backward, B, H, cond, a, stream);
-    switch (H) {
-#define X(n) case n: return cond ? launch_decoder<n, true>(backward, B, a, stream) : launch_decoder<n, false>(backward, B, a, stream);
-        GSCAN_DEC_HIDDEN_SIZES(X)
-#undef X
-        default: break;
-    }
+    int rc = decoder_run_part0(backward, B, H, cond, a, stream);
+    if (rc < 0) rc = decoder_run_part1(backward, B, H, cond, a, stream);
+    if (rc < 0) rc = decoder_run_part2(backward, B, H, cond, a, stream);
+    if (rc < 0) rc = decoder_run_part3(backward, B, H, cond, a, stream);
+    if (rc >= 0) return rc;
     GSCAN_CHECK(false, "decoder_hidden_size %d has no compiled kernel (supported: " GSCAN_DEC_HIDDEN_LIST ")", H);
 }
 
 GSCAN_TRACE_TU(decoder)
+#else
+// parts 1-3: their own trace pointer (a per-translation-unit device variable), set with part 0's
+#define GSCAN_DEC_TRACE_NAME GSCAN_DEC_CAT(decoder_p, GSCAN_DEC_PART)
+int GSCAN_DEC_CAT(trace_set_decoder_p, GSCAN_DEC_PART)(unsigned long long *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 }  // namespace gscan

@@ -192,6 +192,10 @@ int trace_set_elementwise(unsigned long long *buf);
 int trace_set_loss(unsigned long long *buf);
 int trace_set_lstm_encoder(unsigned long long *buf);
 int trace_set_decoder(unsigned long long *buf);
+int trace_set_decoder_p1(unsigned long long *buf);
+int trace_set_decoder_p2(unsigned long long *buf);
+int trace_set_decoder_p3(unsigned long long *buf);
+int decoder_run_part0(bool backward, int B, int H, bool cond, const struct DecoderArgs &a, hipStream_t stream);
 int trace_set_decoder_any(unsigned long long *buf);
 int trace_set_attention_grad(unsigned long long *buf);
 
@@ -245,11 +249,21 @@ int sequence_metrics(const float *logp, const int64_t *targets, int B, int T, in
 // Hidden sizes with compiled kernels (the recurrent weights live in registers, so the size is a template parameter):
 // EVERY multiple of 4 — decoder / keys kernels up to 100 (five column quads per unit must fit 128 threads, 7 H^2
 // weights the register file), encoder up to 128.
-#ifdef GSCAN_DEC_HIDDEN_ONLY      // development builds (assembly inspection): one decoder hidden size only
-#define GSCAN_DEC_HIDDEN_SIZES(X) X(GSCAN_DEC_HIDDEN_ONLY)
+// The decoder kernels of all sizes are ONE source compiled as four translation units (-DGSCAN_DEC_PART=0..3, build.py:
+// 80 s of a 95 s build were this one file on one core): part k instantiates the sizes of list k and defines
+// decoder_run_part<k>; part 0 also holds the host functions they share.
+#ifdef GSCAN_DEC_HIDDEN_ONLY      // development builds (assembly inspection): one decoder hidden size only, one part
+#define GSCAN_DEC_HIDDEN_PART0(X) X(GSCAN_DEC_HIDDEN_ONLY)
+#define GSCAN_DEC_HIDDEN_PART1(X)
+#define GSCAN_DEC_HIDDEN_PART2(X)
+#define GSCAN_DEC_HIDDEN_PART3(X)
 #else
-#define GSCAN_DEC_HIDDEN_SIZES(X) X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64) X(68) X(72) X(76) X(80) X(84) X(88) X(92) X(96) X(100)
+#define GSCAN_DEC_HIDDEN_PART0(X) X(4) X(20) X(36) X(52) X(68) X(84) X(100)
+#define GSCAN_DEC_HIDDEN_PART1(X) X(8) X(24) X(40) X(56) X(72) X(88)
+#define GSCAN_DEC_HIDDEN_PART2(X) X(12) X(28) X(44) X(60) X(76) X(92)
+#define GSCAN_DEC_HIDDEN_PART3(X) X(16) X(32) X(48) X(64) X(80) X(96)
 #endif
+#define GSCAN_DEC_HIDDEN_SIZES(X) GSCAN_DEC_HIDDEN_PART0(X) GSCAN_DEC_HIDDEN_PART1(X) GSCAN_DEC_HIDDEN_PART2(X) GSCAN_DEC_HIDDEN_PART3(X)
 #define GSCAN_DEC_HIDDEN_LIST "multiples of 4 from 4 to 100"
 #define GSCAN_ENC_HIDDEN_SIZES(X) X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) X(60) X(64) X(68) X(72) X(76) X(80) X(84) X(88) X(92) X(96) X(100) X(104) X(108) X(112) X(116) X(120) X(124) X(128)
 #define GSCAN_ENC_HIDDEN_LIST "multiples of 4 from 4 to 128"

@@ -31,21 +31,24 @@ FLAGS = ["--offload-host-only", "-DGSCAN_PLAN_ONLY", "-O1", "-g", "-std=c++17", 
 def build(force: bool = False) -> str:
     os.makedirs(OUT, exist_ok=True)
     hipcc = product._hipcc()
-    sources = [os.path.join(product.CSRC, s) for s in product.SOURCES] + [os.path.join(HERE, "driver.hip")]
+    units = [(os.path.join(product.CSRC, s), o, [f for f in extra if f.startswith("-D")]) for s, o, extra in product.units()]
+    units.append((os.path.join(HERE, "driver.hip"), "driver.o", []))
+    sources = [u[0] for u in units]
     deps = sources + [os.path.join(product.CSRC, f) for f in os.listdir(product.CSRC) if f.endswith(".h")] + \
         [os.path.join(product.INCLUDE, "gscan_hip.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(BINARY) and all(os.path.getmtime(d) <= os.path.getmtime(BINARY) for d in deps):
         return BINARY
 
-    def compile_one(src: str) -> str:
-        obj = os.path.join(OUT, os.path.basename(src).replace(".hip", ".o"))
-        r = subprocess.run([hipcc, *FLAGS, "-c", src, "-o", obj], capture_output=True, text=True)
+    def compile_one(unit) -> str:
+        src, name, defines = unit
+        obj = os.path.join(OUT, name)
+        r = subprocess.run([hipcc, *FLAGS, *defines, "-c", src, "-o", obj], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"host-only build of {src} failed:\n{r.stdout}\n{r.stderr}")
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as pool:
-        objs = list(pool.map(compile_one, sources))
+        objs = list(pool.map(compile_one, units))
     # the device code objects these host halves would register: empty stand-ins, one per translation unit
     nm = subprocess.run(["nm", *objs], capture_output=True, text=True, check=True).stdout
     fat = sorted({line.split()[-1] for line in nm.splitlines() if " U __hip_fatbin_" in line})

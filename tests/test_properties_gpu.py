@@ -267,55 +267,79 @@ def test_file_fed_training_loop_keeps_up_with_resident_batches(tmp_path):
     speed of the same step on batches resident in HBM — 97 % at the benchmark shape (bench.py --with-batcher) — and a
     fall below 93 % fails here.  Paper dims, 256-row batches of a generated dataset file in the reference's order and in
     length buckets (every batch another padded shape: the dropout masks drawn ahead by the optimiser launch must serve
-    any shape, Model._draw_masks), 150 batches each after 60 of warm-up, best of two passes."""
-    import time
-    from multimodal_seq2seq_gscan_amd.dataset import BatchStager, GroundedScanDataset
-    from multimodal_seq2seq_gscan_amd.model import Model
-    from multimodal_seq2seq_gscan_amd.synthetic import write_dataset_file
-    from multimodal_seq2seq_gscan_amd.train import TrainStep
-    import numpy as np
-    B = 256
-    path = str(tmp_path / "dataset.txt")
-    write_dataset_file(path, {"train": 30000}, Shape(batch=1, max_command=10, max_target=20), seed=7)
-    data = GroundedScanDataset(path, str(tmp_path), k=0, split="train", generate_vocabulary=True)
-    data.read_dataset()
-    cfg = model_kwargs("compositional", input_vocabulary_size=data.input_vocabulary_size,
-                       target_vocabulary_size=data.target_vocabulary_size, num_cnn_channels=data.image_channels)
-    torch.manual_seed(1)
-    model = Model(**cfg).cuda()
-    step = TrainStep(model, learning_rate=1e-3)
-    stager = BatchStager(torch.device("cuda"), data.slab_bytes(B))
-    keys = ("commands", "cmd_lengths", "world", "targets", "tgt_lengths", "target_positions")
-    np.random.seed(2)
-    for bucket in (0, 8):
-        best = 0.0
-        for attempt in range(2):
-            data.shuffle_data(bucket_batches=bucket, batch_size=B)
-            launches_before = None
-            n, t0, last, shapes = 0, None, None, set()
-            for i, b in enumerate(data.batches(B, stager=stager)):
-                if b["commands"].shape[0] != B:
-                    continue
-                if i == 60:
-                    torch.cuda.synchronize()
-                    t0, n = time.perf_counter(), 0
-                step({k: b[k] for k in keys})
-                n, last = n + 1, b
-                shapes.add((b["commands"].shape[1], b["targets"].shape[1]))
-                if i >= 60 + 150:
-                    break
+    any shape, Model._draw_masks; that order must be FASTER per batch than the reference order).  A timing test: it runs
+    in a process of its own (inside the suite's process, hundreds of tests in, the host side of the loop runs at 2/3 of
+    its speed), whole passes over the file after a warm-up pass, the best of up to four passes counts."""
+    import os, subprocess, sys
+    worker = r"""
+import sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from multimodal_seq2seq_gscan_amd.config import model_kwargs
+from multimodal_seq2seq_gscan_amd.dataset import BatchStager, GroundedScanDataset
+from multimodal_seq2seq_gscan_amd.model import Model
+from multimodal_seq2seq_gscan_amd.synthetic import Shape, write_dataset_file
+from multimodal_seq2seq_gscan_amd.train import TrainStep
+tmp = sys.argv[2]
+B = 256
+path = tmp + "/dataset.txt"
+write_dataset_file(path, {"train": 30000}, Shape(batch=1, max_command=10, max_target=20), seed=7)
+data = GroundedScanDataset(path, tmp, k=0, split="train", generate_vocabulary=True)
+data.read_dataset()
+cfg = model_kwargs("compositional", input_vocabulary_size=data.input_vocabulary_size,
+                   target_vocabulary_size=data.target_vocabulary_size, num_cnn_channels=data.image_channels)
+torch.manual_seed(1)
+model = Model(**cfg).cuda()
+step = TrainStep(model, learning_rate=1e-3)
+stager = BatchStager(torch.device("cuda"), data.slab_bytes(B))
+keys = ("commands", "cmd_lengths", "world", "targets", "tgt_lengths", "target_positions")
+np.random.seed(2)
+
+def fed_epoch(bucket):
+    data.shuffle_data(bucket_batches=bucket, batch_size=B)
+    n, t0, last, shapes = 0, None, None, set()
+    for i, b in enumerate(data.batches(B, stager=stager)):
+        if b["commands"].shape[0] != B:
+            continue
+        if i == 30:
             torch.cuda.synchronize()
-            fed = (time.perf_counter() - t0) / n
-            resident = {k: last[k].clone() for k in keys}
-            for _ in range(20):
-                step(resident)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                step(resident)
-            torch.cuda.synchronize()
-            best = max(best, ((time.perf_counter() - t0) / n) / fed)
-        if bucket:
-            assert len(shapes) > 3, shapes                   # the bucketed order really changes the padded shape
-        assert best >= 0.93, f"file-fed loop at {100 * best:.1f} % of resident batches (length buckets {bucket})"
-    step.close()
+            t0, n = time.perf_counter(), 0
+        step({k: b[k] for k in keys})
+        n, last = n + 1, b
+        shapes.add((b["commands"].shape[1], b["targets"].shape[1]))
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, {k: last[k].clone() for k in keys}, shapes, n
+
+def resident_loop(batch, n):
+    for _ in range(20):
+        step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step(batch)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+fed_epoch(0)                                             # allocator blocks, slab views, kernel attributes
+ratios, fed_ref = [], []
+for attempt in range(4):
+    fed, last, _, n = fed_epoch(0)
+    ratios.append(resident_loop(last, n) / fed)
+    fed_ref.append(fed)
+    if ratios[-1] >= 0.95:
+        break
+fed_epoch(8)
+fed_b, _, shapes, _ = min((fed_epoch(8) for _ in range(2)), key=lambda r: r[0])
+step.close()
+print("RESULT", max(ratios), min(fed_ref), fed_b, len(shapes), flush=True)
+"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", worker, os.path.dirname(here), str(tmp_path)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "RESULT" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    ratio, fed_ref, fed_bucketed, shapes = [float(x) for x in r.stdout.split("RESULT")[1].split()[:4]]
+    assert ratio >= 0.93, f"file-fed loop at {100 * ratio:.1f} % of resident batches"
+    # length buckets: fewer padded decoder steps per batch, every batch another shape — faster per batch than the
+    # reference order (the resident comparison batch would be ONE of those shapes: not a yardstick here)
+    assert shapes > 3
+    assert fed_bucketed < fed_ref, (fed_bucketed, fed_ref)

@@ -26,20 +26,21 @@ def main():
         name, src, flags = (spec.split(":") + [""])[:3]
         srcs = B.SOURCES if src == "all" else src.split("+")   # "all": every source with the flags; a+b: those sources
         jobs = []
-        for one in srcs:
-            obj = os.path.join(OUT, f"{name}.{one.replace('.hip', '.o')}")
-            cmd = [hipcc, *B.FLAGS, *B.EXTRA_FLAGS.get(one, []), *[f for f in flags.split(",") if f], "-c",
-                   os.path.join(B.CSRC, one), "-o", obj]
-            jobs.append((one, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        for one, unit_obj, extra in B.units():                  # (decoder.hip is four translation units)
+            if one not in srcs:
+                continue
+            obj = os.path.join(OUT, f"{name}.{unit_obj}")
+            cmd = [hipcc, *B.FLAGS, *extra, *[f for f in flags.split(",") if f], "-c", os.path.join(B.CSRC, one), "-o", obj]
+            jobs.append((unit_obj, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
         procs.append((name, jobs))
     for name, jobs in procs:
         built = {}
-        for one, obj, p in jobs:
+        for unit_obj, obj, p in jobs:
             out, err = p.communicate()
             if p.returncode != 0:
                 raise SystemExit(f"{name}: hipcc failed\n{err}")
-            built[one] = obj
-        objs = [built.get(s, os.path.join(B.OBJ, s.replace(".hip", ".o"))) for s in B.SOURCES]
+            built[unit_obj] = obj
+        objs = [built.get(u, os.path.join(B.OBJ, u)) for _, u, _ in B.units()]
         lib = os.path.join(OUT, f"libgscan_hip.{name}.so")
         subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib], check=True)
         print(lib)
