@@ -520,7 +520,9 @@ def main():
             families[name] = {"ms_per_step": ms.value / args.steps, "launches_per_step": n.value / args.steps,
                               "avg_us": 1e3 * ms.value / n.value,
                               "tflops": fl.value * per_s,                    # ALGORITHMIC flops / time
-                              "executed_tflops": xfl.value * per_s,          # 2 M N K of what was launched
+                              # multiply-adds the launches EXECUTE (GEMMs: 2 M N K incl. the gate-image products; decoder:
+                              # DESIGN.md 4.1's count); None where that depends on the data (the input-sparse convolutions)
+                              "executed_tflops": xfl.value * per_s if xfl.value > 0 else None,
                               "algorithmic_gflop_per_launch": fl.value / n.value / 1e9}
     fence()
 
@@ -545,7 +547,7 @@ def main():
             f, b = merged.pop("decoder_forward"), merged.pop("decoder_backward")
             ms = f["ms_per_step"] + b["ms_per_step"]
             alg = f["tflops"] * f["ms_per_step"] + b["tflops"] * b["ms_per_step"]      # TFLOP/s x ms = GFLOP per step
-            xalg = f["executed_tflops"] * f["ms_per_step"] + b["executed_tflops"] * b["ms_per_step"]
+            xalg = (f["executed_tflops"] or 0.0) * f["ms_per_step"] + (b["executed_tflops"] or 0.0) * b["ms_per_step"]
             n = f["launches_per_step"] + b["launches_per_step"]
             merged["decoder_pair"] = {"ms_per_step": ms, "launches_per_step": n, "tflops": alg / ms if ms > 0 else 0.0,
                                       "executed_tflops": xalg / ms if ms > 0 else 0.0, "avg_us": 1e3 * ms / n,
@@ -575,7 +577,7 @@ def main():
                     "ms_per_step": round(d["ms_per_step"], 4), "launches_per_step": round(d["launches_per_step"], 2),
                     "avg_launch_us": round(d["avg_us"], 2),
                     "algorithmic_gflop_per_launch": round(d["algorithmic_gflop_per_launch"], 4),
-                    "executed_over_algorithmic": round(d["executed_tflops"] / d["tflops"], 3) if d["tflops"] > 0 else None,
+                    "executed_over_algorithmic": round(d["executed_tflops"] / d["tflops"], 3) if d["tflops"] > 0 and d["executed_tflops"] else None,
                     "note": "achieved = ALGORITHMIC flops of the family's launches (SURVEY.md 8d; per-family formulas in "
                             "DESIGN.md 4) / their HIP-event time on the launch streams; fp32 matrix peak = fp32 vector "
                             "peak on gfx950; traffic = HBM-side bytes per launch from the rocprofv3 PMC passes named in "
@@ -611,7 +613,7 @@ def main():
             "roofline_gemm": roofline_block("gemm") if dominant != "gemm" and "gemm" in merged else None,
             "step_hbm_traffic": step_traffic(pmc_workload, mflop, B),
             "families_ranked": ranked,
-            "kernel_families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in families.items()},
+            "kernel_families": {k: {kk: (None if vv is None else round(vv, 3)) for kk, vv in v.items()} for k, v in families.items()},
             "step_algorithmic_tflops": round(ex_per_s * mflop / 1e6, 3),
             "final_loss": round(loss, 4),
         }

@@ -1239,7 +1239,14 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
     // query projections, both score/context reductions, and the [ctx_text|ctx_vis|h] part of the LSTM.
     const double macs = (double)H * H + 2.0 * a.L * H + (COND ? 2.0 * H * H : 0.0) + (double)H * H +
                         2.0 * a.M * H + 4.0 * H * 3.0 * H + 4.0 * H * H + (double)H * a.V;   // + the fused head
-    ProbeScope probe(backward ? P_DECODER_BWD : P_DECODER_FWD, stream, 2.0 * macs * B * a.T);
+    // What the kernel EXECUTES per step is about half of that: the context part of the LSTM input product is a weighted
+    // sum of the gate images (L + M rows of 4H instead of 4H x 2H), the head is one [V, 4H] matrix instead of H x 4H +
+    // V x H.  Forward: 6 H^2 dots (+ H^2 conditional), scores L H + M H, column sums of [U | PK (| U2)], head;
+    // backward: the same matrices transposed, d alpha rows, two passes over the score terms.
+    const double hh = (double)H * H, lh = (double)a.L * H, mh = (double)a.M * H;
+    const double exec_macs = backward ? (COND ? 7.0 : 6.0) * hh + 7.0 * mh + (COND ? 8.0 : 7.0) * lh + 4.0 * H * a.V
+                                      : (COND ? 7.0 : 6.0) * hh + 6.0 * mh + (COND ? 7.0 : 6.0) * lh + 4.0 * H * a.V;
+    ProbeScope probe(backward ? P_DECODER_BWD : P_DECODER_FWD, stream, 2.0 * exec_macs * B * a.T, 2.0 * macs * B * a.T);
     auto launch = [&](auto kernel, const char *name) -> int {
         static bool attr_set = false;                          // one flag per kernel instantiation (generic lambda)
         if (!attr_set) {
