@@ -73,7 +73,10 @@ __device__ __forceinline__ float pair_sum(float v) { return v + dpp_move<0x141, 
 // (v_pk_fma_f32).  The vector is read in chunks of four float4; the next chunk's reads are issued before the
 // current chunk's FMAs, so the LDS latency is paid about once per dot instead of once per read.
 constexpr int kWaitVmcnt0 = 0x0F70;   // s_waitcnt vmcnt(0) only (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
-constexpr int kDotChunk = 4;
+#ifndef GSCAN_DEC_DOT_CHUNK
+#define GSCAN_DEC_DOT_CHUNK 4
+#endif
+constexpr int kDotChunk = GSCAN_DEC_DOT_CHUNK;
 #ifndef GSCAN_DEC_BWD_CHUNK
 #define GSCAN_DEC_BWD_CHUNK 4
 #endif
@@ -131,7 +134,10 @@ __device__ __forceinline__ float half_dot(const float (&w)[K0], const float *v) 
 // and the G DPP reductions instead of running them one after the other between branches — a lone reduction is a
 // ~140-cycle dependent chain, and the 36 cells of a 6x6 grid are one round of five.  A lane owns the feature
 // indices lane and lane+64; v and q for them are read once.
-constexpr int kScoreGroup = 5;
+#ifndef GSCAN_DEC_SCORE_GROUP
+#define GSCAN_DEC_SCORE_GROUP 5
+#endif
+constexpr int kScoreGroup = GSCAN_DEC_SCORE_GROUP;
 template <int H, int G>
 __device__ __forceinline__ void score_round(float v1, float v2, float q1, float q2, int k1, int k2, const float *pk,
                                             int n, float *sc_s, int m0, int nwave, int lane) {
@@ -318,7 +324,10 @@ __device__ __forceinline__ float quad_bcast(float v) { return dpp_move<I * 0x55,
 // pass stride = 0 and ignore the result.  n is uniform in the workgroup.
 template <bool GLOBAL = false>
 __device__ __forceinline__ float quad_column_sum(const float *base, int stride, int n, int j, float alpha) {
-    constexpr int U = 3;
+#ifndef GSCAN_DEC_QCS_U
+#define GSCAN_DEC_QCS_U 3
+#endif
+    constexpr int U = GSCAN_DEC_QCS_U;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int i0 = 0; i0 < n; i0 += 4 * U) {
         f32x4 x[U];
@@ -773,7 +782,10 @@ __device__ __forceinline__ void score_backward(float dsm, const float *q_s, cons
     const float v1 = has1 ? v_s[k1] : 0.f, v2 = has2 ? v_s[k2] : 0.f;
     const float q1 = q_s[k1], q2 = q_s[k2];
     float pdq1 = 0.f, pdq2 = 0.f;
-#pragma unroll 2
+#ifndef GSCAN_DEC_SB_UNROLL
+#define GSCAN_DEC_SB_UNROLL 2
+#endif
+#pragma unroll GSCAN_DEC_SB_UNROLL
     for (int m = wave; m < n; m += nwave) {
         const float ds = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dsm), m));
         const float th1 = tanhf_(q1 + pk[m * H + k1]), th2 = tanhf_(q2 + pk[m * H + k2]);

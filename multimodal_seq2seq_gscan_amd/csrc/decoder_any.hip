@@ -70,7 +70,8 @@ __host__ __device__ inline AnyLds any_lds_fwd(int H, int L, int M) {
 // ------------------------------------------------------------------------------------------
 template <bool V4, bool GREEDY>
 __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArgs a, int H, int cond) {
-    TraceScope trace_scope(TK_DECODER_FWD);
+    // (no TraceScope: with -DGSCAN_TRACE its destructor's branch on blockIdx makes this compiler's back end fail on the
+    // kernel — 'illegal VGPR to SGPR copy' — and the in-kernel timeline is a tool for the resident kernels' schedule)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.T, L = a.L, M = a.M, V = a.V;
@@ -373,7 +374,6 @@ __device__ __forceinline__ void attention_bwd_any(const float *dctx, const float
 
 template <bool V4>
 __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArgs a, int H, int cond) {
-    TraceScope trace_scope(TK_DECODER_BWD);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.T, L = a.L, M = a.M, V = a.V;
