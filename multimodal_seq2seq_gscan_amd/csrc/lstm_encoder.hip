@@ -50,12 +50,8 @@ __device__ __forceinline__ void dots_lds(const float (&w)[R][HE], const float *v
 #endif
 
 template <int HE> struct EncShape {
-    // Hidden sizes up to 100 run on the unit-major kernels below (round 5): a LANE PAIR (forward) or a lane OCTET (backward)
-    // shares a hidden unit's weights, 4 x KC per lane.  Larger sizes (to 128) keep a weight row (column) per thread.
-    static constexpr bool kPair = HE <= 100;
-    static constexpr int R = kPair ? 4 : 1;                           // rows per slot of the forward register image
-    static constexpr int KC = ((HE / 2 + 3) / 4) * 4;                 // a lane's share of a dot product, in whole 16-byte reads
-    static constexpr int kThreads = ((kPair ? 2 * HE : 4 * HE) + 63) / 64 * 64;
+    static constexpr int R = HE <= 100 ? 2 : 1;                       // weight rows (forward) / columns (backward) per thread
+    static constexpr int kThreads = ((4 * HE / R + 63) / 64) * 64;
 };
 
 // LDS residency.  A wait for a prefetched load (s_waitcnt vmcnt) also waits for every store the wave issued
@@ -69,26 +65,44 @@ template <int HE> struct EncShape {
 //   backward  d_s [len][4He] gate activations  ->  gate pre-activation gradients (in place)
 //             c_s [len][He] cells, o_s [len][He] gradient wrt the summed outputs, part_s [4He] partial dh
 constexpr size_t kEncLdsLimit = 160 * 1024;
-// (the unit-major kernels' double-buffered step vectors: 2 x 2 KC forward, 2 x 8 KC backward, KC <= HE / 2 + 2)
-inline size_t encoder_fwd_lds(int L, int HE, int E = 0) { return ((size_t)L * 6 * HE + 2 * (HE + 8) + (size_t)((L + 15) & ~15) * (E ? E + 1 : 0)) * sizeof(float); }
-inline size_t encoder_bwd_lds(int L, int HE) { return ((size_t)L * 6 * HE + 8 * HE + 64) * sizeof(float); }
+inline size_t encoder_fwd_lds(int L, int HE, int E = 0) { return ((size_t)L * 6 * HE + HE + (size_t)((L + 15) & ~15) * (E ? E + 1 : 0)) * sizeof(float); }
+inline size_t encoder_bwd_lds(int L, int HE) { return ((size_t)L * 6 * HE + 4 * HE) * sizeof(float); }
 
-// g_s[t][row] for the whole command, before the recurrence: either the first layer's own input projection (in.x) or the
-// staged projections gx with the recurrent bias added.  x_s: scratch behind the step vectors.  All threads take part.
-template <int HE, int NTHREADS>
-__device__ __forceinline__ void encoder_stage_projections(const EncInput &in, const float *__restrict__ gx,
-                                                          const float *__restrict__ b_hh_f, const float *__restrict__ b_hh_r,
-                                                          int D, int dir, int len, int64_t row0, float *g_s, float *x_s,
-                                                          long long &est_prev) {
-    const int j = threadIdx.x, nthr = NTHREADS;
-    (void)est_prev;
+// grid (B, D): the two directions of a row run as two workgroups (they only meet in the sums below).
+// The LAST encoder layer passes `out` / `h_final` (direction sums), a layer below it passes `hcat` instead: its h per
+// direction, [B, L, D*He] = the next layer's input (nn.LSTM concatenates the directions), times `hcat_mask` (the
+// inter-layer dropout, or NULL), zero at padded positions.
+// `out` and `h_final` must be zero on entry: each direction ADDS its h (0 + h_f + h_r in either order is the same
+// float: two-operand addition commutes), which is how the directions are summed (seq2seq_model.py:77-81).
+// Thread j < 4He/R owns gate rows j + r*(4He/R), r < R  (R = 2: [i | f] rows and the matching [g | o] rows).
+template <int HE>
+__global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_kernel(int L, int D, const float *__restrict__ gx,
+                                        const int32_t *__restrict__ lengths, const float *__restrict__ b_hh_f,
+                                        const float *__restrict__ b_hh_r, float *__restrict__ out,
+                                        float *__restrict__ h_final, float *__restrict__ gates,
+                                        float *__restrict__ cells, float *__restrict__ hprev,
+                                        const float *__restrict__ w_image, float *__restrict__ hcat,
+                                        const float *__restrict__ hcat_mask, EncInput in) {
+    TraceScope trace_scope(TK_ENCODER_FWD);
+    constexpr int R = EncShape<HE>::R, NT = 4 * HE / R;              // owning threads
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x, nthr = blockDim.x;
+    int len = lengths[b];
+    len = max(0, min(len, L));
+    float *g_s = lds, *c_s = g_s + len * 4 * HE, *h_s = c_s + len * HE, *z_s = h_s + len * HE;
+    const bool is_gate = j < NT, is_unit = j < HE;
+    const int64_t row0 = (int64_t)b * L;                             // row of (b, t, dir) = (row0 + t) * D + dir
+#ifdef GSCAN_ENC_STAMPS
+    long long est_prev = clock64();
+#endif
+
     if (in.x) {
         // the first layer projects its own input: g_s[t][row] = W_ih[row] . x[b,t] + b_ih[row] + b_hh[row]
         // (seq2seq_model.py:70,74).  x = the embedded, dropped-out command (E floats per token, staged in LDS); a
         // thread computes the projections of the gate rows it owns, so nothing crosses threads but x — and the
         // launch that used to compute them for the whole batch is off the critical chain of the step.
         const int E = in.E;
-        // x_s: [E][LP] time-contiguous, LP = len rounded up to 16
+        float *x_s = z_s + HE;                                       // [E][LP] time-contiguous, LP = len rounded up to 16
         const int LP = (len + 15) & ~15;
         for (int idx = j; idx < LP * (E + 1); idx += nthr) {         // row E: ones (the bias column of the image)
             const int e = idx / LP, t = idx - e * LP;
@@ -106,7 +120,7 @@ __device__ __forceinline__ void encoder_stage_projections(const EncInput &in, co
             const int EK = E + 1;                                    // K of the product: E inputs and the bias column
             const float *wt = in.w_ih_t + (int64_t)dir * EK * 4 * HE;
             const int lane = j & 63, wave = j >> 6, fr = lane & 15, fg = lane >> 4;
-            constexpr int NTILE = 4 * HE / 16, SU = 8, NW = NTHREADS / 64, TPW = (NTILE + NW - 1) / NW;
+            constexpr int NTILE = 4 * HE / 16, SU = 8, NW = EncShape<HE>::kThreads / 64, TPW = (NTILE + NW - 1) / NW;
             static_assert(HE % 4 == 0, "gate rows come in whole tiles of 16");
             // every global load of a wave's tiles (A fragments of up to 32 columns) is issued before the first MFMA: a
             // tile at a time, each tile waited out its own L2 round trip (~1 200 cycles)
@@ -151,37 +165,6 @@ __device__ __forceinline__ void encoder_stage_projections(const EncInput &in, co
             *reinterpret_cast<float4 *>(g_s + t * 4 * HE + 4 * q) = float4{x.x + bb.x, x.y + bb.y, x.z + bb.z, x.w + bb.w};
         }
     }
-}
-
-// grid (B, D): the two directions of a row run as two workgroups (they only meet in the sums below).
-// The LAST encoder layer passes `out` / `h_final` (direction sums), a layer below it passes `hcat` instead: its h per
-// direction, [B, L, D*He] = the next layer's input (nn.LSTM concatenates the directions), times `hcat_mask` (the
-// inter-layer dropout, or NULL), zero at padded positions.
-// `out` and `h_final` must be zero on entry: each direction ADDS its h (0 + h_f + h_r in either order is the same
-// float: two-operand addition commutes), which is how the directions are summed (seq2seq_model.py:77-81).
-// Thread j < 4He/R owns gate rows j + r*(4He/R), r < R  (R = 2: [i | f] rows and the matching [g | o] rows).
-template <int HE>
-__global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_kernel(int L, int D, const float *__restrict__ gx,
-                                        const int32_t *__restrict__ lengths, const float *__restrict__ b_hh_f,
-                                        const float *__restrict__ b_hh_r, float *__restrict__ out,
-                                        float *__restrict__ h_final, float *__restrict__ gates,
-                                        float *__restrict__ cells, float *__restrict__ hprev,
-                                        const float *__restrict__ w_image, float *__restrict__ hcat,
-                                        const float *__restrict__ hcat_mask, EncInput in) {
-    TraceScope trace_scope(TK_ENCODER_FWD);
-    constexpr int R = 1, NT = 4 * HE / R;                            // owning threads (hidden sizes above 100: a row per thread)
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x, nthr = blockDim.x;
-    int len = lengths[b];
-    len = max(0, min(len, L));
-    float *g_s = lds, *c_s = g_s + len * 4 * HE, *h_s = c_s + len * HE, *z_s = h_s + len * HE;
-    const bool is_gate = j < NT, is_unit = j < HE;
-    const int64_t row0 = (int64_t)b * L;                             // row of (b, t, dir) = (row0 + t) * D + dir
-    long long est_prev = 0;
-#ifdef GSCAN_ENC_STAMPS
-    est_prev = clock64();
-#endif
-    encoder_stage_projections<HE, EncShape<HE>::kThreads>(in, gx, b_hh_f, b_hh_r, D, dir, len, row0, g_s, z_s + HE, est_prev);
     EST(1)
     // padded positions: zero saved h_prev (it multiplies delta = 0 in a GEMM later); out stays zero
     for (int idx = j; idx < (L - len) * HE; idx += nthr) {
@@ -259,7 +242,7 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_ke
                                         float *__restrict__ delta, int d_out_row, int d_out_dir,
                                         const float *__restrict__ d_out_mask) {
     TraceScope trace_scope(TK_ENCODER_BWD);
-    constexpr int R = 1, KQ = HE / R, NT = 4 * KQ;
+    constexpr int R = EncShape<HE>::R, KQ = HE / R, NT = 4 * KQ;
     static_assert(HE % R == 0, "hidden size must divide by the columns per thread");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
@@ -327,229 +310,6 @@ __global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_ke
             dots_lds<HE, R>(wt, g + seg * HE, part);
 #pragma unroll
             for (int r = 0; r < R; ++r) part_s[seg * HE + q + r * KQ] = part[r];
-        }
-        lds_barrier();
-    }
-    for (int idx = tid; idx < len * HE; idx += nthr) {
-        const int t = idx / HE, k4 = idx - t * HE;
-        *reinterpret_cast<float4 *>(delta + ((row0 + t) * D + dir) * 4 * HE + 4 * k4) =
-            *reinterpret_cast<const float4 *>(d_s + t * 4 * HE + 4 * k4);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Round 5: unit-major recurrences for hidden sizes up to 100 (EncShape::kPair).
-//
-// The kernels above give a thread whole weight rows, so every wave reads the WHOLE state vector from LDS each step:
-// a 16-byte wave read costs the LDS pipe 8 cycles whatever the lanes hold (64 lanes x 16 bytes), 25 of them per wave,
-// eight waves per CU = 1 600 cycles of LDS time per step against 800 of packed FMAs — the step was bound by those reads
-// — and the gates crossed threads through LDS behind a second barrier.  Here the lanes that share a hidden unit split
-// the K extent instead:
-//   forward   lane pair (unit u, half): the FOUR gate rows of u against its half of h_{t-1} (13 reads instead of 25),
-//             one DPP swap adds the halves, each lane activates two of the gates, a second swap hands them over and the
-//             cell update stays in registers: ONE barrier per step, h double-buffered in LDS;
-//   backward  lane octet (column quad q, chunk o): columns 4q..4q+3 of W_hh against chunk o (He/2 rows) of delta_{t+1},
-//             three DPP steps add the eight chunks, lanes 0..3 of the octet run the cell backward of units 4q..4q+3 and
-//             write delta_t both to the command's history and to the next step's chunked vector: ONE barrier per step,
-//             and the weights come straight from W_hh as 16-byte loads (a row's four columns).
-// Same arguments, same saved tensors, same outputs as the kernels above.
-// ------------------------------------------------------------------------------------------
-template <int HE>
-__global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_fwd_pair_kernel(int L, int D, const float *__restrict__ gx,
-                                        const int32_t *__restrict__ lengths, const float *__restrict__ b_hh_f,
-                                        const float *__restrict__ b_hh_r, float *__restrict__ out,
-                                        float *__restrict__ h_final, float *__restrict__ gates,
-                                        float *__restrict__ cells, float *__restrict__ hprev,
-                                        const float *__restrict__ w_image, float *__restrict__ hcat,
-                                        const float *__restrict__ hcat_mask, EncInput in) {
-    TraceScope trace_scope(TK_ENCODER_FWD);
-    constexpr int KC = EncShape<HE>::KC, HP = 2 * KC, NTHR = EncShape<HE>::kThreads;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x, nthr = NTHR;
-    int len = lengths[b];
-    len = max(0, min(len, L));
-    float *g_s = lds, *c_s = g_s + len * 4 * HE, *h_s = c_s + len * HE, *hbuf = h_s + len * HE, *x_s = hbuf + 2 * HP;
-    const int u = min(j >> 1, HE - 1), half = j & 1;
-    const bool active = j < 2 * HE;
-    const int64_t row0 = (int64_t)b * L;                             // row of (b, t, dir) = (row0 + t) * D + dir
-    long long est_prev = 0;
-#ifdef GSCAN_ENC_STAMPS
-    est_prev = clock64();
-#endif
-    encoder_stage_projections<HE, NTHR>(in, gx, b_hh_f, b_hh_r, D, dir, len, row0, g_s, x_s, est_prev);
-    EST(1)
-    // padded positions: zero saved h_prev (it multiplies delta = 0 in a GEMM later); out stays zero
-    for (int idx = j; idx < (L - len) * HE; idx += nthr) {
-        const int t = len + idx / HE, k = idx % HE;
-        hprev[((row0 + t) * D + dir) * HE + k] = 0.f;
-        if (hcat) hcat[((row0 + t) * D + dir) * HE + k] = 0.f;
-    }
-    // register image [dir][gate][k][unit] (encoder_weight_image with four rows per slot): consecutive units are consecutive
-    // floats; this lane keeps k = half * KC .. half * KC + KC - 1 of its unit's four gate rows, zero past He
-    float w[4][KC];
-    {
-        const float *img = w_image + ((int64_t)dir * 4 * HE + half * KC) * HE + u;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int i = 0; i < KC; ++i) {
-                const bool inside = i < HE - KC || half == 0;        // (KC + i < He for the upper half)
-                const float v = img[((int64_t)g * HE + (inside ? i : 0)) * HE];
-                w[g][i] = inside ? v : 0.f;
-            }
-    }
-    for (int i = j; i < 2 * HP; i += nthr) hbuf[i] = 0.f;            // h_{-1} = 0 and the padding of both buffers
-    // this lane activates gates ga, ga + 1 of its unit: (i, f) in the lower lane, (g, o) in the upper; gate g is a tanh =
-    // 2 sigmoid(2x) - 1, so every lane runs a * sigmoid(s x) + c
-    const int ga = 2 * half;
-    const float act_s = half ? -2.8853900817779268f : -1.4426950408889634f, act_a = half ? 2.f : 1.f, act_c = half ? -1.f : 0.f;
-    float c = 0.f;
-    lds_barrier();
-    EST(2)
-    for (int s = 0; s < len; ++s) {
-        const int t = dir ? (len - 1 - s) : s;
-        float *g = g_s + t * 4 * HE;
-        const float *hin = hbuf + (s & 1) * HP + half * KC;
-        float *hout = hbuf + ((s + 1) & 1) * HP;
-        const float xa = g[ga * HE + u], xb = g[(ga + 1) * HE + u];   // input projections (+ biases) of this lane's gates
-        float dot[4];
-        dots_lds<KC, 4>(w, hin, dot);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dot[r] += dpp_move<0xb1, 0xf>(dot[r]);      // the other half (lanes 2i <-> 2i + 1)
-        const float pa = xa + (half ? dot[2] : dot[0]), pb = xb + (half ? dot[3] : dot[1]);
-        const float aa = fmaf(act_a, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(act_s * pa)), act_c);
-        const float ab = sigmoidf_(pb);
-        const float oa = dpp_move<0xb1, 0xf>(aa), ob = dpp_move<0xb1, 0xf>(ab);
-        const float ig = half ? oa : aa, fg = half ? ob : ab, gg = half ? aa : oa, og = half ? ab : ob;
-        c = fg * c + ig * gg;
-        const float h = og * tanhf_(c);
-        if (active) {
-            g[ga * HE + u] = aa;
-            g[(ga + 1) * HE + u] = ab;
-            if (half == 0) {
-                c_s[t * HE + u] = c;
-                h_s[t * HE + u] = h;
-                hout[u] = h;
-            }
-        }
-        lds_barrier();
-    }
-    EST(3)
-    // write-back: saved activations for the backward pass, the direction sums (atomics: two addends commute)
-    for (int idx = j; idx < len * HE; idx += nthr) {
-        const int t = idx / HE, q = idx - t * HE;
-        *reinterpret_cast<float4 *>(gates + ((row0 + t) * D + dir) * 4 * HE + 4 * q) =
-            *reinterpret_cast<const float4 *>(g_s + t * 4 * HE + 4 * q);
-    }
-    for (int idx = j; idx < len * HE; idx += nthr) {
-        const int t = idx / HE, k = idx - t * HE;
-        const int64_t row = (row0 + t) * D + dir;
-        const bool first = dir ? (t == len - 1) : (t == 0);
-        cells[row * HE + k] = c_s[idx];
-        hprev[row * HE + k] = first ? 0.f : h_s[(dir ? t + 1 : t - 1) * HE + k];
-        if (out) atomicAdd(out + (row0 + t) * HE + k, h_s[idx]);
-        if (hcat) hcat[row * HE + k] = hcat_mask ? h_s[idx] * hcat_mask[row * HE + k] : h_s[idx];
-    }
-    if (h_final && j < HE && len > 0) atomicAdd(h_final + (int64_t)b * HE + j, h_s[(dir ? 0 : len - 1) * HE + j]);
-    EST(4)
-}
-
-template <int HE>
-__global__ __launch_bounds__(EncShape<HE>::kThreads, 2) void encoder_lstm_bwd_octet_kernel(int L, int D, const int32_t *__restrict__ lengths,
-                                        const float *__restrict__ w_hh_f, const float *__restrict__ w_hh_r,
-                                        const float *__restrict__ gates, const float *__restrict__ cells,
-                                        const float *__restrict__ d_out, const float *__restrict__ d_h_final,
-                                        float *__restrict__ delta, int d_out_row, int d_out_dir,
-                                        const float *__restrict__ d_out_mask) {
-    TraceScope trace_scope(TK_ENCODER_BWD);
-    // chunk o of delta = rows o * RC .. o * RC + RC - 1 of the [i | f | g | o] vector, RC = He / 2: gate g of unit u sits in
-    // chunk 2 g + (u >= RC); in LDS every chunk is padded to KC floats (whole 16-byte reads, zero padding)
-    constexpr int KC = EncShape<HE>::KC, RC = HE / 2, NQ = HE / 4, DV = 8 * KC;
-    static_assert(HE % 4 == 0, "hidden size must be a multiple of 4");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
-    int len = lengths[b];
-    len = max(0, min(len, L));
-    float *d_s = lds, *c_s = d_s + len * 4 * HE, *o_s = c_s + len * HE, *dv = o_s + len * HE;     // dv [2][8][KC]
-    const int oct = tid & 7, kq = min(tid >> 3, NQ - 1);
-    const bool active = tid < 8 * NQ;
-    const int64_t row0 = (int64_t)b * L;
-    for (int idx = tid; idx < len * HE; idx += nthr) {                // saved activations of the whole command
-        const int t = idx / HE, k4 = idx - t * HE;
-        *reinterpret_cast<float4 *>(d_s + t * 4 * HE + 4 * k4) =
-            *reinterpret_cast<const float4 *>(gates + ((row0 + t) * D + dir) * 4 * HE + 4 * k4);
-    }
-    for (int idx = tid; idx < len * HE / 4; idx += nthr) {
-        const int t = idx / (HE / 4), k4 = idx - t * (HE / 4);
-        *reinterpret_cast<float4 *>(c_s + t * HE + 4 * k4) =
-            *reinterpret_cast<const float4 *>(cells + ((row0 + t) * D + dir) * HE + 4 * k4);
-        // gradient wrt this direction's h_t: the shared sum [B,L,He] for the last layer (row stride He, direction
-        // offset 0), the direction's half of d(next layer's input) [B,L,D*He] times the dropout mask below it
-        const int64_t at = (row0 + t) * d_out_row + dir * d_out_dir + 4 * k4;
-        float4 g4 = *reinterpret_cast<const float4 *>(d_out + at);
-        if (d_out_mask) {
-            const float4 m4 = *reinterpret_cast<const float4 *>(d_out_mask + at);
-            g4 = float4{g4.x * m4.x, g4.y * m4.y, g4.z * m4.z, g4.w * m4.w};
-        }
-        *reinterpret_cast<float4 *>(o_s + t * HE + 4 * k4) = g4;
-    }
-    for (int i = tid; i < 2 * DV; i += nthr) dv[i] = 0.f;             // delta_{len} = 0 and the chunks' padding
-    for (int idx = tid; idx < (L - len) * HE; idx += nthr) {          // padded positions get delta = 0
-        const int t = len + idx / HE, k4 = idx % HE;
-        *reinterpret_cast<float4 *>(delta + ((row0 + t) * D + dir) * 4 * HE + 4 * k4) = float4{0.f, 0.f, 0.f, 0.f};
-    }
-    // wt[c][r] = W_hh[oct * RC + r][4 kq + c]: a row's four columns are one 16-byte load
-    const float *w_hh = dir ? w_hh_r : w_hh_f;
-    float wt[4][KC];
-    {
-        const float *src = w_hh + (int64_t)oct * RC * HE + 4 * kq;
-#pragma unroll
-        for (int r = 0; r < KC; ++r) {
-            if (r < RC) {
-                const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)r * HE);
-                wt[0][r] = v.x; wt[1][r] = v.y; wt[2][r] = v.z; wt[3][r] = v.w;
-            } else {
-                wt[0][r] = 0.f; wt[1][r] = 0.f; wt[2][r] = 0.f; wt[3][r] = 0.f;
-            }
-        }
-    }
-    // the unit of this lane in the cell backward: lanes 0..3 of the octet own units 4 kq + lane (lanes 4..7 mirror them and
-    // write nothing)
-    const int u = 4 * kq + (oct & 3);
-    const bool writer = active && oct < 4;
-    float dc = 0.f;
-    float dh_carry = d_h_final ? d_h_final[(int64_t)b * HE + u] : 0.f;   // joins dh at the command's last step only
-    const int cu = u >= RC ? 1 : 0, pu = u - cu * RC;                 // chunk parity / position of this unit's deltas
-    lds_barrier();
-    for (int s = len - 1; s >= 0; --s) {
-        const int t = dir ? (len - 1 - s) : s, it = len - 1 - s;
-        float *g = d_s + t * 4 * HE;
-        const float *dcur = dv + (it & 1) * DV + oct * KC;
-        float *dnxt = dv + ((it + 1) & 1) * DV;
-        const float ig = g[u], fg = g[HE + u], gg = g[2 * HE + u], og = g[3 * HE + u];
-        const float cc = c_s[t * HE + u], go = o_s[t * HE + u];
-        const float c_prev = (s > 0) ? c_s[(dir ? t + 1 : t - 1) * HE + u] : 0.f;
-        float part[4];
-        dots_lds<KC, 4>(wt, dcur, part);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part[r] += dpp_move<0xb1, 0xf>(part[r]);    // lanes 2i <-> 2i + 1
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part[r] += dpp_move<0x4e, 0xf>(part[r]);    // pairs within a quad
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part[r] += dpp_move<0x141, 0xf>(part[r]);   // row_half_mirror: the other quad of the octet
-        const int sel = oct & 3;
-        const float dsum = sel == 0 ? part[0] : sel == 1 ? part[1] : sel == 2 ? part[2] : part[3];
-        const float dh = dsum + go + dh_carry;
-        dh_carry = 0.f;
-        const float tc = tanhf_(cc);
-        const float dct = dc + dh * og * (1.f - tc * tc);
-        dc = dct * fg;
-        const float di = dct * gg * ig * (1.f - ig), df = dct * c_prev * fg * (1.f - fg), dg = dct * ig * (1.f - gg * gg),
-                    dO = dh * tc * og * (1.f - og);
-        if (writer) {
-            g[u] = di; g[HE + u] = df; g[2 * HE + u] = dg; g[3 * HE + u] = dO;
-            dnxt[(0 + cu) * KC + pu] = di; dnxt[(2 + cu) * KC + pu] = df;
-            dnxt[(4 + cu) * KC + pu] = dg; dnxt[(6 + cu) * KC + pu] = dO;
         }
         lds_barrier();
     }
@@ -678,14 +438,6 @@ __global__ __launch_bounds__(kAnyThreads) void encoder_lstm_bwd_any_kernel(int L
     }
 }
 
-// the kernel of a compiled hidden size: unit-major up to 100, a row per thread above
-template <int HE> constexpr auto encoder_fwd_kernel_of() {
-    if constexpr (EncShape<HE>::kPair) return &encoder_lstm_fwd_pair_kernel<HE>; else return &encoder_lstm_fwd_kernel<HE>;
-}
-template <int HE> constexpr auto encoder_bwd_kernel_of() {
-    if constexpr (EncShape<HE>::kPair) return &encoder_lstm_bwd_octet_kernel<HE>; else return &encoder_lstm_bwd_kernel<HE>;
-}
-
 template <typename K>
 static int encoder_lds_attr(K kernel, size_t bytes, bool &attr_set) {
     GSCAN_CHECK(bytes <= kEncLdsLimit, "encoder lstm: a command of this length needs %zu bytes of LDS (limit %zu)", bytes,
@@ -704,12 +456,11 @@ static int launch_fwd(int B, int L, int D, const float *gx, const int32_t *lengt
     const int nt = EncShape<HE>::kThreads;
     static bool attr_set = false;
     const size_t lds = encoder_fwd_lds(L, HE, in.x ? in.E : 0);
-    constexpr auto kernel = encoder_fwd_kernel_of<HE>();
-    if (int rc = encoder_lds_attr(kernel, lds, attr_set)) return rc;
+    if (int rc = encoder_lds_attr(encoder_lstm_fwd_kernel<HE>, lds, attr_set)) return rc;
     // algorithmic work: the recurrent product h.W_hh^T per (row, step, direction), plus the input projection when the
     // kernel computes it itself; padded steps counted
     ProbeScope probe(P_ENCODER_FWD, stream, 2.0 * B * L * D * 4 * HE * (HE + (in.x ? in.E : 0)));
-    hipLaunchKernelGGL(kernel, dim3(B, D), dim3(nt), lds, stream, L, D, gx, lengths,
+    hipLaunchKernelGGL(encoder_lstm_fwd_kernel<HE>, dim3(B, D), dim3(nt), lds, stream, L, D, gx, lengths,
                        bf, br, out, hfin, gates, cells, hprev, w_image, hcat, hcat_mask, in);
     GSCAN_LAUNCHED("encoder_lstm_fwd_kernel");
     return 0;
@@ -720,10 +471,9 @@ static int launch_bwd(int B, int L, int D, const int32_t *lengths, const float *
                       int d_out_row, int d_out_dir, const float *d_out_mask, hipStream_t stream) {
     const int nt = EncShape<HE>::kThreads;
     static bool attr_set = false;
-    constexpr auto kernel = encoder_bwd_kernel_of<HE>();
-    if (int rc = encoder_lds_attr(kernel, encoder_bwd_lds(L, HE), attr_set)) return rc;
+    if (int rc = encoder_lds_attr(encoder_lstm_bwd_kernel<HE>, encoder_bwd_lds(L, HE), attr_set)) return rc;
     ProbeScope probe(P_ENCODER_BWD, stream, 2.0 * B * L * D * 4 * HE * HE);
-    hipLaunchKernelGGL(kernel, dim3(B, D), dim3(nt), encoder_bwd_lds(L, HE), stream, L, D, lengths, wf,
+    hipLaunchKernelGGL(encoder_lstm_bwd_kernel<HE>, dim3(B, D), dim3(nt), encoder_bwd_lds(L, HE), stream, L, D, lengths, wf,
                        wr, gates, cells, d_out, d_hfin, delta, d_out_row, d_out_dir, d_out_mask);
     GSCAN_LAUNCHED("encoder_lstm_bwd_kernel");
     return 0;
