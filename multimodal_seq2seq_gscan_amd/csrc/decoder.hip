@@ -479,6 +479,15 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
                   HP = 2 * K0;
     constexpr int NQ2 = (COND ? 2 : 1) * H / 4;   // column quads of [PK_t | U2_t]
+#ifndef GSCAN_DEC_DEFER0
+#define GSCAN_DEC_DEFER0 1
+#endif
+    // Round 5: the dot products of slot 0 — W_hh rows only once 4H >= 256 — leave phase A for phase E: their result is not
+    // needed before the gates of phase F, and phase A (the densest in FMAs) no longer waits for them.  Phase A 1 269 -> 909
+    // cycles, phase E 2 125 -> 2 557, the other phases -170: forward kernel 101.5 -> 100.4 us (profiles/
+    // r05_decoder_fwd_deferred_slot0_ab.txt; in phase B or D, or staggered between a SIMD's two waves, the same dot costs
+    // what it saves).
+    constexpr bool DEFER0 = GSCAN_DEC_DEFER0 && 4 * H >= kDecPairs && NS >= 2 && !GREEDY;
     static_assert(H <= 128 && 4 * NQ2 <= kDecThreads, "hidden size too large for the quad roles");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = kDecThreads / 64;
@@ -582,10 +591,18 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
 
         // ---- A: everything that multiplies h_{t-1} -------------------------------------------
         float gh[NS];
-        shared_dots<NS, K0>(w, h_s + half * K0, gh);        // rows >= 6H (phase D rows) compute an unused value
+        if constexpr (DEFER0) {                             // slot 0 (W_hh rows only) waits for phase E
+            gh[0] = 0.f;
+            float gh12[NS - 1];
+            shared_dots<NS - 1, K0>(reinterpret_cast<const float(&)[NS - 1][K0]>(w[1]), h_s + half * K0, gh12);
+#pragma unroll
+            for (int s = 1; s < NS; ++s) gh[s] = gh12[s - 1];
+        } else {
+            shared_dots<NS, K0>(w, h_s + half * K0, gh);    // rows >= 6H (phase D rows) compute an unused value
+        }
         float ghh = 0.f;                                    // W_hh h of this lane's (unit, gate)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
+        for (int s = DEFER0 ? 1 : 0; s < NS; ++s) {
             const int r = s * kDecPairs + pair;
             const float acc = pair_sum(gh[s]);
             if (s * kDecPairs < 4 * H && s < 2) { if (gl.upper == (s == 1)) ghh = acc; }
@@ -650,6 +667,10 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
         GSCAN_STAMP(5)
 
         // ---- E: visual scores over all M cells (no mask: every row has M memories) -----------
+        if constexpr (DEFER0) {   // slot 0's W_hh rows against h_{t-1} (still in h_s: phase F writes h_t)
+            const float g0 = pair_sum(half_dot<K0>(w[0], h_s + half * K0));
+            if (!gl.upper) pre += g0;
+        }
         attention_scores<H>(vv_s, qv_s, PKv, M, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(6)
