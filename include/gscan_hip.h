@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 12
+#define GSCAN_ABI_VERSION 13
 #define GSCAN_MAX_ENC_LAYERS 4
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102).
@@ -93,12 +93,22 @@ typedef struct gscan_batch {
                                   * element crosses PCIe and HBM instead of 4 */
 } gscan_batch;
 
-/* Scaled dropout masks (0 or 1/(1-p)), or NULL for "no dropout" (eval mode / p = 0).
- * cnn [B,G*G,3*Co], enc [B,L,E], dec [B,T,H] in batch-row order; enc_deep only with more than one encoder layer.  The caller either draws
- * them with gscan_dropout_mask() or supplies masks of its own (host-mask parity mode). */
+/* Dropout.  Two forms:
+ *  - in_kernel != 0 (ABI 13, the production mode: SURVEY.md 7 hard part 3): the kernels that apply dropout draw it
+ *    themselves from a counter-based generator (Philox-4x32-10, key = seed, counter = [element | segment | stream_id]):
+ *    no mask ever exists in memory.  p_cnn / p_enc / p_dec are the three drop probabilities (0 = none), the pointers
+ *    cnn / enc / dec are ignored.  forward and backward of one step must be given the same seed and stream_id;
+ *    gscan_dropout_masks_kernel_layout() writes the masks such a step uses (tests, host-mask parity mode).
+ *  - in_kernel == 0: scaled masks in memory (0 or 1/(1-p)), or NULL for "no dropout" (eval mode / p = 0):
+ *    cnn [B,G*G,3*Co], enc [B,L,E], dec [B,T,H] in batch-row order.  The caller draws them with gscan_dropout_mask() or
+ *    supplies masks of its own (host-mask parity mode).
+ * enc_deep (only with more than one encoder layer) is always a mask in memory. */
 typedef struct gscan_masks {
     const float *cnn, *enc, *dec;
     const float *enc_deep;   /* [enc_layers-1, B, L, D*He]: inputs of encoder layers 1.. (nn.LSTM's inter-layer dropout) */
+    int32_t in_kernel;
+    float p_cnn, p_enc, p_dec;
+    uint64_t seed, stream_id;
 } gscan_masks;
 
 int         gscan_abi_version(void);
@@ -260,6 +270,13 @@ int gscan_dropout_masks(float *out, size_t n_cnn, size_t n_enc, size_t n_dec, fl
 
 /* Counter-based (Philox-4x32-10) scaled dropout mask: out[i] = keep ? 1/(1-p) : 0. */
 int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, void *stream);
+
+/* The masks that a step with gscan_masks::in_kernel != 0 and the same (seed, stream_id, p) draws inside its kernels,
+ * written to memory: cnn [B,G*G,3*Co], enc [B,L,E], dec [B,T,H] (a NULL pointer skips that mask; p = 0 gives ones).
+ * Feeding them back through the pointer form of gscan_masks reproduces that step bit for bit: tests, and the way to
+ * hand the masks of a production step to an external checker (the oracle). */
+int gscan_dropout_masks_kernel_layout(const gscan_dims *dims, float *cnn, float *enc, float *dec, float p_cnn, float p_enc,
+                                      float p_dec, uint64_t seed, uint64_t stream_id, void *stream);
 
 /* ---- data-parallel gradient exchange (NOT in the reference, which is single-process: seq2seq/train.py:24,65;
  * SURVEY.md 8(b) `flat_allreduce`, 8(e)).  One RCCL communicator per process (one process per GPU); the all-reduce

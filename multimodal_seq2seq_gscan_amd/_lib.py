@@ -11,7 +11,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # GSCAN_HIP_LIB: development override, used by tools/variants.py to time experimental builds side by side
 LIB_PATH = os.environ.get("GSCAN_HIP_LIB") or os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_ENC_LAYERS = 4
 COMM_ID_BYTES = 128
 
@@ -65,7 +65,9 @@ class Batch(C.Structure):
 
 
 class Masks(C.Structure):
-    _fields_ = [("cnn", C.c_void_p), ("enc", C.c_void_p), ("dec", C.c_void_p), ("enc_deep", C.c_void_p)]
+    _fields_ = [("cnn", C.c_void_p), ("enc", C.c_void_p), ("dec", C.c_void_p), ("enc_deep", C.c_void_p),
+                ("in_kernel", C.c_int32), ("p_cnn", C.c_float), ("p_enc", C.c_float), ("p_dec", C.c_float),
+                ("seed", C.c_uint64), ("stream_id", C.c_uint64)]
 
 
 _vp, _i, _f, _sz, _i64, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64, C.c_uint64
@@ -104,6 +106,7 @@ PROTOTYPES = {
                                    _u64, _u64, _vp]),
     "gscan_trace_set": (_i, [_vp]),
     "gscan_dropout_masks": (_i, [_vp, _sz, _sz, _sz, _f, _f, _f, _u64, _u64, _vp, _vp]),
+    "gscan_dropout_masks_kernel_layout": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _u64, _u64, _vp]),
     "gscan_comm_available": (_i, []),
     "gscan_comm_unique_id": (_i, [_vp]),
     "gscan_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),

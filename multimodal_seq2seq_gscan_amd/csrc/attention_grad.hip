@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kKbThreads, 4) void keys_backward_kernel(KeysBackwa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = mbase + 4 * fg + r;
-            gate[r] = 1.f; mk[r] = 1.f;
+            gate[r] = 1.f; mk[r] = (a.mask == nullptr && a.mask_scale != 0.f) ? a.mask_scale : 1.f;   // drawn in the world encoder
             if (vis && m < mx && col_ok) {
                 const int64_t at = ((int64_t)b * mx + m) * ncols + col;
                 gate[r] = a.feat[at];
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kKbThreads) void keys_backward_any_kernel(KeysBackw
         for (int k = 0; k < H; ++k) acc = fmaf(dpk_s[q * H + k], wsrc[(int64_t)k * ncols + col], acc);
         const int64_t at = ((int64_t)b * mx + m) * ncols + col;
         if (vis) {               // feat = relu(conv) * mask  =>  d conv = (feat != 0) ? d feat * mask : 0
-            const float gate = a.feat[at], mk = a.mask ? a.mask[at] : 1.f;
+            const float gate = a.feat[at], mk = a.mask ? a.mask[at] : (a.mask_scale != 0.f ? a.mask_scale : 1.f);
             a.dfeat[at] = (gate == 0.f) ? 0.f : acc * mk;
         } else {
             a.denc[at] = acc;

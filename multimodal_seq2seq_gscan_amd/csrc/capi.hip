@@ -236,6 +236,13 @@ int gscan_dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t st
     return dropout_mask(out, n, p, seed, stream_id, (hipStream_t)stream);
 }
 
+int gscan_dropout_masks_kernel_layout(const gscan_dims *dims, float *cnn, float *enc, float *dec, float p_cnn, float p_enc,
+                                      float p_dec, uint64_t seed, uint64_t stream_id, void *stream) {
+    ARG(dims, "dropout_masks_kernel_layout: NULL dims");
+    return dropout_masks_kernel_layout(cnn, enc, dec, dims->B, dims->G * dims->G, dims->Co, dims->L, dims->E, dims->T, dims->H,
+                                       p_cnn, p_enc, p_dec, seed, stream_id, (hipStream_t)stream);
+}
+
 int gscan_comm_available(void) { return comm_available(); }
 int gscan_comm_unique_id(void *id_host) { return comm_unique_id(id_host); }
 int gscan_comm_init(void **comm, int nranks, int rank, const void *id_host) { return comm_init(comm, nranks, rank, id_host); }

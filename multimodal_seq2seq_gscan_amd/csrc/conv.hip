@@ -59,6 +59,7 @@ struct ConvArgs {
     const float *img;            // forward: [tap][ch][o]
     const float *b[3];           // forward: biases
     const float *mask;           // forward: [B, G*G, 3Co] scaled keep mask or NULL
+    DropSpec drop;               // forward: drop.on — the dropout is drawn here (dropout.h), `mask` is not read
     float *feat;                 // forward: [B, G*G, 3Co]
     const float *dfeat;          // backward: [B, G*G, 3Co] gradient wrt the pre-activation
     float *gw[3], *gb[3];        // backward: gradients (added to)
@@ -195,7 +196,7 @@ __device__ __forceinline__ void fused_image_chunk(const FusedImageArgs &ia, cons
     }
 }
 
-template <typename T>
+template <typename T, bool DRAWN = false>
 __device__ __forceinline__ void world_conv_fwd_body(const ConvArgs &a, const T *__restrict__ world, int b, int y, int ny,
                                                     uint32_t *flags, int nflags, uint32_t epoch,
                                                     const FusedImageArgs &img_args = FusedImageArgs{}, int late_after = 0,
@@ -254,7 +255,7 @@ __device__ __forceinline__ void world_conv_fwd_body(const ConvArgs &a, const T *
     }
     // an example's (output cell, convolution) pairs are dealt to ny workgroups x 8 waves
     const int ochunks = (Co + 63) >> 6, npairs = M * 3 * ochunks, CoP = conv_row_floats(Co);
-    for (int pair = y * kConvWaves + wave; pair < npairs; pair += ny * kConvWaves) {
+    auto one_pair = [&](int pair, float keep, bool use_keep) {
         const int q = pair / (3 * ochunks), rem = pair - q * 3 * ochunks, conv = rem / ochunks, oc = rem - conv * ochunks;
         const int o = oc * 64 + lane, oo = min(o, Co - 1);
         const int k = conv_ksize(conv, a.K3), h = k >> 1, tap0 = conv_tap0(conv, a.K3);
@@ -274,16 +275,39 @@ __device__ __forceinline__ void world_conv_fwd_body(const ConvArgs &a, const T *
             const int f = conv * Co + o;
             const int64_t at = ((int64_t)b * M + q) * F + f;
             float val = fmaxf(acc + a.b[conv][o], 0.f);
-            if (a.mask) val *= a.mask[at];
+            if (use_keep) val *= keep;
+            else if (a.mask) val *= a.mask[at];
             a.feat[at] = val;
         }
+    };
+    // Dealing.  Masks in memory (or none): pair = first, first + stride, ...  Dropout drawn here (a.drop.on, dropout.h): a
+    // wave takes FOUR consecutive pairs at a time and one Philox call per lane serves them — word j of counter
+    // (b, group, lane) is the keep value of channel `lane` of pair 4 group + j.  (Strided pairs would need a call each;
+    // the longest wave has four pairs either way.)  One call site for both: the pair's code exists once.
+    const bool drawn = DRAWN && a.drop.on != 0;
+    const int stride = ny * kConvWaves, first = y * kConvWaves + wave, ngroups = (npairs + 3) >> 2;
+    uint32_t keep_bits = 0;          // one register across the group's four pairs (the fused launch runs on 63 VGPRs)
+#pragma unroll 1
+    for (int it = 0;; ++it) {
+        int pair;
+        if (drawn) {
+            const int grp = first + (it >> 2) * stride;
+            if (grp >= ngroups) break;
+            if ((it & 3) == 0) keep_bits = drop_quad_bits(a.drop, kDropSegCnn, ((uint64_t)b * ngroups + grp) * 64 + lane);
+            pair = 4 * grp + (it & 3);
+            if (pair >= npairs) continue;
+        } else {
+            pair = first + it * stride;
+            if (pair >= npairs) break;
+        }
+        one_pair(pair, ((keep_bits >> (it & 3)) & 1u) ? a.drop.scale : 0.f, drawn);
     }
 }
 
-template <typename T>
+template <typename T, bool DRAWN = false>
 __global__ __launch_bounds__(kConvThreads) void world_conv_fwd_kernel(ConvArgs a, const T *__restrict__ world) {
     TraceScope trace_scope(TK_CONV_FWD);
-    world_conv_fwd_body<T>(a, world, blockIdx.x, blockIdx.y, gridDim.y, nullptr, 0, 0u);
+    world_conv_fwd_body<T, DRAWN>(a, world, blockIdx.x, blockIdx.y, gridDim.y, nullptr, 0, 0u);
 }
 
 // The step prologue and the world encoder in ONE launch (step.hip's default prelude).  The two have nothing in common
@@ -306,7 +330,7 @@ struct FusedPrologueArgs {
     int acquire;                // agent-scope acquire between the flags and the first read of the image
     int skip_image;             // test hook: the image workgroups do nothing (every chunk is then self-served)
 };
-template <typename T>
+template <typename T, bool DRAWN = false>
 __global__ __launch_bounds__(kConvThreads, 8) void prologue_world_kernel(PrologueArgs pa, ConvArgs a, FusedPrologueArgs f,
                                                                          const T *__restrict__ world) {
     TraceScope trace_scope(TK_PROLOGUE);
@@ -334,11 +358,11 @@ __global__ __launch_bounds__(kConvThreads, 8) void prologue_world_kernel(Prologu
     if (!is_conv) {
         const int64_t total = pa.end[13];
         for (int64_t idx = (int64_t)pb * kConvThreads + threadIdx.x; idx < total; idx += (int64_t)f.n_pro * kConvThreads)
-            prologue_element<8>(pa, idx);
+            prologue_element<8, DRAWN>(pa, idx);
         return;
     }
-    world_conv_fwd_body(a, world, cb % f.n_examples, cb / f.n_examples, f.ny, f.flags, f.n_img, f.epoch, ia, f.late_after,
-                        f.acquire != 0);
+    world_conv_fwd_body<T, DRAWN>(a, world, cb % f.n_examples, cb / f.n_examples, f.ny, f.flags, f.n_img, f.epoch, ia,
+                                  f.late_after, f.acquire != 0);
 }
 
 // Backward, pass 1: the non-zeros of input channel ch among the examples of batch segment s, compacted in scan
@@ -467,18 +491,24 @@ static int conv_check(int B, int G, int C, int Co, int K3) {
 }
 
 int world_conv_forward(const void *world, int world_is_u8, const float *img, const float *const (&b)[3],
-                       const float *mask, int B, int G, int C, int Co, int K3, float *feat, hipStream_t stream) {
+                       const float *mask, int B, int G, int C, int Co, int K3, float *feat, hipStream_t stream,
+                       const DropSpec *drop) {
     TRY_RC(conv_check(B, G, C, Co, K3));
     const size_t lds = (size_t)G * G * C * 8 + 4 * kConvWaves;
     GSCAN_CHECK(lds <= 128 * 1024, "world encoder: a %dx%dx%d world does not fit the non-zero list in LDS", G, G, C);
     ConvArgs a{};
     a.B = B; a.G = G; a.C = C; a.Co = Co; a.K3 = K3; a.img = img; a.mask = mask; a.feat = feat;
+    if (drop) a.drop = *drop;
     for (int i = 0; i < 3; ++i) a.b[i] = b[i];
     static bool attr_set = false;
     if (!attr_set) {
-        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&world_conv_fwd_kernel<float>),
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&world_conv_fwd_kernel<float, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&world_conv_fwd_kernel<uint8_t>),
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&world_conv_fwd_kernel<uint8_t, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&world_conv_fwd_kernel<float, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&world_conv_fwd_kernel<uint8_t, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
@@ -486,12 +516,14 @@ int world_conv_forward(const void *world, int world_is_u8, const float *img, con
     // four workgroups per example: 32 waves per CU keep ~256 row loads in flight, and the examples' unequal numbers
     // of non-zeros (5 ... 38) spread over the chip instead of one CU carrying the heaviest example alone
     const dim3 grid(B, 4);
-    if (world_is_u8)
-        hipLaunchKernelGGL(world_conv_fwd_kernel<uint8_t>, grid, dim3(kConvThreads), lds, stream, a,
-                           static_cast<const uint8_t *>(world));
-    else
-        hipLaunchKernelGGL(world_conv_fwd_kernel<float>, grid, dim3(kConvThreads), lds, stream, a,
-                           static_cast<const float *>(world));
+    const bool drawn = a.drop.on != 0;                      // dropout drawn in the kernel: its own instantiation
+    if (world_is_u8) {
+        if (drawn) hipLaunchKernelGGL((world_conv_fwd_kernel<uint8_t, true>), grid, dim3(kConvThreads), lds, stream, a, static_cast<const uint8_t *>(world));
+        else hipLaunchKernelGGL((world_conv_fwd_kernel<uint8_t, false>), grid, dim3(kConvThreads), lds, stream, a, static_cast<const uint8_t *>(world));
+    } else {
+        if (drawn) hipLaunchKernelGGL((world_conv_fwd_kernel<float, true>), grid, dim3(kConvThreads), lds, stream, a, static_cast<const float *>(world));
+        else hipLaunchKernelGGL((world_conv_fwd_kernel<float, false>), grid, dim3(kConvThreads), lds, stream, a, static_cast<const float *>(world));
+    }
     GSCAN_LAUNCHED("world_conv_fwd_kernel");
     return 0;
 }
@@ -501,19 +533,24 @@ int world_conv_forward(const void *world, int world_is_u8, const float *img, con
 // words of the workspace.  Returns -1 (nothing launched) when the shape does not fit the fused form.
 int prologue_world_forward(const PrologueArgs &pa, const void *world, int world_is_u8, const float *const (&b)[3],
                            const float *mask, int B, int G, int C, int Co, int K3, float *feat, uint32_t *flags,
-                           hipStream_t stream) {
+                           hipStream_t stream, const DropSpec *drop) {
     TRY_RC(conv_check(B, G, C, Co, K3));
     const size_t lds = (size_t)G * G * C * 8 + 4 * kConvWaves;
     const int n_img = cdiv(conv_image_floats(C, Co, K3), kImageElems);
     if (lds > 128 * 1024 || n_img > kFusedMaxFlags || pa.end[10] != pa.end[9]) return -1;
     ConvArgs a{};
     a.B = B; a.G = G; a.C = C; a.Co = Co; a.K3 = K3; a.img = pa.conv_img; a.mask = mask; a.feat = feat;
+    if (drop) a.drop = *drop;
     for (int i = 0; i < 3; ++i) a.b[i] = b[i];
     static bool attr_set = false;
     if (!attr_set) {
-        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_world_kernel<float>),
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_world_kernel<float, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_world_kernel<uint8_t>),
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_world_kernel<uint8_t, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_world_kernel<float, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_world_kernel<uint8_t, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
@@ -543,12 +580,14 @@ int prologue_world_forward(const PrologueArgs &pa, const void *world, int world_
     f.late_after = late_after; f.acquire = acquire; f.skip_image = skip;
     ProbeScope probe(P_CONV_FWD, stream, 0.0, conv_algorithmic_flops(B, G, C, Co, K3));
     const dim3 grid(f.n_img + f.n_pro + B * f.ny);
-    if (world_is_u8)
-        hipLaunchKernelGGL(prologue_world_kernel<uint8_t>, grid, dim3(kConvThreads), lds, stream, pa, a, f,
-                           static_cast<const uint8_t *>(world));
-    else
-        hipLaunchKernelGGL(prologue_world_kernel<float>, grid, dim3(kConvThreads), lds, stream, pa, a, f,
-                           static_cast<const float *>(world));
+    const bool drawn = a.drop.on || pa.drop_enc.on || pa.drop_dec.on;     // any dropout drawn in this launch: its own instantiation
+    if (world_is_u8) {
+        if (drawn) hipLaunchKernelGGL((prologue_world_kernel<uint8_t, true>), grid, dim3(kConvThreads), lds, stream, pa, a, f, static_cast<const uint8_t *>(world));
+        else hipLaunchKernelGGL((prologue_world_kernel<uint8_t, false>), grid, dim3(kConvThreads), lds, stream, pa, a, f, static_cast<const uint8_t *>(world));
+    } else {
+        if (drawn) hipLaunchKernelGGL((prologue_world_kernel<float, true>), grid, dim3(kConvThreads), lds, stream, pa, a, f, static_cast<const float *>(world));
+        else hipLaunchKernelGGL((prologue_world_kernel<float, false>), grid, dim3(kConvThreads), lds, stream, pa, a, f, static_cast<const float *>(world));
+    }
     GSCAN_LAUNCHED("prologue_world_kernel");
     return 0;
 }

@@ -294,6 +294,55 @@ int adam_step_masks(float *param, float *grad, float *exp_avg, float *exp_avg_sq
     return 0;
 }
 
+// The masks a step with dropout drawn in its kernels uses (dropout.h), written to memory: one thread per Philox counter of
+// each segment.  cnn [B, M, 3Co], enc [rows_e, E], dec [rows_d, H]; a NULL pointer skips the segment.
+__global__ void dropout_kernel_layout_kernel(float *__restrict__ cnn, float *__restrict__ enc, float *__restrict__ dec,
+                                             DropSpec dc, DropSpec de, DropSpec dd, int B, int M, int Co, int64_t rows_e,
+                                             int E, int64_t rows_d, int H) {
+    const int ochunks = (Co + 63) >> 6, npairs = M * 3 * ochunks, ngroups = (npairs + 3) >> 2, F = 3 * Co;
+    const int64_t n_c = cnn ? (int64_t)B * ngroups * 64 : 0, n_e = enc ? (rows_e + 3) / 4 * E : 0, n_d = dec ? (rows_d + 3) / 4 * H : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_c + n_e + n_d; i += (int64_t)gridDim.x * blockDim.x) {
+        float keep[4];
+        if (i < n_c) {
+            const int lane = (int)(i & 63);
+            const int64_t bg = i >> 6;
+            const int b = (int)(bg / ngroups), grp = (int)(bg - (int64_t)b * ngroups);
+            drop_quad(dc, kDropSegCnn, (uint64_t)i, keep);
+            for (int j = 0; j < 4; ++j) {
+                const int pair = 4 * grp + j;
+                if (pair >= npairs) continue;
+                const int q = pair / (3 * ochunks), rem = pair - q * 3 * ochunks, conv = rem / ochunks, oc = rem - conv * ochunks;
+                const int o = oc * 64 + lane;
+                if (o < Co) cnn[((int64_t)b * M + q) * F + conv * Co + o] = dc.on ? keep[j] : 1.f;
+            }
+        } else if (i < n_c + n_e) {
+            const int64_t k = i - n_c, rq = k / E;
+            const int d = (int)(k - rq * E);
+            drop_quad(de, kDropSegEnc, (uint64_t)k, keep);
+            for (int j = 0; j < 4; ++j)
+                if (4 * rq + j < rows_e) enc[(4 * rq + j) * E + d] = de.on ? keep[j] : 1.f;
+        } else {
+            const int64_t k = i - n_c - n_e, rq = k / H;
+            const int d = (int)(k - rq * H);
+            drop_quad(dd, kDropSegDec, (uint64_t)k, keep);
+            for (int j = 0; j < 4; ++j)
+                if (4 * rq + j < rows_d) dec[(4 * rq + j) * H + d] = dd.on ? keep[j] : 1.f;
+        }
+    }
+}
+
+int dropout_masks_kernel_layout(float *cnn, float *enc, float *dec, int B, int M, int Co, int L, int E, int T, int H,
+                                float p_cnn, float p_enc, float p_dec, uint64_t seed, uint64_t stream_id, hipStream_t stream) {
+    for (float p : {p_cnn, p_enc, p_dec}) GSCAN_CHECK(p >= 0.f && p < 1.f, "dropout: p=%g out of [0,1)", p);
+    GSCAN_CHECK(B > 0 && M > 0 && Co > 0 && L > 0 && E > 0 && T > 0 && H > 0, "dropout_masks_kernel_layout: bad dimensions");
+    const int64_t total = (int64_t)B * drop_cnn_groups(M, Co) * 64 + ((int64_t)B * L + 3) / 4 * E + ((int64_t)B * T + 3) / 4 * H;
+    hipLaunchKernelGGL(dropout_kernel_layout_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, stream,
+                       cnn, enc, dec, drop_spec(true, seed, stream_id, p_cnn), drop_spec(true, seed, stream_id, p_enc),
+                       drop_spec(true, seed, stream_id, p_dec), B, M, Co, (int64_t)B * L, E, (int64_t)B * T, H);
+    GSCAN_LAUNCHED("dropout_kernel_layout_kernel");
+    return 0;
+}
+
 int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream) {
     const size_t ns[3] = {n, 0, 0};
     const float ps[3] = {p, 0.f, 0.f};
@@ -320,12 +369,13 @@ int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_i
 //          W_q2k[:, ctx_text] . W_key_text
 // ------------------------------------------------------------------------------------------
 
+template <bool DRAWN>
 __global__ void prologue_kernel(PrologueArgs a) {
     TraceScope trace_scope(TK_PROLOGUE);
     const int64_t total = a.end[13];
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x)
-        prologue_element<20>(a, idx);
+        prologue_element<20, DRAWN>(a, idx);
 }
 
 int step_prologue(const PrologueArgs &args, hipStream_t stream) {
@@ -334,8 +384,9 @@ int step_prologue(const PrologueArgs &args, hipStream_t stream) {
     // two passes per thread at most at the benchmark shape (the kernel is chains of dependent loads, not bandwidth;
     // 2048 / 4096 / 8192 / 16384 workgroups: 0.521 / 0.517 / 0.523 / 0.524 ms per step)
     static const int cap = [] { const char *e = getenv("GSCAN_PROLOGUE_BLOCKS"); return e ? atoi(e) : 4096; }();
-    hipLaunchKernelGGL(prologue_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), cap)), dim3(256), 0, stream,
-                       args);
+    const dim3 grid((int)std::min<int64_t>(cdiv(total, 256), cap));
+    if (args.drop_enc.on || args.drop_dec.on) hipLaunchKernelGGL(prologue_kernel<true>, grid, dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL(prologue_kernel<false>, grid, dim3(256), 0, stream, args);
     GSCAN_LAUNCHED("prologue_kernel");
     return 0;
 }

@@ -6,7 +6,9 @@
 
 namespace gscan {
 
-template <int U>
+// DRAWN: the embedding dropout is drawn here (a.drop_enc / a.drop_dec, dropout.h) — a separate instantiation, so that the
+// launches with masks in memory keep the code (and the registers) they had.
+template <int U, bool DRAWN = false>
 __device__ __forceinline__ void prologue_element(const PrologueArgs &a, int64_t idx) {
     const int H = a.H;
     if (idx < a.end[0]) {
@@ -51,20 +53,54 @@ __device__ __forceinline__ void prologue_element(const PrologueArgs &a, int64_t 
         a.dwc[idx - a.end[2]] = 0.f;
     } else if (idx < a.end[4]) {
         const int64_t i = idx - a.end[3];
-        const int64_t row = i / a.E;
-        const int d = (int)(i % a.E);
-        const int64_t t = a.commands[row];
-        float v = (t >= 0 && t < a.Vi) ? a.enc_emb[t * a.E + d] : 0.f;
-        if (a.mask_enc) v *= a.mask_enc[i];
-        a.xe[i] = v;
+        if (DRAWN && a.drop_enc.on) {    // (four rows, column): one Philox call, four gathers (dropout.h)
+            const int64_t rq = i / a.E;
+            const int d = (int)(i % a.E);
+            const DropSpec ds = drop_spec_here(a.drop_enc);
+            const uint32_t bits = drop_quad_bits(ds, kDropSegEnc, (uint64_t)i);
+#pragma unroll 1                         // one row at a time: this launch runs on 63 VGPRs (conv.hip)
+            for (int j = 0; j < 4; ++j) {
+                const int64_t row = 4 * rq + j;
+                if (row < a.BL) {
+                    const int64_t t = a.commands[row];
+                    const float keep = ((bits >> j) & 1u) ? ds.scale : 0.f;
+                    a.xe[row * a.E + d] = (t >= 0 && t < a.Vi) ? a.enc_emb[t * a.E + d] * keep : 0.f;
+                    a.mask_enc_out[row * a.E + d] = keep;        // for the embedding gradient of the backward pass
+                }
+            }
+        } else {
+            const int64_t row = i / a.E;
+            const int d = (int)(i % a.E);
+            const int64_t t = a.commands[row];
+            float v = (t >= 0 && t < a.Vi) ? a.enc_emb[t * a.E + d] : 0.f;
+            if (a.mask_enc) v *= a.mask_enc[i];
+            a.xe[i] = v;
+        }
     } else if (idx < a.end[5]) {
         const int64_t i = idx - a.end[4];
-        const int64_t row = i / H;
-        const int d = (int)(i % H);
-        const int64_t t = a.targets[row];
-        float v = (t >= 0 && t < a.V) ? a.dec_emb[t * H + d] : 0.f;
-        if (a.mask_dec) v *= a.mask_dec[i];
-        a.S[row * 4 * H + d] = v;
+        if (DRAWN && a.drop_dec.on) {
+            const int64_t rq = i / H;
+            const int d = (int)(i % H);
+            const DropSpec ds = drop_spec_here(a.drop_dec);
+            const uint32_t bits = drop_quad_bits(ds, kDropSegDec, (uint64_t)i);
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const int64_t row = 4 * rq + j;
+                if (row < a.BT) {
+                    const int64_t t = a.targets[row];
+                    const float keep = ((bits >> j) & 1u) ? ds.scale : 0.f;
+                    a.S[row * 4 * H + d] = (t >= 0 && t < a.V) ? a.dec_emb[t * H + d] * keep : 0.f;
+                    a.mask_dec_out[row * H + d] = keep;
+                }
+            }
+        } else {
+            const int64_t row = i / H;
+            const int d = (int)(i % H);
+            const int64_t t = a.targets[row];
+            float v = (t >= 0 && t < a.V) ? a.dec_emb[t * H + d] : 0.f;
+            if (a.mask_dec) v *= a.mask_dec[i];
+            a.S[row * 4 * H + d] = v;
+        }
     } else if (idx < a.end[6]) {
         const int64_t i = idx - a.end[5];
         const int row = (int)(i / (3 * H)), col = (int)(i % (3 * H));

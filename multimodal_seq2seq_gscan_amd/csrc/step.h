@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "gscan_hip.h"
+#include "dropout.h"
 
 namespace gscan {
 
@@ -147,6 +148,11 @@ struct PrologueArgs {
     int cond;
     int64_t zero_extra_count;
     int H, He, E, D, BL, BT, Vi, V;
+    // drop_enc.on / drop_dec.on: the embedding dropout is drawn in the gather (dropout.h); segments 4 / 5 then have one
+    // element per (FOUR rows, column), mask_enc / mask_dec are not read and the keep values go to mask_enc_out /
+    // mask_dec_out ([BL,E], [BT,H]: the embedding gradients of the backward pass read them there)
+    DropSpec drop_enc, drop_dec;
+    float *mask_enc_out, *mask_dec_out;
     int64_t end[14];
     DecoderImageArgs img;
     // seg 9: register image of the encoder's recurrent weights, [dir][r][k][thread] (lstm_encoder.hip)
@@ -182,6 +188,8 @@ int adam_step_masks(float *param, float *grad, float *exp_avg, float *exp_avg_sq
 void adam_scalars(float lr, float beta1, float beta2, float lr_decay, float lr_decay_steps, int64_t step,
                   float *step_size, float *inv_sqrt_bc2);
 int dropout_mask(float *out, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t stream);
+int dropout_masks_kernel_layout(float *cnn, float *enc, float *dec, int B, int M, int Co, int L, int E, int T, int H,
+                                float p_cnn, float p_enc, float p_dec, uint64_t seed, uint64_t stream_id, hipStream_t stream);
 int dropout_masks(float *out, const size_t (&n)[3], const float (&p)[3], uint64_t seed, uint64_t stream_id,
                   const uint64_t *dev_stream_id, hipStream_t stream);
 // in-kernel timeline (common.h): one setter per translation unit with kernels
@@ -222,12 +230,13 @@ __device__ __forceinline__ float conv_image_element(const float *w1, const float
 #endif
 int conv_weight_image(const float *const (&w)[3], int C, int Co, int K3, float *img, hipStream_t stream);
 int world_conv_forward(const void *world, int world_is_u8, const float *img, const float *const (&b)[3],
-                       const float *mask, int B, int G, int C, int Co, int K3, float *feat, hipStream_t stream);
+                       const float *mask, int B, int G, int C, int Co, int K3, float *feat, hipStream_t stream,
+                       const DropSpec *drop = nullptr);
 // the step prologue and the world encoder in one launch (conv.hip); -1: the shape does not fit, nothing was launched
 constexpr int kFusedMaxFlags = 512;
 int prologue_world_forward(const PrologueArgs &pa, const void *world, int world_is_u8, const float *const (&b)[3],
                            const float *mask, int B, int G, int C, int Co, int K3, float *feat, uint32_t *flags,
-                           hipStream_t stream);
+                           hipStream_t stream, const DropSpec *drop = nullptr);
 size_t world_conv_backward_scratch_floats(int B, int G, int C);
 int world_conv_lists(const void *world, int world_is_u8, int B, int G, int C, float *scratch, hipStream_t stream);
 size_t world_conv_bias_partial_floats(int B, int G, int Co);
@@ -356,6 +365,8 @@ struct KeysBackwardArgs {
     const float *dh0;                      // [B,H]
     const float *w_kt, *w_kv, *w_b;        // [H,He] [H,F] [H,He]
     const float *feat, *mask;              // [B,M,F]; mask may be NULL
+    float mask_scale;                      // mask == NULL and != 0: dropout was drawn in the world encoder (dropout.h): the
+                                           // gradient passes where feat != 0, times 1 / (1 - p)
     float *denc, *dhN, *dfeat;             // [B,L,He] [B,He] [B,M,F]
 };
 int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream);
@@ -392,7 +403,8 @@ struct Workspace {
         dwc, wih_stack, wih_t, w_sk, w_ck, w_2kk, dec_w_fwd, dec_w_bwd, enc_w_image, conv_img, conv_flags, conv_lists, wcat5,
         deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image,   // encoder layers below the last
         ge_table, head_wc,        // [V,4H] tables: greedy decoding's embedded gates; the composite head
-        gemm_slabs_side, gemm_slabs_main, conv_bias_part, embed_part_dec, embed_part_enc;
+        gemm_slabs_side, gemm_slabs_main, conv_bias_part, embed_part_dec, embed_part_enc,
+        drawn_mask_enc, drawn_mask_dec;    // [B,L,E] [B,T,H]: embedding dropout drawn in the gathers, kept for the backward pass
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;

@@ -123,6 +123,8 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(deep_image, deep * D * 4 * He * He);
     SLOT(ge_table, V * 4 * H);                       // greedy decoding: Emb . W_ih[:, :H]^T + biases
     SLOT(head_wc, V * 4 * H);                        // the output head as one matrix: W_h2o . W_o2h (S order), step prologue
+    SLOT(drawn_mask_enc, B * L * E);                 // dropout drawn in the kernels (gscan_masks::in_kernel): the embedding
+    SLOT(drawn_mask_dec, B * T * H);                 // gathers leave their keep values here for the embedding gradients
 #undef SLOT
     ws->nslots = n;
     ws->total_floats = p;
@@ -253,6 +255,19 @@ static int order_after(hipStream_t waiter, hipStream_t signaller, hipStream_t wa
 // `given` (Model.decode_input_batched, model.py:190-204): the encodings come from the caller — the two encoders are
 // skipped, the given tensors take the place of their outputs in the workspace and everything behind them runs.
 struct GivenEncodings { const float *feat, *enc_out, *hN; };   // [B,G*G,3Co] [B,L,He] [B,He]
+// the dropout of segment `seg` as the kernels see it: drawn in the kernels (gscan_masks::in_kernel) or, if not, the mask
+// pointer decides as before
+static DropSpec drop_of(const gscan_masks &mk, int seg) {
+    const float p = seg == kDropSegCnn ? mk.p_cnn : seg == kDropSegEnc ? mk.p_enc : mk.p_dec;
+    return drop_spec(mk.in_kernel != 0, mk.seed, mk.stream_id, p);
+}
+static int check_drop(const gscan_masks &mk) {
+    if (!mk.in_kernel) return 0;
+    for (float p : {mk.p_cnn, mk.p_enc, mk.p_dec})
+        GSCAN_CHECK(p >= 0.f && p < 1.f, "dropout drawn in the kernels: p=%g out of [0,1)", p);
+    return 0;
+}
+
 static int encode_branches(const gscan_dims &d, const gscan_params &p, const gscan_batch &bt, const gscan_masks &mk,
                            float *w, const Workspace &ws, bool teacher_forced, hipStream_t st,
                            const GivenEncodings *given = nullptr) {
@@ -265,6 +280,8 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
     GSCAN_CHECK(bt.cmd_lengths && (given || (bt.commands && (bt.world || bt.world_u8))) && (!teacher_forced || bt.targets),
                 "forward: NULL array in the batch");
     TRY(side_init());
+    TRY(check_drop(mk));
+    const DropSpec drop_cnn = drop_of(mk, kDropSegCnn), drop_enc = drop_of(mk, kDropSegEnc), drop_dec = drop_of(mk, kDropSegDec);
     hipStream_t sd = g_side.single ? st : g_side.stream;
 
     // ================= prelude schedule ============================================================================
@@ -284,7 +301,9 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         PrologueArgs a{};
         a.b_ih = p.dec_b_ih; a.b_hh = p.dec_b_hh; a.w_o2h = p.out2hid_w; a.w_h2o = p.hid2out_w;
         a.w_ih_f = p.enc_w_ih; a.w_ih_r = p.enc_w_ih_rev; a.enc_emb = p.enc_emb; a.dec_emb = p.dec_emb;
-        a.mask_enc = mk.enc; a.mask_dec = mk.dec; a.commands = bt.commands;
+        a.mask_enc = mk.in_kernel ? nullptr : mk.enc; a.mask_dec = mk.in_kernel ? nullptr : mk.dec; a.commands = bt.commands;
+        a.drop_enc = drop_enc; a.drop_dec = drop_dec;
+        a.mask_enc_out = w + ws.drawn_mask_enc; a.mask_dec_out = w + ws.drawn_mask_dec;
         a.targets = teacher_forced ? bt.targets : nullptr;
         a.bsum = w + ws.bsum; a.head_wc = w + ws.head_wc; a.wih_stack = w + ws.wih_stack; a.wih_t = w + ws.wih_t;
         a.dwc = w + ws.dwc; a.xe = w + ws.xe; a.S = w + ws.S;
@@ -307,7 +326,9 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         a.w_key_vis = p.vis_key_w; a.w_key_txt = p.txt_key_w; a.F = F;
         a.w_sk = w + ws.w_sk; a.w_ck = w + ws.w_ck; a.w_2kk = w + ws.w_2kk;
         const int64_t n[14] = {4 * H, (int64_t)V * 4 * H, (int64_t)D * 4 * He * (E + 1), (int64_t)V * 4 * H,
-                               given ? 0 : (int64_t)B * L * E, teacher_forced ? (int64_t)B * T * H : 0, (int64_t)5 * H * 3 * H,
+                               given ? 0 : (drop_enc.on ? (int64_t)cdiv((int64_t)B * L, 4) * E : (int64_t)B * L * E),   // in-kernel dropout: an element per (four rows, column)
+                               teacher_forced ? (drop_dec.on ? (int64_t)cdiv((int64_t)B * T, 4) * H : (int64_t)B * T * H) : 0,
+                               (int64_t)5 * H * 3 * H,
                                a.zero_extra_count, fast ? 2 * geo.image_floats : 0,
                                encoder_fast_supported(He, L, E) ? (int64_t)D * 4 * He * He : 0,
                                (given || fuse_world) ? 0 : conv_image_floats(C, Co, d.K3),
@@ -323,8 +344,8 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         if (fuse_world) {
             const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
             return prologue_world_forward(a, bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world,
-                                          bt.world_u8 != nullptr, cb, mk.cnn, B, d.G, C, Co, d.K3, w + ws.feat,
-                                          reinterpret_cast<uint32_t *>(w + ws.conv_flags), stream);
+                                          bt.world_u8 != nullptr, cb, mk.in_kernel ? nullptr : mk.cnn, B, d.G, C, Co, d.K3, w + ws.feat,
+                                          reinterpret_cast<uint32_t *>(w + ws.conv_flags), stream, &drop_cnn);
         }
         return step_prologue(a, stream);
     };
@@ -356,7 +377,8 @@ static int encode_branches(const gscan_dims &d, const gscan_params &p, const gsc
         }
         const float *const cb[3] = {p.conv1_b, p.conv2_b, p.conv3_b};
         return world_conv_forward(bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world, bt.world_u8 != nullptr,
-                                  w + ws.conv_img, cb, mk.cnn, B, d.G, C, Co, d.K3, w + ws.feat, stream);
+                                  w + ws.conv_img, cb, mk.in_kernel ? nullptr : mk.cnn, B, d.G, C, Co, d.K3, w + ws.feat, stream,
+                                  &drop_cnn);
     };
     // Default: the whole prelude on the caller's stream — one prologue, the world encoder, the recurrence, and ONE GEMM
     // launch with every dense product.  No cross-stream event: each costs 25-30 us of latency on this stack (record ->
@@ -578,6 +600,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     const int BT = B * T, BL = B * L, BM_ = B * M;
     const bool cond = d.conditional != 0;
     GSCAN_CHECK(dlogp || nll, "backward: dlogp is NULL");
+    TRY(check_drop(mk));
+    const DropSpec drop_cnn = drop_of(mk, kDropSegCnn), drop_enc = drop_of(mk, kDropSegEnc), drop_dec = drop_of(mk, kDropSegDec);
     // deterministic mode (GSCAN_DETERMINISTIC=1): every sum formed across workgroups in a fixed order — split-K partial
     // tiles through slabs (gemm_mt.hip), embedding and convolution-bias gradients by their ordered kernels
     const bool ordered_sums = gemm_macro_tile_mode() > 0;
@@ -648,8 +672,9 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
             TRY(b.launch(sd));
             TRY(head_grad_finish(w + ws.dwc, p.hid2out_w, p.out2hid_w, g.out2hid_w, g.hid2out_w, H, V, sd, w + ws.dv_t,
                                  w + ws.dv_v, B, g.txt_energy_w, g.vis_energy_w));
-            TRY(embed_grad(bt.targets, dS, 4 * H, mk.dec, BT, H, V, d.pad_tgt, g.dec_emb, sd,
-                           ordered_sums ? w + ws.embed_part_dec : nullptr));
+            // (dropout drawn in the kernels: the gather of the forward pass left its keep values in the workspace)
+            TRY(embed_grad(bt.targets, dS, 4 * H, mk.in_kernel ? (drop_dec.on ? w + ws.drawn_mask_dec : nullptr) : mk.dec, BT, H,
+                           V, d.pad_tgt, g.dec_emb, sd, ordered_sums ? w + ws.embed_part_dec : nullptr));
         }
         return 0;
     };
@@ -658,7 +683,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     k.alpha_c = w + ws.alpha_c; k.alpha_s = w + ws.alpha_s; k.ds = dS;
     k.dpk_t = w + ws.dpk_t; k.dpk_v = w + ws.dpk_v; k.dh0 = w + ws.dh0;
     k.w_kt = p.txt_key_w; k.w_kv = p.vis_key_w; k.w_b = p.bridge_w;
-    k.feat = w + ws.feat; k.mask = mk.cnn;
+    k.feat = w + ws.feat; k.mask = mk.in_kernel ? nullptr : mk.cnn;
+    k.mask_scale = drop_cnn.on ? drop_cnn.scale : 0.f;
     k.denc = w + ws.denc; k.dhN = w + ws.dhN; k.dfeat = w + ws.dfeat;
     float *const gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
     float *const gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
@@ -747,8 +773,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         g_split_override = 0;
         TRY(b.launch(st));
     }
-    TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.enc, BL, E, d.Vi, d.pad_in, g.enc_emb, st,
-                   ordered_sums ? w + ws.embed_part_enc : nullptr));
+    TRY(embed_grad(bt.commands, w + ws.dxe, E, mk.in_kernel ? (drop_enc.on ? w + ws.drawn_mask_enc : nullptr) : mk.enc, BL, E,
+                   d.Vi, d.pad_in, g.enc_emb, st, ordered_sums ? w + ws.embed_part_enc : nullptr));
     // join: every gradient is complete when the caller's stream continues.  Side 1 (done long before) waits for side 2,
     // the caller's stream for side 1: ONE wait packet in front of the optimiser instead of two (each costs the queue
     // ~2.5 us even when its event completed long ago)

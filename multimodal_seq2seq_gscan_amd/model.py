@@ -112,6 +112,12 @@ class _DecoderParams(_Holder):
         return message.clone(), message.clone()
 
 
+def _dropout_in_kernel() -> bool:
+    """GSCAN_DROPOUT_IN_KERNEL (default 1): training-mode dropout is drawn inside the kernels that apply it; 0: masks in
+    memory (round 4's path, kept for A/B runs)."""
+    return os.environ.get("GSCAN_DROPOUT_IN_KERNEL", "1") != "0"
+
+
 def _as_int32_lengths(lengths, device) -> torch.Tensor:
     """Lengths arrive as lists, numpy float64 arrays (gSCAN_dataset.py:276) or tensors."""
     if isinstance(lengths, torch.Tensor):
@@ -256,6 +262,7 @@ class Model(nn.Module):
         self._workspace: Optional[torch.Tensor] = None
         self._generation = 0
         self._host_masks = None
+        self._kernel_drop = None         # (seed, Philox stream id) of dropout the next launch draws inside its kernels
         self._dropout_seed = int(kwargs.get("seed", 42))
         self._dropout_calls = 0
         self._dropout_rank = 0
@@ -373,13 +380,52 @@ class Model(nn.Module):
         (4 bits) | draw counter (40 bits)]; the seed is the Philox key."""
         return (self._dropout_rank << 44) | (int(deep) << 40) | (self._dropout_calls & ((1 << 40) - 1))
 
-    def _draw_masks(self, B: int, L: int, T: int, M: int, device) -> Tuple[Optional[torch.Tensor], ...]:
+    def _deep_masks(self, B: int, L: int, device, deep_stream: int) -> Optional[torch.Tensor]:
+        """nn.LSTM(dropout=p) drops the outputs of every layer but the last (seq2seq_model.py:44-45): masks in memory."""
+        h = self._hyper
+        if h["NL"] <= 1 or self.dropout_p[1] <= 0.0:
+            return None
+        D = 2 if self.encoder_bidirectional else 1
+        shape = (h["NL"] - 1, B, L, D * h["He"])
+        n = shape[0] * shape[1] * shape[2] * shape[3]
+        if self._mask_buffer_deep is None or self._mask_buffer_deep.numel() != n:
+            self._mask_buffer_deep = torch.empty(n, dtype=torch.float32, device=device)
+        _lib.check(_lib.load().gscan_dropout_mask(self._mask_buffer_deep.data_ptr(), n, self.dropout_p[1],
+                                                  self._dropout_seed, deep_stream,
+                                                  torch.cuda.current_stream().cuda_stream), "gscan_dropout_mask")
+        return self._mask_buffer_deep.view(shape)
+
+    def _draw_masks(self, B: int, L: int, T: int, M: int, device, materialize: bool = False) -> Tuple[Optional[torch.Tensor], ...]:
+        """The dropout of the next training-mode forward call.  Production mode (SURVEY.md 7 hard part 3, round 5): the
+        masks are DRAWN INSIDE THE KERNELS that apply them (csrc/dropout.h) — this only fixes (seed, Philox stream id)
+        for `_launch_forward`, returns no tensors and launches nothing.  `materialize=True` returns the same masks as
+        tensors instead (gscan_dropout_masks_kernel_layout; a step fed with them through `set_dropout_masks` equals the
+        in-kernel step bit for bit).  GSCAN_DROPOUT_IN_KERNEL=0: round 4's masks in memory, drawn by one Philox launch
+        (or by the previous step's optimiser launch)."""
+        self._kernel_drop = None
         if self._host_masks is not None:
             masks, self._host_masks = self._host_masks, None
             return tuple(None if m is None else m.to(device=device, dtype=torch.float32).contiguous()
                          for m in masks)
         if not self.training or max(self.dropout_p) <= 0.0:
             return (None, None, None)
+        if _dropout_in_kernel():
+            stream_id, deep_stream = self._philox_stream(), self._philox_stream(deep=True)
+            self._dropout_calls += 1
+            deep = self._deep_masks(B, L, device, deep_stream)
+            if materialize:
+                h = self._hyper
+                out = [torch.empty(s, dtype=torch.float32, device=device)
+                       for s in ((B, M, 3 * h["Co"]), (B, L, h["E"]), (B, T, h["H"]))]
+                dims = self._dims(B, L, T, int(round(M ** 0.5)))
+                _lib.check(_lib.load().gscan_dropout_masks_kernel_layout(
+                    C.byref(dims), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), self.dropout_p[0],
+                    self.dropout_p[1], self.dropout_p[2], self._dropout_seed, stream_id,
+                    torch.cuda.current_stream().cuda_stream), "gscan_dropout_masks_kernel_layout")
+                out = [m if p > 0.0 else None for m, p in zip(out, self.dropout_p)]
+                return tuple(out) + ((deep,) if deep is not None else ())
+            self._kernel_drop = (self._dropout_seed, stream_id)
+            return (None, None, None) + ((deep,) if deep is not None else ())
         # the three masks of a step are one buffer filled by one Philox launch (cnn | enc | dec)
         lib = _lib.load()
         h = self._hyper
@@ -416,17 +462,9 @@ class Model(nn.Module):
         for shape, n, cap, p in zip(shapes, sizes, caps, self.dropout_p):
             out.append(buf[off:off + n].view(shape) if p > 0.0 else None)
             off += cap
-        if h["NL"] > 1 and self.dropout_p[1] > 0.0:
-            # nn.LSTM(dropout=p) drops the outputs of every layer but the last (seq2seq_model.py:44-45)
-            D = 2 if self.encoder_bidirectional else 1
-            shape = (h["NL"] - 1, B, L, D * h["He"])
-            n = shape[0] * shape[1] * shape[2] * shape[3]
-            if self._mask_buffer_deep is None or self._mask_buffer_deep.numel() != n:
-                self._mask_buffer_deep = torch.empty(n, dtype=torch.float32, device=device)
-            _lib.check(lib.gscan_dropout_mask(self._mask_buffer_deep.data_ptr(), n, self.dropout_p[1],
-                                              self._dropout_seed, deep_stream,
-                                              torch.cuda.current_stream().cuda_stream), "gscan_dropout_mask")
-            out.append(self._mask_buffer_deep.view(shape))
+        deep = self._deep_masks(B, L, device, deep_stream)
+        if deep is not None:
+            out.append(deep)
         return tuple(out)
 
     # ---- the two launches ---------------------------------------------------------------------
@@ -465,6 +503,11 @@ class Model(nn.Module):
         batch = _lib.Batch(commands.data_ptr(), lengths.data_ptr(), None if world.dtype == torch.uint8 else world.data_ptr(),
                            targets.data_ptr(), _lib.ptr(positions), world.data_ptr() if world.dtype == torch.uint8 else None)
         mstruct = _lib.Masks(*[_lib.ptr(m) for m in masks])
+        if self._kernel_drop is not None:      # dropout drawn inside the kernels: (seed, stream id) fixed by _draw_masks
+            mstruct.in_kernel = 1
+            mstruct.p_cnn, mstruct.p_enc, mstruct.p_dec = self.dropout_p
+            mstruct.seed, mstruct.stream_id = self._kernel_drop
+            self._kernel_drop = None
         logp = torch.empty(B, T, self._hyper["V"], dtype=torch.float32, device=commands.device)
         aux = torch.empty(B, G * G, dtype=torch.float32, device=commands.device) if self.auxiliary_task else None
         if train_nll is None:

@@ -36,7 +36,7 @@ def test_abi_version_and_struct_sizes(lib):
     assert lib.gscan_abi_version() == _lib.ABI_VERSION
     assert ctypes.sizeof(_lib.Dims) == 18 * 4
     assert ctypes.sizeof(_lib.Params) == (32 + 8 * (_lib.MAX_ENC_LAYERS - 1)) * 8
-    assert ctypes.sizeof(_lib.Batch) == 6 * 8 and ctypes.sizeof(_lib.Masks) == 4 * 8
+    assert ctypes.sizeof(_lib.Batch) == 6 * 8 and ctypes.sizeof(_lib.Masks) == 8 * 8
 
 
 def test_workspace_query_and_errors(lib):

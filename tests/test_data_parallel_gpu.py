@@ -148,7 +148,7 @@ def test_dropout_streams_differ_by_rank_and_repeat_per_rank():
         m.set_dropout_rank(rank)
         out = []
         for _ in range(steps):
-            out.append([x.clone() for x in m._draw_masks(8, 10, 20, 36, torch.device("cuda"))])
+            out.append([x.clone() for x in m._draw_masks(8, 10, 20, 36, torch.device("cuda"), materialize=True)])
         return out
     r0, r0_again, r1 = draws(0), draws(0), draws(1)
     for step in range(2):

@@ -107,6 +107,41 @@ def test_backward_is_linear_in_the_upstream_gradient(setup):
     assert (g23 - ref).abs().max().item() < 1e-6 + 1e-4 * ref.abs().max().item()
 
 
+def test_dropout_drawn_inside_the_kernels_equals_the_same_masks_in_memory():
+    """SURVEY.md 7 hard part 3 (production mode: a counter RNG inside the kernels).  A training-mode step draws its dropout
+    where it is applied (csrc/dropout.h) and no mask exists in memory; gscan_dropout_masks_kernel_layout writes the masks
+    of the same (seed, Philox stream) to memory, and the step fed with them through the pointer form is the same step: the
+    forward pass bit for bit, the gradients up to the order of the float atomics.  Odd row counts (B*L and B*T are not
+    multiples of four: partial row quads) and a ragged batch."""
+    from multimodal_seq2seq_gscan_amd.model import Model, _dropout_in_kernel
+    assert _dropout_in_kernel(), "GSCAN_DROPOUT_IN_KERNEL=0 in the environment of the test run"
+    torch.manual_seed(5)
+    for shape in (Shape(batch=37, ragged=True, max_target=19), Shape(batch=256)):
+        model = Model(**model_kwargs("compositional", auxiliary_task=True)).cuda().train()
+        batch = make_batch(shape, seed=13)
+        B, L = batch["commands"].shape
+        T, M = batch["targets"].shape[1], batch["world"].shape[1] ** 2
+        calls = model._dropout_calls
+        masks = model._draw_masks(B, L, T, M, torch.device("cuda"), materialize=True)
+        model._dropout_calls = calls                      # rewind: the step below draws the same masks in its kernels
+        for m, p in zip(masks, model.dropout_p):
+            keep = 1.0 / (1.0 - p)
+            assert bool(((m == 0) | ((m - keep).abs() < 1e-6)).all())
+            assert abs((m == 0).float().mean().item() - p) < 0.02
+        assert model._mask_buffer is None                 # nothing was drawn into memory by the model itself
+        logp_k, aux_k, loss_k, grad_k = step(model, batch)
+        model.set_dropout_masks(*masks)
+        logp_m, aux_m, loss_m, grad_m = step(model, batch)
+        assert torch.equal(logp_k, logp_m), "in-kernel dropout and the same masks in memory give different forward passes"
+        assert abs(loss_k - loss_m) < 1e-6
+        assert (grad_k - grad_m).abs().max().item() < 1e-6 + 1e-5 * grad_m.abs().max().item()
+        logp_2, _, _, _ = step(model, batch)
+        assert not torch.equal(logp_2, logp_k), "the next step drew the same dropout again"
+        model.eval()
+        logp_e, _, _, _ = step(model, batch)
+        assert not torch.equal(logp_e, logp_k)            # and eval mode draws none
+
+
 def test_training_memorises_one_batch():
     """End-to-end sanity of gradients + fused Adam/LR on the device: with dropout off, a few hundred steps on one
     fixed batch of random targets drive the loss from ~log(V) to near zero and the exact-match rate to 100 %."""
