@@ -44,9 +44,12 @@ int embed_rows(const int64_t *tok, const float *table, int vocab, const float *m
 // ------------------------------------------------------------------------------------------
 constexpr int kEmbedRows = 32;
 constexpr int kEmbedThreads = 256;
+// Columns c0 .. c0 + D - 1 of a table that is DT columns wide (wider tables than a workgroup has threads are walked in
+// column blocks by the host: round 5, any embedding width).
 __global__ __launch_bounds__(kEmbedThreads) void embed_grad_kernel(const int64_t *__restrict__ tok, const float *__restrict__ g, int64_t ldg,
                                   const float *__restrict__ mask, int rows, int D, int DP, int v0, int vocab, int pad,
-                                  float *__restrict__ dtable, float *__restrict__ part, int vocab_all) {   // tokens v0 .. v0 + vocab - 1
+                                  float *__restrict__ dtable, float *__restrict__ part, int vocab_all,     // tokens v0 .. v0 + vocab - 1
+                                  int c0, int DT) {
     TraceScope trace_scope(TK_EMBED_GRAD);
     extern __shared__ float priv[];                       // [vocab][kEmbedThreads]
     const int tid = threadIdx.x, d = tid & (DP - 1), slot = tid / DP, slots = kEmbedThreads / DP;
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_grad_kernel(const int64_t
             for (int u = 0; u < U; ++u) {
                 const int rr = min(r + u * slots, r1 - 1);
                 t[u] = tok[rr];
-                x[u] = g[(int64_t)rr * ldg + d];
-                m[u] = mask ? mask[(int64_t)rr * D + d] : 1.f;
+                x[u] = g[(int64_t)rr * ldg + c0 + d];
+                m[u] = mask ? mask[(int64_t)rr * DT + c0 + d] : 1.f;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_grad_kernel(const int64_t
         const int v = i / D, c = i - v * D;
         float sum = 0.f;
         for (int s = 0; s < slots; ++s) sum += priv[v * kEmbedThreads + s * DP + c];
-        if (part) part[((int64_t)blockIdx.x * vocab_all + v0) * D + i] = sum;
-        else if (sum != 0.f) atomicAdd(&dtable[(int64_t)v0 * D + i], sum);
+        if (part) part[((int64_t)blockIdx.x * vocab_all + v0 + v) * DT + c0 + c] = sum;
+        else if (sum != 0.f) atomicAdd(&dtable[(int64_t)(v0 + v) * DT + c0 + c], sum);
     }
 }
 
@@ -96,16 +99,19 @@ size_t embed_grad_partial_floats(int rows, int D, int vocab) { return (size_t)cd
 
 int embed_grad(const int64_t *tok, const float *g, int64_t ldg, const float *mask, int rows, int D, int vocab,
                int pad, float *dtable, hipStream_t stream, float *part) {
-    GSCAN_CHECK(D >= 1 && D <= kEmbedThreads, "embed_grad: embedding dimension %d is not supported (1..%d)", D, kEmbedThreads);
-    int DP = 1;
-    while (DP < D) DP <<= 1;
+    GSCAN_CHECK(D >= 1, "embed_grad: embedding dimension %d", D);
     constexpr int kChunk = 64;                             // vocabulary entries per launch: 64 KB of per-thread sums
-    for (int v0 = 0; v0 < vocab; v0 += kChunk) {
-        const int n = std::min(kChunk, vocab - v0);
-        hipLaunchKernelGGL(embed_grad_kernel, dim3(cdiv(rows, kEmbedRows)), dim3(kEmbedThreads),
-                           (size_t)n * kEmbedThreads * sizeof(float), stream, tok, g, ldg, mask, rows, D, DP, v0, n, pad,
-                           dtable, part, vocab);
-        GSCAN_LAUNCHED("embed_grad_kernel");
+    for (int c0 = 0; c0 < D; c0 += kEmbedThreads) {        // column blocks of a workgroup's width (one block up to 256 columns)
+        const int Dt = std::min(kEmbedThreads, D - c0);
+        int DP = 1;
+        while (DP < Dt) DP <<= 1;
+        for (int v0 = 0; v0 < vocab; v0 += kChunk) {
+            const int n = std::min(kChunk, vocab - v0);
+            hipLaunchKernelGGL(embed_grad_kernel, dim3(cdiv(rows, kEmbedRows)), dim3(kEmbedThreads),
+                               (size_t)n * kEmbedThreads * sizeof(float), stream, tok, g, ldg, mask, rows, Dt, DP, v0, n, pad,
+                               dtable, part, vocab, c0, D);
+            GSCAN_LAUNCHED("embed_grad_kernel");
+        }
     }
     if (part) {
         hipLaunchKernelGGL(embed_grad_reduce_kernel, dim3(cdiv(vocab * D, 64)), dim3(64), 0, stream, part,

@@ -139,9 +139,9 @@ int check_dims(const gscan_dims &d) {
     // Hidden sizes, command lengths and grid sizes outside what the register/LDS-resident kernels take run on the
     // streaming kernels (decoder_any.hip, lstm_encoder.hip's *_any kernels); what remains are the limits of those.
     GSCAN_CHECK(d.He >= 1 && d.He <= 2048, "dims: encoder_hidden_size %d is outside 1..2048", d.He);
-    GSCAN_CHECK(d.H >= 1 && d.H <= 256, "dims: decoder_hidden_size %d is outside 1..256 (the target embedding's width: "
-                "the embedding-gradient kernel takes up to 256 columns)", d.H);
-    GSCAN_CHECK(d.E <= 256, "dims: embedding_dimension %d is outside 1..256", d.E);
+    GSCAN_CHECK(d.H >= 1 && d.H <= 1024, "dims: decoder_hidden_size %d is outside 1..1024 (the streaming decoder gives every "
+                "feature of an attention a thread)", d.H);
+    GSCAN_CHECK(d.E <= 1024, "dims: embedding_dimension %d is outside 1..1024", d.E);
     GSCAN_CHECK((int64_t)d.B * d.T * 4 * d.H < (1ll << 31) && (int64_t)d.B * d.G * d.G * 4 * d.H < (1ll << 31),
                 "dims: batch too large for 32-bit activation offsets (B=%d T=%d H=%d)", d.B, d.T, d.H);
     GSCAN_CHECK(d.enc_layers >= 0 && d.enc_layers <= GSCAN_MAX_ENC_LAYERS,

@@ -59,10 +59,10 @@ def test_workspace_query_and_errors(lib):
         dd = _lib.Dims(**kw)
         assert lib.gscan_workspace_bytes(ctypes.byref(dd)) > 0, odd
     # ... and what no kernel takes fails with the reason
-    bad = _lib.Dims(B=4, L=10, T=20, G=6, C=16, Co=50, K3=7, E=25, He=100, H=300, Vi=21, V=9, conditional=1,
+    bad = _lib.Dims(B=4, L=10, T=20, G=6, C=16, Co=50, K3=7, E=25, He=100, H=1100, Vi=21, V=9, conditional=1,
                     auxiliary=0, bidirectional=1, pad_in=0, pad_tgt=0)
     assert lib.gscan_workspace_bytes(ctypes.byref(bad)) == 0
-    assert b"decoder_hidden_size 300" in lib.gscan_last_error()
+    assert b"decoder_hidden_size 1100" in lib.gscan_last_error()
     even = _lib.Dims(B=4, L=10, T=20, G=6, C=16, Co=50, K3=4, E=25, He=100, H=100, Vi=21, V=9, conditional=1,
                      auxiliary=0, bidirectional=1, pad_in=0, pad_tgt=0)
     assert lib.gscan_workspace_bytes(ctypes.byref(even)) == 0

@@ -703,6 +703,11 @@ EDGE_CASES = [
     ("hidden256_nocond_unidirectional", {"encoder_hidden_size": 256, "decoder_hidden_size": 256, "embedding_dimension": 32,
                                          "conditional_attention": False, "encoder_bidirectional": False},
      dict(batch=2, max_target=4), None),
+    # round 5 — decoder hidden sizes / embedding widths above 256 (the embedding gradients walk column blocks of 256)
+    ("hidden320_embedding300", {"encoder_hidden_size": 100, "decoder_hidden_size": 320, "embedding_dimension": 300},
+     dict(batch=2, max_target=4), None),
+    ("hidden513_odd_aux", {"encoder_hidden_size": 36, "decoder_hidden_size": 513, "embedding_dimension": 7,
+                           "auxiliary_task": True}, dict(batch=2, grid=4, max_target=3), None),
     ("hidden50_encoder30_not_multiples_of_4", {"encoder_hidden_size": 30, "decoder_hidden_size": 50, "embedding_dimension": 5},
      dict(batch=3), None),
     ("grid12_144_cells_aux", {"encoder_hidden_size": 100, "decoder_hidden_size": 100, "embedding_dimension": 25,

@@ -45,6 +45,8 @@ EXTREMES = [
     (64, 64, 33, 3, 70, 1, 1, 1, 3, 5, 7, 9, 3),
     (100, 100, 25, 7, 200, 1, 0, 1, 1, 2, 6, 10, 20),    # 200 output channels: four 64-lane chunks in the world encoder
     (96, 100, 25, 7, 50, 1, 0, 1, 1, 257, 6, 10, 4),     # one row more than the chip has CUs
+    (1024, 64, 300, 3, 8, 1, 1, 1, 1, 2, 3, 4, 2),       # round 5: the widest decoder / embedding the library takes
+    (700, 300, 513, 3, 8, 0, 0, 0, 2, 1, 2, 3, 2),       # embedding gradients in three column blocks
 ]
 if args.extremes:
     args.cases = len(EXTREMES)
