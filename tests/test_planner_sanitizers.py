@@ -4,7 +4,7 @@ tests/planner/build.py compiles the host half of every source of libgscan_hip.so
 device code, device calls are no-ops, launches are checked against the hardware limits and counted) and
 tests/planner/driver.hip calls the C ABI over a list of shapes: the benchmark configurations, the degenerate / limit
 shapes of tools/fuzz_parity.py --extremes, and random shapes over the whole range the reference's flags accept
-(--wide: hidden sizes 1..256, grids to 12 x 12, commands to 128 tokens, 1-3 encoder layers).  Runs on the CPU; nothing
+(--wide: hidden sizes 1..1024, grids to 12 x 12, commands to 128 tokens, 1-3 encoder layers).  Runs on the CPU; nothing
 here touches a GPU."""
 import os
 import random
@@ -32,17 +32,17 @@ EXTREMES = [(100, 100, 25, 7, 50, 1, 0, 1, 1, 1, 2, 1, 1), (100, 100, 25, 7, 50,
             (100, 128, 64, 7, 50, 1, 0, 1, 2, 2, 6, 10, 5), (64, 64, 33, 3, 70, 1, 1, 1, 3, 5, 7, 9, 3),
             (100, 100, 25, 7, 200, 1, 0, 1, 1, 2, 6, 10, 20), (96, 100, 25, 7, 50, 1, 0, 1, 1, 257, 6, 10, 4)]
 # beyond every limit: each must come back as a message, not as a crash
-REJECTED = [(257, 100, 25, 7, 50, 1, 0, 1, 1, 2, 6, 10, 4, 21, 9, 16), (100, 4096, 25, 7, 50, 1, 0, 1, 1, 2, 6, 10, 4, 21, 9, 16),
+REJECTED = [(1025, 100, 25, 7, 50, 1, 0, 1, 1, 2, 6, 10, 4, 21, 9, 16), (100, 4096, 25, 7, 50, 1, 0, 1, 1, 2, 6, 10, 4, 21, 9, 16),
             (100, 100, 25, 6, 50, 1, 0, 1, 1, 2, 6, 10, 4, 21, 9, 16), (100, 100, 25, 7, 50, 1, 0, 1, 5, 2, 6, 10, 4, 21, 9, 16),
             (100, 100, 25, 7, 50, 1, 0, 1, 1, 0, 6, 10, 4, 21, 9, 16), (100, 100, 25, 7, 50, 1, 0, 1, 1, 60000, 6, 10, 100, 21, 9, 16),
-            (100, 100, 300, 7, 50, 1, 0, 1, 1, 2, 6, 10, 4, 21, 9, 16), (100, 100, 25, 7, 50, 1, 0, 1, 1, 2, 70, 10, 4, 21, 9, 16)]
+            (100, 100, 1300, 7, 50, 1, 0, 1, 1, 2, 6, 10, 4, 21, 9, 16), (100, 100, 25, 7, 50, 1, 0, 1, 1, 2, 70, 10, 4, 21, 9, 16)]
 
 
 def _wide(cases: int, seed: int):
     rng = random.Random(seed)
     out = []
     for _ in range(cases):
-        H = rng.choice([rng.randint(1, 256), rng.choice([128, 200, 256]), rng.choice(list(range(4, 101, 4)))])
+        H = rng.choice([rng.randint(1, 256), rng.choice([128, 200, 256, 600, 1024]), rng.choice(list(range(4, 101, 4)))])
         He = rng.choice([rng.randint(1, 256), rng.choice([128, 200, 256]), rng.choice(list(range(4, 129, 4)))])
         out.append((H, He, rng.choice([4, 5, 8, 25, 64]), rng.choice([1, 3, 5, 7, 13]), rng.choice([8, 20, 50, 70, 200]),
                     int(rng.random() < 0.6), int(rng.random() < 0.5), int(rng.random() < 0.7), rng.choice([1, 1, 2, 3]),
