@@ -187,6 +187,35 @@ def test_dropout_host_masks():
     assert abs(loss.item() - float(fx["loss"])) < TOL
 
 
+def test_dropout_drawn_inside_the_kernels_against_the_oracle():
+    """SURVEY.md 7 hard part 3, production mode: a training-mode step draws its dropout inside the kernels (csrc/dropout.h).
+    The masks of its (seed, Philox stream) — written to memory by gscan_dropout_masks_kernel_layout — handed to the CPU oracle
+    give the same log-probabilities, loss and gradients: two encoder layers (the inter-layer mask stays in memory), the
+    auxiliary head, a ragged batch."""
+    from oracle import seq2seq_oracle as oracle
+    from multimodal_seq2seq_gscan_amd.model import _dropout_in_kernel
+    assert _dropout_in_kernel()
+    cfg = model_kwargs("demo", num_encoder_layers=2, auxiliary_task=True)
+    fx = load_fixture("demo_enc2.npz")
+    params = fixture_params(cfg, fx)
+    batch = fixture_batch(fx)
+    B, L = batch["commands"].shape
+    T, M = batch["targets"].shape[1], batch["world"].shape[1] ** 2
+    model = build_model(cfg, params)
+    model.train()
+    model._dropout_seed = 1234
+    calls = model._dropout_calls
+    masks = [m.cpu() for m in model._draw_masks(B, L, T, M, torch.device("cuda"), materialize=True)]
+    assert len(masks) == 4                                  # cnn, enc, dec and the inter-layer mask
+    model._dropout_calls = calls                            # the step below draws the same ones, in its kernels
+    ref_loss, ref_grads, ref_logp = oracle.loss_and_grads(params, batch, conditional=True, auxiliary=True, masks=tuple(masks))
+    logp, aux, loss, grads = run_step(model, batch, cfg)
+    assert model._mask_buffer is None
+    assert (logp - ref_logp).abs().max().item() < TOL and abs(loss - ref_loss.item()) < TOL
+    for k, g in grads.items():
+        assert torch.allclose(g, ref_grads[k], atol=TOL, rtol=1e-3), k
+
+
 def test_inter_layer_dropout_of_a_two_layer_encoder():
     """nn.LSTM(dropout=p) drops the outputs of every encoder layer but the last: with host masks the HIP step
     matches the oracle (forward and every gradient); with device masks training runs and the loss moves."""
