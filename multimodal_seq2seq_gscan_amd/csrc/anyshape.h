@@ -93,13 +93,105 @@ __device__ __forceinline__ void matvec_cols(const float *__restrict__ W, int ldw
             for (; r < R; r += P) a0 = fmaf(wcol[(int64_t)r * ldw], x[r], a0);
         }
         scratch[tid] = (a0 + a1) + (a2 + a3);
-        __syncthreads();
+        lds_barrier();
         if (tid < CB && c < C) {
             float sum = 0.f;
             for (int q = 0; q < P; ++q) sum += scratch[q * CB + tid];
             store(c, sum);
         }
-        __syncthreads();
+        lds_barrier();
+    }
+}
+
+// The transposed product with 16-byte loads (round 5): C, ldw and c0 multiples of 4, W 16-byte aligned.  A thread owns a
+// column QUAD and every P-th row (one float4 per row, four in flight): a lane per column with 4-byte loads had every thread
+// walk R / P rows four at a time — W_hh^T (4H x H) was sixteen dependent L2 round trips of 16 KB per workgroup; this form
+// makes it four of 64 KB.  The groups' partial sums meet in `scratch` (kAnyThreads floats), one component at a time.
+template <typename Store>
+__device__ __forceinline__ void matvec_cols4(const float *__restrict__ W, int ldw, int c0, int R, int C, const float *x,
+                                             float *scratch, Store store) {
+    const int tid = threadIdx.x;
+    const int Q = C >> 2, QB = min((Q + 15) & ~15, kAnyThreads), P = kAnyThreads / QB;
+    const int qq = tid % QB, p = tid / QB;
+    for (int qbase = 0; qbase < Q; qbase += QB) {
+        const int q = qbase + qq;
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (p < P && q < Q) {
+            const float *wq = W + c0 + 4 * q;
+            int r = p;
+#pragma unroll 1
+            for (; r + 3 * P < R; r += 4 * P) {
+                const float4 w0 = *reinterpret_cast<const float4 *>(wq + (int64_t)r * ldw),
+                             w1 = *reinterpret_cast<const float4 *>(wq + (int64_t)(r + P) * ldw),
+                             w2 = *reinterpret_cast<const float4 *>(wq + (int64_t)(r + 2 * P) * ldw),
+                             w3 = *reinterpret_cast<const float4 *>(wq + (int64_t)(r + 3 * P) * ldw);
+                const float x0 = x[r], x1 = x[r + P], x2 = x[r + 2 * P], x3 = x[r + 3 * P];
+                acc.x = fmaf(w0.x, x0, fmaf(w1.x, x1, fmaf(w2.x, x2, fmaf(w3.x, x3, acc.x))));
+                acc.y = fmaf(w0.y, x0, fmaf(w1.y, x1, fmaf(w2.y, x2, fmaf(w3.y, x3, acc.y))));
+                acc.z = fmaf(w0.z, x0, fmaf(w1.z, x1, fmaf(w2.z, x2, fmaf(w3.z, x3, acc.z))));
+                acc.w = fmaf(w0.w, x0, fmaf(w1.w, x1, fmaf(w2.w, x2, fmaf(w3.w, x3, acc.w))));
+            }
+            for (; r < R; r += P) {
+                const float4 w0 = *reinterpret_cast<const float4 *>(wq + (int64_t)r * ldw);
+                const float x0 = x[r];
+                acc.x = fmaf(w0.x, x0, acc.x); acc.y = fmaf(w0.y, x0, acc.y); acc.z = fmaf(w0.z, x0, acc.z); acc.w = fmaf(w0.w, x0, acc.w);
+            }
+        }
+#pragma unroll
+        for (int comp = 0; comp < 4; ++comp) {
+            scratch[tid] = comp == 0 ? acc.x : comp == 1 ? acc.y : comp == 2 ? acc.z : acc.w;
+            lds_barrier();
+            if (tid < QB && q < Q) {
+                float sum = 0.f;
+                for (int g = 0; g < P; ++g) sum += scratch[g * QB + tid];
+                store(4 * q + comp, sum);
+            }
+            lds_barrier();
+        }
+    }
+}
+
+// The transposed product over up to NA arrays that share the rows and the vector x (an attention's memories: projected
+// keys [n, H], gate images [n, 4H], U2 [n, H] against the same attention distribution): y_j[c] = sum_{r < R} A_j[r, c] * x[r],
+// through `store(j, c, value)`, as ONE pass over the concatenated columns — one exchange through `scratch` and two barriers
+// for the lot instead of per array (round 5: a call costs a load round trip and two barriers whatever it moves).
+struct ColsArray { const float *A; int ld, C; };
+template <typename Store>
+__device__ __forceinline__ void matvec_cols_arrays(const ColsArray a0, const ColsArray a1, const ColsArray a2, int R, const float *x,
+                                                   float *scratch, Store store) {           // an unused array: C = 0
+    const int tid = threadIdx.x;
+    const int Ctot = a0.C + a1.C + a2.C;
+    const int CB = min((Ctot + 63) & ~63, kAnyThreads), P = kAnyThreads / CB;
+    const int cc = tid % CB, p = tid / CB;
+    for (int cbase = 0; cbase < Ctot; cbase += CB) {
+        const int c = cbase + cc;
+        // this thread's array and its column in it (plain scalars: an array of descriptors indexed per lane would live in scratch)
+        const int j = c < a0.C ? 0 : (c < a0.C + a1.C ? 1 : 2);
+        const int cl = j == 0 ? c : (j == 1 ? c - a0.C : c - a0.C - a1.C);
+        const float *wcol = (j == 0 ? a0.A : (j == 1 ? a1.A : a2.A)) + cl;
+        const int ldw = j == 0 ? a0.ld : (j == 1 ? a1.ld : a2.ld);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (p < P && c < Ctot) {
+            int r = p;
+#pragma unroll 2
+            for (; r + 3 * P < R; r += 4 * P) {
+                const float w0 = wcol[(int64_t)r * ldw], w1 = wcol[(int64_t)(r + P) * ldw],
+                            w2 = wcol[(int64_t)(r + 2 * P) * ldw], w3 = wcol[(int64_t)(r + 3 * P) * ldw];
+                s0 = fmaf(w0, x[r], s0);
+                s1 = fmaf(w1, x[r + P], s1);
+                s2 = fmaf(w2, x[r + 2 * P], s2);
+                s3 = fmaf(w3, x[r + 3 * P], s3);
+            }
+            for (; r < R; r += P) s0 = fmaf(wcol[(int64_t)r * ldw], x[r], s0);
+        }
+        scratch[tid] = (s0 + s1) + (s2 + s3);
+        lds_barrier();
+        if (tid < CB && c < Ctot) {
+            float sum = 0.f;
+            for (int q = 0; q < P; ++q) sum += scratch[q * CB + tid];
+            store(j, cl, sum);
+        }
+        lds_barrier();
     }
 }
 

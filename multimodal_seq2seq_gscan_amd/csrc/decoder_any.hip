@@ -19,6 +19,11 @@
 // there to scratch (bwd: 44 VGPR spills, 164 B of scratch per lane).  LAUNDER makes a scalar opaque at the top of an
 // iteration, so what derives from it is recomputed per step (a few dozen SALU operations against 30+ us of streaming).
 #define LAUNDER(x) asm volatile("" : "+s"(x))
+// Barriers inside the two time loops are lds_barrier() (s_waitcnt lgkmcnt(0) + s_barrier, common.h), not __syncthreads():
+// everything that crosses threads inside a step goes through LDS (the resident memories included: FLAT accesses count on
+// lgkmcnt), while __syncthreads() also drains vmcnt — i.e. every one of the ~12 (forward) / ~20 (backward) barriers of a step
+// waited for the global STORES of saved activations issued in its phase, a store round trip each.  (Round 5; the resident
+// kernels have done the same since round 1.)
 
 namespace gscan {
 
@@ -49,6 +54,44 @@ __device__ __forceinline__ void scores_any(const float *v_s, const float *q_s, c
     }
 }
 
+// Round 5: the row's memories RESIDENT IN LDS where they fit (the streaming kernels took them from global memory every
+// step so that any number of memories works: ~10 dependent L2 round trips per forward step, ~20 per backward step, 1.5-2 us
+// each with 256 workgroups loading at once — the step was a chain of load latencies, not of streamed bytes).  What a kernel
+// holds is a PREFIX of: projected keys (both attentions) | backward: their score-path gradients | textual gate images U_t,
+// U2_t | visual gate images U_v; the rest stays in global memory.  The arrays are reached through generic pointers (an LDS
+// address or a global one: FLAT loads), so one body serves every residency.
+enum { kAnyMemPK = 1, kAnyMemDPK = 2, kAnyMemUT = 4, kAnyMemUV = 8 };
+struct AnyResidency { int flags, pkt, pkv, dpkt, dpkv, ut, u2t, uv, floats; };
+__host__ __device__ inline AnyResidency any_residency(int H, int L, int M, bool cond, bool use_u, bool backward, int base_floats,
+                                                     int limit_floats) {
+    AnyResidency r{};
+    int p = (base_floats + 3) & ~3;
+    auto take = [&](int n) { const int at = p; p += (n + 3) & ~3; return at; };
+    const int start = p;
+    if (p + (L + M) * H + 8 <= limit_floats) {
+        r.flags |= kAnyMemPK; r.pkt = take(L * H); r.pkv = take(M * H);
+        if (!backward || p + (L + M) * H + 8 <= limit_floats) {
+            if (backward) { r.flags |= kAnyMemDPK; r.dpkt = take(L * H); r.dpkv = take(M * H); }
+            if (use_u && p + L * (cond ? 5 : 4) * H + 8 <= limit_floats) {
+                r.flags |= kAnyMemUT; r.ut = take(L * 4 * H); r.u2t = take(cond ? L * H : 0);
+                if (p + M * 4 * H + 4 <= limit_floats) { r.flags |= kAnyMemUV; r.uv = take(M * 4 * H); }
+            }
+        }
+    }
+    r.floats = p - start;
+    return r;
+}
+constexpr int kAnyLdsFloats = 160 * 1024 / 4;
+// cooperative global -> LDS copy (n floats, both 16-byte aligned when n % 4 == 0)
+__device__ __forceinline__ void any_stage(float *dst, const float *__restrict__ src, int n) {
+    if ((n & 3) == 0) {
+        for (int i = threadIdx.x; i < n / 4; i += kAnyThreads)
+            reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += kAnyThreads) dst[i] = src[i];
+    }
+}
+
 struct AnyLds { int hc, qt, q2, qv, vt, vv, bq, pre, cell, sc, misc, scr, total; };
 __host__ __device__ inline AnyLds any_lds_fwd(int H, int L, int M) {
     const int HP = (H + 3) / 4 * 4, NM = ((L > M ? L : M) + 3) / 4 * 4;
@@ -68,6 +111,9 @@ __host__ __device__ inline AnyLds any_lds_fwd(int H, int L, int M) {
 // ------------------------------------------------------------------------------------------
 // forward (teacher forcing, or GREEDY: the row feeds its own argmax back and stops at <EOS>; predict.py:101-112)
 // ------------------------------------------------------------------------------------------
+// diagnostic phase stamps (DecoderArgs::stamps set: tools/decoder_stamps.py): thread 0 of workgroup 0 adds the cycles since
+// the previous stamp to slot i of an LDS table, written out at the end of the kernel
+#define ANY_STAMP(i) if (a.stamps && blockIdx.x == 0 && tid == 0) { const long long n_ = clock64(); stamp_s[i] += (float)(n_ - stamp_prev); stamp_prev = n_; }
 template <bool V4, bool GREEDY>
 __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArgs a, int H, int cond) {
     // (no TraceScope: with -DGSCAN_TRACE its destructor's branch on blockIdx makes this compiler's back end fail on the
@@ -80,6 +126,9 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
           *vv_s = smem + o.vv, *bq_s = smem + o.bq, *pre_s = smem + o.pre, *c_s = smem + o.cell, *sc = smem + o.sc,
           *scr = smem + o.scr;
     int *tok_s = reinterpret_cast<int *>(smem + o.misc);
+    float *stamp_s = smem + o.misc + 16;
+    long long stamp_prev = 0;
+    if (tid < 16) stamp_s[tid] = 0.f;
     float *h_s = hc, *ctxt_s = hc + H, *ctxv_s = hc + 2 * H;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
@@ -91,6 +140,11 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
     // the reference's own parameter layouts (row-major [out, in]), carried in the argument struct by decoder_run
     const float *W_hh = a.any_w_hh, *W_ih = a.any_w_ih, *W_qt = a.any_w_qt, *W_qv = a.any_w_qv, *W_q2k = a.any_w_q2k;
     const bool use_u = a.any_use_u != 0;       // decoder_any_uses_gate_images: wide hidden sizes with few memories
+    // the memories this launch keeps in LDS (any_residency; the host computed the same plan for the LDS size)
+    const AnyResidency res = any_residency(H, L, M, cond != 0, use_u, false, o.total, a.any_lds_floats);
+    if (res.flags & kAnyMemPK) { any_stage(smem + res.pkt, pk_t, L * H); any_stage(smem + res.pkv, pk_v, M * H); }
+    if (res.flags & kAnyMemUT) { any_stage(smem + res.ut, u_t, L * 4 * H); if (cond) any_stage(smem + res.u2t, u2_t, L * H); }
+    if (res.flags & kAnyMemUV) any_stage(smem + res.uv, u_v, M * 4 * H);
 
     for (int k = tid; k < H; k += kAnyThreads) {
         const float h0 = a.hprev[(int64_t)b * (GREEDY ? 1 : T) * H + k];
@@ -109,71 +163,95 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
     for (int t = 0; t < T; ++t) {
         LAUNDER(Hl); LAUNDER(Ll); LAUNDER(Ml); LAUNDER(lenl);
         const int H = Hl, L = Ll, M = Ml, len = lenl;
-        const float *pk_t = a.pk_t + (int64_t)b * L * H, *pk_v = a.pk_v + (int64_t)b * M * H;
-        const float *u_t = a.u_t + (int64_t)b * L * 4 * H, *u2_t = a.u2_t + (int64_t)b * L * H, *u_v = a.u_v + (int64_t)b * M * 4 * H;
+        const float *pk_t = (res.flags & kAnyMemPK) ? smem + res.pkt : a.pk_t + (int64_t)b * L * H;
+        const float *pk_v = (res.flags & kAnyMemPK) ? smem + res.pkv : a.pk_v + (int64_t)b * M * H;
+        const float *u_t = (res.flags & kAnyMemUT) ? smem + res.ut : a.u_t + (int64_t)b * L * 4 * H;
+        const float *u2_t = (res.flags & kAnyMemUT) ? smem + res.u2t : a.u2_t + (int64_t)b * L * H;
+        const float *u_v = (res.flags & kAnyMemUV) ? smem + res.uv : a.u_v + (int64_t)b * M * 4 * H;
         const int64_t bt = (int64_t)b * T + t;
+        if (t == 0 && a.stamps && blockIdx.x == 0 && tid == 0) stamp_prev = clock64();
         // ---- everything that multiplies h_{t-1}: W_query_text h, the gates' recurrent part
-        matvec_rows<V4>(W_qt, H, H, H, h_s, [&](int r, float v) { qt_s[r] = v; });
         {
             const int64_t ge_row = GREEDY ? (int64_t)tok_s[0] : bt;    // greedy: row of the [V, 4H] table of the token fed in
             const float *ge = a.ge + ge_row * 4 * H;
+            matvec_rows<V4>(W_qt, H, H, H, h_s, [&](int r, float v) { qt_s[r] = v; });
             matvec_rows<V4>(W_hh, H, 4 * H, H, h_s, [&](int r, float v) { pre_s[r] = v + ge[r]; });
+            if (cond && use_u) matvec_rows<V4>(W_q2k, 2 * H, H, H, h_s, [&](int r, float v) { q2_s[r] = v + bq_s[r]; });   // W_q2k[:, :H] h + b
         }
-        if (cond && use_u) matvec_rows<V4>(W_q2k, 2 * H, H, H, h_s, [&](int r, float v) { q2_s[r] = v + bq_s[r]; });   // W_q2k[:, :H] h + b
-        __syncthreads();
+        lds_barrier();
+        ANY_STAMP(0)
         // ---- textual attention (seq2seq_model.py:129-139)
         scores_any(vt_s, qt_s, pk_t, len, H, sc);
-        __syncthreads();
+        lds_barrier();
+        ANY_STAMP(1)
         softmax_lds(sc, len);
-        __syncthreads();
+        lds_barrier();
+        ANY_STAMP(2)
         for (int m = tid; m < L; m += kAnyThreads) a.alpha_c[bt * L + m] = m < len ? sc[m] : 0.f;
-        matvec_cols(pk_t, H, 0, len, H, sc, scr, [&](int k, float acc) {      // context = alpha . PK (:138-139)
-            ctxt_s[k] = acc;
-            if (!GREEDY) { a.s[bt * 4 * H + H + k] = acc; a.qt[bt * H + k] = qt_s[k]; }
-        });
-        // ---- the query of the visual attention: conditional (tanh(W_q2k [h; ctx_text] + b), :394-396) or h itself
-        if (use_u) {
-            // the textual part of the gates' input product and of the conditional query, through the gate images
-            matvec_cols(u_t, 4 * H, 0, len, 4 * H, sc, scr, [&](int c, float v) { pre_s[(c & 3) * H + (c >> 2)] += v; });
-            if (cond)
-                matvec_cols(u2_t, H, 0, len, H, sc, scr, [&](int k, float v) {
+        // context = alpha . PK (:138-139) and, through the gate images, the textual part of the gates' input product and of the
+        // conditional query (tanh(W_q2k [h; ctx_text] + b), :394-396): one pass over [PK_t | U_t | U2_t]
+        {
+            matvec_cols_arrays(ColsArray{pk_t, H, H}, ColsArray{u_t, 4 * H, use_u ? 4 * H : 0},
+                               ColsArray{u2_t, H, (use_u && cond) ? H : 0}, len, sc, scr, [&](int j, int k, float v) {
+                if (j == 0) {
+                    ctxt_s[k] = v;
+                    if (!GREEDY) { a.s[bt * 4 * H + H + k] = v; a.qt[bt * H + k] = qt_s[k]; }
+                } else if (j == 1) {
+                    pre_s[(k & 3) * H + (k >> 2)] += v;
+                } else {
                     const float q = tanhf_(q2_s[k] + v);
                     q2_s[k] = q;
                     if (!GREEDY) a.q2[bt * H + k] = q;
-                });
+                }
+            });
+        }
+        if (use_u) {
         } else if (cond) {
             matvec_rows<V4>(W_q2k, 2 * H, H, 2 * H, hc, [&](int r, float v) {
                 const float q = tanhf_(v + bq_s[r]);
                 q2_s[r] = q;
                 if (!GREEDY) a.q2[bt * H + r] = q;
             });
-            __syncthreads();
+            lds_barrier();
         }
+        ANY_STAMP(3)
         matvec_rows<V4>(W_qv, H, H, H, cond ? q2_s : h_s, [&](int r, float v) {
             qv_s[r] = v;
             if (!GREEDY) a.qv[bt * H + r] = v;
         });
-        __syncthreads();
+        lds_barrier();
+        ANY_STAMP(4)
         // ---- visual attention over all M cells
         scores_any(vv_s, qv_s, pk_v, M, H, sc);
-        __syncthreads();
+        lds_barrier();
+        ANY_STAMP(5)
         softmax_lds(sc, M);
-        __syncthreads();
+        lds_barrier();
+        ANY_STAMP(6)
         for (int m = tid; m < M; m += kAnyThreads) {
             a.alpha_s[bt * M + m] = sc[m];
             a.att_sum[(int64_t)b * M + m] += sc[m];                    // seq2seq_model.py:479,490 (this thread's element)
         }
-        matvec_cols(pk_v, H, 0, M, H, sc, scr, [&](int k, float acc) {
-            ctxv_s[k] = acc;
-            if (!GREEDY) a.s[bt * 4 * H + 2 * H + k] = acc;
-        });
+        // visual context and (gate images) the visual part of the gates' input product: one pass over [PK_v | U_v]
+        {
+            matvec_cols_arrays(ColsArray{pk_v, H, H}, ColsArray{u_v, 4 * H, use_u ? 4 * H : 0}, ColsArray{pk_v, H, 0}, M, sc, scr,
+                               [&](int j, int k, float v) {
+                if (j == 0) {
+                    ctxv_s[k] = v;
+                    if (!GREEDY) a.s[bt * 4 * H + 2 * H + k] = v;
+                } else {
+                    pre_s[(k & 3) * H + (k >> 2)] += v;
+                }
+            });
+        }
+        ANY_STAMP(7)
         // ---- LSTM cell (seq2seq_model.py:414): the context part of the input product, then the gates
         if (use_u) {
-            matvec_cols(u_v, 4 * H, 0, M, 4 * H, sc, scr, [&](int c, float v) { pre_s[(c & 3) * H + (c >> 2)] += v; });
         } else {
             matvec_rows<V4>(W_ih + H, 3 * H, 4 * H, 2 * H, ctxt_s, [&](int r, float v) { pre_s[r] += v; });
-            __syncthreads();
+            lds_barrier();
         }
+        ANY_STAMP(8)
         for (int u = tid; u < H; u += kAnyThreads) {
             const float ig = sigmoidf_(pre_s[u]), fg = sigmoidf_(pre_s[H + u]), gg = tanhf_(pre_s[2 * H + u]),
                         og = sigmoidf_(pre_s[3 * H + u]);
@@ -189,7 +267,7 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
                 if (t + 1 < T) a.hprev[(bt + 1) * H + u] = h;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (GREEDY) {
             // output head on [e | ctx_text | ctx_vis | h] as the one matrix Wc = W_h2o . W_o2h ([V, 4H], S order), argmax
             // (the first of equal maxima), feed back, stop at <EOS>
@@ -204,7 +282,7 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
                 p = wave_sum(p);
                 if (lane == 0) logit_s[v] = p;
             }
-            __syncthreads();
+            lds_barrier();
             if (tid == 0) {
                 int best = 0;
                 float top = logit_s[0];
@@ -214,7 +292,7 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
                 a.tokens_out[bt] = best;
             }
             steps_done = t + 1;
-            __syncthreads();
+            lds_barrier();
             if (tok_s[0] == a.eos) break;                              // uniform: every thread reads the same LDS word
         }
     }
@@ -223,6 +301,8 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
         return;
     }
     if (a.h_last) for (int k = tid; k < H; k += kAnyThreads) a.h_last[(int64_t)b * H + k] = h_s[k];
+    ANY_STAMP(9)
+    if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_s[tid];
     __syncthreads();                                                   // the row's S and att_sum are complete
     // ---- auxiliary head: log_softmax over the cells of the summed visual attention (model.py:205) and this row's
     //      get_auxiliary_loss term (model.py:162-164)
@@ -336,7 +416,7 @@ __device__ __forceinline__ void attention_bwd_any(const float *dctx, const float
             p = wave_sum(p);
             if (lane == 0 && m < n) sc[m] = p + (datt ? datt[m] : 0.f);
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (tid < 64) {                                                    // ds_m = alpha_m (dalpha_m - sum alpha dalpha)
         float s = 0.f;
@@ -344,7 +424,7 @@ __device__ __forceinline__ void attention_bwd_any(const float *dctx, const float
         s = wave_sum(s);
         if (tid == 0) red[0] = s;
     }
-    __syncthreads();
+    lds_barrier();
     const float s = red[0];
     const int CB = min((H + 63) & ~63, kAnyThreads), P = kAnyThreads / CB;
     const int k = tid % CB, p = tid / CB;
@@ -363,13 +443,13 @@ __device__ __forceinline__ void attention_bwd_any(const float *dctx, const float
         dv += dvk;
     }
     scratch[tid] = dq;
-    __syncthreads();
+    lds_barrier();
     if (tid < CB && tid < H) {
         float sum = 0.f;
         for (int q = 0; q < P; ++q) sum += scratch[q * CB + tid];
         dq_s[tid] = sum;
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 template <bool V4>
@@ -388,6 +468,16 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
     const float *u_t = a.u_t + (int64_t)b * L * 4 * H, *u2_t = a.u2_t + (int64_t)b * L * H, *u_v = a.u_v + (int64_t)b * M * 4 * H;
     const float *W_hh = a.any_w_hh, *W_ih = a.any_w_ih, *W_qt = a.any_w_qt, *W_qv = a.any_w_qv, *W_q2k = a.any_w_q2k;
     const bool use_u = a.any_use_u != 0;
+    const AnyResidency res = any_residency(H, L, M, cond != 0, use_u, true, o.total, a.any_lds_floats);
+    // transposed weight products: 16-byte loads along the rows when the hidden size is a multiple of 4 (anyshape.h)
+    // — for TALL products only: the quad form pays eight barriers for its exchange, the lane-per-column form two, and a round
+    // trip of the latter moves 16 KB (cheap); from ~20 dependent round trips on the quad form wins (W_hh^T from hidden 144 on,
+    // everything at hidden 200+; measured: hidden 128 1.39 -> 1.63 ms with every product on it, 200 3.54 -> 3.23)
+    auto wcols = [&](const float *W, int ldw, int c0, int R, int C, const float *x, auto store) {
+        const int CB = min((C + 63) & ~63, kAnyThreads), trips = R / (4 * (kAnyThreads / CB));
+        if (V4 && trips >= 20) matvec_cols4(W, ldw, c0, R, C, x, scr, store);
+        else matvec_cols(W, ldw, c0, R, C, x, scr, store);
+    };
 
     // ---- seeds and the head's backward (as decoder_bwd_kernel's prologue): dlogits, dS = Wc^T dlogits
     float aux_scale = (a.seeds && a.daux) ? a.seeds[1] : 1.f;
@@ -457,8 +547,14 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
         }
     }
     for (int k = tid; k < H; k += kAnyThreads) { dh_s[k] = 0.f; dc_s[k] = 0.f; vt_s[k] = a.v_t[k]; vv_s[k] = a.v_v[k]; }
-    for (int i = tid; i < M * H; i += kAnyThreads) dpk_v[i] = 0.f;
-    for (int i = tid; i < L * H; i += kAnyThreads) dpk_t[i] = 0.f;
+    {   // score-path key gradients: accumulated over the steps in LDS when they fit (written out once, below), else in global memory
+        float *zv = (res.flags & kAnyMemDPK) ? smem + res.dpkv : dpk_v, *zt = (res.flags & kAnyMemDPK) ? smem + res.dpkt : dpk_t;
+        for (int i = tid; i < M * H; i += kAnyThreads) zv[i] = 0.f;
+        for (int i = tid; i < L * H; i += kAnyThreads) zt[i] = 0.f;
+    }
+    if (res.flags & kAnyMemPK) { any_stage(smem + res.pkt, pk_t, L * H); any_stage(smem + res.pkv, pk_v, M * H); }
+    if (res.flags & kAnyMemUT) { any_stage(smem + res.ut, u_t, L * 4 * H); if (cond) any_stage(smem + res.u2t, u2_t, L * H); }
+    if (res.flags & kAnyMemUV) any_stage(smem + res.uv, u_v, M * 4 * H);
     float dvt = 0.f, dvv = 0.f;                     // this thread's share of the energy-vector gradients (attention_bwd_any)
     __syncthreads();
 
@@ -466,9 +562,13 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
     for (int t = T - 1; t >= 0; --t) {
         LAUNDER(Hl); LAUNDER(Ll); LAUNDER(Ml); LAUNDER(lenl);
         const int H = Hl, L = Ll, M = Ml, len = lenl;
-        const float *pk_t = a.pk_t + (int64_t)b * L * H, *pk_v = a.pk_v + (int64_t)b * M * H;
-        float *dpk_t = a.dpk_t + (int64_t)b * L * H, *dpk_v = a.dpk_v + (int64_t)b * M * H;
-        const float *u_t = a.u_t + (int64_t)b * L * 4 * H, *u2_t = a.u2_t + (int64_t)b * L * H, *u_v = a.u_v + (int64_t)b * M * 4 * H;
+        const float *pk_t = (res.flags & kAnyMemPK) ? smem + res.pkt : a.pk_t + (int64_t)b * L * H;
+        const float *pk_v = (res.flags & kAnyMemPK) ? smem + res.pkv : a.pk_v + (int64_t)b * M * H;
+        float *dpk_t = (res.flags & kAnyMemDPK) ? smem + res.dpkt : a.dpk_t + (int64_t)b * L * H;
+        float *dpk_v = (res.flags & kAnyMemDPK) ? smem + res.dpkv : a.dpk_v + (int64_t)b * M * H;
+        const float *u_t = (res.flags & kAnyMemUT) ? smem + res.ut : a.u_t + (int64_t)b * L * 4 * H;
+        const float *u2_t = (res.flags & kAnyMemUT) ? smem + res.u2t : a.u2_t + (int64_t)b * L * H;
+        const float *u_v = (res.flags & kAnyMemUV) ? smem + res.uv : a.u_v + (int64_t)b * M * 4 * H;
         const int64_t bt = (int64_t)b * T + t;
         // ---- LSTM cell backward (dh_t = head part + what step t+1 passed back)
         for (int u = tid; u < H; u += kAnyThreads) {
@@ -488,68 +588,74 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
             a.delta[bt * 5 * H + u] = di; a.delta[bt * 5 * H + H + u] = df;
             a.delta[bt * 5 * H + 2 * H + u] = dg; a.delta[bt * 5 * H + 3 * H + u] = d_o;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- d alpha_vis[m] = delta . U_vis[m] + d ctx_vis(head) . PK_vis[m] + d att_sum[m]: the LSTM-input part of the context
         //      gradient reaches d alpha through the gate images (delta . U[m] = (W_ih[:, ctx]^T delta) . PK[m]); the context
         //      gradients themselves (the value path of the keys) are completed by the dS += product behind this kernel
         //      (narrow hidden sizes / many memories, use_u false: d ctx = head part + W_ih[:, ctx]^T delta formed here, streamed)
         if (use_u) for (int c = tid; c < 2 * H; c += kAnyThreads) dctx_s[c] = a.ds[bt * 4 * H + H + c];
-        else matvec_cols(W_ih, 3 * H, H, 4 * H, 2 * H, dl_s, scr, [&](int c, float v) { dctx_s[c] = v + a.ds[bt * 4 * H + H + c]; });
+        else wcols(W_ih, 3 * H, H, 4 * H, 2 * H, dl_s, [&](int c, float v) { dctx_s[c] = v + a.ds[bt * 4 * H + H + c]; });
         for (int m = tid; m < M; m += kAnyThreads) al_s[m] = a.alpha_s[bt * M + m];
         for (int k = tid; k < H; k += kAnyThreads) q_s[k] = a.qv[bt * H + k];
-        __syncthreads();
+        lds_barrier();
         if (use_u) {
             matvec_rows<true>(u_v, 4 * H, M, 4 * H, dlp_s, [&](int m, float v) { sc[m] = v + datt_s[m]; });
-            __syncthreads();
+            lds_barrier();
             matvec_rows<V4>(pk_v, H, M, H, dctx_s + H, [&](int m, float v) { sc[m] += v; });
-            __syncthreads();
+            lds_barrier();
         }
         // ---- visual attention backward
         attention_bwd_any(use_u ? nullptr : dctx_s + H, datt_s, q_s, vv_s, al_s, pk_v, dpk_v, M, H, sc, dq_s, red, scr, dvv);
         for (int k = tid; k < H; k += kAnyThreads) { const float v = dq_s[k]; dqv_s[k] = v; a.dqv[bt * H + k] = v; }
-        __syncthreads();
+        lds_barrier();
         if (cond) {
             // d q2 = W_qv^T dqv, through tanh; the conditional query's share of d ctx_text
-            matvec_cols(W_qv, H, 0, H, H, dqv_s, scr, [&](int c, float v) {
+            wcols(W_qv, H, 0, H, H, dqv_s, [&](int c, float v) {
                 const float q = a.q2[bt * H + c];
                 const float dz = v * (1.f - q * q);
                 dl_s[4 * H + c] = dz;
                 a.delta[bt * 5 * H + 4 * H + c] = dz;
             });
-            if (!use_u) matvec_cols(W_q2k, 2 * H, H, H, H, dl_s + 4 * H, scr, [&](int c, float v) { dctx_s[c] += v; });
+            if (!use_u) wcols(W_q2k, 2 * H, H, H, H, dl_s + 4 * H, [&](int c, float v) { dctx_s[c] += v; });
         }
         for (int m = tid; m < L; m += kAnyThreads) al_s[m] = a.alpha_c[bt * L + m];
         for (int k = tid; k < H; k += kAnyThreads) q_s[k] = a.qt[bt * H + k];
-        __syncthreads();
+        lds_barrier();
         // ---- d alpha_text[m] = delta . U_text[m] + dzq . U2_text[m] + d ctx_text(head) . PK_text[m]
         if (use_u) {
             matvec_rows<true>(u_t, 4 * H, len, 4 * H, dlp_s, [&](int m, float v) { sc[m] = v; });
-            __syncthreads();
+            lds_barrier();
             if (cond) {
                 matvec_rows<V4>(u2_t, H, len, H, dl_s + 4 * H, [&](int m, float v) { sc[m] += v; });
-                __syncthreads();
+                lds_barrier();
             }
             matvec_rows<V4>(pk_t, H, len, H, dctx_s, [&](int m, float v) { sc[m] += v; });
-            __syncthreads();
+            lds_barrier();
         }
         // ---- textual attention backward
         attention_bwd_any(use_u ? nullptr : dctx_s, nullptr, q_s, vt_s, al_s, pk_t, dpk_t, len, H, sc, dq_s, red, scr, dvt);
         for (int k = tid; k < H; k += kAnyThreads) a.dqt[bt * H + k] = dq_s[k];
         // ---- dh_{t-1} = W_hh^T delta + W_qt^T dqt + (W_q2k[:, :H]^T dzq  or  W_qv^T dqv)
-        matvec_cols(W_hh, H, 0, 4 * H, H, dl_s, scr, [&](int c, float v) { dh_s[c] = v; });
-        __syncthreads();
-        matvec_cols(W_qt, H, 0, H, H, dq_s, scr, [&](int c, float v) { dh_s[c] += v; });
-        __syncthreads();
-        if (cond) matvec_cols(W_q2k, 2 * H, 0, H, H, dl_s + 4 * H, scr, [&](int c, float v) { dh_s[c] += v; });
-        else matvec_cols(W_qv, H, 0, H, H, dqv_s, scr, [&](int c, float v) { dh_s[c] += v; });
-        __syncthreads();
+        wcols(W_hh, H, 0, 4 * H, H, dl_s, [&](int c, float v) { dh_s[c] = v; });
+        lds_barrier();
+        wcols(W_qt, H, 0, H, H, dq_s, [&](int c, float v) { dh_s[c] += v; });
+        lds_barrier();
+        if (cond) wcols(W_q2k, 2 * H, 0, H, H, dl_s + 4 * H, [&](int c, float v) { dh_s[c] += v; });
+        else wcols(W_qv, H, 0, H, H, dqv_s, [&](int c, float v) { dh_s[c] += v; });
+        lds_barrier();
     }
     // ---- epilogue: initial-state gradient through the bridge tanh (h0 = c0 = tanh(.), model.py:195), energy vectors
     for (int k = tid; k < H; k += kAnyThreads) {
         const float h0 = a.hprev[(int64_t)b * T * H + k];
         a.dh0[(int64_t)b * H + k] = (dh_s[k] + dc_s[k]) * (1.f - h0 * h0);
     }
-    for (int i = tid; i < (L - len) * H; i += kAnyThreads) dpk_t[(int64_t)len * H + i] = 0.f;
+    if (res.flags & kAnyMemDPK) {                      // the key gradients accumulated in LDS: written once (padded memories: zero)
+        __syncthreads();
+        for (int i = tid; i < M * H; i += kAnyThreads) dpk_v[i] = smem[res.dpkv + i];
+        for (int i = tid; i < L * H; i += kAnyThreads) dpk_t[i] = i < len * H ? smem[res.dpkt + i] : 0.f;
+    } else {
+        for (int i = tid; i < (L - len) * H; i += kAnyThreads) dpk_t[(int64_t)len * H + i] = 0.f;
+    }
     {   // energy-vector gradients of the row: the thread groups' shares of feature k
         const int CB = min((H + 63) & ~63, kAnyThreads), P = kAnyThreads / CB;
         for (int which = 0; which < 2; ++which) {
@@ -574,10 +680,20 @@ constexpr int kAnyMaxHidden = kAnyThreads;         // the backward pass gives ev
 // in place of W_ih's context columns (8 H^2 floats every row's workgroup streams): a gain for wide hidden sizes with few
 // memories — B = 256, T = 20, ms per step: H 160 2.93 -> 2.70, H 200 4.9 -> 3.8, H 256 6.0 -> 4.3 — and a loss or a draw
 // otherwise (H 144 2.54 -> 2.56, H 128 1.57 -> 1.68; H 100 on a 12 x 12 grid 2.0 -> 2.2).  GSCAN_ANY_U=0/1 forces the choice (tests).
+// Round 5: and whenever EVERY memory of the row, gate images included, fits LDS beside the kernels' vectors (hidden 128 on a
+// 6 x 6 grid: 123 KB + 23 KB of key gradients in the backward kernel): the images are then read from LDS and what is left
+// to stream is 7 H^2 floats instead of 16 H^2.
+static bool any_all_resident(int H, int L, int M) {
+    static const int off = [] { const char *e = getenv("GSCAN_ANY_RESIDENT"); return e ? atoi(e) == 0 : false; }();
+    if (off) return false;
+    const AnyResidency f = any_residency(H, L, M, true, true, false, any_lds_fwd(H, L, M).total, kAnyLdsFloats);
+    const AnyResidency b = any_residency(H, L, M, true, true, true, any_lds_bwd(H, L, M).total, kAnyLdsFloats);
+    return (f.flags & kAnyMemUV) && (b.flags & kAnyMemUV);
+}
 bool decoder_any_uses_gate_images(int H, int L, int M) {
     static const int forced = [] { const char *e = getenv("GSCAN_ANY_U"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return forced != 0;
-    return H >= 160 && L + M <= H;
+    return (H >= 160 && L + M <= H) || any_all_resident(H, L, M);
 }
 
 int decoder_run_any(bool backward, int B, int H, bool cond, const DecoderArgs &a_in, hipStream_t stream) {
@@ -588,9 +704,14 @@ int decoder_run_any(bool backward, int B, int H, bool cond, const DecoderArgs &a
     GSCAN_CHECK(a.any_w_hh && a.any_w_ih && a.any_w_qt && a.any_w_qv && (!cond || a.any_w_q2k),
                 "decoder (any shape): the parameter pointers are missing");
     const bool greedy = !backward && a.tokens_out != nullptr;
-    const size_t bytes = (size_t)(backward ? any_lds_bwd(H, a.L, a.M).total : any_lds_fwd(H, a.L, a.M).total) * sizeof(float);
-    GSCAN_CHECK(bytes <= 160 * 1024, "decoder (any shape): %zu bytes of LDS per row (hidden %d, %d + %d memories)", bytes, H,
-                a.L, a.M);
+    const int base = backward ? any_lds_bwd(H, a.L, a.M).total : any_lds_fwd(H, a.L, a.M).total;
+    GSCAN_CHECK((size_t)base * sizeof(float) <= 160 * 1024, "decoder (any shape): %zu bytes of LDS per row (hidden %d, %d + %d memories)",
+                (size_t)base * sizeof(float), H, a.L, a.M);
+    // the memories this launch keeps in LDS (GSCAN_ANY_RESIDENT=0: none, round 4's kernels); the kernel derives the same plan
+    static const int resident = [] { const char *e = getenv("GSCAN_ANY_RESIDENT"); return e ? atoi(e) : 1; }();
+    a.any_lds_floats = resident ? kAnyLdsFloats : 0;
+    const AnyResidency res = any_residency(H, a.L, a.M, cond, a.any_use_u != 0, backward, base, a.any_lds_floats);
+    const size_t bytes = (size_t)(((base + 3) & ~3) + res.floats) * sizeof(float);
     if (greedy) {
         GSCAN_CHECK(a.head_wc && a.dec_emb && a.steps_out, "greedy decoder: missing tables");
         GSCAN_CHECK(a.V <= 4 * H, "greedy decoder (any shape): a vocabulary of %d needs decoder_hidden_size >= %d", a.V, (a.V + 3) / 4);
