@@ -103,6 +103,87 @@ __device__ __forceinline__ void matvec_cols(const float *__restrict__ W, int ldw
     }
 }
 
+// The transposed products of up to three matrices ADDED UP, y[c] = sum_s sum_{r < R_s} W_s[r, c] * x_s[r] for c < C, as one pass
+// over the concatenated rows with 16-byte loads (matvec_cols4's form): dh_{t-1} = W_hh^T delta + W_qt^T dqt + W_q2k[:, :H]^T dzq
+// of the reverse streaming kernel was three calls — three exchanges, six barriers, three ramps — for one vector (round 5).
+// C, every ld multiples of 4; an unused set: R = 0.
+struct ColsRows { const float *W; int ld, R; const float *x; };
+template <typename Store>
+__device__ __forceinline__ void matvec_cols4_sets(const ColsRows s0, const ColsRows s1, const ColsRows s2, int C, float *scratch,
+                                                  Store store) {
+    const int tid = threadIdx.x;
+    const int Q = C >> 2, QB = min((Q + 15) & ~15, kAnyThreads), P = kAnyThreads / QB;
+    const int qq = tid % QB, p = tid / QB;
+    const int R01 = s0.R + s1.R, Rt = R01 + s2.R;
+    for (int qbase = 0; qbase < Q; qbase += QB) {
+        const int q = qbase + qq;
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (p < P && q < Q) {
+            auto at = [&](int r, float &xv) -> const float * {         // virtual row r -> its matrix row and vector element
+                const int set = r < s0.R ? 0 : (r < R01 ? 1 : 2);
+                const int rl = set == 0 ? r : (set == 1 ? r - s0.R : r - R01);
+                const float *W = set == 0 ? s0.W : (set == 1 ? s1.W : s2.W);
+                const int ld = set == 0 ? s0.ld : (set == 1 ? s1.ld : s2.ld);
+                xv = (set == 0 ? s0.x : (set == 1 ? s1.x : s2.x))[rl];
+                return W + (int64_t)rl * ld + 4 * q;
+            };
+            int r = p;
+#pragma unroll 1
+            for (; r + 3 * P < Rt; r += 4 * P) {
+                float x0, x1, x2, x3;
+                const float *p0 = at(r, x0), *p1 = at(r + P, x1), *p2 = at(r + 2 * P, x2), *p3 = at(r + 3 * P, x3);
+                const float4 w0 = *reinterpret_cast<const float4 *>(p0), w1 = *reinterpret_cast<const float4 *>(p1),
+                             w2 = *reinterpret_cast<const float4 *>(p2), w3 = *reinterpret_cast<const float4 *>(p3);
+                acc.x = fmaf(w0.x, x0, fmaf(w1.x, x1, fmaf(w2.x, x2, fmaf(w3.x, x3, acc.x))));
+                acc.y = fmaf(w0.y, x0, fmaf(w1.y, x1, fmaf(w2.y, x2, fmaf(w3.y, x3, acc.y))));
+                acc.z = fmaf(w0.z, x0, fmaf(w1.z, x1, fmaf(w2.z, x2, fmaf(w3.z, x3, acc.z))));
+                acc.w = fmaf(w0.w, x0, fmaf(w1.w, x1, fmaf(w2.w, x2, fmaf(w3.w, x3, acc.w))));
+            }
+            for (; r < Rt; r += P) {
+                float x0;
+                const float4 w0 = *reinterpret_cast<const float4 *>(at(r, x0));
+                acc.x = fmaf(w0.x, x0, acc.x); acc.y = fmaf(w0.y, x0, acc.y); acc.z = fmaf(w0.z, x0, acc.z); acc.w = fmaf(w0.w, x0, acc.w);
+            }
+        }
+#pragma unroll
+        for (int comp = 0; comp < 4; ++comp) {
+            scratch[tid] = comp == 0 ? acc.x : comp == 1 ? acc.y : comp == 2 ? acc.z : acc.w;
+            lds_barrier();
+            if (tid < QB && q < Q) {
+                float sum = 0.f;
+                for (int g = 0; g < P; ++g) sum += scratch[g * QB + tid];
+                store(4 * q + comp, sum);
+            }
+            lds_barrier();
+        }
+    }
+}
+
+// y[m] = A0[m, :] . x0 + A1[m, :] . x1 + A2[m, :] . x2 for m < n: FEW rows (an attention's memories) against long vectors — a
+// wave per row, a lane a 16-byte piece of every array's row per 256 columns, one wave sum per row (round 5).  matvec_rows
+// gives sixteen lanes to a row and four rows to a thread: with 10 or 36 rows nine tenths of its loads were clamped
+// duplicates, and the three arrays were three calls with a barrier each — 12-15 k cycles per attention for 23 k multiply-adds.
+// C0..C2 multiples of 4 (an unused array: C = 0), rows and vectors 16-byte aligned.
+struct FewRows { const float *A; int ld, C; const float *x; };
+template <typename Epi>
+__device__ __forceinline__ void rows_few(const FewRows a0, const FewRows a1, const FewRows a2, int n, Epi epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int m0 = 0; m0 < n; m0 += kAnyWaves) {
+        const int m = m0 + wave, mc = min(m, n - 1);
+        float p = 0.f;
+        auto part = [&](const FewRows &a) {
+            const float *row = a.A + (int64_t)mc * a.ld;
+            for (int c = 4 * lane; c < a.C; c += 256) {
+                const float4 w = *reinterpret_cast<const float4 *>(row + c), v = *reinterpret_cast<const float4 *>(a.x + c);
+                p = fmaf(w.x, v.x, fmaf(w.y, v.y, fmaf(w.z, v.z, fmaf(w.w, v.w, p))));
+            }
+        };
+        part(a0); part(a1); part(a2);
+        p = wave_sum(p);
+        if (lane == 0 && m < n) epi(m, p);
+    }
+}
+
 // The transposed product with 16-byte loads (round 5): C, ldw and c0 multiples of 4, W 16-byte aligned.  A thread owns a
 // column QUAD and every P-th row (one float4 per row, four in flight): a lane per column with 4-byte loads had every thread
 // walk R / P rows four at a time — W_hh^T (4H x H) was sixteen dependent L2 round trips of 16 KB per workgroup; this form

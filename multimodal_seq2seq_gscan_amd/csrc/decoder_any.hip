@@ -469,6 +469,9 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
     const float *W_hh = a.any_w_hh, *W_ih = a.any_w_ih, *W_qt = a.any_w_qt, *W_qv = a.any_w_qv, *W_q2k = a.any_w_q2k;
     const bool use_u = a.any_use_u != 0;
     const AnyResidency res = any_residency(H, L, M, cond != 0, use_u, true, o.total, a.any_lds_floats);
+    float *stamp_s = red + 32;                      // diagnostic phase stamps (ANY_STAMP): slots 16.. of the stamp buffer
+    long long stamp_prev = 0;
+    if (tid < 16) stamp_s[tid] = 0.f;
     // transposed weight products: 16-byte loads along the rows when the hidden size is a multiple of 4 (anyshape.h)
     // — for TALL products only: the quad form pays eight barriers for its exchange, the lane-per-column form two, and a round
     // trip of the latter moves 16 KB (cheap); from ~20 dependent round trips on the quad form wins (W_hh^T from hidden 144 on,
@@ -571,6 +574,7 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
         const float *u_v = (res.flags & kAnyMemUV) ? smem + res.uv : a.u_v + (int64_t)b * M * 4 * H;
         const int64_t bt = (int64_t)b * T + t;
         // ---- LSTM cell backward (dh_t = head part + what step t+1 passed back)
+        if (t == T - 1 && a.stamps && blockIdx.x == 0 && tid == 0) stamp_prev = clock64();
         for (int u = tid; u < H; u += kAnyThreads) {
             const float dh = a.ds[bt * 4 * H + 3 * H + u] + dh_s[u];
             const float ig = a.gates[bt * 4 * H + u], fg = a.gates[bt * 4 * H + H + u], gg = a.gates[bt * 4 * H + 2 * H + u],
@@ -589,6 +593,7 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
             a.delta[bt * 5 * H + 2 * H + u] = dg; a.delta[bt * 5 * H + 3 * H + u] = d_o;
         }
         lds_barrier();
+        ANY_STAMP(0)
         // ---- d alpha_vis[m] = delta . U_vis[m] + d ctx_vis(head) . PK_vis[m] + d att_sum[m]: the LSTM-input part of the context
         //      gradient reaches d alpha through the gate images (delta . U[m] = (W_ih[:, ctx]^T delta) . PK[m]); the context
         //      gradients themselves (the value path of the keys) are completed by the dS += product behind this kernel
@@ -598,16 +603,23 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
         for (int m = tid; m < M; m += kAnyThreads) al_s[m] = a.alpha_s[bt * M + m];
         for (int k = tid; k < H; k += kAnyThreads) q_s[k] = a.qv[bt * H + k];
         lds_barrier();
-        if (use_u) {
+        ANY_STAMP(1)
+        if (use_u && V4) {          // one pass, a wave per cell (rows_few)
+            rows_few(FewRows{u_v, 4 * H, 4 * H, dlp_s}, FewRows{pk_v, H, H, dctx_s + H}, FewRows{pk_v, H, 0, dctx_s}, M,
+                     [&](int m, float v) { sc[m] = v + datt_s[m]; });
+            lds_barrier();
+        } else if (use_u) {
             matvec_rows<true>(u_v, 4 * H, M, 4 * H, dlp_s, [&](int m, float v) { sc[m] = v + datt_s[m]; });
             lds_barrier();
             matvec_rows<V4>(pk_v, H, M, H, dctx_s + H, [&](int m, float v) { sc[m] += v; });
             lds_barrier();
         }
         // ---- visual attention backward
+        ANY_STAMP(2)
         attention_bwd_any(use_u ? nullptr : dctx_s + H, datt_s, q_s, vv_s, al_s, pk_v, dpk_v, M, H, sc, dq_s, red, scr, dvv);
         for (int k = tid; k < H; k += kAnyThreads) { const float v = dq_s[k]; dqv_s[k] = v; a.dqv[bt * H + k] = v; }
         lds_barrier();
+        ANY_STAMP(3)
         if (cond) {
             // d q2 = W_qv^T dqv, through tanh; the conditional query's share of d ctx_text
             wcols(W_qv, H, 0, H, H, dqv_s, [&](int c, float v) {
@@ -621,8 +633,13 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
         for (int m = tid; m < L; m += kAnyThreads) al_s[m] = a.alpha_c[bt * L + m];
         for (int k = tid; k < H; k += kAnyThreads) q_s[k] = a.qt[bt * H + k];
         lds_barrier();
+        ANY_STAMP(4)
         // ---- d alpha_text[m] = delta . U_text[m] + dzq . U2_text[m] + d ctx_text(head) . PK_text[m]
-        if (use_u) {
+        if (use_u && V4) {
+            rows_few(FewRows{u_t, 4 * H, 4 * H, dlp_s}, FewRows{u2_t, H, cond ? H : 0, dl_s + 4 * H}, FewRows{pk_t, H, H, dctx_s}, len,
+                     [&](int m, float v) { sc[m] = v; });
+            lds_barrier();
+        } else if (use_u) {
             matvec_rows<true>(u_t, 4 * H, len, 4 * H, dlp_s, [&](int m, float v) { sc[m] = v; });
             lds_barrier();
             if (cond) {
@@ -633,18 +650,30 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
             lds_barrier();
         }
         // ---- textual attention backward
+        ANY_STAMP(5)
         attention_bwd_any(use_u ? nullptr : dctx_s, nullptr, q_s, vt_s, al_s, pk_t, dpk_t, len, H, sc, dq_s, red, scr, dvt);
         for (int k = tid; k < H; k += kAnyThreads) a.dqt[bt * H + k] = dq_s[k];
+        ANY_STAMP(6)
         // ---- dh_{t-1} = W_hh^T delta + W_qt^T dqt + (W_q2k[:, :H]^T dzq  or  W_qv^T dqv)
-        wcols(W_hh, H, 0, 4 * H, H, dl_s, [&](int c, float v) { dh_s[c] = v; });
-        lds_barrier();
-        wcols(W_qt, H, 0, H, H, dq_s, [&](int c, float v) { dh_s[c] += v; });
-        lds_barrier();
-        if (cond) wcols(W_q2k, 2 * H, 0, H, H, dl_s + 4 * H, [&](int c, float v) { dh_s[c] += v; });
-        else wcols(W_qv, H, 0, H, H, dqv_s, [&](int c, float v) { dh_s[c] += v; });
-        lds_barrier();
+        if (V4) {       // one pass over the 6H concatenated rows (matvec_cols4_sets)
+            matvec_cols4_sets(ColsRows{W_hh, H, 4 * H, dl_s}, ColsRows{W_qt, H, H, dq_s},
+                              cond ? ColsRows{W_q2k, 2 * H, H, dl_s + 4 * H} : ColsRows{W_qv, H, H, dqv_s}, H, scr,
+                              [&](int c, float v) { dh_s[c] = v; });
+            ANY_STAMP(7)
+        } else {
+            wcols(W_hh, H, 0, 4 * H, H, dl_s, [&](int c, float v) { dh_s[c] = v; });
+            lds_barrier();
+            ANY_STAMP(7)
+            wcols(W_qt, H, 0, H, H, dq_s, [&](int c, float v) { dh_s[c] += v; });
+            lds_barrier();
+            if (cond) wcols(W_q2k, 2 * H, 0, H, H, dl_s + 4 * H, [&](int c, float v) { dh_s[c] += v; });
+            else wcols(W_qv, H, 0, H, H, dqv_s, [&](int c, float v) { dh_s[c] += v; });
+            lds_barrier();
+        }
+        ANY_STAMP(8)
     }
     // ---- epilogue: initial-state gradient through the bridge tanh (h0 = c0 = tanh(.), model.py:195), energy vectors
+    if (a.stamps && blockIdx.x == 0 && tid < 16) a.stamps[tid] = stamp_s[tid];
     for (int k = tid; k < H; k += kAnyThreads) {
         const float h0 = a.hprev[(int64_t)b * T * H + k];
         a.dh0[(int64_t)b * H + k] = (dh_s[k] + dc_s[k]) * (1.f - h0 * h0);
@@ -693,7 +722,10 @@ static bool any_all_resident(int H, int L, int M) {
 bool decoder_any_uses_gate_images(int H, int L, int M) {
     static const int forced = [] { const char *e = getenv("GSCAN_ANY_U"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return forced != 0;
-    return (H >= 160 && L + M <= H) || any_all_resident(H, L, M);
+    // (round 5: with the images' sums and dot products as single passes the form pays from FEW memories on, not only for wide
+    // hidden sizes — ms per step at B = 256: hidden 128 1.44 -> 1.18, 144 2.13 -> 1.83, 160 2.24 -> 2.03, 200 3.42 -> 3.01; it still
+    // loses where the memories outnumber the features: a 12 x 12 grid at hidden 100 1.55 -> 1.66, a 128-token command 4.61 -> 4.94)
+    return L + M <= H || any_all_resident(H, L, M);
 }
 
 int decoder_run_any(bool backward, int B, int H, bool cond, const DecoderArgs &a_in, hipStream_t stream) {

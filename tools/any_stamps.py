@@ -15,11 +15,19 @@ for _ in range(3):
     model.zero_grad()
     logp, _ = model(commands_input=batch["commands"], commands_lengths=batch["cmd_lengths"].tolist(), situations_input=batch["world"],
                     target_batch=batch["targets"], target_lengths=batch["tgt_lengths"].tolist())
+    model.get_loss(logp, batch["targets"]).backward()
 torch.cuda.synchronize()
 B, L = batch["commands"].shape
 dims = model._dims(B, L, 20, batch["world"].shape[1])
-st = model.workspace_view(dims, "stamps").cpu()[:16].tolist()
+both = model.workspace_view(dims, "stamps").cpu().tolist()
+st = both[:16]
 names = ["rows h (W_qt W_hh W_q2k_h)", "scores text", "softmax text", "cols text (ctx, U_t, U2_t | W_q2k)", "rows W_qv", "scores vis", "softmax vis", "cols ctx_vis", "cols U_v | rows W_ih ctx", "gates"]
 tot = sum(st[:10])
 print(f"H={H} forward streaming kernel, workgroup 0: {tot / 20:.0f} cycles per step")
 for n, v in zip(names, st): print(f"  {n:38s} {v / 20:8.0f}")
+bw = both[16:32]
+names_b = ["cell backward (saved activations from global)", "d ctx + alpha_vis, q_vis loads", "d alpha_vis rows (U_v, PK_v)", "visual attention backward",
+           "W_qv^T (+ W_q2k ctx), alpha_text, q_text loads", "d alpha_text rows (U_t, U2_t, PK_t)", "textual attention backward", "W_hh^T",
+           "W_qt^T, W_q2k_h^T / W_qv^T"]
+print(f"H={H} backward streaming kernel, workgroup 0: {sum(bw[:9]) / 20:.0f} cycles per step")
+for n, v in zip(names_b, bw): print(f"  {n:52s} {v / 20:8.0f}")
