@@ -21,7 +21,7 @@ namespace gscan {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kKbThreads = 256, kKbWaves = kKbThreads / 64, kKbSteps = 32, kKbMaxTiles = 2;
+constexpr int kKbThreads = 256, kKbWaves = kKbThreads / 64, kKbSteps = 32;
 
 struct KeysLds { int dpk, al, dc, total; };
 __host__ __device__ inline KeysLds keys_lds(int H) {
@@ -36,11 +36,12 @@ __host__ __device__ inline KeysLds keys_lds(int H) {
 }
 
 template <int H>
-__global__ __launch_bounds__(kKbThreads, 4) void keys_backward_kernel(KeysBackwardArgs a) {
+__global__ __launch_bounds__(kKbThreads, H <= 128 ? 4 : 2) void keys_backward_kernel(KeysBackwardArgs a) {   // hidden sizes above 128: 64 B-fragment registers per lane, two workgroups per CU
     TraceScope trace_scope(TK_KEYS_BWD);
     constexpr int HS = (H % 8 == 4) ? H : H + 4;      // dPK row stride: the 16 rows of an A fragment hit distinct banks
     constexpr int NTH = (H + 15) / 16, KS = H / 4, Q = H / 4;
-    static_assert(NTH <= kKbMaxTiles * kKbWaves && H % 4 == 0, "hidden size not supported");
+    constexpr int kKbMaxTiles = (NTH + kKbWaves - 1) / kKbWaves;     // 16-feature tiles of dPK per wave (2 up to hidden 128, 4 up to 256)
+    static_assert(H % 4 == 0 && H <= 256, "hidden size not supported");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int T = a.T, L = a.L, M = a.M;
@@ -244,9 +245,20 @@ __global__ __launch_bounds__(kKbThreads) void keys_backward_any_kernel(KeysBackw
     }
 }
 
+// hidden sizes above the resident decoder kernels' 100 that still get the matrix-core kernel (any other size: the plain loops below)
+#define GSCAN_KEYS_EXTRA_SIZES(X) X(104) X(108) X(112) X(116) X(120) X(124) X(128) X(144) X(160) X(176) X(192) X(200) X(208) X(224) X(240) X(256)
+
 template <int H>
 static int launch_keys_backward(int B, const KeysBackwardArgs &a, hipStream_t stream) {
     const size_t bytes = (size_t)keys_lds(H).total * sizeof(float);
+    if (bytes > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            GSCAN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&keys_backward_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)bytes));
+            attr_set = true;
+        }
+    }
     const int tiles = (a.M + 15) / 16 + (a.L + 15) / 16;
     hipLaunchKernelGGL((keys_backward_kernel<H>), dim3(B, tiles + 1), dim3(kKbThreads), bytes, stream, a);
     GSCAN_LAUNCHED("keys_backward_kernel");
@@ -265,6 +277,7 @@ int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream) {
     switch (H) {
 #define X(n) case n: return launch_keys_backward<n>(B, a, stream);
         GSCAN_DEC_HIDDEN_SIZES(X)
+        GSCAN_KEYS_EXTRA_SIZES(X)      // round 5: the matrix-core kernel for the usual sizes above 100 too (the decoder streams there)
 #undef X
         default: break;
     }
