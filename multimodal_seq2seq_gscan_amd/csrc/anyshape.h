@@ -8,6 +8,26 @@ namespace gscan {
 
 constexpr int kAnyThreads = 1024, kAnyWaves = kAnyThreads / 64;     // sixteen waves: the loads in flight hide the L2 latency
 
+// threadIdx.x behind a compiler barrier.  The products below are inlined at a dozen call sites inside the kernels' time loops, and
+// every per-thread address they derive from the thread index is loop-invariant: hoisted out of the time loop those were dozens of
+// 64-bit pointers held in VGPRs across it, and the loops' loads were issued TWO at a time with a full wait in between (the ISA
+// of round 4's kernels) because no registers were left to keep more in flight.  From an opaque index they are recomputed per call.
+__device__ __forceinline__ int any_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+// acc += w . v as two packed FMAs on register pairs that come out of ONE 16-byte load each ((x, y) and (z, w)).  Written as four
+// scalar FMAs per row, the compiler packed ACROSS rows instead ({w[u].x, w[u+1].x} ...), shuffled every loaded float4 into
+// that layout with v_mov right behind the loads, and so waited for the loads two at a time (the ISA of round 4's kernels):
+// a thread never had more than 32 bytes in flight, whatever the source said.
+using any_f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ void any_fma4(any_f32x2 &a01, any_f32x2 &a23, const float4 &w, const float4 &v) {
+    a01 += any_f32x2{w.x, w.y} * any_f32x2{v.x, v.y};
+    a23 += any_f32x2{w.z, w.w} * any_f32x2{v.z, v.w};
+}
+
 // sum over the sixteen lanes of a DPP row; every lane of the row gets it (all 64 lanes active)
 __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_move<0xb1, 0xf>(v);        // quad_perm [1,0,3,2]
@@ -24,7 +44,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <bool V4, typename Store>
 __device__ __forceinline__ void matvec_rows(const float *__restrict__ W, int ldw, int R, int C, const float *x, Store store) {
     constexpr int U = 4, ngrp = kAnyThreads / 16;
-    const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+    const int tid = any_tid(), l16 = tid & 15, grp = tid >> 4;
     for (int r0 = 0; r0 < R; r0 += ngrp * U) {                // uniform trip count: the DPP sums need every lane
         const float *wrow[U];
         float acc[U];
@@ -34,6 +54,9 @@ __device__ __forceinline__ void matvec_rows(const float *__restrict__ W, int ldw
             acc[u] = 0.f;
         }
         if (V4) {
+            any_f32x2 a01[U], a23[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a01[u] = any_f32x2{0.f, 0.f}; a23[u] = any_f32x2{0.f, 0.f}; }
 #pragma unroll 2
             for (int c = 4 * l16; c < C; c += 64) {
                 float4 w[U];
@@ -41,9 +64,10 @@ __device__ __forceinline__ void matvec_rows(const float *__restrict__ W, int ldw
                 for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const float4 *>(wrow[u] + c);
                 const float4 v = *reinterpret_cast<const float4 *>(x + c);
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    acc[u] = fmaf(w[u].x, v.x, fmaf(w[u].y, v.y, fmaf(w[u].z, v.z, fmaf(w[u].w, v.w, acc[u]))));
+                for (int u = 0; u < U; ++u) any_fma4(a01[u], a23[u], w[u], v);
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = (a01[u].x + a01[u].y) + (a23[u].x + a23[u].y);
         } else {
 #pragma unroll 2
             for (int c = l16; c < C; c += 16) {
@@ -64,6 +88,54 @@ __device__ __forceinline__ void matvec_rows(const float *__restrict__ W, int ldw
     }
 }
 
+// matvec_rows fed from a TRIP-MAJOR image of the matrix (any_stream_image_*) and software-pipelined over the trips (a trip = this
+// thread's four rows x one 64-column piece = four 16-byte loads; trip t + 1 is requested before trip t is consumed, across row
+// blocks: two buffers, the registers of the plain form's loads).  Element (trip t, row slot u, thread) of the image is one
+// float4 at ((t * 4 + u) * kAnyThreads + thread): every wave load is 1 KB of consecutive addresses, pieces outside the matrix
+// are stored zeros (no clamping).  Used for the one long product of a forward step, [W_hh ; W_q2k_h ; W_qt] . h (any_wcat).
+__host__ __device__ inline int any_stream_trips(int R, int C) { return ((R + 255) / 256) * ((C + 63) >> 6); }
+__host__ __device__ inline size_t any_stream_image_floats(int R, int C) { return (size_t)any_stream_trips(R, C) * 4 * kAnyThreads * 4; }
+template <typename Store>
+__device__ __forceinline__ void matvec_rows_image(const float *__restrict__ img, int R, int C, const float *x, Store store) {
+    constexpr int U = 4, ngrp = kAnyThreads / 16, RB = ngrp * U;
+    const int tid = any_tid(), l16 = tid & 15, grp = tid >> 4;
+    const int ncc = (C + 63) >> 6, ntrips = ((R + RB - 1) / RB) * ncc;
+    const float4 *img4 = reinterpret_cast<const float4 *>(img) + tid;
+    auto issue = [&](int t, float4 (&w)[U]) {
+        if (t >= ntrips) return;
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = img4[(size_t)(t * U + u) * kAnyThreads];
+    };
+    any_f32x2 a01[U], a23[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { a01[u] = any_f32x2{0.f, 0.f}; a23[u] = any_f32x2{0.f, 0.f}; }
+    auto consume = [&](int t, const float4 (&w)[U]) {
+        if (t >= ntrips) return;
+        const int rb = t / ncc, cc = t - rb * ncc;
+        const int col = cc * 64 + 4 * l16;
+        const float4 v = col < C ? *reinterpret_cast<const float4 *>(x + col) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < U; ++u) any_fma4(a01[u], a23[u], w[u], v);
+        if (cc == ncc - 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float sum = row16_sum((a01[u].x + a01[u].y) + (a23[u].x + a23[u].y));
+                const int r = rb * RB + grp + u * ngrp;
+                if (l16 == 0 && r < R) store(r, sum);
+                a01[u] = any_f32x2{0.f, 0.f}; a23[u] = any_f32x2{0.f, 0.f};
+            }
+        }
+    };
+    float4 w0[U], w1[U];
+    issue(0, w0);
+    for (int t = 0; t < ntrips; t += 2) {
+        issue(t + 1, w1);
+        consume(t, w0);
+        issue(t + 2, w0);
+        consume(t + 1, w1);
+    }
+}
+
 // y[c] = sum_{r < R} W[r, c0 + c] * x[r]  for c < C (the transposed product), through `store(c, value)`.  A lane per
 // column (coalesced across lanes), the rows dealt round-robin to the kAnyThreads / CB thread groups that share a
 // column block (CB = C rounded up to a wave, at most the workgroup), four loads in flight per thread; the groups'
@@ -72,7 +144,7 @@ __device__ __forceinline__ void matvec_rows(const float *__restrict__ W, int ldw
 template <typename Store>
 __device__ __forceinline__ void matvec_cols(const float *__restrict__ W, int ldw, int c0, int R, int C, const float *x,
                                             float *scratch, Store store) {
-    const int tid = threadIdx.x;
+    const int tid = any_tid();
     const int CB = min((C + 63) & ~63, kAnyThreads), P = kAnyThreads / CB;
     const int cc = tid % CB, p = tid / CB;
     for (int cbase = 0; cbase < C; cbase += CB) {
@@ -111,7 +183,7 @@ struct ColsRows { const float *W; int ld, R; const float *x; };
 template <typename Store>
 __device__ __forceinline__ void matvec_cols4_sets(const ColsRows s0, const ColsRows s1, const ColsRows s2, int C, float *scratch,
                                                   Store store) {
-    const int tid = threadIdx.x;
+    const int tid = any_tid();
     const int Q = C >> 2, QB = min((Q + 15) & ~15, kAnyThreads), P = kAnyThreads / QB;
     const int qq = tid % QB, p = tid / QB;
     const int R01 = s0.R + s1.R, Rt = R01 + s2.R;
@@ -167,7 +239,7 @@ __device__ __forceinline__ void matvec_cols4_sets(const ColsRows s0, const ColsR
 struct FewRows { const float *A; int ld, C; const float *x; };
 template <typename Epi>
 __device__ __forceinline__ void rows_few(const FewRows a0, const FewRows a1, const FewRows a2, int n, Epi epi) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid_ = any_tid(), lane = tid_ & 63, wave = tid_ >> 6;
     for (int m0 = 0; m0 < n; m0 += kAnyWaves) {
         const int m = m0 + wave, mc = min(m, n - 1);
         float p = 0.f;
@@ -191,7 +263,7 @@ __device__ __forceinline__ void rows_few(const FewRows a0, const FewRows a1, con
 template <typename Store>
 __device__ __forceinline__ void matvec_cols4(const float *__restrict__ W, int ldw, int c0, int R, int C, const float *x,
                                              float *scratch, Store store) {
-    const int tid = threadIdx.x;
+    const int tid = any_tid();
     const int Q = C >> 2, QB = min((Q + 15) & ~15, kAnyThreads), P = kAnyThreads / QB;
     const int qq = tid % QB, p = tid / QB;
     for (int qbase = 0; qbase < Q; qbase += QB) {
@@ -240,7 +312,7 @@ struct ColsArray { const float *A; int ld, C; };
 template <typename Store>
 __device__ __forceinline__ void matvec_cols_arrays(const ColsArray a0, const ColsArray a1, const ColsArray a2, int R, const float *x,
                                                    float *scratch, Store store) {           // an unused array: C = 0
-    const int tid = threadIdx.x;
+    const int tid = any_tid();
     const int Ctot = a0.C + a1.C + a2.C;
     const int CB = min((Ctot + 63) & ~63, kAnyThreads), P = kAnyThreads / CB;
     const int cc = tid % CB, p = tid / CB;

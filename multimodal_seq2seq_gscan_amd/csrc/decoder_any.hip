@@ -174,9 +174,18 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
         {
             const int64_t ge_row = GREEDY ? (int64_t)tok_s[0] : bt;    // greedy: row of the [V, 4H] table of the token fed in
             const float *ge = a.ge + ge_row * 4 * H;
-            matvec_rows<V4>(W_qt, H, H, H, h_s, [&](int r, float v) { qt_s[r] = v; });
-            matvec_rows<V4>(W_hh, H, 4 * H, H, h_s, [&](int r, float v) { pre_s[r] = v + ge[r]; });
-            if (cond && use_u) matvec_rows<V4>(W_q2k, 2 * H, H, H, h_s, [&](int r, float v) { q2_s[r] = v + bq_s[r]; });   // W_q2k[:, :H] h + b
+            if (V4 && use_u) {      // one call over the concatenated [W_hh ; W_q2k[:, :H] or W_query_vis ; W_query_text] (any_wcat)
+                matvec_rows_image(a.any_wcat_stream, 6 * H, H, h_s, [&](int r, float v) {
+                    if (r < 4 * H) pre_s[r] = v + ge[r];
+                    else if (r >= 5 * H) qt_s[r - 5 * H] = v;
+                    else if (cond) q2_s[r - 4 * H] = v + bq_s[r - 4 * H];          // W_q2k[:, :H] h + b
+                    else { qv_s[r - 4 * H] = v; if (!GREEDY) a.qv[bt * H + r - 4 * H] = v; }   // the visual query comes straight from h
+                });
+            } else {
+                matvec_rows<V4>(W_qt, H, H, H, h_s, [&](int r, float v) { qt_s[r] = v; });
+                matvec_rows<V4>(W_hh, H, 4 * H, H, h_s, [&](int r, float v) { pre_s[r] = v + ge[r]; });
+                if (cond && use_u) matvec_rows<V4>(W_q2k, 2 * H, H, H, h_s, [&](int r, float v) { q2_s[r] = v + bq_s[r]; });   // W_q2k[:, :H] h + b
+            }
         }
         lds_barrier();
         ANY_STAMP(0)
@@ -215,11 +224,13 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_fwd_any_kernel(DecoderArg
             lds_barrier();
         }
         ANY_STAMP(3)
-        matvec_rows<V4>(W_qv, H, H, H, cond ? q2_s : h_s, [&](int r, float v) {
-            qv_s[r] = v;
-            if (!GREEDY) a.qv[bt * H + r] = v;
-        });
-        lds_barrier();
+        if (cond || !(V4 && use_u)) {                                  // (unconditional, one-call form: computed with the others above)
+            matvec_rows<V4>(W_qv, H, H, H, cond ? q2_s : h_s, [&](int r, float v) {
+                qv_s[r] = v;
+                if (!GREEDY) a.qv[bt * H + r] = v;
+            });
+            lds_barrier();
+        }
         ANY_STAMP(4)
         // ---- visual attention over all M cells
         scores_any(vv_s, qv_s, pk_v, M, H, sc);
@@ -384,10 +395,11 @@ __host__ __device__ inline AnyLdsB any_lds_bwd(int H, int L, int M) {
     AnyLdsB o;
     int p = 0;
     o.dh = p; p += HP; o.dc = p; p += HP;
-    o.dl = p; p += 5 * HP;             // delta (4H) | dzq (H)
+    o.dl = p; p += 5 * HP;             // delta (4H) | dzq (H; without the conditional query: d (projected visual query))
+    o.dq = p; p += HP;                 // d (projected query) of the attention being processed — RIGHT BEHIND dl: [delta | dzq | dqt] is
+                                       // the vector of the one-pass dh product over the concatenated weights (any_wcat)
     o.dlp = p; p += 4 * HP;            // delta unit-major (4 unit + gate): the order of the gate images' columns
     o.dctx = p; p += 2 * HP;           // d ctx_text | d ctx_vis: the head's part (the rest reaches d alpha through the gate images)
-    o.dq = p; p += HP;                 // d (projected query) of the attention being processed
     o.dqv = p; p += HP;                // d (projected visual query), kept until the dh sum
     o.q = p; p += HP;                  // the saved projected query
     o.v1 = p; p += HP; o.v2 = p; p += HP;      // energy vectors
@@ -617,7 +629,12 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
         // ---- visual attention backward
         ANY_STAMP(2)
         attention_bwd_any(use_u ? nullptr : dctx_s + H, datt_s, q_s, vv_s, al_s, pk_v, dpk_v, M, H, sc, dq_s, red, scr, dvv);
-        for (int k = tid; k < H; k += kAnyThreads) { const float v = dq_s[k]; dqv_s[k] = v; a.dqv[bt * H + k] = v; }
+        for (int k = tid; k < H; k += kAnyThreads) {
+            const float v = dq_s[k];
+            dqv_s[k] = v;
+            a.dqv[bt * H + k] = v;
+            if (!cond) dl_s[4 * H + k] = v;                             // the middle block of the dh product's vector (any_wcat)
+        }
         lds_barrier();
         ANY_STAMP(3)
         if (cond) {
@@ -655,7 +672,10 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
         for (int k = tid; k < H; k += kAnyThreads) a.dqt[bt * H + k] = dq_s[k];
         ANY_STAMP(6)
         // ---- dh_{t-1} = W_hh^T delta + W_qt^T dqt + (W_q2k[:, :H]^T dzq  or  W_qv^T dqv)
-        if (V4) {       // one pass over the 6H concatenated rows (matvec_cols4_sets)
+        if (V4 && use_u) {  // one transposed product over the concatenated rows: x = [delta | dzq or dqv | dqt] = dl_s .. dq_s (adjacent)
+            matvec_cols4(a.any_wcat, H, 0, 6 * H, H, dl_s, scr, [&](int c, float v) { dh_s[c] = v; });
+            ANY_STAMP(7)
+        } else if (V4) {    // one pass over the 6H concatenated rows (matvec_cols4_sets)
             matvec_cols4_sets(ColsRows{W_hh, H, 4 * H, dl_s}, ColsRows{W_qt, H, H, dq_s},
                               cond ? ColsRows{W_q2k, 2 * H, H, dl_s + 4 * H} : ColsRows{W_qv, H, H, dqv_s}, H, scr,
                               [&](int c, float v) { dh_s[c] = v; });
@@ -698,6 +718,26 @@ __global__ __launch_bounds__(kAnyThreads) void decoder_bwd_any_kernel(DecoderArg
             }
         }
     }
+}
+
+// [W_hh ; mid ; W_query_text] (mid = W_q2k[:, :H], row stride 2H, or W_query_vis) as ONE [6H, H] matrix, written twice per step:
+// row-major (`plain`: dh_{t-1} of a reverse step is one transposed product over its rows) and trip-major (`stream`,
+// matvec_rows_image: the three products with h_{t-1} of a forward step are one stream of consecutive kilobytes).
+__global__ void any_wcat_kernel(const float *__restrict__ w_hh, const float *__restrict__ w_mid, int ld_mid,
+                                const float *__restrict__ w_qt, int H, float *__restrict__ plain, float *__restrict__ stream) {
+    const int R = 6 * H, ncc = (H + 63) >> 6;
+    auto at = [&](int r, int c) -> float {
+        if (r >= R || c >= H) return 0.f;
+        return r < 4 * H ? w_hh[(int64_t)r * H + c] : (r < 5 * H ? w_mid[(int64_t)(r - 4 * H) * ld_mid + c] : w_qt[(int64_t)(r - 5 * H) * H + c]);
+    };
+    const int64_t total = (int64_t)any_stream_image_floats(R, H);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3), tid = (int)((i >> 2) % kAnyThreads);
+        const int tu = (int)((i >> 2) / kAnyThreads), u = tu & 3, t = tu >> 2;
+        const int rb = t / ncc, cc = t - rb * ncc;
+        stream[i] = at(rb * 256 + (tid >> 4) + u * 64, cc * 64 + 4 * (tid & 15) + e);
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R * H; i += gridDim.x * blockDim.x) plain[i] = at(i / H, i % H);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -759,6 +799,14 @@ int decoder_run_any(bool backward, int B, int H, bool cond, const DecoderArgs &a
         GSCAN_LAUNCHED(name);
         return 0;
     };
+    if (!backward && v4 && a.any_use_u) {       // [W_hh ; W_q2k[:, :H] or W_query_vis ; W_query_text] for this step's two launches
+        GSCAN_CHECK(a.any_wcat != nullptr, "decoder (any shape): no room for the concatenated weights");
+        GSCAN_CHECK(a.any_wcat_stream != nullptr, "decoder (any shape): no room for the streamed weights");
+        hipLaunchKernelGGL(any_wcat_kernel, dim3((int)std::min<int64_t>(cdiv((int64_t)any_stream_image_floats(6 * H, H), 256), 4096)),
+                           dim3(256), 0, stream, a.any_w_hh, cond ? a.any_w_q2k : a.any_w_qv, cond ? 2 * H : H, a.any_w_qt, H,
+                           a.any_wcat, a.any_wcat_stream);
+        GSCAN_LAUNCHED("any_wcat_kernel");
+    }
     if (backward) return v4 ? launch(decoder_bwd_any_kernel<true>, "decoder_bwd_any_kernel") : launch(decoder_bwd_any_kernel<false>, "decoder_bwd_any_kernel");
     if (greedy) return v4 ? launch(decoder_fwd_any_kernel<true, true>, "decoder_fwd_any_kernel") : launch(decoder_fwd_any_kernel<false, true>, "decoder_fwd_any_kernel");
     return v4 ? launch(decoder_fwd_any_kernel<true, false>, "decoder_fwd_any_kernel") : launch(decoder_fwd_any_kernel<false, false>, "decoder_fwd_any_kernel");

@@ -311,6 +311,9 @@ struct DecoderArgs {
     const float *any_w_hh, *any_w_ih, *any_w_qt, *any_w_qv, *any_w_q2k;
     int any_use_u;                      // set by decoder_run_any
     int any_lds_floats;                 // set by decoder_run_any: LDS floats the launch may use (any_residency's limit; 0: no residency)
+    float *any_wcat, *any_wcat_stream;  // [6H, H] = [W_hh ; W_q2k[:, :H] or W_query_vis ; W_query_text], row-major and trip-major
+                                        // (anyshape.h): written by the forward launch of decoder_run_any into the resident kernels' two
+                                        // image slots (unused on this path), read by the reverse / the forward streaming kernel
     float *hprev;                      // [B,T,H]  hprev[b,0] = h0 (= c0 unless c0 is given) on entry; kernel fills t+1
     const float *c0;                   // [B,H] initial cell state, or NULL for c0 = h0 (seq2seq_model.py:494-504)
     float *h_last;                     // [B,H] h after the last step, or NULL

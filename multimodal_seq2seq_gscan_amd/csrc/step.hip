@@ -68,7 +68,9 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(w_sk, 4 * H * F);
     SLOT(w_ck, 4 * H * He);
     SLOT(w_2kk, H * He);
-    SLOT(dec_w_fwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
+    // (the streaming decoder keeps its trip-major copy of the weights that multiply h here: any_stream_image_floats, anyshape.h)
+    SLOT(dec_w_fwd, std::max<int64_t>(decoder_geometry(d.H, d.conditional != 0).image_floats,
+                                      (int64_t)(((6 * d.H + 255) / 256) * ((d.H + 63) / 64)) * 4 * 1024 * 4));
     SLOT(dec_w_bwd, decoder_geometry(d.H, d.conditional != 0).image_floats);
     SLOT(enc_w_image, D * 4 * He * He);
     SLOT(hprev, B * T * H);
@@ -186,6 +188,7 @@ static DecoderArgs decoder_args(const gscan_dims &d, const gscan_params &p, cons
     a.b_q2k = p.q2k_b; a.v_t = p.txt_energy_w; a.v_v = p.vis_energy_w;
     a.any_w_hh = p.dec_w_hh; a.any_w_ih = p.dec_w_ih; a.any_w_qt = p.txt_query_w; a.any_w_qv = p.vis_query_w;
     a.any_w_q2k = p.q2k_w;
+    a.any_wcat = w + ws.dec_w_bwd; a.any_wcat_stream = w + ws.dec_w_fwd;
     a.hprev = w + ws.hprev; a.s = w + ws.S; a.cells = w + ws.cells; a.gates = w + ws.gates;
     a.alpha_c = w + ws.alpha_c; a.alpha_s = w + ws.alpha_s;
     a.q2 = w + ws.q2; a.qt = w + ws.qt; a.qv = w + ws.qv; a.att_sum = w + ws.att_sum;
