@@ -181,38 +181,68 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
     const float alpha = g.alpha;
     gfloat *gc = as_global(g.c);
     const gfloat *gbias = as_global(g.bias), *ggate = as_global(g.gate), *gmask = as_global(g.mask);
+    const bool plain = g.beta == 0.f && !g.bias && g.act == 0 && !g.mask;
+    if (g.atomic || plain) {
 #pragma unroll
-    for (int i = 0; i < TMW; ++i)
+        for (int i = 0; i < TMW; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ri = fg * 4 + r;                                        // MFMA row index 0..15
-            const int row = m0 + wm * 16 * TMW + (pa.is_kc() ? 16 * i + ri : TMW * ri + i);
-            if (row >= g.M) continue;
-            const uint32_t roff = (uint32_t)row * ldc;
-            if (g.atomic) {
+            for (int r = 0; r < 4; ++r) {
+                const int ri = fg * 4 + r;                                    // MFMA row index 0..15
+                const int row = m0 + wm * 16 * TMW + (pa.is_kc() ? 16 * i + ri : TMW * ri + i);
+                if (row >= g.M) continue;
+                const uint32_t roff = (uint32_t)row * ldc;
+                if (g.atomic) {
 #pragma unroll
-                for (int j = 0; j < TNW; ++j)
-                    if (cok[j]) atomicAdd(g.c + (roff + coff[j]), alpha * acc[i][j][r]);
-            } else if (g.beta == 0.f && !g.bias && g.act == 0 && !g.mask) {
+                    for (int j = 0; j < TNW; ++j)
+                        if (cok[j]) atomicAdd(g.c + (roff + coff[j]), alpha * acc[i][j][r]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < TNW; ++j)
-                    if (cok[j]) gc[roff + coff[j]] = alpha * acc[i][j][r];
-            } else {
-#pragma unroll
-                for (int j = 0; j < TNW; ++j) {
-                    if (!cok[j]) continue;
-                    const uint32_t at = roff + coff[j];
-                    float v = alpha * acc[i][j][r];
-                    if (g.beta != 0.f) v += g.beta * gc[at];
-                    if (gbias) v += gbias[coff[j]];
-                    if (g.act == 1) v = fmaxf(v, 0.f);
-                    else if (g.act == 2) v = tanhf_(v);
-                    else if (g.act == 3 && ggate[at] == 0.f) v = 0.f;        // ReLU backward
-                    if (gmask) v *= gmask[at];
-                    gc[at] = v;
+                    for (int j = 0; j < TNW; ++j)
+                        if (cok[j]) gc[roff + coff[j]] = alpha * acc[i][j][r];
                 }
             }
-        }
+    } else {
+        // General epilogue (round 5): EVERY value it reads — the old C (beta), the bias, the ReLU gate, the mask — is requested
+        // first, for all of the thread's elements, and waited for once.  It used to read them element by element inside the
+        // store loop: the compiler's code was load, s_waitcnt vmcnt(0), use, eight times over — eight dependent L2 round trips
+        // per workgroup of the dS += launch (beta = 1, on the step's critical chain) and of the biased products.
+        float cold[TMW][4][TNW], gat[TMW][4][TNW], msk[TMW][4][TNW], bia[TNW];
+        uint32_t at[TMW][4][TNW];
+        bool ok[TMW][4][TNW];
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) bia[j] = (gbias && cok[j]) ? gbias[coff[j]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ri = fg * 4 + r;
+                const int row = m0 + wm * 16 * TMW + (pa.is_kc() ? 16 * i + ri : TMW * ri + i);
+                const uint32_t roff = (uint32_t)min(row, g.M - 1) * ldc;
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) {
+                    ok[i][r][j] = row < g.M && cok[j];
+                    at[i][r][j] = roff + (cok[j] ? coff[j] : 0);              // a valid address either way: the loads are unconditional
+                    cold[i][r][j] = g.beta != 0.f ? gc[at[i][r][j]] : 0.f;
+                    gat[i][r][j] = g.act == 3 ? ggate[at[i][r][j]] : 1.f;
+                    msk[i][r][j] = gmask ? gmask[at[i][r][j]] : 1.f;
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) {
+                    float v = alpha * acc[i][j][r];
+                    if (g.beta != 0.f) v += g.beta * cold[i][r][j];
+                    if (gbias) v += bia[j];
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    else if (g.act == 2) v = tanhf_(v);
+                    else if (g.act == 3 && gat[i][r][j] == 0.f) v = 0.f;      // ReLU backward
+                    if (gmask) v *= msk[i][r][j];
+                    if (ok[i][r][j]) gc[at[i][r][j]] = v;
+                }
+    }
     GST(7)                                   // epilogue
 #ifdef GSCAN_GEMM_STAMPS
     if (g_trace_buf && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
