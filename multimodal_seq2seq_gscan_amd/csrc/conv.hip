@@ -37,7 +37,15 @@ namespace gscan {
 
 constexpr int kConvThreads = 512;
 constexpr int kConvWaves = kConvThreads / 64;
-constexpr int kConvSegments = 4;       // the batch is cut into this many segments for the backward kernel's lists
+#ifndef GSCAN_CONV_SEGMENTS
+#define GSCAN_CONV_SEGMENTS 8
+#endif
+// The batch is cut into this many segments for the backward kernel's lists: a wave of the gradient kernel walks ONE segment's
+// non-zeros of its (channel, tap), a chain of ~16-deep gather rounds.  Round 5: 8 (a workgroup = one tap x eight segments; it
+// was 4 = two taps x four segments): the kernel ends the step together with the caller's chain, and half as
+// long a chain per wave takes it from 46 to 41 us and the step from 0.4724 to 0.4707 ms (2: 50.6 us / 0.4772 ms;
+// profiles/r05_conv_gradient_segments_ab.txt).
+constexpr int kConvSegments = GSCAN_CONV_SEGMENTS;
 
 __global__ void conv_image_kernel(const float *__restrict__ w1, const float *__restrict__ w2,
                                   const float *__restrict__ w3, int C, int Co, int K3, float *__restrict__ img) {
@@ -464,8 +472,14 @@ __global__ __launch_bounds__(kConvThreads) void world_conv_bwd_kernel(ConvArgs a
     partial[wave][lane] = acc;
     __syncthreads();
     if (owns && sg == 0 && o < Co) {
-        const int w0 = wave;          // waves w0 .. w0 + 3 hold the four segment sums of this tap
-        const float sum = (partial[w0][lane] + partial[w0 + 1][lane]) + (partial[w0 + 2][lane] + partial[w0 + 3][lane]);
+        const int w0 = wave;          // waves w0 .. w0 + kConvSegments - 1 hold the segment sums of this tap: added in a fixed order
+        float sum = 0.f;
+        if (kConvSegments == 4) {
+            sum = (partial[w0][lane] + partial[w0 + 1][lane]) + (partial[w0 + 2][lane] + partial[w0 + 3][lane]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < kConvSegments; ++q) sum += partial[w0 + q][lane];
+        }
         a.gw[conv][(o * C + ch) * k * k + t] += sum;
     }
 }
