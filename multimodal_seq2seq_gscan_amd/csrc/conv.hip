@@ -445,7 +445,29 @@ __global__ __launch_bounds__(kConvThreads) void world_conv_bwd_kernel(ConvArgs a
         return;
     }
     constexpr int kTapsPerGroup = kConvWaves / kConvSegments;
-    const int ch = blockIdx.x % C, by = blockIdx.x / C, sg = wave % kConvSegments;
+    // Heaviest channels FIRST in dispatch order (round 5): the grid is more workgroups than the chip holds at once (1 200 for
+    // 1 024 slots at the benchmark shape), a workgroup's time is its channel's count of non-zeros (420-610 for the attribute
+    // channels of a gSCAN world, ~60 for the four direction channels), and with the channels interleaved (channel = block % C)
+    // the second generation was a sixth of every channel — heavy ones included.  Now block / groups is a RANK by count
+    // (from the lists' own counts: C x segments integers, one wave), so what is left for the second generation is the lightest.
+    __shared__ int ch_of_rank;
+    const int ngroups = a.nw_blocks / C, rank = blockIdx.x / ngroups, by = blockIdx.x - rank * ngroups, sg = wave % kConvSegments;
+    if (wave == 0) {
+        int mine = -1;                                     // lane c < C: total of channel c (C <= 64; more channels: identity order)
+        if (C <= 64 && lane < C) {
+            mine = 0;
+            for (int q = 0; q < kConvSegments; ++q) mine += a.seg_count[lane * kConvSegments + q];
+        }
+        int r = 0;
+        for (int c = 0; c < min(C, 64); ++c) {
+            const int other = __builtin_amdgcn_readlane(mine, c);
+            r += (other > mine || (other == mine && c < lane)) ? 1 : 0;
+        }
+        if (C > 64) { if (lane == 0) ch_of_rank = rank; }
+        else if (lane < C && r == rank) ch_of_rank = lane;
+    }
+    __syncthreads();
+    const int ch = ch_of_rank;
     const int ochunks = (Co + 63) >> 6, npairs = (26 + a.K3 * a.K3) * ochunks;
     const int pair = by * kTapsPerGroup + wave / kConvSegments;
     const bool owns = pair < npairs;
