@@ -297,6 +297,139 @@ int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream) {
     return 0;
 }
 
+// ---- sums over time per attention memory (long target sequences; see AlphaReduceArgs in step.h) -------------------------
+// One workgroup per (batch row, pass of 128 columns, group of up to 4 memory tiles): the workgroups of a row split the COLUMNS
+// of x = [delta | dzq], so every gradient row is read once per launch (a workgroup per memory tile read it once per tile:
+// 43 -> 16 us at S3).  Chunks of 32 steps go through LDS — alpha of every memory tile of the group as A operands [memory, step],
+// the chunk's 128 columns as the B operand [step, column] — a wave owns two 16-column tiles x all memory tiles, 16x16x4 MFMAs.
+// Visual tiles skip the columns past 4H (dzq reaches the textual memories only).  Any hidden size (run-time column counts).
+constexpr int kArThreads = 256, kArWaves = kArThreads / 64, kArSteps = 32, kArColTiles = 2, kArMemTiles = 4;
+constexpr int kArCols = 16 * kArWaves * kArColTiles;       // 128 columns per pass
+constexpr int kArStride = kArCols + 16;                    // row stride = 16 mod 32 banks: the four step rows of a B fragment read disjoint banks
+
+__global__ __launch_bounds__(kArThreads, 4) void alpha_reduce_kernel(AlphaReduceArgs a) {
+    TraceScope trace_scope(TK_KEYS_BWD);
+    __shared__ __attribute__((aligned(16))) float al_s[kArMemTiles * kArSteps * 16];
+    __shared__ __attribute__((aligned(16))) float x_s[kArSteps * kArStride];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int T = a.T, MTV = (a.M + 15) / 16, MT = MTV + (a.L + 15) / 16;
+    const int g0 = blockIdx.z * kArMemTiles, ng = min(kArMemTiles, MT - g0);      // this workgroup's memory tiles: g0 .. g0 + ng
+    const int c0 = blockIdx.y * kArCols;
+    const bool any_text = g0 + ng > MTV;
+    const int W = any_text ? max(a.wt, a.wv) : a.wv;                               // widest output among this group's tiles
+    if (c0 >= W) return;
+    const int wc = min(kArCols, W - c0);
+    const bool v4 = ((a.ldx | c0) & 3) == 0 && (wc & 3) == 0;
+
+    f32x4 acc[kArMemTiles][kArColTiles];
+#pragma unroll
+    for (int j = 0; j < kArMemTiles; ++j)
+#pragma unroll
+        for (int i = 0; i < kArColTiles; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // a chunk's loads all in flight at once, and the NEXT chunk's requested before this chunk's MFMAs (the launch is a chain of
+    // T / 32 round trips per workgroup otherwise: 46 us at S3 however little it reads)
+    constexpr int NA = kArMemTiles * kArSteps * 16 / kArThreads, NX = kArSteps * (kArCols / 4) / kArThreads;
+    float av[NA];
+    float4 xv[NX];
+    auto request = [&](int t0) {
+        const int n = min(kArSteps, T - t0);
+        const int64_t bt0 = (int64_t)b * T + t0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {     // alpha of the group's tiles: [tile][step][16 memories]; steps past the end and memories past the last are zeros
+            static_assert(kArSteps * 16 == 2 * kArThreads, "two passes of the workgroup per tile of alpha");
+            const int j = i >> 1, t = (tid >> 4) + (kArThreads / 16) * (i & 1), q = tid & 15;   // element tid + 256 i of [tile][step][memory]
+            const int mt = g0 + j;                                                              // (uniform per i: tile, memory count, base pointer)
+            const bool vis = mt < MTV;
+            const int mx = vis ? a.M : a.L, m = 16 * (vis ? mt : mt - MTV) + q;
+            const float *alpha = vis ? a.alpha_s : a.alpha_c;
+            av[i] = (j < ng && t < n && m < mx) ? alpha[(bt0 + t) * mx + m] : 0.f;
+        }
+        if (v4) {                          // rows past the end of the sequence are zeros (0 * garbage)
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int idx = tid + kArThreads * i, tt = idx / (kArCols / 4), c4 = idx - tt * (kArCols / 4);
+                xv[i] = float4{0.f, 0.f, 0.f, 0.f};
+                if (tt < n && 4 * c4 < wc) xv[i] = *reinterpret_cast<const float4 *>(a.x + (bt0 + tt) * a.ldx + c0 + 4 * c4);
+            }
+        }
+    };
+    request(0);
+    for (int t0 = 0; t0 < T; t0 += kArSteps) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + kArThreads * i;
+            if (idx < ng * kArSteps * 16) al_s[idx] = av[i];
+        }
+        if (v4) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int idx = tid + kArThreads * i, tt = idx / (kArCols / 4), c4 = idx - tt * (kArCols / 4);
+                if (4 * c4 < wc) *reinterpret_cast<float4 *>(x_s + tt * kArStride + 4 * c4) = xv[i];
+            }
+        } else {                           // odd widths: element by element, no prefetch
+            const int n = min(kArSteps, T - t0);
+            const int64_t bt0 = (int64_t)b * T + t0;
+            for (int idx = tid; idx < kArSteps * wc; idx += kArThreads) {
+                const int tt = idx / wc, c = idx - tt * wc;
+                x_s[tt * kArStride + c] = tt < n ? a.x[(bt0 + tt) * a.ldx + c0 + c] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (t0 + kArSteps < T) request(t0 + kArSteps);
+#pragma unroll
+        for (int i = 0; i < kArColTiles; ++i) {
+            const int nt = wave + kArWaves * i;
+            if (16 * nt < wc) {       // columns past wc inside the last tile hold stale LDS: they only reach output columns that are not stored
+                const float *bp = x_s + fg * kArStride + 16 * nt + fr;       // B(t, c)
+                float bv[kArSteps / 4];
+#pragma unroll
+                for (int s = 0; s < kArSteps / 4; ++s) bv[s] = bp[4 * s * kArStride];
+#pragma unroll
+                for (int j = 0; j < kArMemTiles; ++j) {
+                    if (j < ng && (g0 + j >= MTV || c0 + 16 * nt < a.wv)) {
+                        const float *ap = al_s + j * (kArSteps * 16) + fg * 16 + fr;          // A(m, t) = alpha[t][m]
+#pragma unroll
+                        for (int s = 0; s < kArSteps / 4; ++s)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * 16], bv[s], acc[j][i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < kArMemTiles; ++j) {
+        if (j >= ng) continue;
+        const int mt = g0 + j;
+        const bool vis = mt < MTV;
+        const int mx = vis ? a.M : a.L, mbase = 16 * (vis ? mt : mt - MTV), Wj = vis ? a.wv : a.wt;
+        float *g = (vis ? a.g_v : a.g_t) + (int64_t)b * mx * Wj;
+#pragma unroll
+        for (int i = 0; i < kArColTiles; ++i) {
+            const int c = c0 + 16 * (wave + kArWaves * i) + fr;
+            if (c < Wj) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mbase + 4 * fg + r;
+                    if (m < mx) g[(int64_t)m * Wj + c] = acc[j][i][r];
+                }
+            }
+        }
+    }
+}
+
+int alpha_reduce(int B, const AlphaReduceArgs &a, hipStream_t stream) {
+    GSCAN_CHECK(B > 0 && a.T > 0 && a.L > 0 && a.M > 0 && a.wt > 0 && a.wv > 0 && a.ldx >= a.wt && a.ldx >= a.wv,
+                "alpha reduce: bad dims B=%d T=%d L=%d cells=%d columns=%d/%d stride=%d", B, a.T, a.L, a.M, a.wt, a.wv, a.ldx);
+    const int tiles = (a.M + 15) / 16 + (a.L + 15) / 16, groups = (tiles + kArMemTiles - 1) / kArMemTiles;
+    const int passes = (std::max(a.wt, a.wv) + kArCols - 1) / kArCols;
+    const double flops = 2.0 * B * a.T * ((double)a.L * a.wt + (double)a.M * a.wv);
+    ProbeScope probe(P_KEYS_BWD, stream, flops, 0.0);      // executed in place of per-step products the GEMM launches are credited with
+    hipLaunchKernelGGL(alpha_reduce_kernel, dim3(B, passes, groups), dim3(kArThreads), 0, stream, a);
+    GSCAN_LAUNCHED("alpha_reduce_kernel");
+    return 0;
+}
+
 GSCAN_TRACE_TU(attention_grad)
 
 }  // namespace gscan

@@ -375,6 +375,17 @@ struct KeysBackwardArgs {
 };
 int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream);
 
+// attention_grad.hip: the decoder's pre-activation gradients summed over TIME per attention memory,
+//   G_text[b,l,:] = sum_t alpha_text[b,t,l] * [delta | dzq][b,t,:]      G_vis[b,m,:] = sum_t alpha_vis[b,t,m] * delta[b,t,:]
+// (a context is alpha . PK, so everything the LSTM input and the conditional query hand back to the contexts reaches PK
+// and the context columns of W_ih / W_q2k through these sums: step.hip, attention_time_reduced)
+struct AlphaReduceArgs {
+    int T, L, M, wt, wv, ldx;              // columns of G_text (5H conditional, else 4H) / of G_vis (4H); row stride of x
+    const float *alpha_c, *alpha_s, *x;    // [B,T,L] [B,T,M] [B,T,ldx]
+    float *g_t, *g_v;                      // [B,L,wt] [B,M,wv]
+};
+int alpha_reduce(int B, const AlphaReduceArgs &a, hipStream_t stream);
+
 // comm.hip: RCCL all-reduce on the caller's stream (run-time binding)
 int comm_available();                  // 0: RCCL is loadable in this process (no device call, nothing collective)
 int comm_unique_id(void *id_host);
@@ -408,7 +419,8 @@ struct Workspace {
         deep_gates, deep_cells, deep_hprev, deep_y, deep_dy, deep_delta, deep_image,   // encoder layers below the last
         ge_table, head_wc,        // [V,4H] tables: greedy decoding's embedded gates; the composite head
         gemm_slabs_side, gemm_slabs_main, conv_bias_part, embed_part_dec, embed_part_enc,
-        drawn_mask_enc, drawn_mask_dec;    // [B,L,E] [B,T,H]: embedding dropout drawn in the gathers, kept for the backward pass
+        drawn_mask_enc, drawn_mask_dec,    // [B,L,E] [B,T,H]: embedding dropout drawn in the gathers, kept for the backward pass
+        g_t, g_v;                          // [B,L,5H] [B,M,4H]: time-reduced gate gradients per memory (long targets only)
     WorkspaceSlot slot[96];
     int nslots;
     int64_t total_floats;

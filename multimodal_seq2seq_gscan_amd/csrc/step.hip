@@ -26,6 +26,18 @@ static inline EncLayer enc_layer(const gscan_params &p, int l) {
 // --------------------------------------------------------------------------------------
 // workspace
 // --------------------------------------------------------------------------------------
+// Long target sequences (round 5): a context is alpha . PK, so what the LSTM input and the conditional query hand back to
+// the two contexts can be summed over TIME per memory first (alpha_reduce, attention_grad.hip: G = alpha^T . [delta | dzq]) and
+// pushed through the weights afterwards — d PK += G . W over B (L + G^2) rows instead of d ctx = [delta | dzq] . W over B T rows,
+// and the context columns of dW_ih / dW_q2k as G^T . PK with K = B (L + G^2) instead of K = B T.  Pays when T is well above
+// the number of memories (S3: T = 120 against 46): GSCAN_TIME_REDUCED_T=<T> moves the threshold (0 = never; given explicitly it
+// is the only condition, which is how the tests force the path on short sequences).
+bool attention_time_reduced(int T, int L, int M) {
+    static const int given = [] { const char *e = getenv("GSCAN_TIME_REDUCED_T"); return e ? atoi(e) : -1; }();
+    if (given >= 0) return given > 0 && T >= given;
+    return T >= 64 && 2 * T >= 3 * (L + M);
+}
+
 int workspace_layout(const gscan_dims &d, Workspace *ws) {
     const int64_t B = d.B, L = d.L, T = d.T, M = (int64_t)d.G * d.G, Co = d.Co, F = 3 * Co, E = d.E, He = d.He,
                   H = d.H, V = d.V, D = d.bidirectional ? 2 : 1;
@@ -127,6 +139,9 @@ int workspace_layout(const gscan_dims &d, Workspace *ws) {
     SLOT(head_wc, V * 4 * H);                        // the output head as one matrix: W_h2o . W_o2h (S order), step prologue
     SLOT(drawn_mask_enc, B * L * E);                 // dropout drawn in the kernels (gscan_masks::in_kernel): the embedding
     SLOT(drawn_mask_dec, B * T * H);                 // gathers leave their keep values here for the embedding gradients
+    const bool reduced = attention_time_reduced((int)T, (int)L, (int)M);
+    SLOT(g_t, reduced ? B * L * 5 * H : 0);          // sums over time of [delta | dzq] per textual / visual memory
+    SLOT(g_v, reduced ? B * M * 4 * H : 0);
 #undef SLOT
     ws->nslots = n;
     ws->total_floats = p;
@@ -602,6 +617,8 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
               V = d.V, D = d.bidirectional ? 2 : 1;
     const int BT = B * T, BL = B * L, BM_ = B * M;
     const bool cond = d.conditional != 0;
+    const bool reduced = attention_time_reduced(T, L, M);      // long targets: sums over time per memory (above workspace_layout)
+    const int gt_w = cond ? 5 * H : 4 * H;                     // columns of G_text: [delta | dzq]
     GSCAN_CHECK(dlogp || nll, "backward: dlogp is NULL");
     TRY(check_drop(mk));
     const DropSpec drop_cnn = drop_of(mk, kDropSegCnn), drop_enc = drop_of(mk, kDropSegEnc), drop_dec = drop_of(mk, kDropSegDec);
@@ -658,12 +675,24 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
             // 8d) the launch is credited with.
             add_grad(b, V, 4 * H, BT, w + ws.dlogits, 1, V, S, 4 * H, 1, w + ws.dwc, 4 * H);
             b.credit(2.0 * BT * ((double)H * 4 * H + (double)V * H) - 2.0 * BT * (double)V * 4 * H);
-            add_grad(b, 4 * H, 3 * H, BT, delta, 1, 5 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
+            if (reduced) {     // context columns of dW_ih (and of dW_q2k below) from the sums over time: K = B (L + G^2), not B T
+                add_grad(b, 4 * H, H, BT, delta, 1, 5 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
+                add_grad(b, 4 * H, H, BL, w + ws.g_t, 1, gt_w, w + ws.pkt, H, 1, g.dec_w_ih + H, 3 * H);
+                add_grad(b, 4 * H, H, BM_, w + ws.g_v, 1, 4 * H, w + ws.pkv, H, 1, g.dec_w_ih + 2 * H, 3 * H);
+                b.credit(2.0 * 4 * H * 2 * H * (double)BT - 2.0 * 4 * H * H * (double)(BL + BM_));
+            } else {
+                add_grad(b, 4 * H, 3 * H, BT, delta, 1, 5 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
+            }
             add_grad(b, 4 * H, H, BT, delta, 1, 5 * H, hprev, H, 1, g.dec_w_hh, H, g.dec_b_ih, g.dec_b_hh);
             add_grad(b, H, H, BT, w + ws.dqt, 1, H, hprev, H, 1, g.txt_query_w, H);
             if (cond) {
                 add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, hprev, H, 1, g.q2k_w, 2 * H, g.q2k_b);
-                add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H);
+                if (reduced) {
+                    add_grad(b, H, H, BL, w + ws.g_t + 4 * H, 1, gt_w, w + ws.pkt, H, 1, g.q2k_w + H, 2 * H);
+                    b.credit(2.0 * H * H * (double)(BT - BL));
+                } else {
+                    add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H);
+                }
                 add_grad(b, H, H, BT, w + ws.dqv, 1, H, w + ws.q2, H, 1, g.vis_query_w, H);
             } else {
                 add_grad(b, H, H, BT, w + ws.dqv, 1, H, hprev, H, 1, g.vis_query_w, H);
@@ -692,6 +721,21 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     float *const gw[3] = {g.conv1_w, g.conv2_w, g.conv3_w};
     float *const gb[3] = {g.conv1_b, g.conv2_b, g.conv3_b};
     const void *world = bt.world_u8 ? (const void *)bt.world_u8 : (const void *)bt.world;
+    if (reduced) {
+        // long targets: sums over time per memory first (the leaves need them too, so they fork behind this launch), then
+        // d PK += G . [W_ih[:, ctx] ; W_q2k[:, ctx_text]] — B (L + G^2) rows through the weights instead of B T; keys_backward
+        // below adds what the output head hands to the contexts (dS from the reverse kernel's prologue) as before
+        AlphaReduceArgs r{};
+        r.T = T; r.L = L; r.M = M; r.wt = gt_w; r.wv = 4 * H; r.ldx = 5 * H;
+        r.alpha_c = w + ws.alpha_c; r.alpha_s = w + ws.alpha_s; r.x = delta; r.g_t = w + ws.g_t; r.g_v = w + ws.g_v;
+        TRY(alpha_reduce(B, r, st));
+        if (leaves_fork == 0) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
+        GemmBatch b;
+        b.add(BL, H, gt_w, w + ws.g_t, gt_w, 1, w + ws.wcat5 + H, 3 * H, 1, w + ws.dpk_t, H, 1.f);
+        b.add(BM_, H, 4 * H, w + ws.g_v, 4 * H, 1, w + ws.wcat5 + 2 * H, 3 * H, 1, w + ws.dpk_v, H, 1.f);
+        b.credit(2.0 * BT * 2 * H * (double)gt_w - 2.0 * H * ((double)BL * gt_w + (double)BM_ * 4 * H));
+        TRY(b.launch(st));
+    } else {
     if (leaves_fork == 0) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
     // chain: gradient wrt [ctx_text | ctx_vis] through the LSTM input and the conditional query
     // (one product: [delta | dzq] . [W_ih[:, ctx] ; (W_q2k[:, ctx_text] | 0)], K = 5H when conditional)
@@ -705,6 +749,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         if (ds_mt > 0 && BT >= ds_mt) b.prefer_macro_tiles();
         b.add(BT, 2 * H, cond ? 5 * H : 4 * H, delta, 5 * H, 1, w + ws.wcat5 + H, 3 * H, 1, dS + H, 4 * H, 1.f);
         TRY(b.launch(st));
+    }
     }
     if (leaves_fork == 1) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
     // chain: value path of both attentions (dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]), then through the

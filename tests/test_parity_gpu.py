@@ -603,6 +603,25 @@ def test_fixture_suite_in_deterministic_mode():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+@pytest.mark.parametrize("extra_env", [{}, {"GSCAN_DECODER_ANY": "1", "GSCAN_ENCODER_ANY": "1"}, {"GSCAN_DETERMINISTIC": "1"}],
+                         ids=["resident_kernels", "streaming_kernels", "deterministic"])
+def test_fixture_suite_with_attention_gradients_summed_over_time_first(extra_env):
+    """GSCAN_TIME_REDUCED_T=1 (read once per process, hence the child process): the backward pass of long target sequences —
+    G = alpha^T . [delta | dzq] per memory, then d PK += G . W and the context columns of dW_ih / dW_q2k as G^T . PK
+    (csrc/step.hip attention_time_reduced, csrc/attention_grad.hip alpha_reduce_kernel) — forced on EVERY sequence length:
+    the reference's own training-step outputs and gradients through that path (seq2seq_model.py:414-425 and their autograd
+    duals, model.py:190-219)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GSCAN_TIME_REDUCED_T="1", **extra_env)
+    pick = ("demo_variants or more_than_one_encoder_layer or geca_aux or compositional_all_grads or target_length_t120 or "
+            "one_call_train_step or train_step_matches_reference_adam or edge_shapes")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", pick,
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_command_line_train_then_test_modes(tmp_path):
     """`python -m seq2seq --mode=train ... --synthetic_data` then `--mode=test` (seq2seq/__main__.py:21-167): the
     training loop runs, writes the reference's checkpoint dictionary, and the test mode decodes greedily from it

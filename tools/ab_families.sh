@@ -2,7 +2,7 @@
 # A/B of library variants on the GPU box: per-family kernel times of a short bench run.
 #   bash tools/ab_families.sh <out.txt> lib1.so lib2.so ...   ("base" = the in-tree library)
 out=$1; shift
-: > "$out"
+mkdir -p "$(dirname "$out")"; : > "$out"
 for rep in 1 2; do for lib in "$@"; do
   if [ "$lib" = base ]; then unset GSCAN_HIP_LIB; else export GSCAN_HIP_LIB=$lib; fi
   echo "== $lib (rep $rep)" >> "$out"
