@@ -658,7 +658,17 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     // where the decoder's weight-gradient leaves fork off the chain (GSCAN_LEAVES_FORK, A/B): 0 behind the recurrence,
     // 1 behind the dS += product, 2 behind keys_backward (one fork event in the whole backward pass)
     static const int leaves_fork = [] { const char *e = getenv("GSCAN_LEAVES_FORK"); return e ? atoi(e) : 0; }();
-    auto decoder_leaves = [&]() -> int {
+    // GSCAN_LEAVES_SPLIT=1 (A/B, off): the leaves as TWO launches, the second one held back until the command encoder's
+    // reverse recurrence has run.  One launch of K = B T products is thousands of 128-VGPR workgroups that take every freed
+    // slot, and the recurrence — 254 VGPRs, a whole CU's registers per pair of workgroups — does not get onto the chip before
+    // they have drained (S3 timelines, profiles/r05_time_reduced_attention_gradients_S3_ab.txt).  Measured at S3: the chain's
+    // kernels run undisturbed (keys backward 101 -> 66 us, reverse recurrence 35 -> 28) and the step is SLOWER, 1.664 -> 1.685
+    // ms: the held-back half (2.1 GMAC) becomes the tail — this stretch is bound by the GEMM work, not by who runs first.
+    // part: 0 = everything, 1 = first half, 2 = second half.
+    static const bool leaves_split = [] { const char *e = getenv("GSCAN_LEAVES_SPLIT"); return e && atoi(e) > 0; }();
+    auto decoder_leaves = [&](int part = 0) -> int {
+        if (part == 0 && leaves_split) part = 1;
+        const bool early = part != 2, late = part != 1;
         {   // leaves: head weights (the permuted W_o2h gradient is scattered back below) and the decoder parameter
             // gradients (dense products over the B*T saved rows)
             GemmBatch b;
@@ -673,6 +683,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
             // gradients follow from it in head_grad_finish below.  These V x 4H x BT multiply-adds stand in for the
             // reference's two products (H x 4H and V x H over the same BT rows), whose algorithmic flops (SURVEY.md
             // 8d) the launch is credited with.
+            if (early) {
             add_grad(b, V, 4 * H, BT, w + ws.dlogits, 1, V, S, 4 * H, 1, w + ws.dwc, 4 * H);
             b.credit(2.0 * BT * ((double)H * 4 * H + (double)V * H) - 2.0 * BT * (double)V * 4 * H);
             if (reduced) {     // context columns of dW_ih (and of dW_q2k below) from the sums over time: K = B (L + G^2), not B T
@@ -684,15 +695,16 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
                 add_grad(b, 4 * H, 3 * H, BT, delta, 1, 5 * H, S, 4 * H, 1, g.dec_w_ih, 3 * H);
             }
             add_grad(b, 4 * H, H, BT, delta, 1, 5 * H, hprev, H, 1, g.dec_w_hh, H, g.dec_b_ih, g.dec_b_hh);
+            if (cond && reduced) {
+                add_grad(b, H, H, BL, w + ws.g_t + 4 * H, 1, gt_w, w + ws.pkt, H, 1, g.q2k_w + H, 2 * H);
+                b.credit(2.0 * H * H * (double)(BT - BL));
+            }
+            }
+            if (late) {
             add_grad(b, H, H, BT, w + ws.dqt, 1, H, hprev, H, 1, g.txt_query_w, H);
             if (cond) {
                 add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, hprev, H, 1, g.q2k_w, 2 * H, g.q2k_b);
-                if (reduced) {
-                    add_grad(b, H, H, BL, w + ws.g_t + 4 * H, 1, gt_w, w + ws.pkt, H, 1, g.q2k_w + H, 2 * H);
-                    b.credit(2.0 * H * H * (double)(BT - BL));
-                } else {
-                    add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H);
-                }
+                if (!reduced) add_grad(b, H, H, BT, delta + 4 * H, 1, 5 * H, S + H, 4 * H, 1, g.q2k_w + H, 2 * H);
                 add_grad(b, H, H, BT, w + ws.dqv, 1, H, w + ws.q2, H, 1, g.vis_query_w, H);
             } else {
                 add_grad(b, H, H, BT, w + ws.dqv, 1, H, hprev, H, 1, g.vis_query_w, H);
@@ -701,12 +713,16 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
             // this third of the LSTM-input back-propagation is a leaf too
             g_split_override = 0;
             b.add(BT, H, 4 * H, delta, 5 * H, 1, w + ws.wcat5, 3 * H, 1, dS, 4 * H, 1.f);
+            }
+            g_split_override = 0;
             TRY(b.launch(sd));
-            TRY(head_grad_finish(w + ws.dwc, p.hid2out_w, p.out2hid_w, g.out2hid_w, g.hid2out_w, H, V, sd, w + ws.dv_t,
-                                 w + ws.dv_v, B, g.txt_energy_w, g.vis_energy_w));
+            if (early)
+                TRY(head_grad_finish(w + ws.dwc, p.hid2out_w, p.out2hid_w, g.out2hid_w, g.hid2out_w, H, V, sd, w + ws.dv_t,
+                                     w + ws.dv_v, B, g.txt_energy_w, g.vis_energy_w));
             // (dropout drawn in the kernels: the gather of the forward pass left its keep values in the workspace)
-            TRY(embed_grad(bt.targets, dS, 4 * H, mk.in_kernel ? (drop_dec.on ? w + ws.drawn_mask_dec : nullptr) : mk.dec, BT, H,
-                           V, d.pad_tgt, g.dec_emb, sd, ordered_sums ? w + ws.embed_part_dec : nullptr));
+            if (late)
+                TRY(embed_grad(bt.targets, dS, 4 * H, mk.in_kernel ? (drop_dec.on ? w + ws.drawn_mask_dec : nullptr) : mk.dec, BT, H,
+                               V, d.pad_tgt, g.dec_emb, sd, ordered_sums ? w + ws.embed_part_dec : nullptr));
         }
         return 0;
     };
@@ -793,6 +809,7 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
         if (last) {
             TRY(encoder_lstm_backward(B, L, He, D, bt.cmd_lengths, q.w_hh, q.w_hh_rev, lgates, lcells, w + ws.denc,
                                       w + ws.dhN, ldelta, st));
+            if (leaves_split) { TRY(order_after(sd, st)); TRY(decoder_leaves(2)); }     // the held-back half of the decoder's leaves
         } else {
             TRY(encoder_lstm_backward(B, L, He, D, bt.cmd_lengths, q.w_hh, q.w_hh_rev, lgates, lcells,
                                       w + ws.deep_dy + l * lay_h, nullptr, ldelta, st, D * He, He,
