@@ -30,12 +30,12 @@ static inline EncLayer enc_layer(const gscan_params &p, int l) {
 // the two contexts can be summed over TIME per memory first (alpha_reduce, attention_grad.hip: G = alpha^T . [delta | dzq]) and
 // pushed through the weights afterwards — d PK += G . W over B (L + G^2) rows instead of d ctx = [delta | dzq] . W over B T rows,
 // and the context columns of dW_ih / dW_q2k as G^T . PK with K = B (L + G^2) instead of K = B T.  Pays when T is well above
-// the number of memories (S3: T = 120 against 46): GSCAN_TIME_REDUCED_T=<T> moves the threshold (0 = never; given explicitly it
+// the number of memories (S3: T = 120 against 46; on from T >= 1.2 (L + G^2)): GSCAN_TIME_REDUCED_T=<T> moves the threshold (0 = never; given explicitly it
 // is the only condition, which is how the tests force the path on short sequences).
 bool attention_time_reduced(int T, int L, int M) {
     static const int given = [] { const char *e = getenv("GSCAN_TIME_REDUCED_T"); return e ? atoi(e) : -1; }();
     if (given >= 0) return given > 0 && T >= given;
-    return T >= 64 && 2 * T >= 3 * (L + M);
+    return T >= 48 && 5 * T >= 6 * (L + M);      // measured crossover at L + G^2 = 46: T = 40 loses 1 %, 56 gains 0.7 %, 72 1.2 %, 96 2.5 %, 120 3.5 %
 }
 
 int workspace_layout(const gscan_dims &d, Workspace *ws) {
