@@ -85,3 +85,42 @@ def test_full_size_against_oracle(name, workload, overrides, shape_kw, dropout):
         if not torch.allclose(g, r, atol=TOL, rtol=1e-3) or (r.norm() > 1e-6 and e > 2e-4):
             bad.append(f"{k}: max|err| {(g - r).abs().max().item():.3e}, rel L2 {e:.3e}, |ref| {r.norm().item():.3e}")
     assert not bad, f"{name}: gradient mismatches\n" + "\n".join(bad)
+
+
+def test_sums_over_time_per_memory_at_full_size():
+    """csrc/attention_grad.hip alpha_reduce_kernel by itself, at S3's size (256 rows, T = 120: the path is on by default from
+    T >= 1.2 (L + G^2), csrc/step.hip attention_time_reduced): after one backward pass the workspace holds its inputs — the
+    attention rows and the decoder's gate gradients [delta | dzq] — and its outputs G_text / G_vis; they must be
+    G[b,m,:] = sum_t alpha[b,t,m] * x[b,t,:] (float64 einsum of the same device buffers), to fp32 rounding of a 120-term sum."""
+    from multimodal_seq2seq_gscan_amd.model import Model
+    from weights import golden_weights
+
+    cfg = model_kwargs("target_length")
+    batch = make_batch(Shape(batch=256, grid=6, channels=cfg["num_cnn_channels"], input_vocab=cfg["input_vocabulary_size"],
+                             target_vocab=cfg["target_vocabulary_size"], max_command=10, max_target=120, ragged=True), seed=77)
+    B, L = batch["commands"].shape
+    T, G = batch["targets"].shape[1], batch["world"].shape[1]
+    M, H = G * G, cfg["decoder_hidden_size"]
+    model = Model(**cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in golden_weights(cfg, 23).items()}, strict=False)
+    model = model.cuda().eval()
+    d = {k: v.cuda() for k, v in batch.items()}
+    model.zero_grad()
+    logp, _ = model(commands_input=d["commands"], commands_lengths=batch["cmd_lengths"].tolist(), situations_input=d["world"],
+                    target_batch=d["targets"], target_lengths=batch["tgt_lengths"].tolist())
+    model.get_loss(logp, d["targets"]).backward()
+    torch.cuda.synchronize()
+    dims = model._dims(B, L, T, G)
+    view = lambda n: model.workspace_view(dims, n).double()
+    assert model.workspace_view(dims, "g_t").numel() >= B * L * 5 * H, "the time-reduced path is off for this shape"
+    x = view("delta")[:B * T * 5 * H].view(B, T, 5 * H)
+    a_t, a_v = view("alpha_c")[:B * T * L].view(B, T, L), view("alpha_s")[:B * T * M].view(B, T, M)
+    width = 5 * H if cfg["conditional_attention"] else 4 * H
+    g_t = view("g_t")[:B * L * width].view(B, L, width)
+    g_v = view("g_v")[:B * M * 4 * H].view(B, M, 4 * H)
+    ref_t = torch.einsum("btl,btc->blc", a_t, x[:, :, :width])
+    ref_v = torch.einsum("btm,btc->bmc", a_v, x[:, :, :4 * H])
+    for name, got, ref in (("G_text", g_t, ref_t), ("G_vis", g_v, ref_v)):
+        scale = ref.abs().max().item()
+        err = (got - ref).abs().max().item()
+        assert scale > 0 and err <= 2e-6 * scale + 1e-12, f"{name}: max|err| {err:.3e} against max|ref| {scale:.3e}"
