@@ -249,8 +249,8 @@ torch.save({"logp": out.cpu(), "selfserved": _selfserved(model, batch) - before}
     assert res["skip"]["selfserved"] > 0
 
 
-@pytest.mark.parametrize("deep", [False, True])
-def test_deterministic_mode_gives_bitwise_reproducible_training_steps(tmp_path, deep):
+@pytest.mark.parametrize("variant", ["one_encoder_layer", "two_encoder_layers", "sums_over_time_first"])
+def test_deterministic_mode_gives_bitwise_reproducible_training_steps(tmp_path, variant):
     """GSCAN_DETERMINISTIC=1: every sum the step forms across workgroups is added in a fixed order (split-K partial tiles
     through slabs, embedding gradients by one workgroup per vocabulary chunk), so the same step from the same state gives
     the same bits: loss, every gradient, and the parameters after three Adam steps.  (The default mode adds with float
@@ -286,7 +286,9 @@ torch.save(runs, sys.argv[3])
     here = os.path.dirname(os.path.abspath(__file__))
     path = str(tmp_path / "runs.pt")
     r = subprocess.run([sys.executable, "-c", worker, os.path.dirname(here), here, path],
-                       env=dict(os.environ, GSCAN_DETERMINISTIC="1", GSCAN_TEST_DEEP_ENCODER="1" if deep else "0"),
+                       # sums_over_time_first: the long-target backward pass (csrc/step.hip attention_time_reduced) forced on
+                       env=dict(os.environ, GSCAN_DETERMINISTIC="1", GSCAN_TEST_DEEP_ENCODER="1" if variant == "two_encoder_layers" else "0",
+                                **({"GSCAN_TIME_REDUCED_T": "1"} if variant == "sums_over_time_first" else {})),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     runs = torch.load(path)
