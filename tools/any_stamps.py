@@ -6,10 +6,12 @@ from multimodal_seq2seq_gscan_amd.config import model_kwargs
 from multimodal_seq2seq_gscan_amd.model import Model
 from multimodal_seq2seq_gscan_amd.synthetic import Shape, make_batch
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 6          # python tools/any_stamps.py <hidden> [grid] [command length]
+LC = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 lib = _lib.load()
 cfg = model_kwargs("compositional", encoder_hidden_size=min(H, 128), decoder_hidden_size=H)
 model = Model(**cfg).cuda().eval()
-batch = {k: v.cuda() for k, v in make_batch(Shape(batch=256), 1).items()}
+batch = {k: v.cuda() for k, v in make_batch(Shape(batch=256, grid=G, max_command=LC), 1).items()}
 lib.gscan_probe_enable(2)
 for _ in range(3):
     model.zero_grad()
@@ -23,7 +25,7 @@ both = model.workspace_view(dims, "stamps").cpu().tolist()
 st = both[:16]
 names = ["rows h (W_qt W_hh W_q2k_h)", "scores text", "softmax text", "cols text (ctx, U_t, U2_t | W_q2k)", "rows W_qv", "scores vis", "softmax vis", "cols ctx_vis", "cols U_v | rows W_ih ctx", "gates"]
 tot = sum(st[:10])
-print(f"H={H} forward streaming kernel, workgroup 0: {tot / 20:.0f} cycles per step")
+print(f"H={H} grid={G} L={LC} forward streaming kernel, workgroup 0: {tot / 20:.0f} cycles per step")
 for n, v in zip(names, st): print(f"  {n:38s} {v / 20:8.0f}")
 bw = both[16:32]
 names_b = ["cell backward (saved activations from global)", "d ctx + alpha_vis, q_vis loads", "d alpha_vis rows (U_v, PK_v)", "visual attention backward",
