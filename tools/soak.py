@@ -17,11 +17,13 @@ from multimodal_seq2seq_gscan_amd.train import TrainStep  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=40000)
 ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--target-length", type=int, default=0, help="0: the S1 shape; e.g. 120: long targets (S3; sums over time, DESIGN 4.5a)")
 args = ap.parse_args()
 torch.manual_seed(0)
 cfg = model_kwargs("compositional", auxiliary_task=True)
 model = Model(**cfg).cuda()
-shape = Shape(batch=args.batch, input_vocab=cfg["input_vocabulary_size"], target_vocab=cfg["target_vocabulary_size"], ragged=True)
+shape = Shape(batch=args.batch, input_vocab=cfg["input_vocabulary_size"], target_vocab=cfg["target_vocabulary_size"], ragged=True,
+              **({"max_target": args.target_length} if args.target_length else {}))
 batches = []
 for k in range(8):
     b = {key: v.cuda() for key, v in make_batch(shape, seed=100 + k).items()
@@ -35,7 +37,7 @@ t0 = time.perf_counter()
 worst = 0.0
 for i in range(args.steps):
     out = step(batches[i % len(batches)])
-    if (i + 1) % 5000 == 0:
+    if (i + 1) % (5000 if not args.target_length else 1000) == 0:
         loss = out["loss"].item()
         assert loss == loss and abs(loss) < 1e4, loss
         worst = max(worst, loss)
