@@ -27,14 +27,16 @@
 extern "C" {
 #endif
 
-#define GSCAN_ABI_VERSION 13
+#define GSCAN_ABI_VERSION 14
 #define GSCAN_MAX_ENC_LAYERS 4
 
 /* Problem dimensions (names follow the reference's flags, seq2seq/__main__.py:21-102).
  * Accepted (gscan_workspace_bytes returns 0 and gscan_last_error says why otherwise): H 1..1024, He 1..2048, E 1..1024,
  * L and G*G up to 4096, K3 odd, up to GSCAN_MAX_ENC_LAYERS encoder layers, B*T*4H < 2^31.  Shapes outside what the
  * register/LDS-resident kernels are compiled for (H a multiple of 4 up to 100, He a multiple of 4 up to 128, at most 64
- * memories per attention) run on streaming kernels with the same results.
+ * memories per attention, a target vocabulary V of at most 16 — one matrix-core tile of logits —, and a row's memories
+ * within 160 KB of LDS) run on streaming kernels with the same results, several times slower;
+ * gscan_decoder_kernel_family() says which family a shape takes.
  * Environment, read once per process: GSCAN_DETERMINISTIC=1 makes every sum that crosses workgroups fixed-order (bitwise
  * reproducible training steps, +6 % time; it changes the workspace size: set it before gscan_workspace_bytes). */
 typedef struct gscan_dims {
@@ -118,6 +120,11 @@ const char *gscan_last_error(void);
  * must be passed to the backward call that follows a forward call (it holds the saved
  * activations).  Returns 0 if the dimensions are unsupported (see gscan_last_error). */
 size_t gscan_workspace_bytes(const gscan_dims *dims);
+
+/* Which decoder kernels `dims` runs on (ABI 14): 1 = the register/LDS-resident kernels (csrc/decoder.hip), 0 = the
+ * streaming kernels (csrc/decoder_any.hip: any shape, several times slower), negative = unsupported dimensions (see
+ * gscan_last_error).  bench.py prints it as config.decoder_kernels; the conditions are listed above gscan_dims. */
+int gscan_decoder_kernel_family(const gscan_dims *dims);
 
 /* Byte offset and float count of one named activation inside the workspace (for tests and
  * debugging: "feat", "enc_out", "pkt", "S", "gates", "delta", ...; see csrc/step.hip). */

@@ -11,7 +11,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # GSCAN_HIP_LIB: development override, used by tools/variants.py to time experimental builds side by side
 LIB_PATH = os.environ.get("GSCAN_HIP_LIB") or os.path.join(HERE, "libgscan_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_ENC_LAYERS = 4
 COMM_ID_BYTES = 128
 
@@ -77,6 +77,7 @@ PROTOTYPES = {
     "gscan_abi_version": (_i, []),
     "gscan_last_error": (C.c_char_p, []),
     "gscan_workspace_bytes": (_sz, [C.POINTER(Dims)]),
+    "gscan_decoder_kernel_family": (_i, [C.POINTER(Dims)]),
     "gscan_workspace_find": (_i, [C.POINTER(Dims), C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
     "gscan_forward": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp, _vp, _vp]),
     "gscan_backward": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), C.POINTER(Masks), _vp, _vp, _vp,

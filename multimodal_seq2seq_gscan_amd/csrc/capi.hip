@@ -30,6 +30,12 @@ size_t gscan_workspace_bytes(const gscan_dims *dims) {
     return (size_t)ws.total_floats * sizeof(float);
 }
 
+int gscan_decoder_kernel_family(const gscan_dims *dims) {
+    if (!dims) { set_error("decoder_kernel_family: dims is NULL"); return -1; }
+    if (check_dims(*dims)) return -1;
+    return decoder_fast_supported(dims->H, dims->L, dims->G * dims->G, dims->V, dims->conditional != 0) ? 1 : 0;
+}
+
 int gscan_workspace_find(const gscan_dims *dims, const char *name, size_t *offset_bytes, size_t *count) {
     ARG(dims && name && offset_bytes && count, "workspace_find: NULL argument");
     if (int rc = check_dims(*dims)) return rc;

@@ -37,15 +37,18 @@
 
 namespace gscan {
 
-// Diagnostic phase stamps (off unless DecoderArgs::stamps is set): thread 0 of workgroup 0 adds the cycles since
-// the previous stamp to slot i.  Shares, not absolute times, are what to read from them.
+// Diagnostic phase stamps, compiled in with -DGSCAN_DEC_STAMPS only (tools/decoder_stamps.py runs on such a variant, tools/
+// variants.py): thread 0 of workgroup 0 adds the cycles since the previous stamp to slot i.  Shares, not absolute times,
+// are what to read from them.  Until round 5 the stamps were a run-time test of DecoderArgs::stamps in the shipped kernels:
+// eight exec-mask branches per step, two SGPRs for the condition and two VGPRs for the previous clock value, in kernels
+// that spill scalar registers.
+#ifdef GSCAN_DEC_STAMPS
 #define GSCAN_STAMP(i)                                                         \
     if (a.stamps && blockIdx.x == 0 && tid == 0) {                             \
         const long long now_ = clock64();                                      \
         stamp_acc[i] += (float)(now_ - stamp_prev);                            \
         stamp_prev = now_;                                                     \
     }
-
 // Once-per-launch stamps (prologue / epilogue pieces) go straight to slots 10..15 of the stamp buffer.
 #define GSCAN_STAMP_ONCE(i)                                                    \
     if (a.stamps && blockIdx.x == 0 && tid == 0) {                             \
@@ -53,6 +56,12 @@ namespace gscan {
         a.stamps[i] = (float)(now_ - stamp_prev);                              \
         stamp_prev = now_;                                                     \
     }
+#define GSCAN_STAMPS_ON 1
+#else
+#define GSCAN_STAMP(i)
+#define GSCAN_STAMP_ONCE(i)
+#define GSCAN_STAMPS_ON 0
+#endif
 
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -502,12 +511,13 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
     float *qh_s = vv_s + H;                                 // W_q2k[:, :H] h (conditional)
     float *ctxt_s = qh_s + H;                               // textual context (greedy head)
     float *q2_s = ctxt_s + H;                               // dot input, zero-padded to HP
-    float *sc_s = q2_s + HP, *bq_s = sc_s + 64, *stamp_acc = sc_s + 192;
+    float *sc_s = q2_s + HP, *bq_s = sc_s + 64;
+    [[maybe_unused]] float *stamp_acc = sc_s + 192;
     // greedy decoding only: composite head [V,4H] (S order), embedding part of the logits [V,V], visual context,
     // logits, current token (behind everything else in LDS)
     float *wc_s = smem + o.total, *le_s = wc_s + a.V * 4 * H, *ctxv_s = le_s + a.V * a.V, *logit_s = ctxv_s + H;
     int *tok_s = reinterpret_cast<int *>(logit_s + 64);
-    long long stamp_prev = a.stamps ? clock64() : 0;
+    [[maybe_unused]] long long stamp_prev = (GSCAN_STAMPS_ON && a.stamps) ? clock64() : 0;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
     // roles in the column-sum phases
@@ -560,7 +570,7 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
     if (tid < HP) { h_s[tid] = tid < H ? h0_reg : 0.f; q2_s[tid] = 0.f; }   // dot inputs, their padding zero
     if (tid < H) { vt_s[tid] = vt_reg; vv_s[tid] = vv_reg; }
     if (COND && tid < H) bq_s[tid] = bq_reg;
-    if (tid < 16) stamp_acc[tid] = 0.f;
+    if (GSCAN_STAMPS_ON && tid < 16) stamp_acc[tid] = 0.f;
     if (GREEDY && tid == 0) tok_s[0] = a.sos;
     float att_acc = 0.f;                                    // wave 0, lane m
     // The weight registers are complete from here on (and the compiler's wait-count bookkeeping knows: without an
@@ -769,7 +779,7 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
             a.row_stats[4 * b + 2] = 0.f;
         }
     }
-    if (a.stamps && blockIdx.x == 0 && tid < 10) a.stamps[tid] = stamp_acc[tid];
+    if (GSCAN_STAMPS_ON && a.stamps && blockIdx.x == 0 && tid < 10) a.stamps[tid] = stamp_acc[tid];
 
     // ---- output head of the row's T steps (it does not feed back, seq2seq_model.py:421-424).  The reference applies
     //      hidden_to_output(output_to_hidden(.)), two bias-free Linears with NOTHING between them: their product
@@ -794,6 +804,55 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
 // cross-wave sum), and dv_k += ds_m th is kept per lane.  (Round 5 A/B: the two attentions' sums in LDS instead — four
 // registers fewer across the time loop, and no VGPR spill — cost the reverse kernel 1.8 us: two more LDS
 // read-modify-writes per phase outweigh one scratch store and load per step.)
+// x += v on an LDS word that no other lane touches in this phase.  GSCAN_DEC_DPK_ATOMIC=1: as ONE ds_add_f32 without a
+// return value instead of read, add, write.  Measured in round 6 and OFF: with no two lanes on one address the float
+// atomic still takes the score-backward phases from 2 940 + 1 626 to 11 617 + 3 770 cycles per step (reverse kernel
+// 118.7 -> 213.9 us, profiles/r06_decoder_bwd_quad_layout_ab.txt) — the LDS executes them far below the rate of plain
+// reads and writes (round 3 saw the same with eight waves adding onto the same words and blamed the collisions).
+#ifndef GSCAN_DEC_DPK_ATOMIC
+#define GSCAN_DEC_DPK_ATOMIC 0
+#endif
+__device__ __forceinline__ void lds_accumulate(float *x, float v) {
+#if GSCAN_DEC_DPK_ATOMIC
+    __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)x, v, 0, 0, false);
+#else
+    *x += v;
+#endif
+}
+
+// Round 6: the same backward with a thread per (feature k = tid >> 2, group of memories g = tid & 3: m = g, g + 4, ...)
+// instead of a wave per memory.  The terms of d q_k then sit in the four lanes of a QUAD and are added with two DPP steps:
+// no per-wave partial sums through LDS, no summing phase, no barrier behind it (two phases and two barriers of the nine
+// a reverse step had: 436 + 428 of its 12.9 k cycles).  ds_m comes from lane m of dsm (ds_bpermute; every wave holds the
+// whole distribution), the energy-vector gradient dv_k is one loop-carried register per attention (it was two).
+// Returns d q_k in every lane of the quad of feature k (undefined for k >= H).
+#ifndef GSCAN_DEC_SB_QUAD
+#define GSCAN_DEC_SB_QUAD 1
+#endif
+template <int H>
+__device__ __forceinline__ float score_backward_quads(float dsm, const float *q_s, const float *v_s, const float *pk,
+                                                      float *dpk, int n, float &dv_acc, int tid) {
+    const int t4 = opaque(tid);
+    const int k = t4 >> 2, g = t4 & 3;
+    const bool has = k < H;
+    const int kk = has ? k : 0;
+    const float v = has ? v_s[kk] : 0.f;
+    const float q = q_s[kk];
+    float pdq = 0.f;
+#pragma unroll 3
+    for (int m0 = 0; m0 < n; m0 += 4) {                         // the same number of rounds in every lane
+        const int m = m0 + g, mc = min(m, n - 1);
+        const float dsl = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mc, __float_as_int(dsm)));
+        const float ds = m < n ? dsl : 0.f;
+        const float th = tanhf_(q + pk[mc * H + kk]);
+        const float t = ds * v * (1.f - th * th);
+        if (has && m < n) lds_accumulate(dpk + m * H + kk, t);
+        pdq += t;
+        dv_acc = fmaf(ds, th, dv_acc);
+    }
+    return quad_sum(pdq);
+}
+
 template <int H>
 __device__ __forceinline__ void score_backward(float dsm, const float *q_s, const float *v_s, const float *pk,
                                                float *dpk, int n, float *part_s, f32x2 &dv_acc, int wave, int nwave,
@@ -811,8 +870,8 @@ __device__ __forceinline__ void score_backward(float dsm, const float *q_s, cons
         const float ds = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dsm), m));
         const float th1 = tanhf_(q1 + pk[m * H + k1]), th2 = tanhf_(q2 + pk[m * H + k2]);
         const float t1 = ds * v1 * (1.f - th1 * th1), t2 = ds * v2 * (1.f - th2 * th2);
-        if (has1) dpk[m * H + k1] += t1;
-        if (has2) dpk[m * H + k2] += t2;
+        if (has1) lds_accumulate(dpk + m * H + k1, t1);
+        if (has2) lds_accumulate(dpk + m * H + k2, t2);
         pdq1 += t1;
         pdq2 += t2;
         dv_acc.x = fmaf(ds, th1, dv_acc.x);
@@ -911,8 +970,9 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     float *qt_s = vec + 7 * HP, *q2_s = qt_s + H, *qv_s = q2_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H,
           *exc_s = vv_s + H, *exs_s = exc_s + H, *part_s = exs_s + H;    // part_s: 8H
     float *dperm_s = part_s + 8 * H;  // [H][4] the gate deltas again, unit-major (the layout of the U images)
-    float *sc_s = dperm_s + 4 * H, *al_s = sc_s + 64, *datt_s = sc_s + 128, *stamp_acc = sc_s + 192;
-    long long stamp_prev = a.stamps ? clock64() : 0;
+    float *sc_s = dperm_s + 4 * H, *al_s = sc_s + 64, *datt_s = sc_s + 128;
+    [[maybe_unused]] float *stamp_acc = sc_s + 192;
+    [[maybe_unused]] long long stamp_prev = (GSCAN_STAMPS_ON && a.stamps) ? clock64() : 0;
     int len = a.cmd_lengths[b];
     len = max(1, min(len, L));
 
@@ -1066,13 +1126,17 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     for (int i = tid; i < L * H; i += kDecThreads) dPKt[i] = 0.f;
     for (int i = tid; i < 7 * HP; i += kDecThreads) vec[i] = 0.f;        // d_s / dqv_s incl. padding
     for (int i = tid; i < 8 * H; i += kDecThreads) part_s[i] = 0.f;      // dh_T = 0 (summed at the top of the loop)
+#if GSCAN_DEC_SB_QUAD
+    float dvv_acc = 0.f, dvt_acc = 0.f;                     // thread (feature tid >> 2, memories tid & 3, + 4, ...)
+#else
     f32x2 dvv_acc = {0.f, 0.f}, dvt_acc = {0.f, 0.f};
+#endif
     if (tid < H) { vt_s[tid] = vt_reg; vv_s[tid] = vv_reg; }
     if (tid < 64) {
         const float sum = wave_sum(aux_dy);
         datt_s[tid] = (has_aux && tid < M) ? aux_scale * (aux_dy - expf(aux_y) * sum) : 0.f;
     }
-    if (tid >= 64 && tid < 80) stamp_acc[tid - 64] = 0.f;
+    if (GSCAN_STAMPS_ON && tid >= 64 && tid < 80) stamp_acc[tid - 64] = 0.f;
     staged_barrier();                                       // weights, memories and the small loads above are complete
     GSCAN_STAMP_ONCE(11)
 
@@ -1130,10 +1194,21 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             const float al = (lane < M) ? alpha_v_pf : 0.f;
             const float da = (lane < M) ? sc_s[lane] : 0.f;
             const float dsm = al * (da - wave_sum(al * da));
+#if GSCAN_DEC_SB_QUAD
+            const float dq = score_backward_quads<H>(dsm, qv_s, vv_s, PKv, dPKv, M, dvv_acc, tid);
+            if ((tid & 3) == 0 && (tid >> 2) < H) {          // lane 0 of the quad of feature k holds d q_k
+                const int k = tid >> 2;
+                dqv_s[k] = dq;
+                a.dqv[bt * H + k] = dq;
+                if (!COND) d_s[5 * HP + k] = dq;             // visual query came straight from h
+            }
+#else
             score_backward<H>(dsm, qv_s, vv_s, PKv, dPKv, M, part_s, dvv_acc, wave, nwave, lane);
+#endif
         }
         lds_barrier();
         GSCAN_STAMP(3)
+#if !GSCAN_DEC_SB_QUAD
         if (tid < H) {
             float dq = 0.f;
 #pragma unroll
@@ -1143,6 +1218,7 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             if (!COND) d_s[5 * HP + tid] = dq;               // visual query came straight from h
         }
         lds_barrier();
+#endif
         GSCAN_STAMP(4)
 
         // ---- 4: conditional query: dq2 = W_qv^T dqv, through tanh ------------------------------
@@ -1170,10 +1246,16 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             const float al = (lane < len) ? alpha_c_pf : 0.f;
             const float da = (lane < len) ? sc_s[lane] : 0.f;
             const float dsm = al * (da - wave_sum(al * da));
+#if GSCAN_DEC_SB_QUAD
+            const float dq = score_backward_quads<H>(dsm, qt_s, vt_s, PKt, dPKt, len, dvt_acc, tid);
+            if ((tid & 3) == 0 && (tid >> 2) < H) d_s[4 * HP + (tid >> 2)] = dq;
+#else
             score_backward<H>(dsm, qt_s, vt_s, PKt, dPKt, len, part_s, dvt_acc, wave, nwave, lane);
+#endif
         }
         lds_barrier();
         GSCAN_STAMP(7)
+#if !GSCAN_DEC_SB_QUAD
         if (tid < H) {
             float dq = 0.f;
 #pragma unroll
@@ -1181,6 +1263,7 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             d_s[4 * HP + tid] = dq;
         }
         lds_barrier();
+#endif
         GSCAN_STAMP(8)
 
         // ---- 7: dh_{t-1} = [W_hh | W_qt | W_q2k_h or W_qv]^T . [delta | dqt | dzq or dqv] ------
@@ -1209,12 +1292,19 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     }
     for (int i = tid; i < M * H; i += kDecThreads) a.dpk_v[(int64_t)b * M * H + i] = dPKv[i];
     for (int i = tid; i < L * H; i += kDecThreads) a.dpk_t[(int64_t)b * L * H + i] = (i / H < len) ? dPKt[i] : 0.f;
-    // energy-vector gradients of this ROW (every wave holds partial sums for features (lane, lane+64)); the rows are
-    // added up by a leaf launch (energy_grad_sum).  256 workgroups adding into the same 2H addresses with atomics kept
-    // this kernel's last writes — and the whole critical chain behind it — waiting ~9 us (profiles/r03_c_*).
-    // energy-vector gradients of this ROW (every wave holds partial sums for features (lane, lane+64)); the rows are
-    // added up by a leaf launch (head_grad_finish).  256 workgroups adding into the same 2H addresses with atomics kept
-    // this kernel's last writes — and the whole critical chain behind it — waiting ~9 us (profiles/r03_c_*).
+    // energy-vector gradients of this ROW; the rows are added up by a leaf launch (head_grad_finish).  256 workgroups
+    // adding into the same 2H addresses with atomics kept this kernel's last writes — and the whole critical chain behind
+    // it — waiting ~9 us (profiles/r03_c_*).
+#if GSCAN_DEC_SB_QUAD
+    {   // the four lanes of a quad hold the sums over their memories of feature tid >> 2
+        const float xv = quad_sum(dvv_acc), xt = quad_sum(dvt_acc);
+        if ((tid & 3) == 0 && (tid >> 2) < H) {
+            a.dv_v[(int64_t)b * H + (tid >> 2)] = xv;
+            a.dv_t[(int64_t)b * H + (tid >> 2)] = xt;
+        }
+    }
+#else
+    // (every wave holds partial sums for features (lane, lane+64))
     lds_barrier();
     if (lane < H) part_s[wave * H + lane] = dvv_acc.x;
     if (lane + 64 < H) part_s[wave * H + lane + 64] = dvv_acc.y;
@@ -1233,7 +1323,8 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
         for (int cch = 0; cch < kDecThreads / 64; ++cch) x += part_s[cch * H + tid];
         a.dv_t[(int64_t)b * H + tid] = x;
     }
-    if (a.stamps && blockIdx.x == 0 && tid < 10) a.stamps[tid] = stamp_acc[tid];
+#endif
+    if (GSCAN_STAMPS_ON && a.stamps && blockIdx.x == 0 && tid < 10) a.stamps[tid] = stamp_acc[tid];
     GSCAN_STAMP_ONCE(12)
 }
 

@@ -182,34 +182,50 @@ __device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_
 
 // Up to three consecutive segments (the CNN / encoder / decoder masks of one step) with their own keep
 // probabilities in one launch; the stream id may come from device memory (graph replay).
+// Round 6: a counter is (quad index WITHIN its segment, segment id in bits 24.. of counter word 1) — as
+// drop_quad (dropout.h) does for the masks drawn inside the kernels — not the quad index in the concatenated buffer: the
+// segments are grow-only capacities (model.py:_draw_masks), and with one running index the encoder and decoder masks of a
+// given (seed, step) moved whenever an earlier segment's capacity had grown, i.e. with the history of batch shapes.
 struct MaskSegments { size_t end[3]; float p[3]; };
+
+__device__ __forceinline__ size_t mask_quads(const MaskSegments &seg) {
+    return (seg.end[0] + 3) / 4 + (seg.end[1] - seg.end[0] + 3) / 4 + (seg.end[2] - seg.end[1] + 3) / 4;
+}
+// the four mask values of quad q (numbered segment after segment) of the launch
+__device__ __forceinline__ void mask_quad(float *__restrict__ out, const MaskSegments &seg, size_t q, uint64_t seed,
+                                          uint64_t stream_id) {
+    const size_t q0 = (seg.end[0] + 3) / 4, q1 = q0 + (seg.end[1] - seg.end[0] + 3) / 4;
+    const int sid = q < q0 ? 0 : (q < q1 ? 1 : 2);
+    const size_t ql = q - (sid == 0 ? 0 : (sid == 1 ? q0 : q1));
+    const size_t begin = sid == 0 ? 0 : seg.end[sid - 1], end = seg.end[sid];
+    const float p = seg.p[sid];
+    uint32_t c0 = (uint32_t)ql, c1 = (uint32_t)(ql >> 32) | ((uint32_t)sid << 24), c2 = (uint32_t)stream_id,
+             c3 = (uint32_t)(stream_id >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const uint32_t rnd[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const size_t i = begin + ql * 4 + j;
+        if (i < end) {
+            const float u = (float)(rnd[j] >> 8) * (1.0f / 16777216.0f);   // [0,1)
+            out[i] = (u >= p) ? 1.0f / (1.0f - p) : 0.f;
+        }
+    }
+}
 
 __global__ void dropout_mask_kernel(float *__restrict__ out, MaskSegments seg, uint64_t seed, uint64_t stream_id,
                                     const uint64_t *__restrict__ dev_stream_id) {
     TraceScope trace_scope(TK_DROPOUT);
-    const size_t n = seg.end[2];
-    const size_t nquad = (n + 3) / 4;
+    const size_t nquad = mask_quads(seg);
     if (dev_stream_id) stream_id = dev_stream_id[0];
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (size_t)gridDim.x * blockDim.x) {
-        uint32_t c0 = (uint32_t)q, c1 = (uint32_t)(q >> 32), c2 = (uint32_t)stream_id, c3 = (uint32_t)(stream_id >> 32);
-        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            philox_round(c0, c1, c2, c3, k0, k1);
-            k0 += 0x9E3779B9u;
-            k1 += 0xBB67AE85u;
-        }
-        const uint32_t rnd[4] = {c0, c1, c2, c3};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const size_t i = q * 4 + j;
-            if (i < n) {
-                const float p = i < seg.end[0] ? seg.p[0] : (i < seg.end[1] ? seg.p[1] : seg.p[2]);
-                const float u = (float)(rnd[j] >> 8) * (1.0f / 16777216.0f);   // [0,1)
-                out[i] = (u >= p) ? 1.0f / (1.0f - p) : 0.f;
-            }
-        }
-    }
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (size_t)gridDim.x * blockDim.x)
+        mask_quad(out, seg, q, seed, stream_id);
 }
 
 int dropout_masks(float *out, const size_t (&n)[3], const float (&p)[3], uint64_t seed, uint64_t stream_id,
@@ -223,7 +239,7 @@ int dropout_masks(float *out, const size_t (&n)[3], const float (&p)[3], uint64_
         seg.p[i] = p[i];
     }
     if (acc == 0) return 0;
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)std::min<size_t>(cdiv((acc + 3) / 4, 256), 2048)), dim3(256), 0,
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)std::min<size_t>(cdiv((acc + 3) / 4 + 2, 256), 2048)), dim3(256), 0,
                        stream, out, seg, seed, stream_id, dev_stream_id);
     GSCAN_LAUNCHED("dropout_mask_kernel");
     return 0;
@@ -252,27 +268,9 @@ __global__ void adam_masks_kernel(float *__restrict__ p, float *__restrict__ g, 
         }
         return;
     }
-    const size_t nm = seg.end[2], nquad = (nm + 3) / 4, blocks = gridDim.x - adam_blocks;
-    for (size_t q = (size_t)(blockIdx.x - adam_blocks) * blockDim.x + threadIdx.x; q < nquad; q += blocks * blockDim.x) {
-        uint32_t c0 = (uint32_t)q, c1 = (uint32_t)(q >> 32), c2 = (uint32_t)stream_id, c3 = (uint32_t)(stream_id >> 32);
-        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            philox_round(c0, c1, c2, c3, k0, k1);
-            k0 += 0x9E3779B9u;
-            k1 += 0xBB67AE85u;
-        }
-        const uint32_t rnd[4] = {c0, c1, c2, c3};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const size_t i = q * 4 + j;
-            if (i < nm) {
-                const float pp = i < seg.end[0] ? seg.p[0] : (i < seg.end[1] ? seg.p[1] : seg.p[2]);
-                const float u = (float)(rnd[j] >> 8) * (1.0f / 16777216.0f);   // [0,1)
-                mask_out[i] = (u >= pp) ? 1.0f / (1.0f - pp) : 0.f;
-            }
-        }
-    }
+    const size_t nquad = mask_quads(seg), blocks = gridDim.x - adam_blocks;
+    for (size_t q = (size_t)(blockIdx.x - adam_blocks) * blockDim.x + threadIdx.x; q < nquad; q += blocks * blockDim.x)
+        mask_quad(mask_out, seg, q, seed, stream_id);
 }
 
 int adam_step_masks(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
@@ -292,7 +290,7 @@ int adam_step_masks(float *param, float *grad, float *exp_avg, float *exp_avg_sq
     }
     GSCAN_CHECK(acc == 0 || mask_out, "adam_step_masks: NULL mask buffer");
     const int adam_blocks = (int)std::min<size_t>(cdiv(n, 256), 2048);
-    const int mask_blocks = acc ? (int)std::min<size_t>(cdiv((acc + 3) / 4, 256), 2048) : 0;
+    const int mask_blocks = acc ? (int)std::min<size_t>(cdiv((acc + 3) / 4 + 2, 256), 2048) : 0;
     hipLaunchKernelGGL(adam_masks_kernel, dim3(adam_blocks + mask_blocks), dim3(256), 0, stream, param, grad, exp_avg,
                        exp_avg_sq, n, step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale, zero_grad, adam_blocks, mask_out,
                        seg, seed, stream_id);

@@ -156,10 +156,16 @@ class RcclCommunicator:
         # that is already up.  Only when every rank voted yes does anyone call gscan_comm_init; otherwise all of them
         # raise (GradientExchange logs it and all fall back to torch.distributed together).  A second vote behind the
         # init catches a rank whose init failed after joining (the others came back from ncclCommInitRank with it).
+        # Round 6: what can fail LOCALLY on the way into ncclCommInitRank is checked in front of the first vote
+        # too — the device this rank was told to use answers (a context exists, a kernel-less round trip completes) — and
+        # the init itself runs under a watchdog: a rank still inside it after GSCAN_COMM_INIT_TIMEOUT seconds (default
+        # 300; 0 = none) ends its PROCESS with a non-zero code (no re-exec; the launcher then ends the other ranks,
+        # bench.py polls all of them), instead of every rank waiting forever for one that died on the way in.
         failure = None
         try:
             _lib.check(lib.gscan_comm_available(), "gscan_comm_available")
-        except _lib.GscanError as e:
+            self._probe_device()
+        except (_lib.GscanError, RuntimeError) as e:
             failure = str(e)
         uid = C.create_string_buffer(_lib.COMM_ID_BYTES)
         box = [None]
@@ -176,15 +182,49 @@ class RcclCommunicator:
         if not self._vote(failure is None, process_group):
             raise RuntimeError(failure or "another rank cannot load RCCL or received no unique id")
         uid = C.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
+        watchdog = self._init_watchdog(self.rank)
         try:
             _lib.check(lib.gscan_comm_init(C.byref(self._handle), self.world_size, self.rank, C.addressof(uid)),
                        "gscan_comm_init")
         except _lib.GscanError as e:
             failure = str(e)
             self._handle = C.c_void_p()
+        finally:
+            if watchdog is not None:
+                watchdog.cancel()
         if not self._vote(failure is None, process_group):
             self.close()
             raise RuntimeError(failure or "another rank could not create its RCCL communicator")
+
+    @staticmethod
+    def _probe_device() -> None:
+        """The device-side preconditions of the collective init, checked where a failure is still a vote: the current
+        device exists and completes a round trip (raises RuntimeError otherwise)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device is visible to this rank")
+        dev = torch.cuda.current_device()
+        if dev >= torch.cuda.device_count():
+            raise RuntimeError(f"device {dev} selected, {torch.cuda.device_count()} visible")
+        torch.zeros(1, device="cuda").add_(1.0)
+        torch.cuda.synchronize()
+
+    @staticmethod
+    def _init_watchdog(rank: int):
+        """A timer that ends this PROCESS if the collective init has not come back in time (None: disabled)."""
+        import threading
+        seconds = float(os.environ.get("GSCAN_COMM_INIT_TIMEOUT", "300"))
+        if seconds <= 0:
+            return None
+
+        def expire():
+            logger.error("rank %d: still inside ncclCommInitRank after %.0f s (a peer never joined?): exiting", rank, seconds)
+            logging.shutdown()
+            os._exit(3)
+
+        timer = threading.Timer(seconds, expire)
+        timer.daemon = True
+        timer.start()
+        return timer
 
     @staticmethod
     def _vote(ok: bool, process_group) -> bool:

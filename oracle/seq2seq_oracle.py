@@ -45,7 +45,11 @@ def world_encoder(p: Params, world: torch.Tensor, mask: Optional[torch.Tensor] =
     The reference transposes dims 1 and 3 before and after the convolutions
     (cnn_model.py:28,34), so with the stored weight W[o,ch,kh,kw] the tap (kh,kw)
     moves along (grid column, grid row) of the *untransposed* input.  Written here as
-    an explicit sum over taps on the [B,row,col,C] tensor, no conv2d call.
+    an explicit gather of the k*k shifted views of the [B,row,col,C] tensor (tap-major
+    im2col) and ONE product per convolution with the weights reordered to
+    [tap, ch, o] — no conv2d call.  (Until round 6 this was a Python loop of k*k small
+    products and adds: the same sum, 10 % of the oracle's CPU time at the benchmark
+    shape, which bench.py's cpu_baseline times.)
     """
     B, G, _, C = world.shape
     outs = []
@@ -56,12 +60,11 @@ def world_encoder(p: Params, world: torch.Tensor, mask: Optional[torch.Tensor] =
         pad = k // 2
         xp = torch.zeros(B, G + 2 * pad, G + 2 * pad, C, dtype=world.dtype)
         xp[:, pad:pad + G, pad:pad + G, :] = world
-        acc = bias.view(1, 1, 1, Co).expand(B, G, G, Co).clone()
-        for kh in range(k):          # kh pairs with the grid *column* offset
-            for kw in range(k):      # kw pairs with the grid *row* offset
-                patch = xp[:, kw:kw + G, kh:kh + G, :]            # [B,G,G,C]
-                acc = acc + patch @ W[:, :, kh, kw].t()           # [B,G,G,Co]
-        outs.append(acc)
+        # kh pairs with the grid *column* offset, kw with the grid *row* offset
+        taps = [xp[:, kw:kw + G, kh:kh + G, :] for kh in range(k) for kw in range(k)]      # k*k views [B,G,G,C]
+        cols = torch.stack(taps, dim=3).reshape(B, G, G, k * k * C)                        # [.., (kh, kw, ch)]
+        Wm = W.permute(2, 3, 1, 0).reshape(k * k * C, Co)                                  # [(kh, kw, ch), o]
+        outs.append(cols @ Wm + bias.view(1, 1, 1, Co))
     feat = torch.relu(torch.cat(outs, dim=-1))                     # order conv_1|conv_2|conv_3
     if mask is not None:                                           # nn.Dropout as a given scaled mask
         feat = feat * mask.view_as(feat)

@@ -214,6 +214,17 @@ def _worker_transport_vote(rank: int, world: int, port: int, failing_rank: int, 
     fake = FakeLib()
     _lib.load = lambda: fake
     train.torch.cuda.synchronize = lambda: None
+
+    def probe():                                               # the device-side preconditions (no device in this test)
+        calls.append("probe")
+        if stage == "device" and rank == failing_rank:
+            raise RuntimeError("stand-in device failure")
+    train.RcclCommunicator._probe_device = staticmethod(probe)
+    if stage == "hang":                                        # the failing rank never comes back from the collective init
+        os.environ["GSCAN_COMM_INIT_TIMEOUT"] = "2"
+        if rank == failing_rank:
+            import time
+            fake.gscan_comm_init = lambda *a: time.sleep(600) or 0
     raised = ""
     try:
         train.RcclCommunicator()
@@ -224,7 +235,7 @@ def _worker_transport_vote(rank: int, world: int, port: int, failing_rank: int, 
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("stage,failing_rank", [("load", 1), ("load", 0), ("init", 1), ("none", -1)])
+@pytest.mark.parametrize("stage,failing_rank", [("load", 1), ("load", 0), ("device", 1), ("init", 1), ("none", -1)])
 def test_rccl_transport_vote_happens_before_the_collective_init(tmp_path, stage, failing_rank):
     world, port = 2, _free_port()
     mp.spawn(_worker_transport_vote, args=(world, port, failing_rank, stage, str(tmp_path)), nprocs=world, join=True)
@@ -235,5 +246,17 @@ def test_rccl_transport_vote_happens_before_the_collective_init(tmp_path, stage,
             assert flag == "0" and "init" in calls, rest
         else:
             assert flag == "1", rest                           # EVERY rank falls back, not only the failing one
-            if stage == "load":
+            if stage in ("load", "device"):
                 assert "init" not in calls, rest               # nobody waits inside ncclCommInitRank for the others
+
+
+def test_rank_stuck_in_the_collective_init_ends_its_process(tmp_path):
+    """A rank that never comes back from gscan_comm_init (a peer died on its way in) exits non-zero after
+    GSCAN_COMM_INIT_TIMEOUT seconds instead of hanging the job (train.RcclCommunicator._init_watchdog)."""
+    import time
+    world, port = 2, _free_port()
+    t0 = time.time()
+    with pytest.raises(Exception) as err:
+        mp.spawn(_worker_transport_vote, args=(world, port, 1, "hang", str(tmp_path)), nprocs=world, join=True)
+    assert time.time() - t0 < 120
+    assert "exit code 3" in str(err.value) or "exitcode" in str(err.value).lower() or "terminated" in str(err.value).lower(), str(err.value)

@@ -57,9 +57,16 @@ def main():
              "fetch_bytes_per_launch": 2.0 * 1024.0 * f / max(nf, 1),
              "write_bytes_per_launch": 1024.0 * w / max(nw, 1),
              # from the trace itself, not from a schedule someone assumed (None: no optimiser launches in the pass)
-             "launches_per_step": round(nf / steps_f, 3) if steps_f else None}
+             "launches_per_step": round(nf / steps_f, 3) if steps_f else None,
+             "launches_per_step_write_pass": round(nw / steps_w, 3) if steps_w else None}
         e["traffic_bytes_per_launch"] = e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
         per[kernel] = e
+    if not per:      # a failed run, or kernel names that no longer demangle to gscan::<name>: say so instead of StopIteration
+        sys.exit(f"pmc_traffic: no gscan:: kernel with FETCH_SIZE / WRITE_SIZE rows in {fpath} / {wpath} "
+                 "(did the profiled run fail, or has the name mangling changed?)")
+    if steps_f != steps_w:
+        print(f"pmc_traffic: warning: {steps_f} steps in the fetch pass, {steps_w} in the write pass — per-launch figures are "
+              "per pass; launches_per_step is given for each pass", file=sys.stderr)
     first = "gemm_group_kernel" if "gemm_group_kernel" in per else next(iter(per))
     out = {"kernel": first, **per[first],
            "corrections": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), unit 1 KB; WRITE_SIZE x1",
