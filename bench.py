@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -41,7 +42,6 @@ PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
 
 def source_hash() -> str:
     """sha256 over the kernel sources and the public header (what libgscan_hip.so is built from)."""
-    import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "multimodal_seq2seq_gscan_amd", "csrc")
     files = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
@@ -107,6 +107,23 @@ def algorithmic_mflop_per_example(cfg: dict, G: int, L: int, T: int) -> float:
     return 6.0 * (mac + T * step) / 1e6
 
 
+CPU_ANCHOR = os.path.join(ROOT, "profiles", "cpu_ref_vs_oracle_latest.json")
+
+
+def reference_over_port():
+    """{workload: reference examples/s / oracle examples/s, ...} as last measured in the build container, with its date,
+    thread count and the oracle source's hash; None when the committed anchor is missing or of another oracle."""
+    try:
+        with open(CPU_ANCHOR) as f:
+            anchor = json.load(f)
+    except (OSError, ValueError):
+        return None
+    with open(os.path.join(ROOT, "oracle", "seq2seq_oracle.py"), "rb") as f:
+        current = hashlib.sha256(f.read()).hexdigest()[:16]
+    anchor["oracle_unchanged_since"] = anchor.get("oracle_sha") == current
+    return anchor
+
+
 def cpu_baseline(cfg: dict, shape, budget_s: float) -> dict:
     """The CPU oracle (oracle/seq2seq_oracle.py, a restatement of the reference's CPU path) on this box's cores:
     the same step definition (forward, loss, backward, Adam + LR) on the same synthetic workload."""
@@ -155,6 +172,9 @@ def cpu_baseline(cfg: dict, shape, budget_s: float) -> dict:
         if el >= budget_s or n >= 64:
             break
     return {"value": round(n * B / el, 1), "unit": "examples/s", "cores": cores, "kind": "port",
+            # how far the port is from the reference it restates: the IMPORTED reference timed beside the oracle in the
+            # build container (tools/cpu_ref_vs_oracle.py --json; the reference cannot travel to the GPU box)
+            "reference_over_port": reference_over_port(),
             "thread_sweep": {str(c): round(v, 1) for c, v in sweep.items()},
             "sample": f"{n} steps of the same workload (B={B}, T={T}) at the best thread count of the sweep, after "
                       f"warm-up, torch {torch.__version__} CPU, {allowed} cores allowed"}
@@ -366,6 +386,8 @@ def main():
                          "COUNT from it and broadcasts the count, so every rank still runs the same number of steps "
                          "(a fresh box needs ~1 s of work before its first timed window is representative)")
     ap.add_argument("--windows", type=int, default=4, help="extra timed windows of K steps for the spread (0 = none)")
+    ap.add_argument("--attempts", type=int, default=3,
+                    help="how often the timed windows are measured while the first window is > 3 %% off their median")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--rotate", type=int, default=4,
                     help="distinct resident batches the steps cycle through (1 = the same batch every step)")
@@ -474,30 +496,40 @@ def main():
     for _ in range(warmup_steps):
         step(next_batch())
     warmup_steps += 2 * calibrate
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(next_batch())
-    fence()
-    elapsed = time.perf_counter() - t0
     tdev = "cpu" if args.backend == "gloo" else "cuda"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    loss = float(out["loss"].item())
-    # spread: further windows of the same K steps (the contract's number is the first window above)
-    windows = [1e3 * elapsed / args.steps]
-    for _ in range(args.windows):
+
+    def timed_window():
+        """exactly K steps between barrier + synchronize pairs; the maximum over ranks, in seconds"""
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step(next_batch())
+            last = step(next_batch())
         fence()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=tdev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        windows.append(1e3 * float(t.item()) / args.steps)
+        return float(t.item()), last
+
+    # The contract's number is the FIRST window after the warm-up; `value` is the median of 1 + --windows such windows (one
+    # window is 25 ms of wall clock: a single host or device stall of a few milliseconds would otherwise be the number of
+    # the round).  The two must agree: when the first window is more than 3 % off the median, the whole measurement is
+    # repeated (up to --attempts times, every rank alike: the decision is taken on the all-reduced times); if it still
+    # is, `value` is the FIRST window (what --steps/--warmup literally describe) and the line says so.
+    attempts = 0
+    while True:
+        attempts += 1
+        elapsed, out = timed_window()
+        windows = [1e3 * elapsed / args.steps]
+        for _ in range(args.windows):
+            windows.append(1e3 * timed_window()[0] / args.steps)
+        median_ms = sorted(windows)[len(windows) // 2]
+        first_off = abs(windows[0] - median_ms) / median_ms
+        if first_off <= 0.03 or attempts >= max(1, args.attempts) or args.windows == 0:
+            break
+        if rank == 0:
+            print(f"bench.py: first window {windows[0]:.4f} ms is {100 * first_off:.1f} % off the median {median_ms:.4f} ms: "
+                  f"measuring again (attempt {attempts + 1})", file=sys.stderr, flush=True)
+    loss = float(out["loss"].item())
 
     # second pass over the same K steps with HIP-event probes around each kernel family
     probe_step = step
@@ -536,7 +568,9 @@ def main():
         # seen twice in some sixty runs of a round: 0.89 ms against 0.49 — would otherwise be the number of the round;
         # the first window and the spread are reported next to it.
         first_window_ms = 1e3 * elapsed / args.steps
-        elapsed = 1e-3 * sorted(windows)[len(windows) // 2] * args.steps
+        first_window_ok = first_off <= 0.03
+        if first_window_ok:
+            elapsed = 1e-3 * sorted(windows)[len(windows) // 2] * args.steps
         ex_per_s = world * B * args.steps / elapsed
         # The roofline block prices the GEMM family (the conv + LSTM + projection products north_star's MFMA target
         # names).  So that the line cannot flatter: `families_ranked` lists EVERY family by time per step with its
@@ -602,7 +636,13 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}", "parameters": model.parameter_count,
                        "launch": "eager (forward on the caller's stream, backward on 3 streams)",
                        "resident_batches": len(batches),
-                       "value_window": "median of the timed windows of K steps each" if len(windows) > 1 else "the one timed window",
+                       "value_window": ("the one timed window" if len(windows) == 1 else
+                                        "median of the timed windows of K steps each" if first_window_ok else
+                                        "FIRST window: it stayed > 3 % off the median of the windows over every attempt"),
+                       "first_window_off_median": round(first_off, 4), "measurement_attempts": attempts,
+                       # 1 = the register/LDS-resident decoder kernels, 0 = the streaming ones (gscan_decoder_kernel_family)
+                       "decoder_kernels": {1: "resident (csrc/decoder.hip)", 0: "streaming (csrc/decoder_any.hip)"}.get(
+                           int(lib.gscan_decoder_kernel_family(C.byref(model._dims(B, L, T, grid)))), "unsupported"),
                        "warmup_steps_run": warmup_steps, "warmup_seconds_target": args.warmup_seconds,
                        "gradient_exchange": (None if not step.exchange.collective else
                                              "gscan_allreduce_f32: RCCL on the step's stream" if step.exchange.comm is not None

@@ -147,6 +147,9 @@ __device__ __forceinline__ float half_dot(const float (&w)[K0], const float *v) 
 #define GSCAN_DEC_SCORE_GROUP 5
 #endif
 constexpr int kScoreGroup = GSCAN_DEC_SCORE_GROUP;
+#ifndef GSCAN_DEC_SCORE_PAIRS
+#define GSCAN_DEC_SCORE_PAIRS 1   // 1 (round 6): a lane owns the ADJACENT features (2 lane, 2 lane + 1): one 8-byte LDS read per memory, v
+#endif                            // and q one each (they were features lane and lane + 64: two 4-byte reads each); 0: round 5's layout
 template <int H, int G>
 __device__ __forceinline__ void score_round(float v1, float v2, float q1, float q2, int k1, int k2, const float *pk,
                                             int n, float *sc_s, int m0, int nwave, int lane) {
@@ -154,8 +157,13 @@ __device__ __forceinline__ void score_round(float v1, float v2, float q1, float 
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int m = min(m0 + i * nwave, n - 1);                  // scalar arithmetic (m0 is an SGPR)
+#if GSCAN_DEC_SCORE_PAIRS
+        const f32x2 x = *reinterpret_cast<const f32x2 *>(pk + m * H + k1);
+        x1[i] = x.x; x2[i] = x.y;
+#else
         x1[i] = pk[m * H + k1];
         x2[i] = pk[m * H + k2];
+#endif
     }
 #pragma unroll
     for (int i = 0; i < G; ++i) p[i] = fmaf(v1, tanhf_(q1 + x1[i]), v2 * tanhf_(q2 + x2[i]));
@@ -170,10 +178,19 @@ __device__ __forceinline__ void attention_scores(const float *v_s, const float *
                                                  float *sc_s, int wave_v, int nwave, int lane) {
     static_assert(H <= 128, "two feature indices per lane");
     const int wave = __builtin_amdgcn_readfirstlane(wave_v);
+#if GSCAN_DEC_SCORE_PAIRS
+    static_assert(H % 2 == 0, "feature pairs");
+    const bool has = 2 * lane < H;
+    const int k1 = has ? 2 * lane : 0, k2 = k1 + 1;
+    const f32x2 vv = *reinterpret_cast<const f32x2 *>(v_s + k1), qq = *reinterpret_cast<const f32x2 *>(q_s + k1);
+    const float v1 = has ? vv.x : 0.f, v2 = has ? vv.y : 0.f;
+    const float q1 = qq.x, q2 = qq.y;
+#else
     const bool has2 = lane + 64 < H, has1 = lane < H;
     const int k1 = has1 ? lane : 0, k2 = has2 ? lane + 64 : 0;
     const float v1 = has1 ? v_s[k1] : 0.f, v2 = has2 ? v_s[k2] : 0.f;
     const float q1 = q_s[k1], q2 = q_s[k2];
+#endif
     const int per = (n + nwave - 1) / nwave;                        // memories of the busiest wave
     const int rounds = (per + kScoreGroup - 1) / kScoreGroup;
     const int grp = (per + rounds - 1) / rounds;                    // memories per wave per round
@@ -331,11 +348,11 @@ __device__ __forceinline__ float quad_bcast(float v) { return dpp_move<I * 0x55,
 // lane j returns column 4c + j.  alpha_m lives in lane m of `alpha` (every wave holds the whole distribution) and is
 // fetched with ds_bpermute, so the loop runs the same number of rounds in every lane; threads without a column quad
 // pass stride = 0 and ignore the result.  n is uniform in the workgroup.
-template <bool GLOBAL = false>
-__device__ __forceinline__ float quad_column_sum(const float *base, int stride, int n, int j, float alpha) {
 #ifndef GSCAN_DEC_QCS_U
 #define GSCAN_DEC_QCS_U 3
 #endif
+template <bool GLOBAL = false>
+__device__ __forceinline__ float quad_column_sum(const float *base, int stride, int n, int j, float alpha) {
     constexpr int U = GSCAN_DEC_QCS_U;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int i0 = 0; i0 < n; i0 += 4 * U) {
@@ -355,6 +372,32 @@ __device__ __forceinline__ float quad_column_sum(const float *base, int stride, 
     }
     const float s0 = quad_sum(acc[0]), s1 = quad_sum(acc[1]), s2 = quad_sum(acc[2]), s3 = quad_sum(acc[3]);
     return j == 0 ? s0 : j == 1 ? s1 : j == 2 ? s2 : s3;
+}
+
+// Two such sums over the SAME memories with one fetch of the attention weights (the command's gate images and its
+// [PK | U2] columns in phase C: the waves that own both ran the two loops one after the other).
+__device__ __forceinline__ void quad_column_sum2(const float *base_a, int stride_a, const float *base_b, int stride_b, int n,
+                                                 int j, float alpha, float &out_a, float &out_b) {
+    constexpr int U = GSCAN_DEC_QCS_U;
+    f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < n; i0 += 4 * U) {
+        f32x4 xa[U], xb[U];
+        float am[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = i0 + 4 * u + j, mc = min(m, n - 1);
+            xa[u] = *reinterpret_cast<const f32x4 *>(base_a + __mul24(mc, stride_a));
+            xb[u] = *reinterpret_cast<const f32x4 *>(base_b + __mul24(mc, stride_b));
+            const float al = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mc, __float_as_int(alpha)));
+            am[u] = m < n ? al : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc_a += am[u] * xa[u]; acc_b += am[u] * xb[u]; }
+    }
+    const float a0 = quad_sum(acc_a[0]), a1 = quad_sum(acc_a[1]), a2 = quad_sum(acc_a[2]), a3 = quad_sum(acc_a[3]);
+    const float b0 = quad_sum(acc_b[0]), b1 = quad_sum(acc_b[1]), b2 = quad_sum(acc_b[2]), b3 = quad_sum(acc_b[3]);
+    out_a = j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : a3;
+    out_b = j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3;
 }
 
 // The output head of a row's T steps (see the comment in decoder_fwd_body where it is called), on the matrix cores
@@ -588,6 +631,30 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
         }
         lds_barrier();
     }
+    // Softmax shift (GSCAN_DEC_SOFTMAX_BOUND=1): a score v . tanh(.) lies in [-|v|_1, |v|_1], so |v|_1 can stand in for the
+    // maximum the reference's softmax subtracts (seq2seq_model.py:136; the quotient is the same number) — one 64-lane
+    // reduction chain (six DPP steps + a readlane, ~90 cycles) per attention and step fewer — as long as exp(-2 |v|_1)
+    // stays a normal float: |v|_1 < 40; beyond that the maximum is taken as before (wave-uniform choice per launch).
+#ifndef GSCAN_DEC_SOFTMAX_BOUND
+#define GSCAN_DEC_SOFTMAX_BOUND 1
+#endif
+    float shift_t = 0.f, shift_v = 0.f;
+    bool bound_t = false, bound_v = false;
+    if (GSCAN_DEC_SOFTMAX_BOUND) {
+        const float at1 = (lane < H ? fabsf(vt_s[lane]) : 0.f) + (lane + 64 < H ? fabsf(vt_s[lane + 64]) : 0.f);
+        const float av1 = (lane < H ? fabsf(vv_s[lane]) : 0.f) + (lane + 64 < H ? fabsf(vv_s[lane + 64]) : 0.f);
+        shift_t = wave_sum(at1);
+        shift_v = wave_sum(av1);
+        bound_t = shift_t < 40.f;
+        bound_v = shift_v < 40.f;
+    }
+    // GSCAN_DEC_PRIO=1: the second-dispatched half of the workgroup (waves 4-7: the younger wave of every SIMD, which loses
+    // the issue arbitration by age) runs at priority 1 for the whole loop; 2: the older half instead (A/B).
+#ifndef GSCAN_DEC_PRIO
+#define GSCAN_DEC_PRIO 0
+#endif
+    if (GSCAN_DEC_PRIO == 1) { if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1); }
+    if (GSCAN_DEC_PRIO == 2) { if (__builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_setprio(1); }
     int steps_done = 0;
     GSCAN_STAMP_ONCE(10)
 
@@ -634,17 +701,22 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
         float alpha;
         {
             const float x = (lane < len) ? sc_s[lane] : -INFINITY;
-            const float mx = wave_max(x);
+            const float mx = bound_t ? shift_t : wave_max(x);
             const float e = (lane < len) ? __expf(x - mx) : 0.f;
             alpha = e * __builtin_amdgcn_rcpf(wave_sum(e));
         }
-        const float uct = quad_column_sum(ut_col, ut_stride, len, j4, alpha);     // this lane's gate, textual part
+#ifndef GSCAN_DEC_QCS2
+#define GSCAN_DEC_QCS2 1          // 1 (round 6): the waves that sum the [PK_t | U2_t] columns too do both sums in ONE loop
+#endif
+        float uct, s2 = 0.f;                                                      // this lane's gate, textual part
+        if (GSCAN_DEC_QCS2 && wave < (4 * NQ2 + 63) / 64) quad_column_sum2(ut_col, ut_stride, k2_col, k2_stride, len, j4, alpha, uct, s2);
+        else uct = quad_column_sum(ut_col, ut_stride, len, j4, alpha);
         // This is the one place where a wave waits for a global load (ge): vmcnt counts stores too, so every store
         // of phases A-C is issued behind this wait and has most of a step to be acknowledged before the next one
         float pre = ge + ghh + uct;
         asm volatile("" : "+v"(pre));
         if (wave < (4 * NQ2 + 63) / 64) {
-            const float s2 = quad_column_sum(k2_col, k2_stride, len, j4, alpha);
+            if (!GSCAN_DEC_QCS2) s2 = quad_column_sum(k2_col, k2_stride, len, j4, alpha);
             const int col = 4 * cq2 + j4;
             if (has2) {
                 if (col < H) {
@@ -687,7 +759,7 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
         // ---- F: softmax, column sums over the cells, gates, cell update (seq2seq_model.py:414) ----
         {
             const float x = (lane < M) ? sc_s[lane] : -INFINITY;
-            const float mx = wave_max(x);
+            const float mx = bound_v ? shift_v : wave_max(x);
             const float e = (lane < M) ? __expf(x - mx) : 0.f;
             alpha = e * __builtin_amdgcn_rcpf(wave_sum(e));
             if (wave == 0) {
@@ -804,7 +876,7 @@ __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a)
 // cross-wave sum), and dv_k += ds_m th is kept per lane.  (Round 5 A/B: the two attentions' sums in LDS instead — four
 // registers fewer across the time loop, and no VGPR spill — cost the reverse kernel 1.8 us: two more LDS
 // read-modify-writes per phase outweigh one scratch store and load per step.)
-// x += v on an LDS word that no other lane touches in this phase.  GSCAN_DEC_DPK_ATOMIC=1: as ONE ds_add_f32 without a
+// x += v on an LDS word that no other lane touches in this phase (the wave-per-memory form).  GSCAN_DEC_DPK_ATOMIC=1: as ONE ds_add_f32 without a
 // return value instead of read, add, write.  Measured in round 6 and OFF: with no two lanes on one address the float
 // atomic still takes the score-backward phases from 2 940 + 1 626 to 11 617 + 3 770 cycles per step (reverse kernel
 // 118.7 -> 213.9 us, profiles/r06_decoder_bwd_quad_layout_ab.txt) — the LDS executes them far below the rate of plain
@@ -827,7 +899,13 @@ __device__ __forceinline__ void lds_accumulate(float *x, float v) {
 // whole distribution), the energy-vector gradient dv_k is one loop-carried register per attention (it was two).
 // Returns d q_k in every lane of the quad of feature k (undefined for k >= H).
 #ifndef GSCAN_DEC_SB_QUAD
-#define GSCAN_DEC_SB_QUAD 1
+#define GSCAN_DEC_SB_QUAD 2       // 0: round 5's wave per memory; 1: quads (a feature per lane); 2: groups of eight (a feature pair)
+#endif
+#ifndef GSCAN_DEC_SBO_UV
+#define GSCAN_DEC_SBO_UV 5        // rounds per straight-line block of the group-of-eight form: grid cells (36 = 5 rounds of 8)
+#endif
+#ifndef GSCAN_DEC_SBO_UT
+#define GSCAN_DEC_SBO_UT 2        // ... command tokens (10 = 2 rounds of 8)
 #endif
 template <int H>
 __device__ __forceinline__ float score_backward_quads(float dsm, const float *q_s, const float *v_s, const float *pk,
@@ -839,18 +917,88 @@ __device__ __forceinline__ float score_backward_quads(float dsm, const float *q_
     const float v = has ? v_s[kk] : 0.f;
     const float q = q_s[kk];
     float pdq = 0.f;
-#pragma unroll 3
-    for (int m0 = 0; m0 < n; m0 += 4) {                         // the same number of rounds in every lane
-        const int m = m0 + g, mc = min(m, n - 1);
-        const float dsl = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mc, __float_as_int(dsm)));
-        const float ds = m < n ? dsl : 0.f;
-        const float th = tanhf_(q + pk[mc * H + kk]);
-        const float t = ds * v * (1.f - th * th);
-        if (has && m < n) lds_accumulate(dpk + m * H + kk, t);
-        pdq += t;
-        dv_acc = fmaf(ds, th, dv_acc);
+    // Rounds of U memories per lane, straight-line: every LDS read of a round (projected key, ds through ds_bpermute, the
+    // running key gradient) is issued before the first tanh — as a loop over single memories with a guarded
+    // read-add-write the compiler kept one dependent LDS round trip + transcendental chain + round trip per memory
+    // (phase 3: 3 248 cycles for 9 memories per lane).  Lanes without a memory (m >= n) or a feature (k >= H) read a
+    // clamped address and store nothing.
+#ifndef GSCAN_DEC_SBQ_U
+#define GSCAN_DEC_SBQ_U 3
+#endif
+    constexpr int U = GSCAN_DEC_SBQ_U;
+    for (int m0 = 0; m0 < n; m0 += 4 * U) {                     // the same number of rounds in every lane
+        float x[U], dsl[U], old[U];
+        int at[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = m0 + 4 * u + g, mc = min(m, n - 1);
+            live[u] = m < n;
+            at[u] = mc * H + kk;
+            x[u] = pk[at[u]];
+            dsl[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mc, __float_as_int(dsm)));
+            old[u] = dpk[at[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float ds = live[u] ? dsl[u] : 0.f;
+            const float th = tanhf_(q + x[u]);
+            const float t = ds * v * (1.f - th * th);
+            if (has && live[u]) dpk[at[u]] = old[u] + t;
+            pdq += t;
+            dv_acc = fmaf(ds, th, dv_acc);
+        }
     }
     return quad_sum(pdq);
+}
+
+// The same with a thread per (feature PAIR k2 = tid >> 3, group of memories g = tid & 7: m = g, g + 8, ...): the projected
+// keys, the running key gradients and their updates are 8-byte LDS accesses (half as many LDS instructions per term as
+// the quad form: the phase is bound by LDS issue and transcendentals about equally), U rounds straight-line, and the two
+// d q sums are added over the eight lanes of a group with three DPP steps (two in the quad, one row_half_mirror).
+// Returns (d q_{2 k2}, d q_{2 k2 + 1}) in every lane of the group.
+template <int H, int U>
+__device__ __forceinline__ f32x2 score_backward_octs(float dsm, const float *q_s, const float *v_s, const float *pk,
+                                                     float *dpk, int n, f32x2 &dv_acc, int tid) {
+    static_assert(H % 2 == 0 && H <= 128, "feature pairs over 64 groups of eight lanes");
+    const int t8 = opaque(tid);
+    const int k2 = t8 >> 3, g = t8 & 7;
+    const bool has = 2 * k2 < H;
+    const int kk = has ? 2 * k2 : 0;
+    const f32x2 q = *reinterpret_cast<const f32x2 *>(q_s + kk);
+    f32x2 v = *reinterpret_cast<const f32x2 *>(v_s + kk);
+    if (!has) v = f32x2{0.f, 0.f};
+    f32x2 pdq = {0.f, 0.f};
+    for (int m0 = 0; m0 < n; m0 += 8 * U) {                     // the same number of rounds in every lane
+        f32x2 x[U], old[U];
+        float dsl[U];
+        int at[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = m0 + 8 * u + g, mc = min(m, n - 1);
+            live[u] = m < n;
+            at[u] = mc * H + kk;
+            x[u] = *reinterpret_cast<const f32x2 *>(pk + at[u]);
+            dsl[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mc, __float_as_int(dsm)));
+            old[u] = *reinterpret_cast<const f32x2 *>(dpk + at[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float ds = live[u] ? dsl[u] : 0.f;
+            const f32x2 th = {tanhf_(q.x + x[u].x), tanhf_(q.y + x[u].y)};
+            const f32x2 t = {ds * v.x * (1.f - th.x * th.x), ds * v.y * (1.f - th.y * th.y)};
+            if (has && live[u]) *reinterpret_cast<f32x2 *>(dpk + at[u]) = old[u] + t;
+            pdq += t;
+            dv_acc.x = fmaf(ds, th.x, dv_acc.x);
+            dv_acc.y = fmaf(ds, th.y, dv_acc.y);
+        }
+    }
+    pdq.x = quad_sum(pdq.x);
+    pdq.y = quad_sum(pdq.y);
+    pdq.x += dpp_move<0x141, 0xf>(pdq.x);                       // row_half_mirror: the other quad of the eight
+    pdq.y += dpp_move<0x141, 0xf>(pdq.y);
+    return pdq;
 }
 
 template <int H>
@@ -911,6 +1059,37 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
             yoff[i] = u2_off + 4 * (idx - 5 * Q); ystr[i] = H;
         }
     }
+#ifndef GSCAN_DEC_DALPHA_G
+#define GSCAN_DEC_DALPHA_G 0      // > 0 (round 6 A/B): G memories per straight-line round, their wave sums interleaved (wave_sum_n)
+#endif
+#if GSCAN_DEC_DALPHA_G > 0
+    if constexpr (!UGLOBAL) {
+        constexpr int G = GSCAN_DEC_DALPHA_G;
+        for (int m0 = wave; m0 < n; m0 += G * nwave) {
+            float4 y[G][NI];
+            float p[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int m = min(m0 + i * nwave, n - 1);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) y[i][j] = *reinterpret_cast<const float4 *>(smem + yoff[j] + m * ystr[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                p[i] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) p[i] = dot4(x[j], y[i][j], p[i]);
+            }
+            wave_sum_n<G>(p);
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int m = m0 + i * nwave;
+                if (lane == 0 && m < n) sc_s[m] = p[i] + (add ? add[m] : 0.f);
+            }
+        }
+        return;
+    }
+#endif
     for (int m0 = wave; m0 < n; m0 += 2 * nwave) {
         float p[2];
 #pragma unroll
@@ -1126,7 +1305,9 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     for (int i = tid; i < L * H; i += kDecThreads) dPKt[i] = 0.f;
     for (int i = tid; i < 7 * HP; i += kDecThreads) vec[i] = 0.f;        // d_s / dqv_s incl. padding
     for (int i = tid; i < 8 * H; i += kDecThreads) part_s[i] = 0.f;      // dh_T = 0 (summed at the top of the loop)
-#if GSCAN_DEC_SB_QUAD
+#if GSCAN_DEC_SB_QUAD == 2
+    f32x2 dvv_acc = {0.f, 0.f}, dvt_acc = {0.f, 0.f};       // thread (feature pair tid >> 3, memories tid & 7, + 8, ...)
+#elif GSCAN_DEC_SB_QUAD
     float dvv_acc = 0.f, dvt_acc = 0.f;                     // thread (feature tid >> 2, memories tid & 3, + 4, ...)
 #else
     f32x2 dvv_acc = {0.f, 0.f}, dvt_acc = {0.f, 0.f};
@@ -1138,6 +1319,8 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     }
     if (GSCAN_STAMPS_ON && tid >= 64 && tid < 80) stamp_acc[tid - 64] = 0.f;
     staged_barrier();                                       // weights, memories and the small loads above are complete
+    if (GSCAN_DEC_PRIO == 1) { if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1); }
+    if (GSCAN_DEC_PRIO == 2) { if (__builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_setprio(1); }
     GSCAN_STAMP_ONCE(11)
 
     for (int t = T - 1; t >= 0; --t) {
@@ -1194,7 +1377,15 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             const float al = (lane < M) ? alpha_v_pf : 0.f;
             const float da = (lane < M) ? sc_s[lane] : 0.f;
             const float dsm = al * (da - wave_sum(al * da));
-#if GSCAN_DEC_SB_QUAD
+#if GSCAN_DEC_SB_QUAD == 2
+            const f32x2 dq = score_backward_octs<H, GSCAN_DEC_SBO_UV>(dsm, qv_s, vv_s, PKv, dPKv, M, dvv_acc, tid);
+            if ((tid & 7) == 0 && 2 * (tid >> 3) < H) {      // lane 0 of the eight of feature pair k2 holds both sums
+                const int k = 2 * (tid >> 3);
+                *reinterpret_cast<f32x2 *>(dqv_s + k) = dq;
+                *reinterpret_cast<f32x2 *>(a.dqv + bt * H + k) = dq;
+                if (!COND) *reinterpret_cast<f32x2 *>(d_s + 5 * HP + k) = dq;   // visual query came straight from h
+            }
+#elif GSCAN_DEC_SB_QUAD
             const float dq = score_backward_quads<H>(dsm, qv_s, vv_s, PKv, dPKv, M, dvv_acc, tid);
             if ((tid & 3) == 0 && (tid >> 2) < H) {          // lane 0 of the quad of feature k holds d q_k
                 const int k = tid >> 2;
@@ -1246,7 +1437,10 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             const float al = (lane < len) ? alpha_c_pf : 0.f;
             const float da = (lane < len) ? sc_s[lane] : 0.f;
             const float dsm = al * (da - wave_sum(al * da));
-#if GSCAN_DEC_SB_QUAD
+#if GSCAN_DEC_SB_QUAD == 2
+            const f32x2 dq = score_backward_octs<H, GSCAN_DEC_SBO_UT>(dsm, qt_s, vt_s, PKt, dPKt, len, dvt_acc, tid);
+            if ((tid & 7) == 0 && 2 * (tid >> 3) < H) *reinterpret_cast<f32x2 *>(d_s + 4 * HP + 2 * (tid >> 3)) = dq;
+#elif GSCAN_DEC_SB_QUAD
             const float dq = score_backward_quads<H>(dsm, qt_s, vt_s, PKt, dPKt, len, dvt_acc, tid);
             if ((tid & 3) == 0 && (tid >> 2) < H) d_s[4 * HP + (tid >> 2)] = dq;
 #else
@@ -1295,7 +1489,17 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     // energy-vector gradients of this ROW; the rows are added up by a leaf launch (head_grad_finish).  256 workgroups
     // adding into the same 2H addresses with atomics kept this kernel's last writes — and the whole critical chain behind
     // it — waiting ~9 us (profiles/r03_c_*).
-#if GSCAN_DEC_SB_QUAD
+#if GSCAN_DEC_SB_QUAD == 2
+    {   // the eight lanes of a group hold the sums over their memories of the feature pair tid >> 3
+        f32x2 xv = {quad_sum(dvv_acc.x), quad_sum(dvv_acc.y)}, xt = {quad_sum(dvt_acc.x), quad_sum(dvt_acc.y)};
+        xv.x += dpp_move<0x141, 0xf>(xv.x); xv.y += dpp_move<0x141, 0xf>(xv.y);
+        xt.x += dpp_move<0x141, 0xf>(xt.x); xt.y += dpp_move<0x141, 0xf>(xt.y);
+        if ((tid & 7) == 0 && 2 * (tid >> 3) < H) {
+            *reinterpret_cast<f32x2 *>(a.dv_v + (int64_t)b * H + 2 * (tid >> 3)) = xv;
+            *reinterpret_cast<f32x2 *>(a.dv_t + (int64_t)b * H + 2 * (tid >> 3)) = xt;
+        }
+    }
+#elif GSCAN_DEC_SB_QUAD
     {   // the four lanes of a quad hold the sums over their memories of feature tid >> 2
         const float xv = quad_sum(dvv_acc), xt = quad_sum(dvt_acc);
         if ((tid & 3) == 0 && (tid >> 2) < H) {

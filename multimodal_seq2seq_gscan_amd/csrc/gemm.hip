@@ -78,13 +78,23 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
     __syncthreads();
     GST(2)                                   // first panels landed and staged
 
+    // GSCAN_GEMM_PIPE (round 6 A/B): 0 = the next round's three panel loads are issued in FRONT of this round's fragment reads
+    // and MFMAs (a wave sits in the memory pipeline's queue — ~1 000-1 400 cycles with four workgroups per CU, tools/
+    // gemm_stamps.py — before it reaches its own matrix work); 1 = fragment reads first, then the loads (always issued: a
+    // dead load reads element 0), then the MFMAs; 2 = the same with the loads pinned BETWEEN the MFMAs
+    // (sched_group_barrier: one load, then a share of the MFMAs), so that the queueing overlaps the wave's own matrix work.
+#ifndef GSCAN_GEMM_PIPE
+#define GSCAN_GEMM_PIPE 2
+#endif
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
+#if GSCAN_GEMM_PIPE == 0
         if (more) {   // next round's loads fly while this round's MFMAs run
             ma = pa.load(ra, k0 + BK);
             mb = pb.load(rb, k0 + BK);
         }
+#endif
         GST(3)
 #pragma unroll
         for (int kh = 0; kh < BK; kh += 32) {
@@ -124,6 +134,12 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
                 bf[0][s] = x.x; bf[1][s] = x.y;
             }
         }
+#if GSCAN_GEMM_PIPE != 0
+        if (kh == 0) {
+            ma = pa.load(ra, k0 + BK);
+            mb = pb.load(rb, k0 + BK);
+        }
+#endif
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
@@ -131,6 +147,22 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
 #pragma unroll
                 for (int j = 0; j < TNW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+#if GSCAN_GEMM_PIPE == 2
+        if constexpr (VWA == 4 && VWB == 4 && BK == 32) {      // TMW + 2 sixteen-byte loads, 16 TMW MFMAs
+#define GSCAN_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+            if constexpr (TMW == 1) {
+                GSCAN_SGB(0x020, 1); GSCAN_SGB(0x008, 5);      // one VMEM read, then its share of the MFMAs
+                GSCAN_SGB(0x020, 1); GSCAN_SGB(0x008, 5);
+                GSCAN_SGB(0x020, 1); GSCAN_SGB(0x008, 6);
+            } else {
+                GSCAN_SGB(0x020, 1); GSCAN_SGB(0x008, 8);
+                GSCAN_SGB(0x020, 1); GSCAN_SGB(0x008, 8);
+                GSCAN_SGB(0x020, 1); GSCAN_SGB(0x008, 8);
+                GSCAN_SGB(0x020, 1); GSCAN_SGB(0x008, 8);
+            }
+#undef GSCAN_SGB
+        }
+#endif
         if (do_asum && tid < BM) {           // column sums of A (bias gradients): sum over these 32 k
             const float *sa = lds_a[buf] + (pa.is_kc() ? kh : kh * LDR_A);
             float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
@@ -250,8 +282,13 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
 #endif
 }
 
+// GSCAN_GEMM_WAVES5 (round 6 A/B): the 32-row kernel needs 99 registers = a 104-register allocation = four workgroups per
+// CU; asking for five waves per SIMD (<= 96 registers) lets the fifth workgroup its 27.6 KB of LDS already allow in.
+#ifndef GSCAN_GEMM_WAVES5
+#define GSCAN_GEMM_WAVES5 0
+#endif
 template <int TMW, int BK>
-__global__ __launch_bounds__(256) void gemm_group_kernel(int tb0, int tb1, int tb2, int tb3, int tb4, int tb5, int tb6,
+__global__ __launch_bounds__(256, (GSCAN_GEMM_WAVES5 && TMW == 1 && BK == 32) ? 5 : 1) void gemm_group_kernel(int tb0, int tb1, int tb2, int tb3, int tb4, int tb5, int tb6,
                                                          int tb7, int tb8, int tb9, int tb10, int tb11, GemmGroup grp) {
     // The first workgroup id of every problem arrives as twelve leading scalar arguments: this file is compiled with
     // -mllvm -amdgpu-kernarg-preload-count=12 (build.py), so they sit in SGPRs when the wave starts and the problem

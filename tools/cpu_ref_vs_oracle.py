@@ -1,6 +1,9 @@
 """time the IMPORTED REFERENCE beside this repository's CPU oracle — build container only.
 
-    python tools/cpu_ref_vs_oracle.py [--threads 8] [--steps 5] > profiles/r03_cpu_ref_vs_oracle.txt
+    python tools/cpu_ref_vs_oracle.py [--threads 8] [--steps 5] [--json profiles/cpu_ref_vs_oracle_latest.json] > profiles/rNN_cpu_ref_vs_oracle.txt
+
+--json writes the anchor bench.py puts on its line as cpu_baseline.reference_over_port (ratios, date, threads and a hash of
+the oracle's source: a later edit of the oracle shows up there as oracle_unchanged_since = false).
 
 The reference (`/root/reference/seq2seq/model.py`, read-only, never copied) is imported, seeded with the same golden
 weights as the oracle, and both run the same training step — forward, loss, backward, Adam + LR step, dropout at the
@@ -97,7 +100,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--json", default="")
     args = ap.parse_args()
+    anchor = {}
     torch.set_num_threads(args.threads)
     ReferenceModel = import_reference()
     print(f"# reference (imported from {REFERENCE}) vs oracle/seq2seq_oracle.py, torch {torch.__version__} CPU, "
@@ -116,6 +121,18 @@ def main():
         _, s_ref = reference_step(ReferenceModel, cfg, weights, batch, args.steps, True)
         _, s_orc = oracle_step(cfg, weights, batch, args.steps, True)
         print(f"{label:34} {l_ref:10.6f} {l_orc:12.6f} {abs(l_ref - l_orc):9.1e} {s_ref:9.1f} {s_orc:12.1f} {s_orc / s_ref:10.2f}")
+        anchor[label.split()[0]] = {"reference_examples_per_s": round(s_ref, 1), "port_examples_per_s": round(s_orc, 1),
+                                    "reference_over_port": round(s_ref / s_orc, 3), "loss_abs_diff": abs(l_ref - l_orc)}
+    if args.json:
+        import datetime, hashlib, json
+        with open(os.path.join(ROOT, "oracle", "seq2seq_oracle.py"), "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()[:16]
+        anchor.update(measured="build container (8 CPUs), imported /root/reference beside oracle/seq2seq_oracle.py, "
+                               f"{args.threads} threads, {args.steps} timed steps, torch {torch.__version__}",
+                      date=datetime.date.today().isoformat(), oracle_sha=sha)
+        with open(args.json, "w") as f:
+            json.dump(anchor, f, indent=1)
+            f.write("\n")
 
 
 if __name__ == "__main__":
