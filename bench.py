@@ -213,41 +213,47 @@ def batcher_leg(args, cfg: dict, n_params: int) -> dict:
         # warm-up over the shapes this order produces (allocator blocks, cached slab views, kernel attributes), then
         # a fresh shuffle for the timed run
         data.shuffle_data(bucket_batches=bucket, batch_size=B)
+        keep = []                                # clones of 64 full batches of this order (taken OUTSIDE the timed loop)
         for i, b in enumerate(data.batches(B, stager=stager)):
             if b["commands"].shape[0] == B:
                 step({k: b[k] for k in keys})
+                if len(keep) < 64 and i % 4 == 0:
+                    keep.append({k: b[k].clone() for k in keys})
             if i >= 300:      # (five batches for the reference order, as until round 4, left first-touch costs in the timed loop)
                 break
         data.shuffle_data(bucket_batches=bucket, batch_size=B)
         it = data.batches(B, stager=stager)
         torch.cuda.synchronize()
-        n, rows, full, t0 = 0, 0, None, time.perf_counter()
+        # `resident`: the SAME kind of batches kept in HBM — clones of 64 full batches of this order (from the warm-up pass), cycled
+        # through for as many steps (with length buckets every batch has its own padded lengths: repeating ONE batch, as
+        # until round 5, compared the file-fed run with whatever length its last batch happened to have)
+        n, rows, t0 = 0, 0, time.perf_counter()
         for b in it:
             if b["commands"].shape[0] != B:            # the split's short trailing batch
                 continue
             step({k: b[k] for k in keys})
-            n, rows, full = n + 1, rows + B, b
+            n, rows = n + 1, rows + B
             if n >= max(4 * args.steps, 300):      # at least 300 batches (0.15 s): a 40 ms loop is at the mercy of one hiccup
                 break
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        # the same number of steps on ONE of those batches kept resident (what `value` measures, on these shapes)
-        resident = {k: full[k].clone() for k in keys}
-        for _ in range(args.warmup):
-            step(resident)
+        for i in range(max(args.warmup, len(keep))):
+            step(keep[i % len(keep)])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(n):
-            step(resident)
+        for i in range(n):
+            step(keep[i % len(keep)])
         torch.cuda.synchronize()
         el_res = time.perf_counter() - t0
         results["length_buckets_8" if bucket else "reference_order"] = {
             "examples_per_s": round(rows / el, 1), "ms_per_step": round(1e3 * el / n, 4), "steps": n,
-            "resident_examples_per_s": round(rows / el_res, 1), "fraction_of_resident": round(el_res / el, 3)}
+            "resident_examples_per_s": round(rows / el_res, 1), "fraction_of_resident": round(el_res / el, 3),
+            "mean_target_length": round(sum(int(b["targets"].shape[1]) for b in keep) / len(keep), 2)}
     return {"examples": data.num_examples, "file_write_s": round(t_write, 1), "file_read_s": round(t_read, 1),
             "h2d_bytes_per_batch": data.slab_bytes(B), "parameters": model.parameter_count, **results,
             "note": "ragged lengths from the file (every batch padded to ITS longest rows, gSCAN_dataset.py:200-220); "
-                    "resident = the last full batch of the run repeated from HBM"}
+                    "resident = clones of the run's first 64 full batches cycled from HBM; the host gather runs on a worker "
+                    "thread a batch ahead (GSCAN_BATCHER_THREAD=0: in line)"}
 
 
 def visible_gpu_count(sysfs: str = ""):
@@ -647,6 +653,7 @@ def main():
                        "gradient_exchange": (None if not step.exchange.collective else
                                              "gscan_allreduce_f32: RCCL on the step's stream" if step.exchange.comm is not None
                                              else f"torch.distributed {args.backend}"),
+                       "dp_buckets": step.exchange.buckets if step.exchange.collective else None,
                        # ranks of the communicator the step's all-reduce runs on, as RCCL itself reports them
                        "rccl_nranks": step.exchange.comm.nranks if step.exchange.comm is not None else None},
             "roofline": roofline_block(dominant),

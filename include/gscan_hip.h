@@ -306,6 +306,21 @@ int gscan_allreduce_f32(void *comm, float *buf, size_t n, void *stream);
 int gscan_comm_destroy(void *comm);
 /* ranks of the communicator as RCCL reports them (ncclCommCount): what bench.py prints as rccl_nranks */
 int gscan_comm_count(void *comm, int *nranks);
+/* Two-bucket gradient exchange (ABI 14).  The backward pass finishes its gradients in two groups: EARLY — everything its
+ * first leaf stream produces: the decoder's, both attentions', the bridge's and the conditional query's parameters —
+ * about 45 us before LATE: the convolution kernels (second leaf stream) and the command encoder (embedding + LSTM, the
+ * caller's chain).  gscan_early_gradients_wait makes `stream` wait for the EARLY group of the most recent
+ * gscan_backward* / gscan_train_step_nll call of this process (an event recorded on the leaf stream; no host
+ * synchronisation), so that a communication stream can all-reduce that part of the flat gradient while the tail of the
+ * backward pass still runs.  Returns non-zero when no backward call has been issued yet. */
+int gscan_early_gradients_wait(void *stream);
+/* The same overlap without a stream or an event of the caller's: register a communicator and a range of the flat
+ * gradient buffer (the EARLY group: from the bridge's weight to the end of the buffer, statistics included), and every
+ * following backward pass all-reduces that range ITSELF, on its first leaf stream, right behind the last kernel that
+ * writes into it; the join in front of the optimiser that the pass ends with anyway covers it.  The caller then
+ * all-reduces only the rest on its own stream.  comm = NULL clears the registration (do so before gscan_comm_destroy).
+ * Use a communicator of its own for this (not the one the late group travels on). */
+int gscan_comm_set_early_allreduce(void *comm, float *buf, size_t n);
 
 /* Per-kernel-family timing for roofline reports: when enabled, every launch of a family
  * ("decoder_forward", "decoder_backward", "encoder_forward", "encoder_backward", "gemm", "conv_forward",

@@ -114,6 +114,8 @@ PROTOTYPES = {
     "gscan_allreduce_f32": (_i, [_vp, _vp, _sz, _vp]),
     "gscan_comm_destroy": (_i, [_vp]),
     "gscan_comm_count": (_i, [_vp, C.POINTER(_i)]),
+    "gscan_early_gradients_wait": (_i, [_vp]),
+    "gscan_comm_set_early_allreduce": (_i, [_vp, _vp, _sz]),
     "gscan_probe_enable": (_i, [_i]),
     "gscan_probe_reset": (_i, []),
     "gscan_probe_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),

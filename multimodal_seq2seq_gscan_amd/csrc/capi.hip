@@ -257,6 +257,8 @@ int gscan_allreduce_f32(void *comm, float *buf, size_t n, void *stream) {
 }
 int gscan_comm_destroy(void *comm) { return comm_destroy(comm); }
 int gscan_comm_count(void *comm, int *nranks) { return comm_count(comm, nranks); }
+int gscan_early_gradients_wait(void *stream) { return early_gradients_wait((hipStream_t)stream); }
+int gscan_comm_set_early_allreduce(void *comm, float *buf, size_t n) { return set_early_allreduce(comm, buf, n); }
 
 int gscan_probe_enable(int on) { return probe_enable(on); }
 int gscan_probe_reset(void) { return probe_reset(); }

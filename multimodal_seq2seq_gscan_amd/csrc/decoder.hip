@@ -1060,7 +1060,7 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
         }
     }
 #ifndef GSCAN_DEC_DALPHA_G
-#define GSCAN_DEC_DALPHA_G 0      // > 0 (round 6 A/B): G memories per straight-line round, their wave sums interleaved (wave_sum_n)
+#define GSCAN_DEC_DALPHA_G 0      // > 0 (round 6 A/B, lost: 3 -> +1.5 us, 2 -> flat): G memories per straight-line round, their wave sums interleaved
 #endif
 #if GSCAN_DEC_DALPHA_G > 0
     if constexpr (!UGLOBAL) {

@@ -406,6 +406,8 @@ struct ProbeScope {
 };
 int probe_enable(int on);
 bool probe_stamps_enabled();
+int early_gradients_wait(hipStream_t stream);      // step.hip: the backward pass's first leaf stream is done
+int set_early_allreduce(void *comm, float *buf, size_t n);
 int probe_reset();
 int probe_read(const char *name, double *total_ms, double *flops, double *alg_flops, int64_t *launches);
 

@@ -228,10 +228,17 @@ struct SideStream {
     hipStream_t stream = nullptr, stream2 = nullptr;
     bool single = false;             // GSCAN_SINGLE_STREAM=1 (diagnostic): everything on the caller's stream
     hipEvent_t ev[16] = {};
+    hipEvent_t early = nullptr;      // the backward pass's first leaf stream is done (gscan_early_gradients_wait)
+    bool early_recorded = false;
     bool ready = false;
     int next = 0;
 };
 static SideStream g_side;
+// two-bucket gradient exchange: the range of the flat gradient that the backward pass all-reduces on its first leaf stream
+// (gscan_comm_set_early_allreduce); NULL = none
+static void *g_early_comm = nullptr;
+static float *g_early_buf = nullptr;
+static size_t g_early_n = 0;
 
 static int side_init() {
     if (g_side.ready) return 0;
@@ -249,6 +256,7 @@ static int side_init() {
     const char *evf = getenv("GSCAN_EVENT_FLAGS");
     const unsigned extra = evf ? (unsigned)strtoul(evf, nullptr, 0) : (unsigned)hipEventDisableSystemFence;
     for (auto &e : g_side.ev) GSCAN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | extra));
+    GSCAN_HIP(hipEventCreateWithFlags(&g_side.early, hipEventDisableTiming | extra));
     g_side.ready = true;
     return 0;
 }
@@ -843,8 +851,31 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     // join: every gradient is complete when the caller's stream continues.  Side 1 (done long before) waits for side 2,
     // the caller's stream for side 1: ONE wait packet in front of the optimiser instead of two (each costs the queue
     // ~2.5 us even when its event completed long ago)
+    // the first leaf stream's gradients (decoder, attentions, bridge, conditional query: everything but the convolution
+    // kernels and the command encoder) are complete where this event sits: a data-parallel caller's communication stream
+    // waits for it (gscan_early_gradients_wait) and starts its first all-reduce under the tail of this pass
+    if (g_early_comm && g_early_n) TRY(comm_allreduce_f32(g_early_comm, g_early_buf, g_early_n, sd));
+    if (sd != st) {
+        GSCAN_HIP(hipEventRecord(g_side.early, sd));
+        g_side.early_recorded = true;
+    } else {
+        g_side.early_recorded = false;       // single-stream mode: nothing completes early
+    }
     TRY(order_after(sd, sd2));
     TRY(order_after(st, sd));
+    return 0;
+}
+
+int set_early_allreduce(void *comm, float *buf, size_t n) {
+    GSCAN_CHECK(comm == nullptr || (buf != nullptr && n > 0), "set_early_allreduce: a communicator needs a buffer range");
+    g_early_comm = comm; g_early_buf = buf; g_early_n = comm ? n : 0;
+    return 0;
+}
+
+int early_gradients_wait(hipStream_t stream) {
+    TRY(side_init());
+    GSCAN_CHECK(g_side.early_recorded || g_side.single, "early_gradients_wait: no backward pass has been issued in this process yet");
+    if (g_side.early_recorded) GSCAN_HIP(hipStreamWaitEvent(stream, g_side.early, 0));
     return 0;
 }
 

@@ -276,17 +276,69 @@ class GroundedScanDataset:
         own = stager is None
         if own:
             stager = BatchStager(device, self.slab_bytes(batch_size))
-        pending = None
         rank, world = row_shard
-        for idx in self._index_batches(batch_size, shard):
-            if world > 1:
-                # data-parallel training: this rank gathers and copies ONLY its rows of the global batch (rows
-                # [floor(r B / W), floor((r+1) B / W)), as train.shard_batch cuts them); a trailing batch with fewer
-                # rows than ranks is dropped on every rank
-                if len(idx) < world:
-                    continue
-                idx = idx[rank * len(idx) // world:(rank + 1) * len(idx) // world]
-            staged = stager.stage(self, idx)          # host gather + asynchronous copy of the NEXT batch ...
+
+        def row_sets():
+            for idx in self._index_batches(batch_size, shard):
+                if world > 1:
+                    # data-parallel training: this rank gathers and copies ONLY its rows of the global batch (rows
+                    # [floor(r B / W), floor((r+1) B / W)), as train.shard_batch cuts them); a trailing batch with fewer
+                    # rows than ranks is dropped on every rank
+                    if len(idx) < world:
+                        continue
+                    idx = idx[rank * len(idx) // world:(rank + 1) * len(idx) // world]
+                yield idx
+
+        consumer = torch.cuda.current_stream(device)
+        if os.environ.get("GSCAN_BATCHER_THREAD", "1") != "0" and stager.depth >= 4:
+            # Round 6: the host gather of batch n + 1 runs on a WORKER thread (numpy releases the GIL in
+            # np.take) while this thread issues the step of batch n: with length buckets a step is 0.33 ms of device time and
+            # the training thread spent 0.06 + 0.17 ms per batch staging and launching — host-bound at 0.815 of resident.
+            # The worker is exactly one batch ahead (queue of one): batch n + 1 is being staged while n is consumed and
+            # n - 1's slab is still untouched, which is what the iterator promises with a ring of four slabs.
+            import queue
+            import threading
+            ready: "queue.Queue" = queue.Queue(maxsize=1)
+            stop = threading.Event()
+
+            def put(item) -> bool:
+                while not stop.is_set():
+                    try:
+                        ready.put(item, timeout=0.05)
+                        return True
+                    except queue.Full:
+                        pass
+                return False
+
+            device_index = device.index if device.index is not None else torch.cuda.current_device()
+
+            def produce():
+                try:
+                    torch.cuda.set_device(device_index)
+                    for idx in row_sets():
+                        if not put(stager.stage(self, idx, consumer)):
+                            return
+                    put(None)
+                except BaseException as e:             # delivered to the consumer, which re-raises it
+                    put(e)
+
+            worker = threading.Thread(target=produce, name="gscan-batcher", daemon=True)
+            worker.start()
+            try:
+                while True:
+                    item = ready.get()
+                    if item is None:
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    yield stager.deliver(item)
+            finally:
+                stop.set()
+                worker.join(timeout=5.0)
+            return
+        pending = None
+        for idx in row_sets():
+            staged = stager.stage(self, idx, consumer)          # host gather + asynchronous copy of the NEXT batch ...
             if pending is not None:
                 yield stager.deliver(pending)         # ... while the consumer works on this one
             pending = staged
@@ -341,7 +393,8 @@ class _Slab:
 
 
 class BatchStager:
-    """A ring of `depth` pinned host slabs and as many device slabs, and a copy stream.
+    """A ring of `depth` pinned host slabs and as many device slabs, and a copy stream (depth 4 since round 6: the
+    worker thread of GroundedScanDataset.batches is one batch further ahead than the in-line form was).
 
     stage(): gathers the rows of a batch from the packed arrays straight into the next pinned slab (numpy writes
     into the pinned memory: no intermediate tensors, no per-array pin_memory() allocations) and enqueues ONE
@@ -351,7 +404,7 @@ class BatchStager:
     consumer has enqueued by then — a batch's views stay valid until the iterator has been advanced `depth - 1` times
     more, whatever the consumer launched on them in between."""
 
-    def __init__(self, device: torch.device, slab_bytes: int, depth: int = 3):
+    def __init__(self, device: torch.device, slab_bytes: int, depth: int = 4):
         self.device, self.depth, self.slab_bytes = device, depth, slab_bytes
         self.host = [torch.empty(slab_bytes, dtype=torch.uint8).pin_memory() for _ in range(depth)]
         self.host_np = [h.numpy() for h in self.host]
@@ -388,7 +441,9 @@ class BatchStager:
             hit = self._views[key] = (used, host, dev, self.host[slot][:used], self.dev[slot][:used])
         return hit
 
-    def stage(self, data: "GroundedScanDataset", idx: np.ndarray) -> tuple:
+    def stage(self, data: "GroundedScanDataset", idx: np.ndarray, consumer_stream=None) -> tuple:
+        """consumer_stream: the stream the batches are consumed on (default: the calling thread's current stream; the
+        batcher's worker thread passes the training thread's)."""
         slot = self.count % self.depth
         self.count += 1
         in_len, tgt_len = data._input_lengths[idx], data._target_lengths[idx]
@@ -418,7 +473,7 @@ class BatchStager:
         if self.count > self.depth:                    # the slab held a batch before: everything the consumer has
             if self.released[slot] is None:            # enqueued so far (all of it older than this copy) goes first
                 self.released[slot] = torch.cuda.Event()
-            self.released[slot].record(torch.cuda.current_stream(self.device))
+            self.released[slot].record(consumer_stream if consumer_stream is not None else torch.cuda.current_stream(self.device))
             copy.wait_event(self.released[slot])
         with torch.cuda.stream(copy):
             dev_used.copy_(host_used, non_blocking=True)

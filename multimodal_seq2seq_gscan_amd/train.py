@@ -266,8 +266,15 @@ class GradientExchange:
     communicator on the caller's stream (`RcclCommunicator`).  `native=False`, or a failure to create that
     communicator (logged), leaves them to torch.distributed — RCCL as well, through its communication stream."""
 
-    def __init__(self, process_group=None, always_collective: bool = False, native: Optional[bool] = None):
+    def __init__(self, process_group=None, always_collective: bool = False, native: Optional[bool] = None,
+                 buckets: Optional[int] = None):
         self.group = process_group
+        # GSCAN_DP_BUCKETS=2 (round 6; default 1): the flat gradient crosses in two all-reduces — the group the backward
+        # pass finishes ~45 us early (decoder, attentions, bridge: the tail of the flat buffer, with the loss statistics) on
+        # a communication stream UNDER the rest of the pass, the rest (convolution kernels, command encoder) on the step's
+        # stream behind it (`all_reduce_two_buckets`).
+        self.buckets = int(os.environ.get("GSCAN_DP_BUCKETS", "1")) if buckets is None else int(buckets)
+        self._comm_stream = None
         active = dist.is_available() and dist.is_initialized()
         self.world_size = dist.get_world_size(process_group) if active else 1
         self.rank = dist.get_rank(process_group) if active else 0
@@ -280,39 +287,104 @@ class GradientExchange:
         self.comm: Optional[RcclCommunicator] = None
         if native is None:
             native = os.environ.get("GSCAN_NATIVE_ALLREDUCE", "1") != "0"
+        # two buckets: the early group travels on a communicator OF ITS OWN, bound to the communication stream for good — one
+        # communicator used from two streams in turn makes RCCL order them against each other (measured on one rank with
+        # the auxiliary head's three collectives per step, caller -> communication -> caller: 0.47 -> 0.77 ms per step)
+        self.comm_early: Optional[RcclCommunicator] = None
+        self._registered = None
         if self.collective and not self.host_staged and native and torch.cuda.is_available():
             try:
                 self.comm = RcclCommunicator(process_group)
+                if self.buckets == 2:
+                    self.comm_early = RcclCommunicator(process_group)
             except (_lib.GscanError, RuntimeError) as e:      # raised on EVERY rank or on none (collective decision)
                 logger.warning("RCCL communicator on the caller's stream unavailable (%s): gradients go through "
                                "torch.distributed's RCCL stream instead", e)
+                if self.comm is not None:                     # the second one failed (on every rank): one bucket
+                    self.buckets = 1
 
     def close(self) -> None:
         """Destroy the library's RCCL communicator (include/gscan_hip.h: gscan_comm_destroy at exit); call before
         dist.destroy_process_group()."""
-        if self.comm is not None:
-            self.comm.close()
-            self.comm = None
+        if getattr(self, "_registered", None) is not None:
+            _lib.check(_lib.load().gscan_comm_set_early_allreduce(None, None, 0), "gscan_comm_set_early_allreduce")
+            self._registered = None
+        for name in ("comm_early", "comm"):
+            comm = getattr(self, name)
+            if comm is not None:
+                comm.close()
+                setattr(self, name, None)
 
-    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+    def all_reduce(self, t: torch.Tensor, comm: Optional[RcclCommunicator] = None) -> torch.Tensor:
         if not self.collective:
             return t
+        comm = comm if comm is not None else self.comm
         if t.is_cuda and self.host_staged:
             host = t.detach().cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(host)
-        elif self.comm is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
-            self.comm.all_reduce(t)
+        elif comm is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+            comm.all_reduce(t)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def mean_from_sums(self, grads_and_stats: torch.Tensor):
+    def register_early_range(self, t: torch.Tensor, split: int) -> bool:
+        """Production form of the two-bucket exchange: hand the library the early group's communicator and range ONCE
+        (gscan_comm_set_early_allreduce); every backward pass then all-reduces `t[split:]` itself on its first leaf stream,
+        behind the last kernel that writes into it, and `all_reduce_two_buckets` only reduces `t[:split]`.  False (and
+        nothing registered) when the early group has no communicator of its own (gloo / torch.distributed transports: the
+        communication-stream form below is used)."""
+        if self.comm_early is None or not self.collective or self.buckets != 2:
+            return False
+        early = t[split:]
+        _lib.check(_lib.load().gscan_comm_set_early_allreduce(self.comm_early._handle, early.data_ptr(), early.numel()),
+                   "gscan_comm_set_early_allreduce")
+        self._registered = (t.data_ptr(), split, t.numel())
+        return True
+
+    def all_reduce_two_buckets(self, t: torch.Tensor, split: int, wait_early=None) -> torch.Tensor:
+        """In-place sum of `t` over the ranks as TWO collectives: `t[split:]` — complete on the device as soon as
+        `wait_early(stream)` lets a stream pass (gscan_early_gradients_wait: the backward pass's first leaf stream is
+        done) — is reduced on a communication stream of its own while the producer of `t[:split]` still runs on the
+        current stream; `t[:split]` follows on the current stream, which then waits for the communication stream.  Every
+        rank issues the two collectives in the same order.  Same result as ONE all-reduce of `t` (elementwise sums)."""
+        if not self.collective:
+            return t
+        if not t.is_cuda:                      # host tensors (CPU tests of the arithmetic): nothing to overlap
+            self.all_reduce(t[split:])
+            self.all_reduce(t[:split])
+            return t
+        if getattr(self, "_registered", None) is not None:
+            # the backward pass has all-reduced the early range on its leaf stream (and joined it): the rest follows here
+            base, at, total = self._registered
+            if (t.data_ptr(), split) != (base, at) or t.numel() > total:
+                raise ValueError("two-bucket exchange: the registered early range is of another buffer or split")
+            self.all_reduce(t[:split])
+            return t
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=t.device)
+        caller, cs = torch.cuda.current_stream(), self._comm_stream
+        if wait_early is not None:
+            wait_early(cs.cuda_stream)
+        else:
+            cs.wait_stream(caller)             # no early point known: the communication stream starts behind the producer
+        with torch.cuda.stream(cs):
+            self.all_reduce(t[split:], comm=self.comm_early)
+            done = cs.record_event()
+        self.all_reduce(t[:split])
+        caller.wait_event(done)
+        return t
+
+    def mean_from_sums(self, grads_and_stats: torch.Tensor, split: Optional[int] = None, wait_early=None):
         """grads_and_stats = [d(sum NLL of this rank's rows)/d(params) | sum NLL, tokens, sum aux NLL, rows]: after
         the all-reduce the reference's global-batch loss is stats[0]/stats[1] and its gradient is the reduced
         gradient divided by stats[1] (model.py:147-160: mean over the live tokens of the WHOLE minibatch).  Returns
         (reduced buffer, global token count as a 1-element view, loss)."""
-        self.all_reduce(grads_and_stats)
+        if self.buckets == 2 and split:
+            self.all_reduce_two_buckets(grads_and_stats, split, wait_early)
+        else:
+            self.all_reduce(grads_and_stats)
         stats = grads_and_stats[-4:]
         return grads_and_stats, stats[1:2], stats[0] / stats[1]
 
@@ -342,7 +414,7 @@ class TrainStep:
                  weight_target_loss: float = 0.3, process_group=None,
                  fused_loss: Optional[bool] = None, single_exchange: Optional[bool] = None,
                  always_collective: bool = False, on_gradients=None,
-                 native_allreduce: Optional[bool] = None, **ignored):
+                 native_allreduce: Optional[bool] = None, dp_buckets: Optional[int] = None, **ignored):
         if ignored.pop("graph", None):
             # hipGraph replay left the product path in round 4 (slower than eager launches on this stack)
             logger.warning("TrainStep(graph=True): graph replay is no longer available, the step launches eagerly")
@@ -351,7 +423,22 @@ class TrainStep:
         self.model = model
         self.optimizer = FlatAdam(model, learning_rate, adam_beta_1, adam_beta_2, lr_decay, lr_decay_steps)
         self.weight_target_loss = float(weight_target_loss)
-        self.exchange = GradientExchange(process_group, always_collective, native_allreduce)
+        self.exchange = GradientExchange(process_group, always_collective, native_allreduce, buckets=dp_buckets)
+        # two-bucket exchange (GSCAN_DP_BUCKETS=2): the EARLY group of gradients is the tail of the flat buffer from the
+        # bridge on (named_parameters() order: convolutions, visual attention, command encoder | bridge, textual attention,
+        # decoder) plus the statistics behind it; the visual attention's 25 k floats are early too but sit between the two
+        # late groups and travel with them.  gscan_early_gradients_wait is the device-side "early group complete" point.
+        offsets = getattr(model, "_offsets", {})
+        self._early_split = offsets["enc_hidden_to_dec_hidden.weight"][0] if "enc_hidden_to_dec_hidden.weight" in offsets else 0
+
+        def wait_early(stream_handle):
+            _lib.check(_lib.load().gscan_early_gradients_wait(stream_handle), "gscan_early_gradients_wait")
+        self._wait_early = wait_early
+        if self.exchange.buckets == 2 and self._early_split:
+            # [gradients | 4 statistics]: the one-collective form reduces the statistics with the early group, the
+            # two-collective form (auxiliary head) the gradients only — the registered range covers the larger one, and
+            # summing the statistics slots again is harmless there (they are rewritten by every backward pass)
+            self.exchange.register_early_range(model._grad_store, self._early_split)
         # every rank draws its own dropout masks (Philox streams keyed by seed, rank and step)
         model.set_dropout_rank(self.exchange.rank)
         # on_gradients(flat mean-loss gradient of the global batch): called between the exchange and the optimiser
@@ -447,7 +534,7 @@ class TrainStep:
             else:
                 fw = self._section_forward(batch)
                 model._launch_backward_nll(fw["call"], self.weight_target_loss, store[-4:], self.seeds, sum_reduction=True)
-            _, count, loss = self.exchange.mean_from_sums(store)
+            _, count, loss = self.exchange.mean_from_sums(store, self._early_split, self._wait_early)
             if self.on_gradients is not None:
                 self.on_gradients(model.flat_gradients / count)
             if not self.optimizer.launch_with_next_masks(count):
@@ -460,7 +547,10 @@ class TrainStep:
             fw = self._section_forward(batch)
             self.exchange.all_reduce(self.stats)
             self._section_backward(fw)
-        self.exchange.all_reduce(model.flat_gradients)
+        if self.exchange.buckets == 2 and self._early_split:
+            self.exchange.all_reduce_two_buckets(model.flat_gradients, self._early_split, self._wait_early)
+        else:
+            self.exchange.all_reduce(model.flat_gradients)
         if self.on_gradients is not None:
             self.on_gradients(model.flat_gradients)
         if not self.optimizer.launch_with_next_masks(None):

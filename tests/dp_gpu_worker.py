@@ -75,9 +75,10 @@ def main():
     native = step.exchange.comm is not None
     assert native == (backend == "nccl" and os.environ.get("GSCAN_NATIVE_ALLREDUCE", "1") != "0")
     torch.save({"grad": grad, "losses": losses, "params": params, "tokens": tokens, "native": native,
+                "buckets": step.exchange.buckets if step._early_split else 1,
                 "rows": [int(b["commands"].shape[0]) for b in batches]}, os.path.join(out_dir, f"rank{rank}.pt"))
     if native:
-        step.exchange.comm.close()
+        step.exchange.close()
     dist.barrier()
     dist.destroy_process_group()
 

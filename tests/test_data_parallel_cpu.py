@@ -180,6 +180,39 @@ def test_two_ranks_single_exchange_of_sum_gradients_and_statistics(tmp_path):
         assert text.startswith("1 "), text
 
 
+def _worker_two_buckets(rank: int, world: int, port: int, out_dir: str):
+    """GradientExchange.all_reduce_two_buckets on host tensors: the same sums as one all-reduce, whatever the split."""
+    sys.path[:0] = [ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodal_seq2seq_gscan_amd.train import GradientExchange
+    ex = GradientExchange(buckets=2)
+    ok = ex.collective and ex.buckets == 2
+    g = torch.Generator().manual_seed(100 + rank)
+    for n, split in ((1000, 600), (17, 1), (4096, 4095), (64, 0)):
+        t = torch.randn(n, generator=g)
+        want = t.clone()
+        dist.all_reduce(want)
+        got = ex.all_reduce_two_buckets(t.clone(), split) if split else ex.all_reduce(t.clone())
+        ok = ok and torch.equal(got, want)
+        # through mean_from_sums: [gradients | sum NLL, tokens, ., rows]
+        store = torch.cat([torch.randn(n, generator=g), torch.tensor([3.5 + rank, 10.0 + rank, 0.0, 4.0])])
+        ref = store.clone()
+        dist.all_reduce(ref)
+        out, count, loss = ex.mean_from_sums(store.clone(), split or None)
+        ok = ok and torch.equal(out, ref) and float(count[0]) == float(ref[-3]) and abs(float(loss) - float(ref[-4] / ref[-3])) < 1e-7
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_two_bucket_exchange_sums_like_one_all_reduce(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker_two_buckets, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "1"
+
+
 def _worker_transport_vote(rank: int, world: int, port: int, failing_rank: int, stage: str, out_dir: str):
     """RcclCommunicator's collective transport decision with a stand-in library: `failing_rank` cannot load RCCL
     (stage "load") or fails inside its init (stage "init").  Every rank must raise, and with stage "load" NO rank may

@@ -96,6 +96,22 @@ def test_collectives_on_a_one_rank_rccl_communicator(tmp_path, case):
     _compare(ranks, _single_process(case))
 
 
+@pytest.mark.parametrize("backend,world,case", [("gloo", 2, "compositional"), ("gloo", 2, "demo_aux"), ("nccl", 1, "demo"),
+                                                ("nccl", 1, "compositional_aux")])
+def test_two_bucket_gradient_exchange_matches_the_single_process_step(tmp_path, backend, world, case):
+    """GSCAN_DP_BUCKETS=2: the early group of gradients (bridge, textual attention, decoder + the statistics) is all-reduced
+    on a communication stream behind gscan_early_gradients_wait, the rest on the step's stream; the result must be what
+    ONE all-reduce gives — two ranks sharing the device (gloo, staged through the host: the arithmetic and the order of the
+    collectives) and one rank on the library's RCCL communicator (the production launch sequence and its stream hand-over)."""
+    os.environ["GSCAN_DP_BUCKETS"] = "2"
+    try:
+        ranks = _launch(world, backend, case, tmp_path)
+    finally:
+        del os.environ["GSCAN_DP_BUCKETS"]
+    assert all(r["buckets"] == 2 for r in ranks)
+    _compare(ranks, _single_process(case))
+
+
 def test_collectives_through_torch_distributed_rccl(tmp_path):
     """The fallback transport: torch.distributed's RCCL stream (GSCAN_NATIVE_ALLREDUCE=0)."""
     os.environ["GSCAN_NATIVE_ALLREDUCE"] = "0"

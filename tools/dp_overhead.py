@@ -17,9 +17,9 @@ dist.init_process_group("nccl", rank=0, world_size=1)
 for aux in (False, True):
     cfg = model_kwargs("compositional", auxiliary_task=aux)
     batch = {k: v.cuda() for k, v in make_batch(Shape(batch=256), 1).items()}
-    for collective, native in ((False, None), (True, False), (True, True)):
+    for collective, native, buckets in ((False, None, 1), (True, False, 1), (True, True, 1), (True, True, 2)):
         torch.manual_seed(0)
-        step = TrainStep(Model(**cfg).cuda(), always_collective=collective, native_allreduce=native)
+        step = TrainStep(Model(**cfg).cuda(), always_collective=collective, native_allreduce=native, dp_buckets=buckets)
         for _ in range(20):
             step(batch)
         torch.cuda.synchronize()
@@ -29,6 +29,8 @@ for aux in (False, True):
         torch.cuda.synchronize()
         how = "none" if not collective else ("gscan_allreduce_f32 on the step's stream (1 rank)" if step.exchange.comm is not None
                                               else "torch.distributed RCCL stream (1 rank)")
+        if collective and buckets == 2:
+            how += ", TWO buckets (early group on a communication stream behind gscan_early_gradients_wait)"
         print(f"auxiliary={aux} collectives={how}: "
               f"{1e3 * (time.perf_counter() - t0) / 100:.4f} ms/step", flush=True)
 dist.destroy_process_group()

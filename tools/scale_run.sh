@@ -32,6 +32,8 @@ run() {   # name, gpus, extra bench.py arguments...
       > "$out/$name.json" 2> "$out/$name.err" || { echo "$name: FAILED (rc $?)" | tee -a "$out/summary.txt"; tail -20 "$out/$name.err"; return 1; }
 }
 for n in 1 2 4 8; do run "weak_$n" "$n"; done
+# the two-bucket exchange (GSCAN_DP_BUCKETS=2: early gradients all-reduced under the backward tail) beside the one-bucket line
+for n in 2 4 8; do GSCAN_DP_BUCKETS=2 run "weak2b_$n" "$n"; done
 for n in 2 4 8; do run "strong_$n" "$n" --global-batch 2048; done
 run aux_4 4 --auxiliary
 python3 - "$out" <<'EOF' | tee -a "$out/summary.txt"
@@ -52,8 +54,11 @@ for path in sorted(glob.glob(os.path.join(out, "*.json"))):
             bad.append(f"{name}: rccl_nranks {cfg.get('rccl_nranks')} != {n} (independent replicas, or the fallback transport)")
         if "gscan_allreduce_f32" not in str(cfg.get("gradient_exchange")):
             bad.append(f"{name}: gradient_exchange = {cfg.get('gradient_exchange')!r}, expected the library's RCCL all-reduce")
-    print(f"{name:10s} N={n} {d['scaling']:6s} global batch {cfg['global_batch']:5d}  {d['ms_per_step']:.4f} ms/step  "
-          f"{d['value']:.0f} examples/s  first window {d['ms_per_step_first_window']:.4f}  exchange {cfg.get('gradient_exchange')}")
+    w = d["ms_per_step_windows"]
+    print(f"{name:10s} N={n} {d['scaling']:6s} global batch {cfg['global_batch']:5d}  median {d['ms_per_step']:.4f} ms/step  "
+          f"first window {d['ms_per_step_first_window']:.4f}  windows {w['min']:.4f}-{w['max']:.4f}  {d['value']:.0f} examples/s  "
+          f"rccl_nranks {cfg.get('rccl_nranks')}  buckets {cfg.get('dp_buckets')}  value = {cfg.get('value_window')}  "
+          f"exchange {cfg.get('gradient_exchange')}")
 if "weak_1" in rows:
     base = rows["weak_1"]["value"]
     for n in (2, 4, 8):
@@ -61,6 +66,9 @@ if "weak_1" in rows:
             print(f"weak scaling at {n}: {rows[f'weak_{n}']['value'] / base:.2f}x of one GPU (ideal {n}x; north star: >= 6x at 8)")
 if "weak_8" in rows and rows["weak_8"]["ms_per_step"] > 0.57:
     bad.append(f"weak_8: {rows['weak_8']['ms_per_step']:.4f} ms per step is over DESIGN.md 8's budget of 0.57 ms")
+for n in (2, 4, 8):
+    if f"weak_{n}" in rows and f"weak2b_{n}" in rows:
+        print(f"two buckets at {n}: {rows[f'weak2b_{n}']['ms_per_step']:.4f} vs one bucket {rows[f'weak_{n}']['ms_per_step']:.4f} ms/step")
 for line in bad:
     print("CHECK FAILED:", line)
 sys.exit(1 if bad else 0)
