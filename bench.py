@@ -252,8 +252,8 @@ def batcher_leg(args, cfg: dict, n_params: int) -> dict:
     return {"examples": data.num_examples, "file_write_s": round(t_write, 1), "file_read_s": round(t_read, 1),
             "h2d_bytes_per_batch": data.slab_bytes(B), "parameters": model.parameter_count, **results,
             "note": "ragged lengths from the file (every batch padded to ITS longest rows, gSCAN_dataset.py:200-220); "
-                    "resident = clones of the run's first 64 full batches cycled from HBM; the host gather runs on a worker "
-                    "thread a batch ahead (GSCAN_BATCHER_THREAD=0: in line)"}
+                    "resident = clones of the run's first 64 full batches cycled from HBM; GSCAN_BATCHER_THREAD=1 moves "
+                    "the host gather to a worker thread a batch ahead (measured slower: interpreter-lock contention)"}
 
 
 def visible_gpu_count(sysfs: str = ""):

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(kKbThreads, H <= 128 ? 4 : 2) void keys_backward_ke
     const int mt = blockIdx.y;
 
     if (mt == MT) {
+        if (a.value_path_only) return;
         // ---- bridge: d h_N[e] = sum_k d h0[k] * W_bridge[k][e]
         float *dh_s = sm;
         if (tid < H) dh_s[tid] = a.dh0[(int64_t)b * H + tid];
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(kKbThreads, H <= 128 ? 4 : 2) void keys_backward_ke
             }
         }
     }
+    if (a.value_path_only) return;
     __syncthreads();
 
     // ---- stage 2: through the key layer.  A job = one 16-column tile of d feat (F columns) or of d enc_out (He
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(kKbThreads) void keys_backward_any_kernel(KeysBackw
     const int MTV = (M + 15) / 16, MTT = (L + 15) / 16, MT = MTV + MTT;
     const int mt = blockIdx.y;
     if (mt == MT) {              // bridge: d h_N[e] = sum_k d h0[k] * W_bridge[k][e]
+        if (a.value_path_only) return;
         float *dh_s = sm;
         for (int k = tid; k < H; k += kKbThreads) dh_s[k] = a.dh0[(int64_t)b * H + k];
         __syncthreads();
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(kKbThreads) void keys_backward_any_kernel(KeysBackw
         }
         dpk_s[idx] = acc;
     }
+    if (a.value_path_only) return;
     __syncthreads();
     // stage 2: through the key layer
     const int ncols = vis ? a.F : a.He;

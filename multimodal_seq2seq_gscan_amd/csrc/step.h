@@ -372,6 +372,7 @@ struct KeysBackwardArgs {
     float mask_scale;                      // mask == NULL and != 0: dropout was drawn in the world encoder (dropout.h): the
                                            // gradient passes where feat != 0, times 1 / (1 - p)
     float *denc, *dhN, *dfeat;             // [B,L,He] [B,He] [B,M,F]
+    int value_path_only;                   // != 0: stage 1 only (dPK totals); the key layers and the bridge follow as a GEMM launch
 };
 int keys_backward(int B, int H, const KeysBackwardArgs &a, hipStream_t stream);
 

@@ -778,7 +778,23 @@ int step_backward(const gscan_dims &d, const gscan_params &p, const gscan_batch 
     if (leaves_fork == 1) { TRY(order_after(sd, st)); TRY(decoder_leaves()); }
     // chain: value path of both attentions (dPK[b,m,:] += sum_t alpha[b,t,m] * dctx[b,t,:]), then through the
     // key layers and the bridge to the encoder outputs / final state / conv features — one launch, row per WG
+    // GSCAN_KEYS_GEMM=1 (round 6 A/B): the kernel stops behind the value path (dPK totals written out) and the key layers
+    // and the bridge follow as ONE grouped-GEMM launch on the chain — d feat = (dPK_vis . W_key_vis) with the ReLU gate and
+    // the dropout scale as the epilogue, d enc_out = dPK_text . W_key_text, d h_N = d h0 . W_bridge.  The fused kernel
+    // re-reads W_key (60 KB) per (row, 16 memories): 82 MB of L2 -> CU traffic per launch for 0.26 GMAC.
+    static const int keys_gemm = [] { const char *e = getenv("GSCAN_KEYS_GEMM"); return e ? atoi(e) : 0; }();
+    const bool keys_split = keys_gemm != 0 && k.mask == nullptr;      // a mask in memory stays on the fused path
+    k.value_path_only = keys_split ? 1 : 0;
     TRY(keys_backward(B, H, k, st));
+    if (keys_split) {
+        GemmBatch b;
+        const float scale = k.mask_scale != 0.f ? k.mask_scale : 1.f;
+        b.add(BM_, F, H, w + ws.dpk_v, H, 1, p.vis_key_w, F, 1, w + ws.dfeat, F, 0.f, nullptr, 3, nullptr, 1, nullptr, nullptr,
+              w + ws.feat, scale);
+        b.add(BL, He, H, w + ws.dpk_t, H, 1, p.txt_key_w, He, 1, w + ws.denc, He);
+        b.add(B, He, H, w + ws.dh0, H, 1, p.bridge_w, He, 1, w + ws.dhN, He);
+        TRY(b.launch(st));
+    }
     TRY(order_after(sd, st, sd2));     // one event releases both leaf streams
     if (leaves_fork == 2) TRY(decoder_leaves());
     {   // leaves: key and bridge weights

@@ -290,12 +290,16 @@ class GroundedScanDataset:
                 yield idx
 
         consumer = torch.cuda.current_stream(device)
-        if os.environ.get("GSCAN_BATCHER_THREAD", "1") != "0" and stager.depth >= 4:
-            # Round 6: the host gather of batch n + 1 runs on a WORKER thread (numpy releases the GIL in
-            # np.take) while this thread issues the step of batch n: with length buckets a step is 0.33 ms of device time and
-            # the training thread spent 0.06 + 0.17 ms per batch staging and launching — host-bound at 0.815 of resident.
-            # The worker is exactly one batch ahead (queue of one): batch n + 1 is being staged while n is consumed and
-            # n - 1's slab is still untouched, which is what the iterator promises with a ring of four slabs.
+        if os.environ.get("GSCAN_BATCHER_THREAD", "0") == "1" and stager.depth >= 4:
+            # Round 6, built, measured and OFF by default: the host gather of batch n + 1 on a WORKER
+            # thread (numpy releases the GIL in np.take) while this thread issues the step of batch n.  The worker is
+            # exactly one batch ahead (queue of one): batch n + 1 is being staged while n is consumed and n - 1's slab is
+            # still untouched, which is what the iterator promises with a ring of four slabs.  Measured
+            # (profiles/r06_bench_with_batcher*.json): 0.916 / 0.924 of resident batches (reference order / length buckets)
+            # against 0.974 / 0.918-0.969 in line — a gather of 256 short rows is ~60 us of Python bookkeeping around ~5 us
+            # of copying, so the two threads take turns on the interpreter lock instead of running side by side.  (The
+            # "0.815 of resident" of round 5's bucketed leg compared the file-fed run with ONE batch — the run's last, of
+            # whatever length — repeated from HBM; against 64 batches of the same order it is 0.92-0.97.)
             import queue
             import threading
             ready: "queue.Queue" = queue.Queue(maxsize=1)

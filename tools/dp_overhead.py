@@ -30,7 +30,7 @@ for aux in (False, True):
         how = "none" if not collective else ("gscan_allreduce_f32 on the step's stream (1 rank)" if step.exchange.comm is not None
                                               else "torch.distributed RCCL stream (1 rank)")
         if collective and buckets == 2:
-            how += ", TWO buckets (early group on a communication stream behind gscan_early_gradients_wait)"
+            how += ", TWO buckets (early group all-reduced by the backward pass on its first leaf stream: gscan_comm_set_early_allreduce)"
         print(f"auxiliary={aux} collectives={how}: "
               f"{1e3 * (time.perf_counter() - t0) / 100:.4f} ms/step", flush=True)
 dist.destroy_process_group()
