@@ -658,6 +658,8 @@ def main():
                        "rccl_nranks": step.exchange.comm.nranks if step.exchange.comm is not None else None},
             "roofline": roofline_block(dominant),
             "roofline_gemm": roofline_block("gemm") if dominant != "gemm" and "gemm" in merged else None,
+            # since round 6 the two largest families are within a few per cent of each other: whichever is not `roofline`
+            "roofline_decoder_pair": roofline_block("decoder_pair") if dominant != "decoder_pair" and "decoder_pair" in merged else None,
             "step_hbm_traffic": step_traffic(pmc_workload, mflop, B),
             "families_ranked": ranked,
             "kernel_families": {k: {kk: (None if vv is None else round(vv, 3)) for kk, vv in v.items()} for k, v in families.items()},
