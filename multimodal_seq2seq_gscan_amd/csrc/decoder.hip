@@ -173,11 +173,67 @@ __device__ __forceinline__ void score_round(float v1, float v2, float q1, float 
         if (lane == 0 && m0 + i * nwave < n) sc_s[m0 + i * nwave] = p[i];
 }
 
+// GSCAN_DEC_SCORE_HALF=1 (round 6 A/B): a HALF wave per memory — a lane owns FOUR adjacent features (one 16-byte read of
+// the key, of v and of q), a wave scores two memories per round and ONE five-step DPP sum serves both (wave-per-memory:
+// six steps + a readlane per memory, five of them interleaved).  R rounds straight-line (all reads in flight first).
+#ifndef GSCAN_DEC_SCORE_HALF
+#define GSCAN_DEC_SCORE_HALF 1
+#endif
+template <int H, int R>
+__device__ __forceinline__ void score_rounds_half(const float4 &v4, const float4 &q4, int k, const float *pk, int n,
+                                                  float *sc_s, int m0, int nwave, int l32, int hf) {
+    float4 x[R];
+    float p[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int mc = min(m0 + 2 * nwave * r + hf, n - 1);
+        x[r] = *reinterpret_cast<const float4 *>(pk + mc * H + k);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        p[r] = fmaf(v4.x, tanhf_(q4.x + x[r].x), v4.y * tanhf_(q4.y + x[r].y)) +
+               fmaf(v4.z, tanhf_(q4.z + x[r].z), v4.w * tanhf_(q4.w + x[r].w));
+#pragma unroll
+    for (int r = 0; r < R; ++r) p[r] += dpp_move<0xb1, 0xf>(p[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) p[r] += dpp_move<0x4e, 0xf>(p[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) p[r] += dpp_move<0x124, 0xf>(p[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) p[r] += dpp_move<0x128, 0xf>(p[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) p[r] += dpp_move<0x142, 0xa>(p[r]);     // lanes 16-31 / 48-63: the half's sum
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int m = m0 + 2 * nwave * r + hf;
+        if (l32 == 31 && m < n) sc_s[m] = p[r];
+    }
+}
+
 template <int H>
 __device__ __forceinline__ void attention_scores(const float *v_s, const float *q_s, const float *pk, int n,
                                                  float *sc_s, int wave_v, int nwave, int lane) {
     static_assert(H <= 128, "two feature indices per lane");
     const int wave = __builtin_amdgcn_readfirstlane(wave_v);
+#if GSCAN_DEC_SCORE_HALF
+    {
+        static_assert(H % 4 == 0, "feature quads");
+        const int l32 = lane & 31, hf = lane >> 5;
+        const bool has = 4 * l32 < H;
+        const int k = has ? 4 * l32 : 0;
+        float4 v4 = *reinterpret_cast<const float4 *>(v_s + k);
+        const float4 q4 = *reinterpret_cast<const float4 *>(q_s + k);
+        if (!has) v4 = float4{0.f, 0.f, 0.f, 0.f};
+        const int pairs = (n + 1) >> 1, rounds = (pairs + nwave - 1) / nwave;       // uniform in the workgroup
+        int m0 = 2 * wave;
+        for (int left = rounds; left > 0;) {
+            if (left >= 3) { score_rounds_half<H, 3>(v4, q4, k, pk, n, sc_s, m0, nwave, l32, hf); left -= 3; m0 += 6 * nwave; }
+            else if (left == 2) { score_rounds_half<H, 2>(v4, q4, k, pk, n, sc_s, m0, nwave, l32, hf); left = 0; }
+            else { score_rounds_half<H, 1>(v4, q4, k, pk, n, sc_s, m0, nwave, l32, hf); left = 0; }
+        }
+        return;
+    }
+#endif
 #if GSCAN_DEC_SCORE_PAIRS
     static_assert(H % 2 == 0, "feature pairs");
     const bool has = 2 * lane < H;
@@ -351,6 +407,36 @@ __device__ __forceinline__ float quad_bcast(float v) { return dpp_move<I * 0x55,
 #ifndef GSCAN_DEC_QCS_U
 #define GSCAN_DEC_QCS_U 3
 #endif
+// The same sum when n is a whole number of rounds (n % (4 U) == 0: the 36 cells of a 6 x 6 grid are three rounds of
+// twelve): no clamped indices, no masked weights, addresses by addition — per memory one LDS read, one ds_bpermute and two
+// packed FMAs instead of those plus a min, a 24-bit multiply, two shifts, a compare and a select (round 6: the column-sum
+// phases are bound by instruction issue, two waves per SIMD).
+#ifndef GSCAN_DEC_QCS_EXACT
+#define GSCAN_DEC_QCS_EXACT 1
+#endif
+__device__ __forceinline__ float quad_column_sum_exact(const float *base, int stride, int n, int j, float alpha) {
+    constexpr int U = GSCAN_DEC_QCS_U;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float *ptr = base + j * stride;
+    const int step = 4 * stride;
+    int from = 4 * j;                                            // byte address of lane j + 4 u + i0 for ds_bpermute
+    for (int i0 = 0; i0 < n; i0 += 4 * U) {
+        f32x4 x[U];
+        float am[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            x[u] = *reinterpret_cast<const f32x4 *>(ptr + u * step);
+            am[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(from + 16 * u, __float_as_int(alpha)));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += am[u] * x[u];
+        ptr += U * step;
+        from += 16 * U;
+    }
+    const float s0 = quad_sum(acc[0]), s1 = quad_sum(acc[1]), s2 = quad_sum(acc[2]), s3 = quad_sum(acc[3]);
+    return j == 0 ? s0 : j == 1 ? s1 : j == 2 ? s2 : s3;
+}
+
 template <bool GLOBAL = false>
 __device__ __forceinline__ float quad_column_sum(const float *base, int stride, int n, int j, float alpha) {
     constexpr int U = GSCAN_DEC_QCS_U;
@@ -769,7 +855,8 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
         }
         float ucv;
         if (uv_lds) {
-            ucv = quad_column_sum(uv_col, uv_stride, M, j4, alpha);
+            if (GSCAN_DEC_QCS_EXACT && M % (4 * GSCAN_DEC_QCS_U) == 0) ucv = quad_column_sum_exact(uv_col, uv_stride, M, j4, alpha);
+            else ucv = quad_column_sum(uv_col, uv_stride, M, j4, alpha);
         } else {                                               // U_vis streamed from L2 (it did not fit LDS)
             const float from_l2 = quad_column_sum<true>(a.u_v + (int64_t)b * M * 4 * H + (gl.valid ? 4 * gl.unit : 0),
                                                         gl.valid ? 4 * H : 0, M, j4, alpha);
@@ -1059,6 +1146,40 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
             yoff[i] = u2_off + 4 * (idx - 5 * Q); ystr[i] = H;
         }
     }
+#ifndef GSCAN_DEC_DALPHA_HALF
+#define GSCAN_DEC_DALPHA_HALF 1   // 1 (round 6): a HALF wave per memory, two memories per wave round: four or five 16-byte
+#endif                            // reads per lane and ONE five-step DPP sum for both (it was a wave per memory: two or three
+                                  // reads, then a six-step sum + readlane per memory, one after the other)
+#if GSCAN_DEC_DALPHA_HALF
+    if constexpr (!UGLOBAL) {
+        constexpr int NH = (NQ + 31) / 32;
+        const int l32 = lane & 31, hf = lane >> 5;
+        float4 xh[NH];
+        int yo[NH], ys[NH];
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int idx = l32 + 32 * i;
+            xh[i] = float4{0.f, 0.f, 0.f, 0.f};
+            yo[i] = u_off; ys[i] = 0;
+            if (idx < 4 * Q) { xh[i] = *reinterpret_cast<const float4 *>(dperm_s + 4 * idx); yo[i] = u_off + 4 * idx; ys[i] = 4 * H; }
+            else if (idx < 5 * Q) { xh[i] = *reinterpret_cast<const float4 *>(ext_s + 4 * (idx - 4 * Q)); yo[i] = pk_off + 4 * (idx - 4 * Q); ys[i] = H; }
+            else if (idx < NQ) { xh[i] = *reinterpret_cast<const float4 *>(d_s + 5 * HP + 4 * (idx - 5 * Q)); yo[i] = u2_off + 4 * (idx - 5 * Q); ys[i] = H; }
+        }
+        for (int m0 = 2 * wave; m0 < n; m0 += 2 * nwave) {          // memories m0 (lanes 0-31) and m0 + 1 (lanes 32-63)
+            const int m = m0 + hf, mc = min(m, n - 1);
+            float p = 0.f;
+#pragma unroll
+            for (int j = 0; j < NH; ++j) p = dot4(xh[j], *reinterpret_cast<const float4 *>(smem + yo[j] + mc * ys[j]), p);
+            p += dpp_move<0xb1, 0xf>(p);                            // quad_perm [1,0,3,2]
+            p += dpp_move<0x4e, 0xf>(p);                            // quad_perm [2,3,0,1]
+            p += dpp_move<0x124, 0xf>(p);                           // row_ror:4
+            p += dpp_move<0x128, 0xf>(p);                           // row_ror:8: every lane of a 16-lane row holds the row's sum
+            p += dpp_move<0x142, 0xa>(p);                           // row_bcast:15 into rows 1 and 3: lanes 16-31 / 48-63 hold a half's sum
+            if (l32 == 31 && m < n) sc_s[m] = p + (add ? add[m] : 0.f);
+        }
+        return;
+    }
+#endif
 #ifndef GSCAN_DEC_DALPHA_G
 #define GSCAN_DEC_DALPHA_G 0      // > 0 (round 6 A/B, lost: 3 -> +1.5 us, 2 -> flat): G memories per straight-line round, their wave sums interleaved
 #endif
@@ -1144,6 +1265,11 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     float *Uv = smem + o.uv, *PKv = smem + o.pkv, *Ut = smem + o.ut, *PKt = smem + o.pkt, *U2t = smem + o.u2t;
     float *dPKv = smem + o.dpkv, *dPKt = smem + o.dpkt;
     float *vec = smem + o.vec;
+#ifndef GSCAN_DEC_P1_LATE
+#define GSCAN_DEC_P1_LATE 1       // 1 (round 6): the five global stores of phase 1 leave its two busy waves for waves 4-5, which
+#endif                            // copy them out of LDS at the head of phase 2 (they have a memory fewer to score there)
+    // (not where the visual gate images are streamed from L2: that instantiation has no register to spare)
+    constexpr bool kP1Late = GSCAN_DEC_P1_LATE && UVL && kDecThreads >= 256 + H;
     float *d_s = vec;                 // [6][HP]: delta (4 blocks) | dqt | dzq or dqv, each zero-padded to HP
     float *dqv_s = vec + 6 * HP;      // [HP]
     float *qt_s = vec + 7 * HP, *q2_s = qt_s + H, *qv_s = q2_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H,
@@ -1348,11 +1474,13 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             dc = dct * fg;
             d_s[tid] = di; d_s[HP + tid] = df; d_s[2 * HP + tid] = dg; d_s[3 * HP + tid] = d_o;
             *reinterpret_cast<float4 *>(dperm_s + 4 * tid) = float4{di, df, dg, d_o};
-            const unsigned dp = bt * 5 * uH + utid;      // rows of [delta (4H) | dzq (H)]
-            a.delta[dp] = di; a.delta[dp + uH] = df; a.delta[dp + 2 * uH] = dg; a.delta[dp + 3 * uH] = d_o;
-            // dqt of step t+1, kept in LDS by this thread since phase 7 of that step: stores go out right after
-            // the wait for the prefetched activations above (vmcnt counts them: the next wait is a full step away)
-            if (t + 1 < T) a.dqt[(bt + 1) * uH + utid] = d_s[4 * HP + tid];
+            if constexpr (!kP1Late) {
+                const unsigned dp = bt * 5 * uH + utid;      // rows of [delta (4H) | dzq (H)]
+                a.delta[dp] = di; a.delta[dp + uH] = df; a.delta[dp + 2 * uH] = dg; a.delta[dp + 3 * uH] = d_o;
+                // dqt of step t+1, kept in LDS by this thread since phase 7 of that step: stores go out right after
+                // the wait for the prefetched activations above (vmcnt counts them: the next wait is a full step away)
+                if (t + 1 < T) a.dqt[(bt + 1) * uH + utid] = d_s[4 * HP + tid];
+            }
         } else if (tid >= 128 && tid < 128 + H) {
             // external gradients wrt the two contexts (output head) and the saved queries
             const int kk = tid - 128;
@@ -1366,6 +1494,14 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
         lds_barrier();
         GSCAN_STAMP(1)
 
+        if constexpr (kP1Late) {
+            if (tid >= 256 && tid < 256 + H) {
+                const unsigned k = utid - 256, dp = bt * 5 * uH + k;
+                const float4 dd = *reinterpret_cast<const float4 *>(dperm_s + 4 * k);      // (di, df, dg, do) of unit k
+                a.delta[dp] = dd.x; a.delta[dp + uH] = dd.y; a.delta[dp + 2 * uH] = dd.z; a.delta[dp + 3 * uH] = dd.w;
+                if (t + 1 < T) a.dqt[(bt + 1) * uH + k] = d_s[4 * HP + k];
+            }
+        }
         // ---- 2: d alpha_vis[m] = delta . U_vis[m] + dctx_vis(ext) . PK_vis[m] + d att_sum[m] ---
         dalpha_rows<H, HP, false, !UVL>(smem, d_s, dperm_s, exs_s, o.uv, o.pkv, o.pkv, M, datt_s, sc_s, wave, nwave, lane,
                                         a.u_v + (int64_t)b * M * 4 * H);
