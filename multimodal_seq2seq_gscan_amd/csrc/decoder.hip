@@ -187,7 +187,7 @@ __device__ __forceinline__ void score_rounds_half(const float4 &v4, const float4
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int mc = min(m0 + 2 * nwave * r + hf, n - 1);
-        x[r] = *reinterpret_cast<const float4 *>(pk + mc * H + k);
+        x[r] = *reinterpret_cast<const float4 *>(pk + __mul24(mc, H) + k);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -1021,7 +1021,7 @@ __device__ __forceinline__ float score_backward_quads(float dsm, const float *q_
         for (int u = 0; u < U; ++u) {
             const int m = m0 + 4 * u + g, mc = min(m, n - 1);
             live[u] = m < n;
-            at[u] = mc * H + kk;
+            at[u] = __mul24(mc, H) + kk;
             x[u] = pk[at[u]];
             dsl[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mc, __float_as_int(dsm)));
             old[u] = dpk[at[u]];
@@ -1065,7 +1065,7 @@ __device__ __forceinline__ f32x2 score_backward_octs(float dsm, const float *q_s
         for (int u = 0; u < U; ++u) {
             const int m = m0 + 8 * u + g, mc = min(m, n - 1);
             live[u] = m < n;
-            at[u] = mc * H + kk;
+            at[u] = __mul24(mc, H) + kk;                          // 24-bit multiply: full rate (v_mul_lo_u32 is quarter rate)
             x[u] = *reinterpret_cast<const f32x2 *>(pk + at[u]);
             dsl[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mc, __float_as_int(dsm)));
             old[u] = *reinterpret_cast<const f32x2 *>(dpk + at[u]);
@@ -1153,6 +1153,7 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
 #if GSCAN_DEC_DALPHA_HALF
     if constexpr (!UGLOBAL) {
         constexpr int NH = (NQ + 31) / 32;
+        wave = __builtin_amdgcn_readfirstlane(wave);               // uniform: a scalar loop, not an exec-mask loop
         const int l32 = lane & 31, hf = lane >> 5;
         float4 xh[NH];
         int yo[NH], ys[NH];
@@ -1167,15 +1168,26 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
         }
         for (int m0 = 2 * wave; m0 < n; m0 += 2 * nwave) {          // memories m0 (lanes 0-31) and m0 + 1 (lanes 32-63)
             const int m = m0 + hf, mc = min(m, n - 1);
-            float p = 0.f;
+            // every read of the round in flight before the first multiply (written as one expression the compiler issued
+            // read, wait, four dependent FMAs, four times over: four LDS round trips per round), the products as
+            // independent chains per read, and the additive term fetched with them
+            float4 y[NH];
 #pragma unroll
-            for (int j = 0; j < NH; ++j) p = dot4(xh[j], *reinterpret_cast<const float4 *>(smem + yo[j] + mc * ys[j]), p);
+            for (int j = 0; j < NH; ++j) y[j] = *reinterpret_cast<const float4 *>(smem + yo[j] + __mul24(mc, ys[j]));
+            const float extra = add ? add[mc] : 0.f;
+            asm volatile("" : "+v"(y[0].x));                        // (keeps the reads above the arithmetic)
+            float pj[NH];
+#pragma unroll
+            for (int j = 0; j < NH; ++j) pj[j] = dot4(xh[j], y[j], 0.f);
+            float p = l32 == 0 ? extra : 0.f;                       // ONE lane of the half brings the additive term into the sum
+#pragma unroll
+            for (int j = 0; j < NH; ++j) p += pj[j];
             p += dpp_move<0xb1, 0xf>(p);                            // quad_perm [1,0,3,2]
             p += dpp_move<0x4e, 0xf>(p);                            // quad_perm [2,3,0,1]
             p += dpp_move<0x124, 0xf>(p);                           // row_ror:4
             p += dpp_move<0x128, 0xf>(p);                           // row_ror:8: every lane of a 16-lane row holds the row's sum
             p += dpp_move<0x142, 0xa>(p);                           // row_bcast:15 into rows 1 and 3: lanes 16-31 / 48-63 hold a half's sum
-            if (l32 == 31 && m < n) sc_s[m] = p + (add ? add[m] : 0.f);
+            if (l32 == 31 && m < n) sc_s[m] = p;
         }
         return;
     }
