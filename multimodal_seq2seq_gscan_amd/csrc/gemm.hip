@@ -68,33 +68,41 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
     const int fa = pa.is_kc() ? (wm * 16 * TMW + fr) * LDK + 8 * fg : (8 * fg) * LDR_A + wm * 16 * TMW + TMW * fr;
     const int fb = pb.is_kc() ? (wn * 16 * TNW + fr) * LDK + 8 * fg : (8 * fg) * LDR_B + wn * 16 * TNW + TNW * fr;
 
-    float ra[BM * BK / 256], rb[BN * BK / 256];
-    GST(0)                                   // index math and iterator set-up
-    uint32_t ma = pa.load(ra, kbeg);
-    uint32_t mb = pb.load(rb, kbeg);
-    GST(1)                                   // first loads issued
-    pa.template store<LDR_A>(lds_a[0], ra, ma, tid);
-    pb.template store<LDR_B>(lds_b[0], rb, mb, tid);
-    __syncthreads();
-    GST(2)                                   // first panels landed and staged
-
-    // GSCAN_GEMM_PIPE (round 6 A/B): 0 = the next round's three panel loads are issued in FRONT of this round's fragment reads
-    // and MFMAs (a wave sits in the memory pipeline's queue — ~1 000-1 400 cycles with four workgroups per CU, tools/
-    // gemm_stamps.py — before it reaches its own matrix work); 1 = fragment reads first, then the loads (always issued: a
-    // dead load reads element 0), then the MFMAs; 2 = the same with the loads pinned BETWEEN the MFMAs
-    // (sched_group_barrier: one load, then a share of the MFMAs), so that the queueing overlaps the wave's own matrix work.
+    // K loop.  A round = fragment reads of the current LDS buffer, then the round's MFMAs with the panel loads of a LATER round
+    // pinned between them (sched_group_barrier: one 16-byte load per 5-8 MFMAs — issued in front, a wave sat in the memory
+    // pipeline's queue for ~1 000 cycles before it reached its own matrix work), then the panels of the NEXT round go from
+    // registers to the other LDS buffer, one barrier.
+    // GSCAN_GEMM_PIPE=3 (round 6): the 32-row kernel keeps TWO register sets and loads two rounds ahead — a round's
+    // panels have a whole round to arrive before they are stored, where one round ahead the wave waited ~1 500 cycles in
+    // front of its LDS stores every round (12 more VGPRs: 111, still four workgroups per CU; the 64-row kernel has no
+    // registers for it and stays one round ahead).  2: one round ahead everywhere.
 #ifndef GSCAN_GEMM_PIPE
 #define GSCAN_GEMM_PIPE 2
 #endif
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    constexpr bool DEEP = GSCAN_GEMM_PIPE == 3 && TMW == 1 && BK == 32;
+    constexpr int NSET = DEEP ? 2 : 1, AHEAD = DEEP ? 2 : 1;
+    float ra[NSET][BM * BK / 256], rb[NSET][BN * BK / 256];
+    uint32_t ma[NSET], mb[NSET];
+    GST(0)                                   // index math and iterator set-up
+    ma[0] = pa.load(ra[0], kbeg);
+    mb[0] = pb.load(rb[0], kbeg);
+    GST(1)                                   // first loads issued
+    pa.template store<LDR_A>(lds_a[0], ra[0], ma[0], tid);
+    pb.template store<LDR_B>(lds_b[0], rb[0], mb[0], tid);
+    if constexpr (DEEP) {                    // the second round's panels: in flight across the first barrier
+        ma[1] = pa.load(ra[1], kbeg + BK);
+        mb[1] = pb.load(rb[1], kbeg + BK);
+    }
+    __syncthreads();
+    GST(2)                                   // first panels landed and staged
+
+    // one round on LDS buffer `buf`: loads of round + AHEAD into register set L, set S (the next round's panels) to the other buffer
+    auto round = [&](int k0, int buf, auto lset, auto sset) {
+        constexpr int L = decltype(lset)::value, S = decltype(sset)::value;
+        // (the two inlined copies of this body differ in the register sets only: with `buf` a literal per copy the
+        // compiler kept both buffers' fragment and store addresses live across the loop — 134 VGPRs instead of 91)
+        asm volatile("" : "+s"(buf));
         const bool more = k0 + BK < kend;
-#if GSCAN_GEMM_PIPE == 0
-        if (more) {   // next round's loads fly while this round's MFMAs run
-            ma = pa.load(ra, k0 + BK);
-            mb = pb.load(rb, k0 + BK);
-        }
-#endif
         GST(3)
 #pragma unroll
         for (int kh = 0; kh < BK; kh += 32) {
@@ -134,12 +142,10 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
                 bf[0][s] = x.x; bf[1][s] = x.y;
             }
         }
-#if GSCAN_GEMM_PIPE != 0
-        if (kh == 0) {
-            ma = pa.load(ra, k0 + BK);
-            mb = pb.load(rb, k0 + BK);
+        if (kh == 0) {                       // always issued: a load beyond the K range reads element 0 and is zeroed when stored
+            ma[L] = pa.load(ra[L], k0 + AHEAD * BK);
+            mb[L] = pb.load(rb[L], k0 + AHEAD * BK);
         }
-#endif
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
@@ -147,7 +153,6 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
 #pragma unroll
                 for (int j = 0; j < TNW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-#if GSCAN_GEMM_PIPE == 2
         if constexpr (VWA == 4 && VWB == 4 && BK == 32) {      // TMW + 2 sixteen-byte loads, 16 TMW MFMAs
 #define GSCAN_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
             if constexpr (TMW == 1) {
@@ -162,7 +167,6 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
             }
 #undef GSCAN_SGB
         }
-#endif
         if (do_asum && tid < BM) {           // column sums of A (bias gradients): sum over these 32 k
             const float *sa = lds_a[buf] + (pa.is_kc() ? kh : kh * LDR_A);
             float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
@@ -184,13 +188,27 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
         }
         GST(4)                               // fragment reads + MFMAs
         if (more) {
-            pa.template store<LDR_A>(lds_a[buf ^ 1], ra, ma, tid);
-            pb.template store<LDR_B>(lds_b[buf ^ 1], rb, mb, tid);
+            pa.template store<LDR_A>(lds_a[buf ^ 1], ra[S], ma[S], tid);
+            pb.template store<LDR_B>(lds_b[buf ^ 1], rb[S], mb[S], tid);
         }
         GST(5)                               // wait for the next panels + LDS stores
         __syncthreads();
         GST(6)
-        buf ^= 1;
+    };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, DEEP ? 1 : 0>;
+    if constexpr (DEEP) {
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {     // two copies of the body: the register sets swap roles every round
+            round(k0, 0, Set0{}, Set1{});                  // loads into set 0, stores set 1
+            if (k0 + BK >= kend) break;
+            round(k0 + BK, 1, Set1{}, Set0{});
+        }
+    } else {
+        int buf = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            round(k0, buf, Set0{}, Set0{});
+            buf ^= 1;
+        }
     }
 
     if (do_asum && tid < BM && m0 + tid < g.M) {
@@ -288,7 +306,10 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem &g, int local, float
 #define GSCAN_GEMM_WAVES5 0
 #endif
 template <int TMW, int BK>
-__global__ __launch_bounds__(256, (GSCAN_GEMM_WAVES5 && TMW == 1 && BK == 32) ? 5 : 1) void gemm_group_kernel(int tb0, int tb1, int tb2, int tb3, int tb4, int tb5, int tb6,
+#ifndef GSCAN_GEMM_WAVES4
+#define GSCAN_GEMM_WAVES4 0        // 1 (A/B): the 64-row kernel held to 128 registers = four workgroups per CU (it takes 134 with the pinned loads)
+#endif
+__global__ __launch_bounds__(256, (GSCAN_GEMM_WAVES5 && TMW == 1 && BK == 32) ? 5 : (GSCAN_GEMM_WAVES4 && TMW == 2 && BK == 32) ? 4 : 1) void gemm_group_kernel(int tb0, int tb1, int tb2, int tb3, int tb4, int tb5, int tb6,
                                                          int tb7, int tb8, int tb9, int tb10, int tb11, GemmGroup grp) {
     // The first workgroup id of every problem arrives as twelve leading scalar arguments: this file is compiled with
     // -mllvm -amdgpu-kernarg-preload-count=12 (build.py), so they sit in SGPRs when the wave starts and the problem
