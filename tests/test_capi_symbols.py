@@ -67,3 +67,25 @@ def test_workspace_query_and_errors(lib):
                      auxiliary=0, bidirectional=1, pad_in=0, pad_tgt=0)
     assert lib.gscan_workspace_bytes(ctypes.byref(even)) == 0
     assert b"cnn_kernel_size" in lib.gscan_last_error()
+
+
+def test_decoder_kernel_family_reports_the_resident_path_conditions(lib):
+    """gscan_decoder_kernel_family (ABI 14): 1 = the register/LDS-resident decoder kernels, 0 = the streaming ones; the
+    conditions are the ones the header lists above gscan_dims (a target vocabulary above 16 used to fall to the
+    streaming kernels without a word)."""
+    from multimodal_seq2seq_gscan_amd import _lib
+    base = dict(B=256, L=10, T=20, G=6, C=16, Co=50, K3=7, E=25, He=100, H=100, Vi=21, V=9, conditional=1,
+                auxiliary=0, bidirectional=1, pad_in=0, pad_tgt=0)
+
+    def family(**kw):
+        return lib.gscan_decoder_kernel_family(ctypes.byref(_lib.Dims(**dict(base, **kw))))
+    assert family() == 1                                   # the benchmark shape
+    assert family(V=16) == 1 and family(V=17) == 0         # one matrix-core tile of logits
+    assert family(H=96) == 1 and family(H=98) == 0 and family(H=128) == 0
+    assert family(G=8) == 1 and family(G=9) == 0           # at most 64 memories per attention (81 cells)
+    assert family(L=64, G=6) in (0, 1) and family(L=65) == 0
+    assert family(L=44, G=6) == 1 and family(L=64, G=8) == 0    # the row's memories must fit 160 KB of LDS
+    assert family(H=0) < 0 and b"" != lib.gscan_last_error()
+    assert lib.gscan_decoder_kernel_family(None) < 0
+    # the early-gradient wait needs a backward pass to have been issued in this process
+    assert lib.gscan_comm_set_early_allreduce(None, None, 0) == 0
