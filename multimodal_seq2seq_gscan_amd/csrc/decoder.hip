@@ -258,7 +258,12 @@ __device__ __forceinline__ void attention_scores(const float *v_s, const float *
             v4 = float4{2.f * v4.x, 2.f * v4.y, 2.f * v4.z, 2.f * v4.w};
             q4 = float4{e2m(q4.x), e2m(q4.y), e2m(q4.z), e2m(q4.w)};
         }
-        const int pairs = (n + 1) >> 1, rounds = (pairs + nwave - 1) / nwave;       // uniform in the workgroup
+#ifndef GSCAN_DEC_SCORE_OWN_ROUNDS
+#define GSCAN_DEC_SCORE_OWN_ROUNDS 1    // 1: a wave runs ITS rounds (36 cells = 18 pairs: waves 0-1 three, the others two; a command
+#endif                                  // of ten: waves 5-7 none) instead of the busiest wave's, clamped - the SIMD's other wave issues
+        const int pairs = (n + 1) >> 1;
+        const int rounds = GSCAN_DEC_SCORE_OWN_ROUNDS ? (pairs - wave + nwave - 1) / nwave      // scalar (wave is an SGPR)
+                                                      : (pairs + nwave - 1) / nwave;
         int m0 = 2 * wave;
         for (int left = rounds; left > 0;) {
             if (left >= 3) { score_rounds_half<H, 3, TAB>(v4, q4, k, pk, n, sc_s, m0, nwave, l32, hf); left -= 3; m0 += 6 * nwave; }
