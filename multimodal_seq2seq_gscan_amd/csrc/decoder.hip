@@ -254,10 +254,7 @@ __device__ __forceinline__ void attention_scores(const float *v_s, const float *
         float4 v4 = *reinterpret_cast<const float4 *>(v_s + k);
         float4 q4 = *reinterpret_cast<const float4 *>(q_s + k);
         if (!has) v4 = float4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (TAB) {
-            v4 = float4{2.f * v4.x, 2.f * v4.y, 2.f * v4.z, 2.f * v4.w};
-            q4 = float4{e2m(q4.x), e2m(q4.y), e2m(q4.z), e2m(q4.w)};
-        }
+        if constexpr (TAB) v4 = float4{2.f * v4.x, 2.f * v4.y, 2.f * v4.z, 2.f * v4.w};     // (q_s holds e^{-2q} already)
 #ifndef GSCAN_DEC_SCORE_OWN_ROUNDS
 #define GSCAN_DEC_SCORE_OWN_ROUNDS 1    // 1: a wave runs ITS rounds (36 cells = 18 pairs: waves 0-1 three, the others two; a command
 #endif                                  // of ten: waves 5-7 none) instead of the busiest wave's, clamped - the SIMD's other wave issues
@@ -321,7 +318,7 @@ __host__ __device__ inline int head_fwd_scratch_floats(int H) {
     return sch + kHeadWcRows * SS + kHeadChunk * 16 + kHeadChunk;
 }
 struct DecoderLds {
-    int uv, pkv, ut, pkt, u2t, dpkv, dpkt, ekv, ekt, vec, total;
+    int uv, pkv, ut, pkt, u2t, dpkv, dpkt, ekv, ekt, vec, eq, total;
 };
 // uv_in_lds = false: the gate images of the visual memories U_vis [M,4H] (the largest resident block: 102 KB for an
 // 8x8 grid at H = 100) stay in global memory and the two phases that read them stream them from L2 every step.
@@ -341,6 +338,7 @@ __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bo
     o.ekt = p; p += tables ? L * H : 0;
     o.vec = p;
     p += (backward ? 7 * HP + 19 * H : 2 * HP + 6 * H) + 256;
+    o.eq = p; p += (tables && !backward) ? 2 * H : 0;     // forward with tables: e^{-2q} of both queries (the reverse kernel keeps them in place of q)
     // scratch of the fused output head, overlaid on the memories (forward: after the loop; backward: before staging)
     const int head = backward ? kHeadChunk * kHeadDlStride + kHeadWcRows * 4 * H + 32 : head_fwd_scratch_floats(H);
     o.total = p > head ? p : head;
@@ -679,6 +677,7 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
     float *vec = smem + o.vec;
     float *h_s = vec;                                       // dot input, zero-padded to HP
     float *qt_s = vec + HP, *qv_s = qt_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H;
+    [[maybe_unused]] float *eqt_s = smem + o.eq, *eqv_s = eqt_s + H;   // TAB: e^{-2q}, written with q by the lane that owns the row
     float *qh_s = vv_s + H;                                 // W_q2k[:, :H] h (conditional)
     float *ctxt_s = qh_s + H;                               // textual context (greedy head)
     float *q2_s = ctxt_s + H;                               // dot input, zero-padded to HP
@@ -823,16 +822,16 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
             const float acc = pair_sum(gh[s]);
             if (s * kDecPairs < 4 * H && s < 2) { if (gl.upper == (s == 1)) ghh = acc; }
             if (r >= 4 * H && r < 6 * H && half == 0) {
-                if (r < 5 * H) qt_s[r - 4 * H] = acc;
+                if (r < 5 * H) { qt_s[r - 4 * H] = acc; if (TAB) eqt_s[r - 4 * H] = e2m(acc); }
                 else if (COND) qh_s[r - 5 * H] = acc;
-                else qv_s[r - 5 * H] = acc;
+                else { qv_s[r - 5 * H] = acc; if (TAB) eqv_s[r - 5 * H] = e2m(acc); }
             }
         }
         lds_barrier();
         GSCAN_STAMP(1)
 
         // ---- B: textual scores s_m = v . tanh(q + PK_m), m < len (seq2seq_model.py:129-135) --
-        attention_scores<H, TAB>(vt_s, qt_s, SKt, len, sc_s, wave, nwave, lane);
+        attention_scores<H, TAB>(vt_s, TAB ? eqt_s : qt_s, SKt, len, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(2)
         // ---- C: softmax over the command (seq2seq_model.py:136-137) in every wave's registers: lane m holds
@@ -878,7 +877,11 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
                 const int r = s * kDecPairs + pair;
                 if (r >= 6 * H && r < 7 * H) {
                     const float acc = pair_sum(half_dot<K0>(w[s], q2_s + half * K0));
-                    if (half == 0) { qv_s[r - 6 * H] = acc; if (!GREEDY) a.qv[bt * H + r - 6 * H] = acc; }
+                    if (half == 0) {
+                        qv_s[r - 6 * H] = acc;
+                        if (TAB) eqv_s[r - 6 * H] = e2m(acc);
+                        if (!GREEDY) a.qv[bt * H + r - 6 * H] = acc;
+                    }
                 }
             }
         } else if (!GREEDY && tid < H) {
@@ -892,7 +895,7 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
             const float g0 = pair_sum(half_dot<K0>(w[0], h_s + half * K0));
             if (!gl.upper) pre += g0;
         }
-        attention_scores<H, TAB>(vv_s, qv_s, SKv, M, sc_s, wave, nwave, lane);
+        attention_scores<H, TAB>(vv_s, TAB ? eqv_s : qv_s, SKv, M, sc_s, wave, nwave, lane);
         lds_barrier();
         GSCAN_STAMP(6)
         // ---- F: softmax, column sums over the cells, gates, cell update (seq2seq_model.py:414) ----
@@ -1105,15 +1108,13 @@ __device__ __forceinline__ f32x2 score_backward_octs(float dsm, const float *q_s
     const int k2 = t8 >> 3, g = t8 & 7;
     const bool has = 2 * k2 < H;
     const int kk = has ? 2 * k2 : 0;
-    f32x2 q = *reinterpret_cast<const f32x2 *>(q_s + kk);
+    const f32x2 q = *reinterpret_cast<const f32x2 *>(q_s + kk);
     f32x2 v = *reinterpret_cast<const f32x2 *>(v_s + kk);
     if (!has) v = f32x2{0.f, 0.f};
     f32x2 pdq = {0.f, 0.f};
     [[maybe_unused]] float dssum = 0.f;
-    if constexpr (TAB) {         // pk = the table e^{-2 PK}: r = 1 / (1 + e^{-2q} e^{-2 PK}), tanh = 2 r - 1, 1 - tanh^2 = 4 r (1 - r)
-        q = f32x2{e2m(q.x), e2m(q.y)};
-        v = f32x2{4.f * v.x, 4.f * v.y};
-    }
+    // TAB: pk = the table e^{-2 PK}, q_s = e^{-2q}: r = 1 / (1 + e^{-2q} e^{-2 PK}), tanh = 2 r - 1, 1 - tanh^2 = 4 r (1 - r)
+    if constexpr (TAB) v = f32x2{4.f * v.x, 4.f * v.y};
     for (int m0 = 0; m0 < n; m0 += 8 * U) {                     // the same number of rounds in every lane
         f32x2 x[U], old[U];
         float dsl[U];
@@ -1580,8 +1581,8 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             const int kk = tid - 128;
             exc_s[kk] = pf[0];
             exs_s[kk] = pf[1];
-            qt_s[kk] = pf[2];
-            qv_s[kk] = pf[3];
+            qt_s[kk] = TAB ? e2m(pf[2]) : pf[2];             // (the score terms are the queries' only readers)
+            qv_s[kk] = TAB ? e2m(pf[3]) : pf[3];
             if (COND) q2_s[kk] = pf[4];
         }
         if (t > 0) prefetch(t - 1);
