@@ -173,24 +173,22 @@ __device__ __forceinline__ void score_round(float v1, float v2, float q1, float 
         if (lane == 0 && m0 + i * nwave < n) sc_s[m0 + i * nwave] = p[i];
 }
 
-// GSCAN_DEC_EXPTAB=1 (round 6): the score terms tanh(q + PK) are taken as 2 / (1 + e^{-2q} e^{-2 PK}) - 1 with the factors
-// e^{-2 PK[m][k]} TABULATED per launch (ekv / ekt, beside the keys in LDS) and e^{-2 q_k} computed once per lane, feature and
-// step: ONE transcendental per term (a reciprocal) instead of two, four instructions instead of seven.  Exponents are
-// clamped to +-60 (a saturated tanh either way; no inf x 0).  Costs (M + L) H floats of LDS.
-#ifndef GSCAN_DEC_EXPTAB
-#define GSCAN_DEC_EXPTAB 1
+// GSCAN_DEC_RFORM=1 (round 6): the FORWARD score terms in terms of r = 1 / (1 + e^{-2 (q + PK)}) instead of tanh = 2 r - 1 — the
+// same two transcendentals, two plain instructions fewer per term (five for seven):
+//   * the queries arrive PRE-SCALED, qs = -2 log2(e) q, written beside q by the lane that produces it, so the exponent is ONE
+//     fma(PK, -2 log2 e, qs) instead of an add and a multiply;
+//   * v . tanh(.) = sum_k 2 v_k r_k - sum_k v_k, and the constant is dropped (the softmax over the memories does not see it;
+//     its shift bound becomes 2 sum_k max(v_k, 0)).
+// Exact rewrites (saturation as before: 2^(+big) = inf -> r = 0, 2^(-big) = 0 -> r = 1).
+// (The round's other attempt, TABLES of e^{-2 PK} in LDS against e^{-2 q} — one transcendental per term, pair -3.5 us — is not
+// shipped: a factorised form is wrong when a query and a key are both huge and cancel, and every way of handing such rows to
+// the plain form cost the gain or did not run: LABBOOK 0, profiles/r06_decoder_score_tables_ab.txt.)
+#ifndef GSCAN_DEC_RFORM
+#define GSCAN_DEC_RFORM 1
 #endif
-// e^{-2x} with the exponent clamped to +-60 (2^(+-86.6): finite and non-zero, so that a product of two such factors is never
-// inf x 0); tanh(q + p) = 2 / (1 + e2m(q) e2m(p)) - 1
-__device__ __forceinline__ float e2m(float x) {
-    return __builtin_amdgcn_exp2f(fminf(fmaxf(-2.8853900817779268f * x, -86.56f), 86.56f));
-}
-// the table of a row's projected keys: ek[i] = e2m(pk[i]) (once per launch, before the time loop)
-__device__ __forceinline__ void exp_table(float *ek, const float *pk, int n, int tid) {
-    for (int i = tid; i < n / 4; i += kDecThreads) {
-        const float4 x = reinterpret_cast<const float4 *>(pk)[i];
-        reinterpret_cast<float4 *>(ek)[i] = float4{e2m(x.x), e2m(x.y), e2m(x.z), e2m(x.w)};
-    }
+constexpr float kM2Log2e = -2.8853900817779268f;                // e^{-2x} = 2^(kM2Log2e x)
+__device__ __forceinline__ float r_of(float pk, float qs) {     // 1 / (1 + e^{-2 (q + pk)}), qs = kM2Log2e q
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(pk, kM2Log2e, qs)));
 }
 
 // GSCAN_DEC_SCORE_HALF=1 (round 6 A/B): a HALF wave per memory — a lane owns FOUR adjacent features (one 16-byte read of
@@ -199,7 +197,7 @@ __device__ __forceinline__ void exp_table(float *ek, const float *pk, int n, int
 #ifndef GSCAN_DEC_SCORE_HALF
 #define GSCAN_DEC_SCORE_HALF 1
 #endif
-template <int H, int R, bool TAB>
+template <int H, int R>
 __device__ __forceinline__ void score_rounds_half(const float4 &v4, const float4 &q4, int k, const float *pk, int n,
                                                   float *sc_s, int m0, int nwave, int l32, int hf) {
     float4 x[R];
@@ -209,19 +207,16 @@ __device__ __forceinline__ void score_rounds_half(const float4 &v4, const float4
         const int mc = min(m0 + 2 * nwave * r + hf, n - 1);
         x[r] = *reinterpret_cast<const float4 *>(pk + __mul24(mc, H) + k);
     }
-    if constexpr (TAB) {
-        // here v4 = 2 v, q4 = e^{-2q}, pk = the table e^{-2 PK}: v . tanh(q + PK_m) = sum_k 2 v_k / (1 + q4_k x_k) - sum_k v_k, and
-        // the constant is dropped (the softmax over m does not see it)
+#if GSCAN_DEC_RFORM       // (here v4 = 2 v and q4 = the pre-scaled queries)
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            p[r] = fmaf(v4.x, __builtin_amdgcn_rcpf(fmaf(q4.x, x[r].x, 1.f)), v4.y * __builtin_amdgcn_rcpf(fmaf(q4.y, x[r].y, 1.f))) +
-                   fmaf(v4.z, __builtin_amdgcn_rcpf(fmaf(q4.z, x[r].z, 1.f)), v4.w * __builtin_amdgcn_rcpf(fmaf(q4.w, x[r].w, 1.f)));
-    } else {
+    for (int r = 0; r < R; ++r)
+        p[r] = fmaf(v4.x, r_of(x[r].x, q4.x), v4.y * r_of(x[r].y, q4.y)) + fmaf(v4.z, r_of(x[r].z, q4.z), v4.w * r_of(x[r].w, q4.w));
+#else
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            p[r] = fmaf(v4.x, tanhf_(q4.x + x[r].x), v4.y * tanhf_(q4.y + x[r].y)) +
-                   fmaf(v4.z, tanhf_(q4.z + x[r].z), v4.w * tanhf_(q4.w + x[r].w));
-    }
+    for (int r = 0; r < R; ++r)
+        p[r] = fmaf(v4.x, tanhf_(q4.x + x[r].x), v4.y * tanhf_(q4.y + x[r].y)) +
+               fmaf(v4.z, tanhf_(q4.z + x[r].z), v4.w * tanhf_(q4.w + x[r].w));
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) p[r] += dpp_move<0xb1, 0xf>(p[r]);
 #pragma unroll
@@ -239,10 +234,9 @@ __device__ __forceinline__ void score_rounds_half(const float4 &v4, const float4
     }
 }
 
-template <int H, bool TAB = false>
+template <int H>
 __device__ __forceinline__ void attention_scores(const float *v_s, const float *q_s, const float *pk, int n,
-                                                 float *sc_s, int wave_v, int nwave, int lane) {
-    static_assert(!TAB || GSCAN_DEC_SCORE_HALF, "the tabulated scores exist in the half-wave layout only");
+                                                 float *sc_s, int wave_v, int nwave, int lane, const float *qs_s = nullptr) {
     static_assert(H <= 128, "two feature indices per lane");
     const int wave = __builtin_amdgcn_readfirstlane(wave_v);
 #if GSCAN_DEC_SCORE_HALF
@@ -252,9 +246,9 @@ __device__ __forceinline__ void attention_scores(const float *v_s, const float *
         const bool has = 4 * l32 < H;
         const int k = has ? 4 * l32 : 0;
         float4 v4 = *reinterpret_cast<const float4 *>(v_s + k);
-        float4 q4 = *reinterpret_cast<const float4 *>(q_s + k);
+        const float4 q4 = *reinterpret_cast<const float4 *>((GSCAN_DEC_RFORM ? qs_s : q_s) + k);
         if (!has) v4 = float4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (TAB) v4 = float4{2.f * v4.x, 2.f * v4.y, 2.f * v4.z, 2.f * v4.w};     // (q_s holds e^{-2q} already)
+        if (GSCAN_DEC_RFORM) v4 = float4{2.f * v4.x, 2.f * v4.y, 2.f * v4.z, 2.f * v4.w};
 #ifndef GSCAN_DEC_SCORE_OWN_ROUNDS
 #define GSCAN_DEC_SCORE_OWN_ROUNDS 1    // 1: a wave runs ITS rounds (36 cells = 18 pairs: waves 0-1 three, the others two; a command
 #endif                                  // of ten: waves 5-7 none) instead of the busiest wave's, clamped - the SIMD's other wave issues
@@ -263,9 +257,9 @@ __device__ __forceinline__ void attention_scores(const float *v_s, const float *
                                                       : (pairs + nwave - 1) / nwave;
         int m0 = 2 * wave;
         for (int left = rounds; left > 0;) {
-            if (left >= 3) { score_rounds_half<H, 3, TAB>(v4, q4, k, pk, n, sc_s, m0, nwave, l32, hf); left -= 3; m0 += 6 * nwave; }
-            else if (left == 2) { score_rounds_half<H, 2, TAB>(v4, q4, k, pk, n, sc_s, m0, nwave, l32, hf); left = 0; }
-            else { score_rounds_half<H, 1, TAB>(v4, q4, k, pk, n, sc_s, m0, nwave, l32, hf); left = 0; }
+            if (left >= 3) { score_rounds_half<H, 3>(v4, q4, k, pk, n, sc_s, m0, nwave, l32, hf); left -= 3; m0 += 6 * nwave; }
+            else if (left == 2) { score_rounds_half<H, 2>(v4, q4, k, pk, n, sc_s, m0, nwave, l32, hf); left = 0; }
+            else { score_rounds_half<H, 1>(v4, q4, k, pk, n, sc_s, m0, nwave, l32, hf); left = 0; }
         }
         return;
     }
@@ -318,12 +312,12 @@ __host__ __device__ inline int head_fwd_scratch_floats(int H) {
     return sch + kHeadWcRows * SS + kHeadChunk * 16 + kHeadChunk;
 }
 struct DecoderLds {
-    int uv, pkv, ut, pkt, u2t, dpkv, dpkt, ekv, ekt, vec, eq, total;
+    int uv, pkv, ut, pkt, u2t, dpkv, dpkt, vec, total;
 };
 // uv_in_lds = false: the gate images of the visual memories U_vis [M,4H] (the largest resident block: 102 KB for an
 // 8x8 grid at H = 100) stay in global memory and the two phases that read them stream them from L2 every step.
 __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bool cond, bool backward,
-                                                  bool uv_in_lds = true, bool tables = false) {
+                                                  bool uv_in_lds = true) {
     const int HP = 2 * (((H / 2 + 3) / 4) * 4);       // padded length of every vector a half_dot reads
     DecoderLds o;
     int p = 0;
@@ -334,11 +328,8 @@ __host__ __device__ inline DecoderLds decoder_lds(int H, int L, int M, int V, bo
     o.u2t = p; p += cond ? L * H : 0;
     o.dpkv = p; p += backward ? M * H : 0;
     o.dpkt = p; p += backward ? L * H : 0;
-    o.ekv = p; p += tables ? M * H : 0;
-    o.ekt = p; p += tables ? L * H : 0;
     o.vec = p;
-    p += (backward ? 7 * HP + 19 * H : 2 * HP + 6 * H) + 256;
-    o.eq = p; p += (tables && !backward) ? 2 * H : 0;     // forward with tables: e^{-2q} of both queries (the reverse kernel keeps them in place of q)
+    p += (backward ? 7 * HP + 19 * H : 2 * HP + 8 * H) + 256;
     // scratch of the fused output head, overlaid on the memories (forward: after the loop; backward: before staging)
     const int head = backward ? kHeadChunk * kHeadDlStride + kHeadWcRows * 4 * H + 32 : head_fwd_scratch_floats(H);
     o.total = p > head ? p : head;
@@ -651,7 +642,7 @@ __device__ __forceinline__ void head_epilogue(const DecoderArgs &a, float *smem,
 //   F  softmax, column sums over the grid cells (U_v -> owning lanes; PK_v -> visual context), gate activations —
 //      one gate per lane —, cell update by lane 0 of each quad, h_t -> LDS
 // ------------------------------------------------------------------------------------------
-template <int H, bool COND, bool GREEDY, bool UVL = true, bool TAB = false>
+template <int H, bool COND, bool GREEDY, bool UVL = true>
 __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
                   HP = 2 * K0;
@@ -671,16 +662,15 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
     const int pair = decoder_pair_of(tid), half = decoder_half_of(tid);
     const int T = a.T, L = a.L, M = a.M;
     constexpr bool uv_lds = UVL;
-    constexpr bool tab = TAB;                               // the host found room for the tables (launch_decoder)
-    const DecoderLds o = decoder_lds(H, L, M, a.V, COND, false, uv_lds, tab);
+    const DecoderLds o = decoder_lds(H, L, M, a.V, COND, false, uv_lds);
     float *PKv = smem + o.pkv, *PKt = smem + o.pkt;
     float *vec = smem + o.vec;
     float *h_s = vec;                                       // dot input, zero-padded to HP
     float *qt_s = vec + HP, *qv_s = qt_s + H, *vt_s = qv_s + H, *vv_s = vt_s + H;
-    [[maybe_unused]] float *eqt_s = smem + o.eq, *eqv_s = eqt_s + H;   // TAB: e^{-2q}, written with q by the lane that owns the row
     float *qh_s = vv_s + H;                                 // W_q2k[:, :H] h (conditional)
     float *ctxt_s = qh_s + H;                               // textual context (greedy head)
-    float *q2_s = ctxt_s + H;                               // dot input, zero-padded to HP
+    float *qst_s = ctxt_s + H, *qsv_s = qst_s + H;          // the two queries pre-scaled (GSCAN_DEC_RFORM), written with them
+    float *q2_s = qsv_s + H;                                // dot input, zero-padded to HP
     float *sc_s = q2_s + HP, *bq_s = sc_s + 64;
     [[maybe_unused]] float *stamp_acc = sc_s + 192;
     // greedy decoding only: composite head [V,4H] (S order), embedding part of the logits [V,V], visual context,
@@ -774,18 +764,13 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
         shift_v = wave_sum(av1);
         bound_t = shift_t < 40.f;
         bound_v = shift_v < 40.f;
-        if (tab) {                   // the tabulated form's score is sum_k 2 v_k r_k, r in (0, 1): at most 2 sum_k max(v_k, 0)
+        if (GSCAN_DEC_RFORM && GSCAN_DEC_SCORE_HALF) {   // the r form's score is sum_k 2 v_k r_k, r in (0, 1): at most 2 sum_k max(v_k, 0)
             const float pt1 = (lane < H ? fmaxf(vt_s[lane], 0.f) : 0.f) + (lane + 64 < H ? fmaxf(vt_s[lane + 64], 0.f) : 0.f);
             const float pv1 = (lane < H ? fmaxf(vv_s[lane], 0.f) : 0.f) + (lane + 64 < H ? fmaxf(vv_s[lane + 64], 0.f) : 0.f);
             shift_t = 2.f * wave_sum(pt1);
             shift_v = 2.f * wave_sum(pv1);
         }
     }
-    if (tab) {                       // read first in phase B, behind phase A's barrier
-        exp_table(smem + o.ekv, PKv, M * H, tid);
-        exp_table(smem + o.ekt, PKt, L * H, tid);
-    }
-    const float *SKv = tab ? smem + o.ekv : PKv, *SKt = tab ? smem + o.ekt : PKt;
     // GSCAN_DEC_PRIO=1: the second-dispatched half of the workgroup (waves 4-7: the younger wave of every SIMD, which loses
     // the issue arbitration by age) runs at priority 1 for the whole loop; 2: the older half instead (A/B).
 #ifndef GSCAN_DEC_PRIO
@@ -822,16 +807,16 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
             const float acc = pair_sum(gh[s]);
             if (s * kDecPairs < 4 * H && s < 2) { if (gl.upper == (s == 1)) ghh = acc; }
             if (r >= 4 * H && r < 6 * H && half == 0) {
-                if (r < 5 * H) { qt_s[r - 4 * H] = acc; if (TAB) eqt_s[r - 4 * H] = e2m(acc); }
+                if (r < 5 * H) { qt_s[r - 4 * H] = acc; if (GSCAN_DEC_RFORM) qst_s[r - 4 * H] = kM2Log2e * acc; }
                 else if (COND) qh_s[r - 5 * H] = acc;
-                else { qv_s[r - 5 * H] = acc; if (TAB) eqv_s[r - 5 * H] = e2m(acc); }
+                else { qv_s[r - 5 * H] = acc; if (GSCAN_DEC_RFORM) qsv_s[r - 5 * H] = kM2Log2e * acc; }
             }
         }
         lds_barrier();
         GSCAN_STAMP(1)
 
         // ---- B: textual scores s_m = v . tanh(q + PK_m), m < len (seq2seq_model.py:129-135) --
-        attention_scores<H, TAB>(vt_s, TAB ? eqt_s : qt_s, SKt, len, sc_s, wave, nwave, lane);
+        attention_scores<H>(vt_s, qt_s, PKt, len, sc_s, wave, nwave, lane, qst_s);
         lds_barrier();
         GSCAN_STAMP(2)
         // ---- C: softmax over the command (seq2seq_model.py:136-137) in every wave's registers: lane m holds
@@ -879,7 +864,7 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
                     const float acc = pair_sum(half_dot<K0>(w[s], q2_s + half * K0));
                     if (half == 0) {
                         qv_s[r - 6 * H] = acc;
-                        if (TAB) eqv_s[r - 6 * H] = e2m(acc);
+                        if (GSCAN_DEC_RFORM) qsv_s[r - 6 * H] = kM2Log2e * acc;
                         if (!GREEDY) a.qv[bt * H + r - 6 * H] = acc;
                     }
                 }
@@ -895,7 +880,7 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
             const float g0 = pair_sum(half_dot<K0>(w[0], h_s + half * K0));
             if (!gl.upper) pre += g0;
         }
-        attention_scores<H, TAB>(vv_s, TAB ? eqv_s : qv_s, SKv, M, sc_s, wave, nwave, lane);
+        attention_scores<H>(vv_s, qv_s, PKv, M, sc_s, wave, nwave, lane, qsv_s);
         lds_barrier();
         GSCAN_STAMP(6)
         // ---- F: softmax, column sums over the cells, gates, cell update (seq2seq_model.py:414) ----
@@ -1007,10 +992,10 @@ __device__ __forceinline__ void decoder_fwd_body(const DecoderArgs &a) {
     GSCAN_STAMP_ONCE(11)
 }
 
-template <int H, bool COND, bool GREEDY, bool UVL = true, bool TAB = false>
+template <int H, bool COND, bool GREEDY, bool UVL = true>
 __global__ __launch_bounds__(kDecThreads) void decoder_fwd_kernel(DecoderArgs a) {
     TraceScope trace_scope(TK_DECODER_FWD);
-    decoder_fwd_body<H, COND, GREEDY, UVL, TAB>(a);
+    decoder_fwd_body<H, COND, GREEDY, UVL>(a);
 }
 
 // Backward of s_m = v . tanh(q + PK_m) for one attention.  Lane m of `dsm` holds d s_m.  Wave w owns the memories
@@ -1100,7 +1085,7 @@ __device__ __forceinline__ float score_backward_quads(float dsm, const float *q_
 // the quad form: the phase is bound by LDS issue and transcendentals about equally), U rounds straight-line, and the two
 // d q sums are added over the eight lanes of a group with three DPP steps (two in the quad, one row_half_mirror).
 // Returns (d q_{2 k2}, d q_{2 k2 + 1}) in every lane of the group.
-template <int H, int U, bool TAB>
+template <int H, int U>
 __device__ __forceinline__ f32x2 score_backward_octs(float dsm, const float *q_s, const float *v_s, const float *pk,
                                                      float *dpk, int n, f32x2 &dv_acc, int tid) {
     static_assert(H % 2 == 0 && H <= 128, "feature pairs over 64 groups of eight lanes");
@@ -1112,9 +1097,6 @@ __device__ __forceinline__ f32x2 score_backward_octs(float dsm, const float *q_s
     f32x2 v = *reinterpret_cast<const f32x2 *>(v_s + kk);
     if (!has) v = f32x2{0.f, 0.f};
     f32x2 pdq = {0.f, 0.f};
-    [[maybe_unused]] float dssum = 0.f;
-    // TAB: pk = the table e^{-2 PK}, q_s = e^{-2q}: r = 1 / (1 + e^{-2q} e^{-2 PK}), tanh = 2 r - 1, 1 - tanh^2 = 4 r (1 - r)
-    if constexpr (TAB) v = f32x2{4.f * v.x, 4.f * v.y};
     for (int m0 = 0; m0 < n; m0 += 8 * U) {                     // the same number of rounds in every lane
         f32x2 x[U], old[U];
         float dsl[U];
@@ -1129,33 +1111,19 @@ __device__ __forceinline__ f32x2 score_backward_octs(float dsm, const float *q_s
             dsl[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mc, __float_as_int(dsm)));
             old[u] = *reinterpret_cast<const f32x2 *>(dpk + at[u]);
         }
+        // (the r form of the forward scores, GSCAN_DEC_RFORM, measured here too — 4 r (1 - r) for 1 - tanh^2, 2 ds r - ds for
+        // ds tanh, pre-scaled queries: three instructions fewer per term and no change, 96.2-96.8 -> 96.9-97.1 us: this phase
+        // is not bound by its arithmetic.  profiles/r06_decoder_score_tables_ab.txt, run 10)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float ds = live[u] ? dsl[u] : 0.f;
-            if constexpr (TAB) {
-                const f32x2 r = {__builtin_amdgcn_rcpf(fmaf(q.x, x[u].x, 1.f)), __builtin_amdgcn_rcpf(fmaf(q.y, x[u].y, 1.f))};
-                const f32x2 w = {fmaf(-r.x, r.x, r.x), fmaf(-r.y, r.y, r.y)};        // r (1 - r)
-                const f32x2 dsv = {ds * v.x, ds * v.y};
-                if (has && live[u])
-                    *reinterpret_cast<f32x2 *>(dpk + at[u]) = f32x2{fmaf(dsv.x, w.x, old[u].x), fmaf(dsv.y, w.y, old[u].y)};
-                pdq.x = fmaf(dsv.x, w.x, pdq.x);
-                pdq.y = fmaf(dsv.y, w.y, pdq.y);
-                dv_acc.x = fmaf(ds + ds, r.x, dv_acc.x);
-                dv_acc.y = fmaf(ds + ds, r.y, dv_acc.y);
-                dssum += ds;
-            } else {
-                const f32x2 th = {tanhf_(q.x + x[u].x), tanhf_(q.y + x[u].y)};
-                const f32x2 t = {ds * v.x * (1.f - th.x * th.x), ds * v.y * (1.f - th.y * th.y)};
-                if (has && live[u]) *reinterpret_cast<f32x2 *>(dpk + at[u]) = old[u] + t;
-                pdq += t;
-                dv_acc.x = fmaf(ds, th.x, dv_acc.x);
-                dv_acc.y = fmaf(ds, th.y, dv_acc.y);
-            }
+            const f32x2 th = {tanhf_(q.x + x[u].x), tanhf_(q.y + x[u].y)};
+            const f32x2 t = {ds * v.x * (1.f - th.x * th.x), ds * v.y * (1.f - th.y * th.y)};
+            if (has && live[u]) *reinterpret_cast<f32x2 *>(dpk + at[u]) = old[u] + t;
+            pdq += t;
+            dv_acc.x = fmaf(ds, th.x, dv_acc.x);
+            dv_acc.y = fmaf(ds, th.y, dv_acc.y);
         }
-    }
-    if constexpr (TAB) {
-        dv_acc.x -= dssum;                                      // ds th = 2 ds r - ds
-        dv_acc.y -= dssum;
     }
     pdq.x = quad_sum(pdq.x);
     pdq.y = quad_sum(pdq.y);
@@ -1340,7 +1308,7 @@ __device__ __forceinline__ void dalpha_rows(const float *smem, const float *d_s,
 // (dPK += alpha^T . dctx) is a separate batched product outside (it needs W_ih^T . delta,
 // which is again a dense GEMM).
 // ------------------------------------------------------------------------------------------
-template <int H, bool COND, bool UVL = true, bool TAB = false>
+template <int H, bool COND, bool UVL = true>
 __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     constexpr int R = (COND ? 7 : 6) * H, NS = (R + kDecPairs - 1) / kDecPairs, K0 = ((H / 2 + 3) / 4) * 4,
                   HP = 2 * K0;
@@ -1349,8 +1317,7 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     const int pair = decoder_pair_of(tid), half = decoder_half_of(tid);
     const int T = a.T, L = a.L, M = a.M;
     constexpr bool uv_lds = UVL;
-    constexpr bool tab = TAB;                               // the host found room for the tables (launch_decoder)
-    const DecoderLds o = decoder_lds(H, L, M, a.V, COND, true, uv_lds, tab);
+    const DecoderLds o = decoder_lds(H, L, M, a.V, COND, true, uv_lds);
     float *Uv = smem + o.uv, *PKv = smem + o.pkv, *Ut = smem + o.ut, *PKt = smem + o.pkt, *U2t = smem + o.u2t;
     float *dPKv = smem + o.dpkv, *dPKt = smem + o.dpkt;
     float *vec = smem + o.vec;
@@ -1534,12 +1501,6 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     }
     if (GSCAN_STAMPS_ON && tid >= 64 && tid < 80) stamp_acc[tid - 64] = 0.f;
     staged_barrier();                                       // weights, memories and the small loads above are complete
-    static_assert(!GSCAN_DEC_EXPTAB || GSCAN_DEC_SB_QUAD == 2, "the tabulated scores exist in the octet layout only");
-    if (tab) {                                              // first read in phase 3, behind the barriers of phases 1 and 2
-        exp_table(smem + o.ekv, PKv, M * H, tid);
-        exp_table(smem + o.ekt, PKt, L * H, tid);
-    }
-    const float *SKv = tab ? smem + o.ekv : PKv, *SKt = tab ? smem + o.ekt : PKt;
     if (GSCAN_DEC_PRIO == 1) { if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1); }
     if (GSCAN_DEC_PRIO == 2) { if (__builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_setprio(1); }
     GSCAN_STAMP_ONCE(11)
@@ -1581,8 +1542,8 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             const int kk = tid - 128;
             exc_s[kk] = pf[0];
             exs_s[kk] = pf[1];
-            qt_s[kk] = TAB ? e2m(pf[2]) : pf[2];             // (the score terms are the queries' only readers)
-            qv_s[kk] = TAB ? e2m(pf[3]) : pf[3];
+            qt_s[kk] = pf[2];
+            qv_s[kk] = pf[3];
             if (COND) q2_s[kk] = pf[4];
         }
         if (t > 0) prefetch(t - 1);
@@ -1609,9 +1570,7 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             const float da = (lane < M) ? sc_s[lane] : 0.f;
             const float dsm = al * (da - wave_sum(al * da));
 #if GSCAN_DEC_SB_QUAD == 2
-            // (tabulated scores, no conditional query, gate images in global memory: five rounds in flight spill 13 registers)
-            constexpr int UV = (TAB && !COND && !UVL && GSCAN_DEC_SBO_UV > 3) ? 3 : GSCAN_DEC_SBO_UV;
-            const f32x2 dq = score_backward_octs<H, UV, TAB>(dsm, qv_s, vv_s, SKv, dPKv, M, dvv_acc, tid);
+            const f32x2 dq = score_backward_octs<H, GSCAN_DEC_SBO_UV>(dsm, qv_s, vv_s, PKv, dPKv, M, dvv_acc, tid);
             if ((tid & 7) == 0 && 2 * (tid >> 3) < H) {      // lane 0 of the eight of feature pair k2 holds both sums
                 const int k = 2 * (tid >> 3);
                 *reinterpret_cast<f32x2 *>(dqv_s + k) = dq;
@@ -1671,7 +1630,7 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
             const float da = (lane < len) ? sc_s[lane] : 0.f;
             const float dsm = al * (da - wave_sum(al * da));
 #if GSCAN_DEC_SB_QUAD == 2
-            const f32x2 dq = score_backward_octs<H, GSCAN_DEC_SBO_UT, TAB>(dsm, qt_s, vt_s, SKt, dPKt, len, dvt_acc, tid);
+            const f32x2 dq = score_backward_octs<H, GSCAN_DEC_SBO_UT>(dsm, qt_s, vt_s, PKt, dPKt, len, dvt_acc, tid);
             if ((tid & 7) == 0 && 2 * (tid >> 3) < H) *reinterpret_cast<f32x2 *>(d_s + 4 * HP + 2 * (tid >> 3)) = dq;
 #elif GSCAN_DEC_SB_QUAD
             const float dq = score_backward_quads<H>(dsm, qt_s, vt_s, PKt, dPKt, len, dvt_acc, tid);
@@ -1765,10 +1724,10 @@ __device__ __forceinline__ void decoder_bwd_body(const DecoderArgs &a) {
     GSCAN_STAMP_ONCE(12)
 }
 
-template <int H, bool COND, bool UVL = true, bool TAB = false>
+template <int H, bool COND, bool UVL = true>
 __global__ __launch_bounds__(kDecThreads) void decoder_bwd_kernel(DecoderArgs a) {
     TraceScope trace_scope(TK_DECODER_BWD);
-    decoder_bwd_body<H, COND, UVL, TAB>(a);
+    decoder_bwd_body<H, COND, UVL>(a);
 }
 
 // Register images of the decoder weights are written once per step by the step prologue kernel
@@ -1790,13 +1749,6 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
     DecoderLds o = decoder_lds(H, a.L, a.M, a.V, COND, backward, true);
     const bool uvl = ((size_t)o.total + extra) * sizeof(float) <= kLdsLimit || H < kStreamMinHidden;
     if (!uvl) o = decoder_lds(H, a.L, a.M, a.V, COND, backward, false);
-    // ... and the tables of e^{-2 PK} go beside the keys when there is room left (training kernels: an instantiation each;
-    // one kernel with both forms behind a uniform branch lost the gain, profiles/r06_decoder_score_tables_ab.txt)
-    const char *tables_e = getenv("GSCAN_DEC_TABLES");      // read per launch (0: never; the parity tests run both forms in one process)
-    const int tables_env = tables_e ? atoi(tables_e) : 1;
-    const DecoderLds ot = decoder_lds(H, a.L, a.M, a.V, COND, backward, uvl, true);
-    const bool tables = GSCAN_DEC_EXPTAB && tables_env && !greedy && ((size_t)ot.total + extra) * sizeof(float) <= kLdsLimit;
-    if (tables) o = ot;
     const size_t bytes = ((size_t)o.total + extra) * sizeof(float);
     GSCAN_CHECK(bytes <= kLdsLimit,
                 "decoder: a row's memories need %zu bytes of LDS (> 160 KiB)%s: grid cells=%d command length=%d hidden=%d",
@@ -1829,18 +1781,10 @@ static int launch_decoder(bool backward, int B, const DecoderArgs &a, hipStream_
     if (greedy) GSCAN_CHECK(a.V <= 64 && a.head_wc && a.dec_emb && a.steps_out, "greedy decoder: missing tables or V > 64");
     if constexpr (H >= kStreamMinHidden) {
         if (!uvl) {
-            if constexpr (GSCAN_DEC_EXPTAB) {
-                if (backward && tables) return launch(decoder_bwd_kernel<H, COND, false, true>, "decoder_bwd_kernel");
-                if (!greedy && tables) return launch(decoder_fwd_kernel<H, COND, false, false, true>, "decoder_fwd_kernel");
-            }
             if (backward) return launch(decoder_bwd_kernel<H, COND, false>, "decoder_bwd_kernel");
             if (greedy) return launch(decoder_fwd_kernel<H, COND, true, false>, "decoder_fwd_kernel");
             return launch(decoder_fwd_kernel<H, COND, false, false>, "decoder_fwd_kernel");
         }
-    }
-    if constexpr (GSCAN_DEC_EXPTAB) {
-        if (backward && tables) return launch(decoder_bwd_kernel<H, COND, true, true>, "decoder_bwd_kernel");
-        if (!greedy && tables) return launch(decoder_fwd_kernel<H, COND, false, true, true>, "decoder_fwd_kernel");
     }
     if (backward) return launch(decoder_bwd_kernel<H, COND, true>, "decoder_bwd_kernel");
     if (greedy) return launch(decoder_fwd_kernel<H, COND, true, true>, "decoder_fwd_kernel");

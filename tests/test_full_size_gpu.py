@@ -30,17 +30,12 @@ CASES = [
     ("S1_ragged_eval", "compositional", {}, dict(max_target=20, ragged=True), False),
     ("S4_geca_aux_b256_t20_dropout", "compositional", {"auxiliary_task": True}, dict(max_target=20, ragged=True), True),
     ("S3_target_length_b256_t120", "target_length", {}, dict(max_target=120, ragged=False), False),
-    # the decoder kernels' other form of the score terms (no e^{-2 PK} tables in LDS: what a long command gets, decoder.hip
-    # GSCAN_DEC_EXPTAB), forced at the benchmark shape
-    ("S1_compositional_without_score_tables", "compositional", {}, dict(max_target=20, ragged=True), True),
 ]
 
 
 @pytest.mark.parametrize("name,workload,overrides,shape_kw,dropout", CASES, ids=[c[0] for c in CASES])
-def test_full_size_against_oracle(name, workload, overrides, shape_kw, dropout, monkeypatch):
+def test_full_size_against_oracle(name, workload, overrides, shape_kw, dropout):
     from multimodal_seq2seq_gscan_amd.model import Model
-    if name.endswith("without_score_tables"):
-        monkeypatch.setenv("GSCAN_DEC_TABLES", "0")         # read by the library at every decoder launch
     from oracle import seq2seq_oracle as oracle            # the checker
     from weights import golden_weights
 
@@ -129,3 +124,96 @@ def test_sums_over_time_per_memory_at_full_size():
         scale = ref.abs().max().item()
         err = (got - ref).abs().max().item()
         assert scale > 0 and err <= 2e-6 * scale + 1e-12, f"{name}: max|err| {err:.3e} against max|ref| {scale:.3e}"
+
+
+def _scaled_attention(cfg, which, scale):
+    from weights import golden_weights
+    params = {k: torch.from_numpy(v) for k, v in golden_weights(cfg, 23).items()}
+    for k in params:
+        if any(k.endswith(f"attention.{w}.weight") for w in which):
+            params[k] = params[k] * scale
+    return params
+
+
+@pytest.mark.parametrize("which", [("key_layer",), ("query_layer",)], ids=["huge_keys", "huge_queries"])
+def test_saturated_attention_scores_against_oracle(which):
+    """Key layers, or query layers, of both attentions scaled by 600 (|PK| up to 160, |q| up to 90): the decoder kernels take
+    the score terms as 2 r - 1, r = 1 / (1 + 2^(-2 log2(e) (q + PK))) (decoder.hip GSCAN_DEC_RFORM), which must saturate like
+    tanh does (seq2seq_model.py:131) — 2^(+-big) is inf or 0, r is 0 or 1, and 1 - tanh^2 = 4 r (1 - r) is 0 either way; 32 rows
+    of the benchmark shape, log-probabilities, loss and every gradient against the oracle."""
+    from multimodal_seq2seq_gscan_amd.model import Model
+    from oracle import seq2seq_oracle as oracle            # the checker
+
+    cfg = model_kwargs("compositional")
+    batch = make_batch(Shape(batch=32, grid=6, channels=cfg["num_cnn_channels"], input_vocab=cfg["input_vocabulary_size"],
+                             target_vocab=cfg["target_vocabulary_size"], max_command=10, max_target=20, ragged=True), seed=5)
+    params = _scaled_attention(cfg, which, 600.0)
+    ref_loss, ref_grads, ref_logp = oracle.loss_and_grads(params, batch, conditional=cfg["conditional_attention"],
+                                                          auxiliary=False, masks=None)
+    model = Model(**cfg)
+    model.load_state_dict(params, strict=False)
+    model = model.cuda().eval()
+    d = {k: v.cuda() for k, v in batch.items()}
+    model.zero_grad()
+    logp, _ = model(commands_input=d["commands"], commands_lengths=batch["cmd_lengths"].tolist(), situations_input=d["world"],
+                    target_batch=d["targets"], target_lengths=batch["tgt_lengths"].tolist())
+    loss = model.get_loss(logp, d["targets"])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(logp).all()
+    dims = model._dims(*batch["commands"].shape, batch["targets"].shape[1], batch["world"].shape[1])
+    big = model.workspace_view(dims, "pkv" if which == ("key_layer",) else "qv").abs().max().item()
+    assert big > 60.0, f"max |{which[0]} output| = {big}: scale the layers further"
+    # contexts are sums of the keys (seq2seq_model.py:138: values = projected keys), so with huge keys everything downstream
+    # is huge too: tolerances relative to the largest reference value
+    scale = max(1.0, ref_logp.abs().max().item())
+    err = (logp.detach().cpu() - ref_logp).abs().max().item()
+    assert err < TOL * scale, f"max|dlogp| = {err:.3e} (max|ref| {scale:.3e})"
+    assert abs(loss.item() - ref_loss.item()) < TOL * scale
+    bad = []
+    for k, p in model.named_parameters():
+        g, r = p.grad.detach().cpu(), ref_grads[k]
+        assert torch.isfinite(g).all(), k
+        if not torch.allclose(g, r, atol=TOL * max(1.0, r.abs().max().item()), rtol=1e-3):
+            bad.append(f"{k}: max|err| {(g - r).abs().max().item():.3e}, max|ref| {r.abs().max().item():.3e}")
+    assert not bad, "gradient mismatches\n" + "\n".join(bad)
+
+
+def test_huge_queries_and_keys_that_cancel():
+    """Query AND key layers scaled by 600: q + PK is then a small difference of two huge numbers for some (memory, feature)
+    pairs — the case a factorised e^{-2q} e^{-2 PK} (round 6's tables, not shipped) gets wrong.  The recurrence amplifies rounding
+    differences at this scale (every step's query is 600 W h), so only the FIRST step is compared: its two attention
+    distributions, contexts and hidden state against the oracle's."""
+    from multimodal_seq2seq_gscan_amd.model import Model
+    from oracle import seq2seq_oracle as oracle            # the checker
+
+    cfg = model_kwargs("compositional")
+    batch = make_batch(Shape(batch=32, grid=6, channels=cfg["num_cnn_channels"], input_vocab=cfg["input_vocabulary_size"],
+                             target_vocab=cfg["target_vocabulary_size"], max_command=10, max_target=20, ragged=True), seed=5)
+    params = _scaled_attention(cfg, ("key_layer", "query_layer"), 600.0)
+    keep = {}
+    oracle.forward(params, batch["commands"], batch["cmd_lengths"], batch["world"], batch["targets"], keep=keep)
+    model = Model(**cfg)
+    model.load_state_dict(params, strict=False)
+    model = model.cuda().eval()
+    d = {k: v.cuda() for k, v in batch.items()}
+    with torch.no_grad():
+        model(commands_input=d["commands"], commands_lengths=batch["cmd_lengths"].tolist(), situations_input=d["world"],
+              target_batch=d["targets"], target_lengths=batch["tgt_lengths"].tolist())
+    torch.cuda.synchronize()
+    B, L = batch["commands"].shape
+    T, G = batch["targets"].shape[1], batch["world"].shape[1]
+    H, M = cfg["decoder_hidden_size"], G * G
+    dims = model._dims(B, L, T, G)
+    view = lambda n: model.workspace_view(dims, n).cpu()
+    assert view("pkv").abs().max().item() > 100.0 and view("qv").view(B, T, H)[:, 0].abs().max().item() > 40.0
+    S = view("S").view(B, T, 4 * H)
+    pairs = {"alpha_c": (view("alpha_c").view(B, T, L)[:, 0], keep["a_c"][0]), "alpha_s": (view("alpha_s").view(B, T, M)[:, 0], keep["a_s"][0]),
+             "ctx_text": (S[:, 0, H:2 * H], keep["ctx_c"][0]), "ctx_vis": (S[:, 0, 2 * H:3 * H], keep["ctx_s"][0]),
+             "h": (S[:, 0, 3 * H:], keep["h"][0])}
+    bad = []
+    for k, (got, ref) in pairs.items():
+        err, scale = (got - ref).abs().max().item(), max(1.0, ref.abs().max().item())
+        if not err < 1e-4 * scale:
+            bad.append(f"{k}: max|err| {err:.3e} against max|ref| {scale:.3e}")
+    assert not bad, "\n".join(bad)
