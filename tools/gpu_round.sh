@@ -1,6 +1,7 @@
 #!/bin/bash
 # One GPU call's worth of evidence: parity tests, bench line, rocprofv3 kernel stats, PMC traffic passes.
 # usage (on the GPU box, from the repo root): bash tools/gpu_round.sh <tag>   -> files under gpurun_out/<tag>/
+# (then copy <tag>/pmc_traffic.json to profiles/pmc_traffic_latest.json and run tools/final_round.sh <tag> for the bound bench lines)
 set -eo pipefail
 tag=${1:-run}
 out=gpurun_out/$tag
